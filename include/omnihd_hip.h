@@ -1,0 +1,199 @@
+/*
+ * omnihd_hip.h — C ABI of libomnihd_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the camera + 4D-radar BEV-fusion hot path of
+ * TJRadarLab/OmniHD-Scenes.  Every entry point takes plain device pointers, sizes and a
+ * hipStream_t passed as void*; nothing here depends on torch.  All functions return
+ * OMNIHD_OK (0) or a negative omnihd_status and never throw across the boundary.
+ * A human readable message for the last failure on the calling thread is available from
+ * omnihd_last_error().
+ *
+ * "ref:" lines cite the reference interface (path relative to the reference repo root)
+ * that each entry point replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name starts with h_;
+ *   - `stream` is a hipStream_t (0 = the null stream); work is only enqueued, never
+ *     synchronised, except where a function documents a host read-back;
+ *   - tables are int32, features are float32 (the reference forces both:
+ *     ops/bev_pool_v2/bev_pool.py:19-25);
+ *   - workspaces are caller-owned scratch; ask the matching *_workspace_bytes() first.
+ */
+#ifndef OMNIHD_HIP_H_
+#define OMNIHD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum omnihd_status {
+  OMNIHD_OK = 0,
+  OMNIHD_ERR_ARG = -1,       /* null pointer / negative size / unsupported shape   */
+  OMNIHD_ERR_LAUNCH = -2,    /* hipGetLastError() after a launch was not hipSuccess */
+  OMNIHD_ERR_WORKSPACE = -3, /* workspace too small                                  */
+  OMNIHD_ERR_RUNTIME = -4    /* any other HIP runtime failure                        */
+} omnihd_status;
+
+/* Library identification / diagnostics. */
+const char* omnihd_version(void);
+const char* omnihd_last_error(void);
+/* Number of HIP devices visible to the library (0 when no GPU): lets host code fail loudly. */
+int omnihd_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * bev_pool_v2 — LSS "BEVPoolv2" (depth x feature gather by rank tables, segment-sum per voxel)
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: projects/mmdet3d_plugin/ops/bev_pool_v2/src/bev_pool.cpp:30-57 (bev_pool_v2_forward)
+ *      -> bev_pool_cuda.cu:21-48 (bev_pool_v2_kernel), launcher :125-131.
+ * out[ranks_bev[s]*c + ch] = sum_{i<len} depth[ranks_depth[s+i]] * feat[ranks_feat[s+i]*c + ch]
+ * for every interval (s = interval_starts[k], len = interval_lengths[k]).  `out` rows that no
+ * interval names are NOT touched (the caller zero-fills, as bev_pool.py:27 does).
+ * Summation runs in table order with one fused multiply-add per point (same chain as the
+ * reference kernel), except for intervals longer than 512 points, which are split over the
+ * lanes of one workgroup and combined in a fixed order (run-to-run deterministic).        */
+int omnihd_bev_pool_v2_fwd(const float* depth, const float* feat,
+                           const int* ranks_depth, const int* ranks_feat, const int* ranks_bev,
+                           const int* interval_starts, const int* interval_lengths,
+                           float* out, int c, int n_intervals, void* stream);
+
+/* ref: ops/bev_pool_v2/src/bev_pool.cpp:74-104 (bev_pool_v2_backward)
+ *      -> bev_pool_cuda.cu:67-121 (bev_pool_grad_kernel), launcher :133-140.
+ * Tables are the BACKWARD tables: sorted so that an interval is a run of equal ranks_feat
+ * (bev_pool.py:47-57).  depth_grad[ranks_depth[p]] = sum_ch out_grad[ranks_bev[p]*c+ch] *
+ * feat[ranks_feat[p]*c+ch];  feat_grad[ranks_feat[s]*c+ch] = sum_p out_grad[ranks_bev[p]*c+ch]
+ * * depth[ranks_depth[p]].  Entries not named by the tables are NOT touched.               */
+int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const float* feat,
+                           const int* ranks_depth, const int* ranks_feat, const int* ranks_bev,
+                           const int* interval_starts, const int* interval_lengths,
+                           float* depth_grad, float* feat_grad, int c, int n_intervals,
+                           void* stream);
+
+/* Fused forward used by our own LSS module (no reference counterpart: it removes the
+ * reference's zero-fill (bev_pool.py:27), permute copy (:91) and s2c concat copy
+ * (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:374-376)).
+ * The points are grouped by OUTPUT ROW in CSR form: row r owns points
+ * [row_ptr[r], row_ptr[r+1]) of ranks_depth/ranks_feat.  Every one of the n_rows rows is
+ * written (zeros for empty rows), so `out` needs no initialisation.  The row numbering is
+ * whatever the plan builder chose (reference (b,z,y,x) order, or (b,y,x,z) = channels-last
+ * of the s2c tensor).                                                                      */
+int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
+                               const int* ranks_depth, const int* ranks_feat,
+                               const int* row_ptr, float* out, int c, int n_rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bev_pool (v1) — imported by the plugin at load time (projects/mmdet3d_plugin/__init__.py:20)
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: ops/bev_pool/src/bev_pool.cpp:22-47 (bev_pool_forward) -> bev_pool_cuda.cu:20-42.
+ * x is [n,c] sorted by rank; geom_feats is [n,4] = (h_idx, w_idx, d_idx, b_idx);
+ * out is [b,d,h,w,c]; out rows not named are NOT touched (reference allocates zeros).     */
+int omnihd_bev_pool_v1_fwd(const float* x, const int* geom_feats,
+                           const int* interval_starts, const int* interval_lengths,
+                           float* out, int b, int d, int h, int w, int n, int c,
+                           int n_intervals, void* stream);
+
+/* ref: ops/bev_pool/src/bev_pool.cpp:60-87 (bev_pool_backward) -> bev_pool_cuda.cu:61-84.
+ * x_grad[(s+i)*c + ch] = out_grad[voxel(s), ch].                                         */
+int omnihd_bev_pool_v1_bwd(const float* out_grad, const int* geom_feats,
+                           const int* interval_starts, const int* interval_lengths,
+                           float* x_grad, int b, int d, int h, int w, int n, int c,
+                           int n_intervals, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rank-table preparation (voxel_pooling_prepare_v2 and the backward re-sort)
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:302-346.
+ * geom is the (B,N,D,H,W,3) fp32 frustum geometry; n_total = B*N*D*H*W;
+ * pts_per_batch = N*D*H*W.  off[a] = bx[a]-dx[a]/2 and dx[a] are fp32 values computed by the
+ * host exactly as the reference's tensor arithmetic does.  For point i:
+ *   t = (geom[i][a] - off[a]) / dx[a]   (IEEE fp32, no contraction, true division)
+ *   coor = trunc(t)  (toward zero — reference defect D3 is kept)
+ *   kept = 0 <= coor[a] < nx[a] for a in x,y,z  (NaN is dropped)
+ *   keys[i] = b*nz*ny*nx + z*ny*nx + y*nx + x   or  sentinel (= B*nz*ny*nx) when not kept
+ *   idx[i]  = i
+ * keys/idx have n_total entries.                                                           */
+int omnihd_bev_rank_keys(const float* geom, int64_t n_total, int64_t pts_per_batch,
+                         const float* h_off3, const float* h_dx3, const int* h_nx3,
+                         uint32_t* keys, int* idx, uint32_t sentinel, void* stream);
+
+/* Stable sort of (key, payload...) by key + run-length encoding of the sorted keys.
+ * ref: the argsort + RLE blocks at cam_stream_lss_bevpoolv2_depthnet.py:347-359 and
+ *      ops/bev_pool_v2/bev_pool.py:47-57 (torch argsort is not guaranteed stable, reference
+ *      defect D6; we always produce the stable = canonical order).
+ * keys_in[n] (uint32, < 2^key_bits), up to three int payloads (null = absent) are permuted
+ * alike into *_out.  Keys equal to `sentinel` (pass 0xFFFFFFFF for "none") sort last and are
+ * excluded from the result.  On return (after stream completes):
+ *   h_counts[0] = number of non-sentinel elements (n_points)
+ *   h_counts[1] = number of runs among them (n_intervals)
+ * interval_starts/lengths receive the runs (capacity n each).  counts is a 2-int device
+ * buffer; if h_counts is non-null the function synchronises the stream and copies it back. */
+size_t omnihd_sort_ranks_workspace_bytes(int64_t n);
+int omnihd_sort_ranks(const uint32_t* keys_in, const int* p0_in, const int* p1_in,
+                      const int* p2_in, int64_t n, int key_bits, uint32_t sentinel,
+                      uint32_t* keys_out, int* p0_out, int* p1_out, int* p2_out,
+                      int* interval_starts, int* interval_lengths, int* counts, int* h_counts,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ranks_feat[i] = (ranks_depth[i] / (D*HW)) * HW + ranks_depth[i] % HW
+ * ref: cam_stream_lss_bevpoolv2_depthnet.py:321-326 (ranks_feat = pixel index of a frustum
+ * point whose flat (B,N,D,H,W) index is ranks_depth).                                      */
+int omnihd_ranks_feat_from_depth(const int* ranks_depth, int64_t n, int d, int hw,
+                                 int* ranks_feat, void* stream);
+
+/* row_ptr[r] (r in [0,n_rows]) = index of the first point whose sorted key is >= r
+ * (lower bound), i.e. CSR offsets over output rows for omnihd_bev_pool_v2_fwd_csr.
+ * sorted_keys are the n_points non-sentinel keys produced by omnihd_sort_ranks.            */
+int omnihd_csr_from_sorted_keys(const uint32_t* sorted_keys, int n_points, int n_rows,
+                                int* row_ptr, void* stream);
+
+/* rows_out[i] = row index of voxel rows_in[i] after moving from the reference (b,z,y,x)
+ * order to (b,y,x,z) order — the row numbering of a channels-last s2c tensor
+ * (cam_stream_lss_bevpoolv2_depthnet.py:374-376 puts channel = z*C + c).                  */
+int omnihd_permute_rows_zyx_to_yxz(const int* rows_in, int64_t n, int nz, int ny, int nx,
+                                   int* rows_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Radar point cloud: hard voxelisation and pillar scatter
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: call site bevfusion/detectors/bevf_faster_rcnn_bevdepth.py:97 (self.voxelize), config
+ * projects/configs/bevfusion_NewScenes/bevfusion.py:46-50; the op itself is mmdet3d v0.17.1
+ * Voxelization/hard_voxelize (un-vendored; semantics restated in oracle/voxelize.c).
+ * points [n, f] fp32 (x,y,z first).  Voxels are numbered in first-occurrence point order; the
+ * first max_points points of a voxel are kept in point order; voxels beyond max_voxels are
+ * refused.  Outputs (capacity max_voxels): voxels [M,max_points,f] zero padded,
+ * coors [M,3] = (z,y,x), num_points [M].  voxel_num (device int) = M; if h_voxel_num is
+ * non-null the stream is synchronised and M copied back.                                   */
+size_t omnihd_voxelize_workspace_bytes(int n_points);
+int omnihd_voxelize_hard(const float* points, int n_points, int n_feat,
+                         const float* h_voxel_size3, const float* h_range6,
+                         int max_points, int max_voxels,
+                         float* voxels, int* coors, int* num_points, int* voxel_num,
+                         int* h_voxel_num, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* ref: call site bevf_faster_rcnn_bevdepth.py:101 (pts_middle_encoder), config
+ * bevfusion.py:60-61; op = mmdet3d PointPillarsScatter.forward_batch (un-vendored).
+ * feats [m,c]; coors [m,4] = (b,z,y,x).  Writes the WHOLE canvas (zeros where no pillar):
+ *   channels_last == 0: canvas [batch, c, ny, nx]   (reference layout)
+ *   channels_last == 1: canvas [batch, ny, nx, c]
+ * cell_map is scratch of batch*ny*nx ints.                                                 */
+size_t omnihd_pillar_scatter_workspace_bytes(int batch, int ny, int nx);
+int omnihd_pillar_scatter(const float* feats, const int* coors, int m, int c,
+                          int batch, int ny, int nx, int channels_last, float* canvas,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the scatter: feats_grad[v, ch] = canvas_grad[b, ch, y, x] (gather).          */
+int omnihd_pillar_gather(const float* canvas_grad, const int* coors, int m, int c,
+                         int batch, int ny, int nx, int channels_last, float* feats_grad,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNIHD_HIP_H_ */

@@ -1,0 +1,404 @@
+// bev_pool_v2 forward / backward for gfx950 (MI355X).
+//
+// What the reference computes: ops/bev_pool_v2/src/bev_pool_cuda.cu:21-48 (forward, one CUDA
+// thread per (interval, channel) with a serial loop) and :67-121 (backward, one thread per
+// interval doing len*C serial work twice).  This file is a different program for the same
+// arithmetic:
+//
+//   * a ROW (C floats of one image-feature pixel, or of one BEV voxel) is owned by a group of
+//     C/4 lanes, each lane holding a float4 -> every feature gather / voxel write is one
+//     fully coalesced 16 B-per-lane access (256 B for C=64), 4 rows per 64-wide wavefront;
+//   * the three rank tables are read coalesced, C/4 points at a time, one point per lane, the
+//     per-point depth value is gathered by that lane in parallel, and rank / depth are
+//     handed to the row's other lanes through a sub-wave shuffle (no LDS round trip);
+//   * intervals longer than kLongLen (near-ego voxels collect thousands of frustum points)
+//     are parked in an LDS list and afterwards split over all groups of the workgroup, with
+//     a fixed-order LDS combine -> no atomics anywhere, results are run-to-run identical;
+//   * the dense (CSR) forward writes every output row, so the caller's zero-fill pass, the
+//     permute copy and the s2c concat copy of the reference disappear.
+//
+// Arithmetic: one fmaf per (point, channel) in table order, i.e. the same rounding chain as
+// the reference's `psum += feat * depth` under nvcc's default contraction.
+#include "common.h"
+
+namespace omnihd {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLongLen = 512;  // intervals longer than this are split over the workgroup
+constexpr int kMaxLong = 48;   // capacity of the per-workgroup deferred list
+
+__device__ __forceinline__ float4 fma4(float s, float4 v, float4 a) {
+  a.x = fmaf(v.x, s, a.x);
+  a.y = fmaf(v.y, s, a.y);
+  a.z = fmaf(v.z, s, a.z);
+  a.w = fmaf(v.w, s, a.w);
+  return a;
+}
+
+// Accumulate points [start, start+len) of the tables into one float4 (4 channels of one row).
+// All C4 lanes of the group call this together with the same (start, len).
+template <int C4>
+__device__ __forceinline__ float4 pool_range(const float* __restrict__ depth,
+                                             const float4* __restrict__ feat4,
+                                             const int* __restrict__ ranks_depth,
+                                             const int* __restrict__ ranks_feat, int start,
+                                             int len, int sub) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = 0; base < len; base += C4) {
+    const int mine = base + sub;
+    int my_rf = 0;
+    float my_d = 0.f;
+    if (mine < len) {
+      my_rf = ranks_feat[start + mine];
+      my_d = depth[ranks_depth[start + mine]];
+    }
+    const int n = min(C4, len - base);
+    int j = 0;
+    // 4 independent feature-row gathers in flight per group.
+    for (; j + 4 <= n; j += 4) {
+      const int f0 = __shfl(my_rf, j + 0, C4), f1 = __shfl(my_rf, j + 1, C4);
+      const int f2 = __shfl(my_rf, j + 2, C4), f3 = __shfl(my_rf, j + 3, C4);
+      const float d0 = __shfl(my_d, j + 0, C4), d1 = __shfl(my_d, j + 1, C4);
+      const float d2 = __shfl(my_d, j + 2, C4), d3 = __shfl(my_d, j + 3, C4);
+      const float4 v0 = feat4[(size_t)f0 * C4 + sub];
+      const float4 v1 = feat4[(size_t)f1 * C4 + sub];
+      const float4 v2 = feat4[(size_t)f2 * C4 + sub];
+      const float4 v3 = feat4[(size_t)f3 * C4 + sub];
+      acc = fma4(d0, v0, acc);
+      acc = fma4(d1, v1, acc);
+      acc = fma4(d2, v2, acc);
+      acc = fma4(d3, v3, acc);
+    }
+    for (; j < n; ++j) {
+      const int f0 = __shfl(my_rf, j, C4);
+      const float d0 = __shfl(my_d, j, C4);
+      acc = fma4(d0, feat4[(size_t)f0 * C4 + sub], acc);
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void store_row(float4* p, float4 v, bool streaming) {
+  if (streaming) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z);
+    __builtin_nontemporal_store(v.w, &p->w);
+  } else {
+    *p = v;
+  }
+}
+
+// DENSE == false: unit = interval (tables from the reference API), only named rows written.
+// DENSE == true : unit = output row r with points [row_ptr[r], row_ptr[r+1]), all rows written.
+template <int C4, bool DENSE>
+__global__ __launch_bounds__(kBlock) void k_pool_fwd(
+    const float* __restrict__ depth, const float4* __restrict__ feat4,
+    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
+    const int* __restrict__ ranks_bev, const int* __restrict__ starts,
+    const int* __restrict__ lengths_or_rowptr, float4* __restrict__ out4, int n_units) {
+  constexpr int G = kBlock / C4;  // rows in flight per workgroup
+  __shared__ int s_long[kMaxLong];
+  __shared__ int s_nlong;
+  __shared__ float4 s_part[kBlock];
+  const int tid = threadIdx.x;
+  const int sub = tid % C4;
+  const int grp = tid / C4;
+  if (tid == 0) s_nlong = 0;
+  __syncthreads();
+
+  for (int base = blockIdx.x * G; base < n_units; base += gridDim.x * G) {
+    const int u = base + grp;
+    if (u >= n_units) continue;
+    int s, len, row;
+    if (DENSE) {
+      s = lengths_or_rowptr[u];
+      len = lengths_or_rowptr[u + 1] - s;
+      row = u;
+    } else {
+      s = starts[u];
+      len = lengths_or_rowptr[u];
+      if (len <= 0) continue;
+      row = ranks_bev[s];
+    }
+    if (len > kLongLen) {
+      int slot = 0;
+      if (sub == 0) slot = atomicAdd(&s_nlong, 1);
+      slot = __shfl(slot, 0, C4);
+      if (slot < kMaxLong) {
+        if (sub == 0) s_long[slot] = u;
+        continue;
+      }
+    }
+    const float4 acc = pool_range<C4>(depth, feat4, ranks_depth, ranks_feat, s, len, sub);
+    store_row(out4 + (size_t)row * C4 + sub, acc, DENSE);
+  }
+  __syncthreads();
+
+  const int n_long = min(s_nlong, kMaxLong);
+  for (int k = 0; k < n_long; ++k) {
+    const int u = s_long[k];
+    int s, len, row;
+    if (DENSE) {
+      s = lengths_or_rowptr[u];
+      len = lengths_or_rowptr[u + 1] - s;
+      row = u;
+    } else {
+      s = starts[u];
+      len = lengths_or_rowptr[u];
+      row = ranks_bev[s];
+    }
+    const int chunk = (len + G - 1) / G;
+    const int a = min(grp * chunk, len);
+    const int b = min(a + chunk, len);
+    s_part[tid] = pool_range<C4>(depth, feat4, ranks_depth, ranks_feat, s + a, b - a, sub);
+    __syncthreads();
+    if (grp == 0) {
+      float4 t = s_part[sub];
+      for (int g = 1; g < G; ++g) {
+        const float4 p = s_part[g * C4 + sub];
+        t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+      }
+      store_row(out4 + (size_t)row * C4 + sub, t, DENSE);
+    }
+    __syncthreads();
+  }
+}
+
+// Any channel count / any alignment: one thread per (unit, channel), serial over the points.
+template <bool DENSE>
+__global__ __launch_bounds__(kBlock) void k_pool_fwd_generic(
+    const float* __restrict__ depth, const float* __restrict__ feat,
+    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
+    const int* __restrict__ ranks_bev, const int* __restrict__ starts,
+    const int* __restrict__ lengths_or_rowptr, float* __restrict__ out, int c, int n_units) {
+  const int64_t total = (int64_t)n_units * c;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int u = (int)(t / c);
+    const int ch = (int)(t % c);
+    int s, len, row;
+    if (DENSE) {
+      s = lengths_or_rowptr[u];
+      len = lengths_or_rowptr[u + 1] - s;
+      row = u;
+    } else {
+      s = starts[u];
+      len = lengths_or_rowptr[u];
+      if (len <= 0) continue;
+      row = ranks_bev[s];
+    }
+    float acc = 0.f;
+    for (int i = 0; i < len; ++i)
+      acc = fmaf(feat[(size_t)ranks_feat[s + i] * c + ch], depth[ranks_depth[s + i]], acc);
+    out[(size_t)row * c + ch] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: one group of C4 lanes per backward interval (= one image-feature pixel).
+// ---------------------------------------------------------------------------------------------
+template <int C4>
+__global__ __launch_bounds__(kBlock) void k_pool_bwd(
+    const float4* __restrict__ og4, const float* __restrict__ depth,
+    const float4* __restrict__ feat4, const int* __restrict__ ranks_depth,
+    const int* __restrict__ ranks_feat, const int* __restrict__ ranks_bev,
+    const int* __restrict__ starts, const int* __restrict__ lengths,
+    float* __restrict__ depth_grad, float4* __restrict__ feat_grad4, int n_intervals) {
+  constexpr int G = kBlock / C4;
+  const int tid = threadIdx.x;
+  const int sub = tid % C4;
+  const int grp = tid / C4;
+  for (int base = blockIdx.x * G; base < n_intervals; base += gridDim.x * G) {
+    const int iv = base + grp;
+    if (iv >= n_intervals) continue;
+    const int s = starts[iv];
+    const int len = lengths[iv];
+    if (len <= 0) continue;
+    float4 fg = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cb = 0; cb < len; cb += C4) {
+      const int mine = cb + sub;
+      int my_rb = 0, my_rf = 0, my_rd = 0;
+      float my_d = 0.f, my_dot = 0.f;
+      if (mine < len) {
+        my_rb = ranks_bev[s + mine];
+        my_rf = ranks_feat[s + mine];
+        my_rd = ranks_depth[s + mine];
+        my_d = depth[my_rd];
+      }
+      const int n = min(C4, len - cb);
+      for (int j = 0; j < n; ++j) {
+        const int v = __shfl(my_rb, j, C4);
+        const int f = __shfl(my_rf, j, C4);
+        const float d = __shfl(my_d, j, C4);
+        const float4 g = og4[(size_t)v * C4 + sub];
+        const float4 x = feat4[(size_t)f * C4 + sub];
+        float dot = fmaf(g.w, x.w, fmaf(g.z, x.z, fmaf(g.y, x.y, g.x * x.x)));
+#pragma unroll
+        for (int o = C4 / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, C4);
+        if (sub == j) my_dot = dot;
+        fg = fma4(d, g, fg);
+      }
+      if (mine < len) depth_grad[my_rd] = my_dot;
+    }
+    feat_grad4[(size_t)ranks_feat[s] * C4 + sub] = fg;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_pool_bwd_generic(
+    const float* __restrict__ og, const float* __restrict__ depth, const float* __restrict__ feat,
+    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
+    const int* __restrict__ ranks_bev, const int* __restrict__ starts,
+    const int* __restrict__ lengths, float* __restrict__ depth_grad,
+    float* __restrict__ feat_grad, int c, int n_intervals) {
+  // thread per (interval, channel) for feat_grad; channel 0's thread also does depth_grad.
+  const int64_t total = (int64_t)n_intervals * c;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    const int iv = (int)(t / c);
+    const int ch = (int)(t % c);
+    const int s = starts[iv];
+    const int len = lengths[iv];
+    if (len <= 0) continue;
+    float acc = 0.f;
+    for (int i = 0; i < len; ++i)
+      acc = fmaf(og[(size_t)ranks_bev[s + i] * c + ch], depth[ranks_depth[s + i]], acc);
+    feat_grad[(size_t)ranks_feat[s] * c + ch] = acc;
+    if (ch == 0) {
+      for (int i = 0; i < len; ++i) {
+        const float* g = og + (size_t)ranks_bev[s + i] * c;
+        const float* x = feat + (size_t)ranks_feat[s + i] * c;
+        float dsum = 0.f;
+        for (int k = 0; k < c; ++k) dsum = fmaf(g[k], x[k], dsum);
+        depth_grad[ranks_depth[s + i]] = dsum;
+      }
+    }
+  }
+}
+
+inline bool vec_ok(int c, const void* a, const void* b, const void* c3 = nullptr) {
+  if (c % 4 != 0) return false;
+  const int c4 = c / 4;
+  if (c4 > 64 || (64 % c4) != 0) return false;
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  return al(a) && al(b) && al(c3);
+}
+
+template <bool DENSE>
+int launch_fwd(const float* depth, const float* feat, const int* ranks_depth,
+               const int* ranks_feat, const int* ranks_bev, const int* starts,
+               const int* lengths_or_rowptr, float* out, int c, int n_units,
+               hipStream_t st) {
+  if (n_units == 0) return OMNIHD_OK;
+  if (vec_ok(c, feat, out)) {
+    const int c4 = c / 4;
+    const int G = kBlock / c4;
+    // ~4 rows per group and workgroup so a deferred long interval is found early.
+    const int grid = grid_for(n_units, G * 4);
+    const float4* f4 = reinterpret_cast<const float4*>(feat);
+    float4* o4 = reinterpret_cast<float4*>(out);
+#define OMNIHD_FWD_CASE(C4)                                                                  \
+  case C4:                                                                                   \
+    hipLaunchKernelGGL((k_pool_fwd<C4, DENSE>), dim3(grid), dim3(kBlock), 0, st, depth, f4,  \
+                       ranks_depth, ranks_feat, ranks_bev, starts, lengths_or_rowptr, o4,    \
+                       n_units);                                                             \
+    break;
+    switch (c4) {
+      OMNIHD_FWD_CASE(1)
+      OMNIHD_FWD_CASE(2)
+      OMNIHD_FWD_CASE(4)
+      OMNIHD_FWD_CASE(8)
+      OMNIHD_FWD_CASE(16)
+      OMNIHD_FWD_CASE(32)
+      OMNIHD_FWD_CASE(64)
+      default:
+        set_error("unreachable c4=%d", c4);
+        return OMNIHD_ERR_ARG;
+    }
+#undef OMNIHD_FWD_CASE
+  } else {
+    const int grid = grid_for((int64_t)n_units * c, kBlock);
+    hipLaunchKernelGGL((k_pool_fwd_generic<DENSE>), dim3(grid), dim3(kBlock), 0, st, depth, feat,
+                       ranks_depth, ranks_feat, ranks_bev, starts, lengths_or_rowptr, out, c,
+                       n_units);
+  }
+  return check_launch(DENSE ? "bev_pool_v2_fwd_csr" : "bev_pool_v2_fwd");
+}
+
+}  // namespace
+}  // namespace omnihd
+
+using namespace omnihd;
+
+extern "C" int omnihd_bev_pool_v2_fwd(const float* depth, const float* feat,
+                                      const int* ranks_depth, const int* ranks_feat,
+                                      const int* ranks_bev, const int* interval_starts,
+                                      const int* interval_lengths, float* out, int c,
+                                      int n_intervals, void* stream) {
+  OMNIHD_REQUIRE(c > 0 && n_intervals >= 0, "c > 0 and n_intervals >= 0");
+  if (n_intervals == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(depth && feat && ranks_depth && ranks_feat && ranks_bev && interval_starts &&
+                     interval_lengths && out,
+                 "null pointer");
+  return launch_fwd<false>(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                           interval_lengths, out, c, n_intervals, (hipStream_t)stream);
+}
+
+extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
+                                          const int* ranks_depth, const int* ranks_feat,
+                                          const int* row_ptr, float* out, int c, int n_rows,
+                                          void* stream) {
+  OMNIHD_REQUIRE(c > 0 && n_rows >= 0, "c > 0 and n_rows >= 0");
+  if (n_rows == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(depth && feat && ranks_depth && ranks_feat && row_ptr && out, "null pointer");
+  return launch_fwd<true>(depth, feat, ranks_depth, ranks_feat, nullptr, nullptr, row_ptr, out, c,
+                          n_rows, (hipStream_t)stream);
+}
+
+extern "C" int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth,
+                                      const float* feat, const int* ranks_depth,
+                                      const int* ranks_feat, const int* ranks_bev,
+                                      const int* interval_starts, const int* interval_lengths,
+                                      float* depth_grad, float* feat_grad, int c,
+                                      int n_intervals, void* stream) {
+  OMNIHD_REQUIRE(c > 0 && n_intervals >= 0, "c > 0 and n_intervals >= 0");
+  if (n_intervals == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(out_grad && depth && feat && ranks_depth && ranks_feat && ranks_bev &&
+                     interval_starts && interval_lengths && depth_grad && feat_grad,
+                 "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(c, out_grad, feat, feat_grad)) {
+    const int c4 = c / 4;
+    const int G = kBlock / c4;
+    const int grid = grid_for(n_intervals, G * 2);
+    const float4* og4 = reinterpret_cast<const float4*>(out_grad);
+    const float4* f4 = reinterpret_cast<const float4*>(feat);
+    float4* fg4 = reinterpret_cast<float4*>(feat_grad);
+#define OMNIHD_BWD_CASE(C4)                                                                   \
+  case C4:                                                                                    \
+    hipLaunchKernelGGL((k_pool_bwd<C4>), dim3(grid), dim3(kBlock), 0, st, og4, depth, f4,     \
+                       ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, \
+                       depth_grad, fg4, n_intervals);                                         \
+    break;
+    switch (c4) {
+      OMNIHD_BWD_CASE(1)
+      OMNIHD_BWD_CASE(2)
+      OMNIHD_BWD_CASE(4)
+      OMNIHD_BWD_CASE(8)
+      OMNIHD_BWD_CASE(16)
+      OMNIHD_BWD_CASE(32)
+      OMNIHD_BWD_CASE(64)
+      default:
+        set_error("unreachable c4=%d", c4);
+        return OMNIHD_ERR_ARG;
+    }
+#undef OMNIHD_BWD_CASE
+  } else {
+    const int grid = grid_for((int64_t)n_intervals * c, kBlock);
+    hipLaunchKernelGGL(k_pool_bwd_generic, dim3(grid), dim3(kBlock), 0, st, out_grad, depth, feat,
+                       ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths,
+                       depth_grad, feat_grad, c, n_intervals);
+  }
+  return check_launch("bev_pool_v2_bwd");
+}

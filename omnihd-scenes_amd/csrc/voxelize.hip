@@ -1,0 +1,247 @@
+// Hard voxelisation of one radar point cloud on the device, deterministic, no O(N^2) search.
+//
+// Semantics (mmdet3d v0.17.1 Voxelization / hard_voxelize, un-vendored in the reference; call
+// site bevfusion/detectors/bevf_faster_rcnn_bevdepth.py:97, config bevfusion.py:46-50; restated
+// sequentially in oracle/voxelize.c): a point's cell is floor((p - range_min) / voxel_size) per
+// axis, points outside the grid are dropped, voxels are numbered in order of their FIRST point,
+// a voxel keeps its first max_points points in point order, and voxels whose number would be
+// >= max_voxels are refused together with all their points.
+//
+// The upstream GPU path searches, for every point, all earlier points (O(N^2)) and then numbers
+// the voxels in a <<<1,1>>> kernel.  Here the same result comes from a stable radix sort:
+//   sort (cell, point index) stably  ->  inside a run of equal cells the points are in point
+//   order, so  rank-in-voxel = position - run head,  first point = the run head's point;
+//   an exclusive scan of "is a first point" over the ORIGINAL point order numbers the voxels
+//   in first-occurrence order.
+#include "common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+#include <rocprim/functional.hpp>
+
+namespace omnihd {
+namespace {
+
+constexpr int kBlock = 256;
+
+struct VoxSpec {
+  float vs[3];
+  float lo[3];
+  int grid[3];  // x, y, z
+};
+
+__global__ __launch_bounds__(kBlock) void k_vox_keys(const float* __restrict__ pts, int n, int f,
+                                                     VoxSpec s, uint32_t sentinel,
+                                                     uint32_t* __restrict__ keys,
+                                                     int* __restrict__ idx) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float* p = pts + (size_t)i * f;
+    const float tx = (p[0] - s.lo[0]) / s.vs[0];
+    const float ty = (p[1] - s.lo[1]) / s.vs[1];
+    const float tz = (p[2] - s.lo[2]) / s.vs[2];
+    // floor(t) in [0, g)  <=>  0 <= t < g ; NaN fails.
+    const bool ok = tx >= 0.f && tx < (float)s.grid[0] && ty >= 0.f && ty < (float)s.grid[1] &&
+                    tz >= 0.f && tz < (float)s.grid[2];
+    uint32_t key = sentinel;
+    if (ok) {
+      const int x = (int)floorf(tx), y = (int)floorf(ty), z = (int)floorf(tz);
+      key = (uint32_t)((z * s.grid[1] + y) * s.grid[0] + x);
+    }
+    keys[i] = key;
+    idx[i] = i;
+  }
+}
+
+struct HeadPos {
+  const uint32_t* keys;
+  __host__ __device__ int operator()(int j) const {
+    return (j == 0 || keys[j - 1] != keys[j]) ? j : 0;
+  }
+};
+
+// Per sorted position j: rank in voxel, first point of the voxel; the last element of a run
+// records the run length at the voxel's first point (cnt doubles as the "is first" flag).
+__global__ __launch_bounds__(kBlock) void k_vox_runs(const uint32_t* __restrict__ keys,
+                                                     const int* __restrict__ idx_sorted,
+                                                     const int* __restrict__ headpos, int n,
+                                                     uint32_t sentinel, int* __restrict__ rank_of,
+                                                     int* __restrict__ first_of,
+                                                     int* __restrict__ cnt) {
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+    const int i = idx_sorted[j];
+    const uint32_t k = keys[j];
+    if (k == sentinel) {
+      rank_of[i] = -1;
+      first_of[i] = -1;
+      continue;
+    }
+    const int h = headpos[j];
+    const int first = idx_sorted[h];
+    rank_of[i] = j - h;
+    first_of[i] = first;
+    if (j == n - 1 || keys[j + 1] != k) cnt[first] = j - h + 1;
+  }
+}
+
+struct IsFirst {
+  const int* cnt;
+  __host__ __device__ int operator()(int i) const { return cnt[i] > 0 ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(kBlock) void k_vox_write(
+    const float* __restrict__ pts, const uint32_t* __restrict__ keys_unsorted, int n, int f,
+    VoxSpec s, int max_points, int max_voxels, const int* __restrict__ rank_of,
+    const int* __restrict__ first_of, const int* __restrict__ cnt, const int* __restrict__ voxid,
+    float* __restrict__ voxels, int* __restrict__ coors, int* __restrict__ num_points,
+    int* __restrict__ voxel_num) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int r = rank_of[i];
+    if (r >= 0) {
+      const int v = voxid[first_of[i]];
+      if (v < max_voxels) {
+        if (r < max_points) {
+          float* dst = voxels + ((size_t)v * max_points + r) * f;
+          const float* src = pts + (size_t)i * f;
+          for (int k = 0; k < f; ++k) dst[k] = src[k];
+        }
+        if (cnt[i] > 0) {  // i is the voxel's first point
+          uint32_t key = keys_unsorted[i];
+          const int x = key % s.grid[0]; key /= s.grid[0];
+          const int y = key % s.grid[1];
+          const int z = key / s.grid[1];
+          coors[(size_t)v * 3 + 0] = z;
+          coors[(size_t)v * 3 + 1] = y;
+          coors[(size_t)v * 3 + 2] = x;
+          num_points[v] = min(cnt[i], max_points);
+        }
+      }
+    }
+    if (i == n - 1) {
+      const int total = voxid[i] + (cnt[i] > 0 ? 1 : 0);
+      *voxel_num = min(total, max_voxels);
+    }
+  }
+}
+
+struct VoxWs {
+  size_t tmp_bytes, off_keys, off_keys_s, off_idx, off_idx_s, off_head, off_rank, off_first,
+      off_cnt, off_voxid, total;
+};
+
+int vox_ws_layout(int n, VoxWs* w) {
+  size_t a = 0, b = 0, c = 0;
+  uint32_t* k = nullptr;
+  int* v = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, a, k, k, v, v, (size_t)n, 0, 32, 0, false);
+  if (e != hipSuccess) { set_error("voxelize: sort size query: %s", hipGetErrorString(e)); return OMNIHD_ERR_RUNTIME; }
+  auto hp = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), HeadPos{nullptr});
+  e = rocprim::inclusive_scan(nullptr, b, hp, v, (size_t)n, rocprim::maximum<int>(), 0, false);
+  if (e != hipSuccess) { set_error("voxelize: scan size query: %s", hipGetErrorString(e)); return OMNIHD_ERR_RUNTIME; }
+  auto fi = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), IsFirst{nullptr});
+  e = rocprim::exclusive_scan(nullptr, c, fi, v, 0, (size_t)n, rocprim::plus<int>(), 0, false);
+  if (e != hipSuccess) { set_error("voxelize: scan2 size query: %s", hipGetErrorString(e)); return OMNIHD_ERR_RUNTIME; }
+  size_t m = a > b ? a : b;
+  m = m > c ? m : c;
+  const size_t arr = align_up((size_t)n * 4, 256);
+  w->tmp_bytes = align_up(m, 256) + 256;
+  size_t o = w->tmp_bytes;
+  w->off_keys = o; o += arr;
+  w->off_keys_s = o; o += arr;
+  w->off_idx = o; o += arr;
+  w->off_idx_s = o; o += arr;
+  w->off_head = o; o += arr;
+  w->off_rank = o; o += arr;
+  w->off_first = o; o += arr;
+  w->off_cnt = o; o += arr;
+  w->off_voxid = o; o += arr;
+  w->total = o;
+  return OMNIHD_OK;
+}
+
+}  // namespace
+}  // namespace omnihd
+
+using namespace omnihd;
+
+extern "C" size_t omnihd_voxelize_workspace_bytes(int n_points) {
+  if (n_points <= 0) return 256;
+  VoxWs w;
+  if (vox_ws_layout(n_points, &w) != OMNIHD_OK) return 0;
+  return w.total;
+}
+
+extern "C" int omnihd_voxelize_hard(const float* points, int n_points, int n_feat,
+                                    const float* h_voxel_size3, const float* h_range6,
+                                    int max_points, int max_voxels, float* voxels, int* coors,
+                                    int* num_points, int* voxel_num, int* h_voxel_num,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  OMNIHD_REQUIRE(n_points >= 0 && n_feat >= 3 && max_points > 0 && max_voxels > 0, "sizes");
+  OMNIHD_REQUIRE(h_voxel_size3 && h_range6 && voxel_num, "null pointer");
+  VoxSpec s;
+  int64_t cells = 1;
+  for (int a = 0; a < 3; ++a) {
+    s.vs[a] = h_voxel_size3[a];
+    s.lo[a] = h_range6[a];
+    // grid_size = round((max - min) / voxel_size)  (mmdet3d Voxelization.__init__, fp32)
+    s.grid[a] = (int)lroundf((h_range6[a + 3] - h_range6[a]) / h_voxel_size3[a]);
+    OMNIHD_REQUIRE(s.grid[a] > 0, "empty grid");
+    cells *= s.grid[a];
+  }
+  OMNIHD_REQUIRE(cells < ((int64_t)1 << 31), "grid too large for 32-bit keys");
+  OMNIHD_HIP_TRY(hipMemsetAsync(voxel_num, 0, sizeof(int), st));
+  if (n_points > 0) {
+    OMNIHD_REQUIRE(points && voxels && coors && num_points && workspace, "null pointer");
+    VoxWs w;
+    int rc = vox_ws_layout(n_points, &w);
+    if (rc != OMNIHD_OK) return rc;
+    if (workspace_bytes < w.total) {
+      set_error("voxelize: workspace %zu < required %zu", workspace_bytes, w.total);
+      return OMNIHD_ERR_WORKSPACE;
+    }
+    char* base = static_cast<char*>(workspace);
+    uint32_t* keys = reinterpret_cast<uint32_t*>(base + w.off_keys);
+    uint32_t* keys_s = reinterpret_cast<uint32_t*>(base + w.off_keys_s);
+    int* idx = reinterpret_cast<int*>(base + w.off_idx);
+    int* idx_s = reinterpret_cast<int*>(base + w.off_idx_s);
+    int* headpos = reinterpret_cast<int*>(base + w.off_head);
+    int* rank_of = reinterpret_cast<int*>(base + w.off_rank);
+    int* first_of = reinterpret_cast<int*>(base + w.off_first);
+    int* cnt = reinterpret_cast<int*>(base + w.off_cnt);
+    int* voxid = reinterpret_cast<int*>(base + w.off_voxid);
+    const uint32_t sentinel = (uint32_t)cells;
+    int key_bits = 1;
+    while (((uint64_t)1 << key_bits) <= (uint64_t)sentinel) ++key_bits;
+    const int grid = grid_for(n_points, kBlock);
+
+    OMNIHD_HIP_TRY(hipMemsetAsync(voxels, 0, (size_t)max_voxels * max_points * n_feat * sizeof(float), st));
+    OMNIHD_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)n_points * sizeof(int), st));
+    hipLaunchKernelGGL(k_vox_keys, dim3(grid), dim3(kBlock), 0, st, points, n_points, n_feat, s,
+                       sentinel, keys, idx);
+    size_t tmp = w.tmp_bytes;
+    OMNIHD_HIP_TRY(rocprim::radix_sort_pairs(base, tmp, keys, keys_s, idx, idx_s, (size_t)n_points,
+                                             0, (unsigned)key_bits, st, false));
+    auto hp = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), HeadPos{keys_s});
+    tmp = w.tmp_bytes;
+    OMNIHD_HIP_TRY(rocprim::inclusive_scan(base, tmp, hp, headpos, (size_t)n_points,
+                                           rocprim::maximum<int>(), st, false));
+    hipLaunchKernelGGL(k_vox_runs, dim3(grid), dim3(kBlock), 0, st, keys_s, idx_s, headpos,
+                       n_points, sentinel, rank_of, first_of, cnt);
+    auto fi = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), IsFirst{cnt});
+    tmp = w.tmp_bytes;
+    OMNIHD_HIP_TRY(rocprim::exclusive_scan(base, tmp, fi, voxid, 0, (size_t)n_points,
+                                           rocprim::plus<int>(), st, false));
+    hipLaunchKernelGGL(k_vox_write, dim3(grid), dim3(kBlock), 0, st, points, keys, n_points,
+                       n_feat, s, max_points, max_voxels, rank_of, first_of, cnt, voxid, voxels,
+                       coors, num_points, voxel_num);
+    rc = check_launch("voxelize_hard");
+    if (rc != OMNIHD_OK) return rc;
+  }
+  if (h_voxel_num) {
+    OMNIHD_HIP_TRY(hipMemcpyAsync(h_voxel_num, voxel_num, sizeof(int), hipMemcpyDeviceToHost, st));
+    OMNIHD_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return OMNIHD_OK;
+}

@@ -1,0 +1,71 @@
+"""ctypes binding of libomnihd_hip.so — one prototype per symbol of include/omnihd_hip.h."""
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int64, c_size_t, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libomnihd_hip.so")
+
+# name -> (restype, argtypes); the authoritative declarations are in include/omnihd_hip.h
+PROTOTYPES = {
+    "omnihd_version": (c_char_p, []),
+    "omnihd_last_error": (c_char_p, []),
+    "omnihd_device_count": (c_int, []),
+    "omnihd_bev_pool_v2_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
+    "omnihd_bev_pool_v2_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
+    "omnihd_bev_pool_v2_fwd_csr": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "omnihd_bev_pool_v1_fwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "omnihd_bev_pool_v1_bwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "omnihd_bev_rank_keys": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_uint32, c_void_p]),
+    "omnihd_sort_ranks_workspace_bytes": (c_size_t, [c_int64]),
+    "omnihd_sort_ranks": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_uint32] + [c_void_p] * 9 +
+                          [c_size_t, c_void_p]),
+    "omnihd_ranks_feat_from_depth": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "omnihd_csr_from_sorted_keys": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "omnihd_permute_rows_zyx_to_yxz": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
+                                               c_void_p]),
+    "omnihd_voxelize_workspace_bytes": (c_size_t, [c_int]),
+    "omnihd_voxelize_hard": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int] +
+                             [c_void_p] * 6 + [c_size_t, c_void_p]),
+    "omnihd_pillar_scatter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "omnihd_pillar_scatter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "omnihd_pillar_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with `make -C omnihd-scenes_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback for the HIP ops.")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def require_gpu():
+    """Fail loudly when the HIP path cannot run (no device)."""
+    if lib().omnihd_device_count() <= 0:
+        raise RuntimeError("omnihd_amd: no HIP device visible; the hot path has no CPU fallback")
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().omnihd_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,317 @@
+"""Tensor-level wrappers over the C ABI (argument checks + pointer/stream hand-over only)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _want(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA(HIP) tensor; the HIP ops have no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _same_device(*ts):
+    dev = ts[0].device
+    for t in ts:
+        if t is not None and t.device != dev:
+            raise ValueError("all tensors must be on the same device")
+    return dev
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+# bev_pool_v2
+# ---------------------------------------------------------------------------------------------
+def bev_pool_v2_forward(depth, feat, out, ranks_depth, ranks_feat, ranks_bev, interval_lengths,
+                        interval_starts):
+    """Same positional signature as the reference pybind function (lengths BEFORE starts):
+    ops/bev_pool_v2/src/bev_pool.cpp:30-39.  Writes into ``out`` (pre-zeroed by the caller)."""
+    _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat")
+    _want(out, torch.float32, "out")
+    for n, t in (("ranks_depth", ranks_depth), ("ranks_feat", ranks_feat), ("ranks_bev", ranks_bev),
+                 ("interval_lengths", interval_lengths), ("interval_starts", interval_starts)):
+        _want(t, torch.int32, n)
+    if feat.dim() != 5:
+        raise ValueError("feat must be 5-D (B,N,H,W,C)")  # C = feat.size(4), bev_pool.cpp:40
+    dev = _same_device(depth, feat, out, ranks_depth, ranks_feat, ranks_bev, interval_lengths, interval_starts)
+    with torch.cuda.device(dev):
+        check(lib().omnihd_bev_pool_v2_fwd(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat),
+                                           _ptr(ranks_bev), _ptr(interval_starts), _ptr(interval_lengths),
+                                           _ptr(out), feat.size(4), interval_lengths.size(0), _stream()),
+              "omnihd_bev_pool_v2_fwd")
+
+
+def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_depth, ranks_feat,
+                         ranks_bev, interval_lengths, interval_starts):
+    """Reference signature: ops/bev_pool_v2/src/bev_pool.cpp:74-85 (tables sorted by ranks_feat)."""
+    for n, t in (("out_grad", out_grad), ("depth_grad", depth_grad), ("feat_grad", feat_grad),
+                 ("depth", depth), ("feat", feat)):
+        _want(t, torch.float32, n)
+    for n, t in (("ranks_depth", ranks_depth), ("ranks_feat", ranks_feat), ("ranks_bev", ranks_bev),
+                 ("interval_lengths", interval_lengths), ("interval_starts", interval_starts)):
+        _want(t, torch.int32, n)
+    if out_grad.dim() != 5:
+        raise ValueError("out_grad must be 5-D (B,Z,Y,X,C)")  # C = out_grad.size(4), bev_pool.cpp:86
+    dev = _same_device(out_grad, depth_grad, feat_grad, depth, feat, ranks_depth)
+    with torch.cuda.device(dev):
+        check(lib().omnihd_bev_pool_v2_bwd(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(ranks_depth),
+                                           _ptr(ranks_feat), _ptr(ranks_bev), _ptr(interval_starts),
+                                           _ptr(interval_lengths), _ptr(depth_grad), _ptr(feat_grad),
+                                           out_grad.size(4), interval_lengths.size(0), _stream()),
+              "omnihd_bev_pool_v2_bwd")
+
+
+def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out):
+    """Dense forward: every row of ``out`` (n_rows = row_ptr.numel()-1, C = feat.size(-1)) is written."""
+    _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
+    _want(ranks_depth, torch.int32, "ranks_depth"); _want(ranks_feat, torch.int32, "ranks_feat")
+    _want(row_ptr, torch.int32, "row_ptr")
+    c = feat.size(-1)
+    n_rows = row_ptr.numel() - 1
+    if out.numel() != n_rows * c:
+        raise ValueError(f"out has {out.numel()} elements, expected {n_rows}*{c}")
+    dev = _same_device(depth, feat, out, ranks_depth, ranks_feat, row_ptr)
+    with torch.cuda.device(dev):
+        check(lib().omnihd_bev_pool_v2_fwd_csr(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat),
+                                               _ptr(row_ptr), _ptr(out), c, n_rows, _stream()),
+              "omnihd_bev_pool_v2_fwd_csr")
+
+
+# ---------------------------------------------------------------------------------------------
+# bev_pool v1
+# ---------------------------------------------------------------------------------------------
+def bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, b, d, h, w):
+    """Reference signature ops/bev_pool/src/bev_pool.cpp:22-28; allocates and returns [b,d,h,w,c]."""
+    _want(x, torch.float32, "x"); _want(geom_feats, torch.int32, "geom_feats")
+    _want(interval_lengths, torch.int32, "interval_lengths"); _want(interval_starts, torch.int32, "interval_starts")
+    n, c = x.shape
+    out = torch.zeros((b, d, h, w, c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().omnihd_bev_pool_v1_fwd(_ptr(x), _ptr(geom_feats), _ptr(interval_starts),
+                                           _ptr(interval_lengths), _ptr(out), b, d, h, w, n, c,
+                                           interval_lengths.size(0), _stream()), "omnihd_bev_pool_v1_fwd")
+    return out
+
+
+def bev_pool_backward(out_grad, geom_feats, interval_lengths, interval_starts, b, d, h, w):
+    """Reference signature ops/bev_pool/src/bev_pool.cpp:60-66; returns x_grad [n,c]."""
+    _want(out_grad, torch.float32, "out_grad"); _want(geom_feats, torch.int32, "geom_feats")
+    _want(interval_lengths, torch.int32, "interval_lengths"); _want(interval_starts, torch.int32, "interval_starts")
+    n = geom_feats.size(0)
+    c = out_grad.size(4)
+    x_grad = torch.zeros((n, c), dtype=out_grad.dtype, device=out_grad.device)
+    with torch.cuda.device(out_grad.device):
+        check(lib().omnihd_bev_pool_v1_bwd(_ptr(out_grad), _ptr(geom_feats), _ptr(interval_starts),
+                                           _ptr(interval_lengths), _ptr(x_grad), b, d, h, w, n, c,
+                                           interval_lengths.size(0), _stream()), "omnihd_bev_pool_v1_bwd")
+    return x_grad
+
+
+# ---------------------------------------------------------------------------------------------
+# rank tables
+# ---------------------------------------------------------------------------------------------
+def _bits_for(max_value):
+    return max(1, int(max_value).bit_length())
+
+
+def sort_ranks(keys, payloads, key_bits, sentinel=0xFFFFFFFF):
+    """Stable sort by key + run-length encode.  ``keys``: int32/uint32-as-int32 tensor; payloads:
+    up to three int32 tensors.  Returns (keys_sorted, payloads_sorted, starts, lengths) trimmed to
+    the non-sentinel part (one host sync to read the two counts)."""
+    _want(keys, torch.int32, "keys")
+    n = keys.numel()
+    dev = keys.device
+    pl = list(payloads) + [None] * (3 - len(payloads))
+    for i, p in enumerate(pl):
+        if p is not None:
+            _want(p, torch.int32, f"payload{i}")
+    keys_out = torch.empty_like(keys)
+    outs = [torch.empty_like(p) if p is not None else None for p in pl]
+    starts = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    lengths = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    h_counts = (ctypes.c_int * 2)(0, 0)
+    with torch.cuda.device(dev):
+        ws_bytes = lib().omnihd_sort_ranks_workspace_bytes(n)
+        if ws_bytes == 0:
+            check(-4, "omnihd_sort_ranks_workspace_bytes")
+        ws = _workspace(ws_bytes, dev)
+        check(lib().omnihd_sort_ranks(_ptr(keys), _ptr(pl[0]), _ptr(pl[1]), _ptr(pl[2]), n, key_bits,
+                                      sentinel, _ptr(keys_out), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                      _ptr(starts), _ptr(lengths), _ptr(counts),
+                                      ctypes.cast(h_counts, ctypes.c_void_p), _ptr(ws), ws.numel(), _stream()),
+              "omnihd_sort_ranks")
+    n_pts, n_int = int(h_counts[0]), int(h_counts[1])
+    return (keys_out[:n_pts], [o[:n_pts] if o is not None else None for o in outs[:len(payloads)]],
+            starts[:n_int], lengths[:n_int])
+
+
+def rank_keys(geom, dx, bx, nx):
+    """Frustum geometry (B,N,D,H,W,3) fp32 -> (keys int32 [Ntot], idx int32 [Ntot], sentinel).
+    ``dx``/``bx`` fp32 and ``nx`` integer triples as produced by the reference's gen_dx_bx
+    (cam_stream_lss_bevpoolv2_depthnet.py:80-85)."""
+    _want(geom, torch.float32, "geom")
+    if geom.dim() != 6 or geom.size(-1) != 3:
+        raise ValueError("geom must be (B,N,D,H,W,3)")
+    B = geom.size(0)
+    n_total = geom.numel() // 3
+    dx = np.asarray(dx, dtype=np.float32)
+    bx = np.asarray(bx, dtype=np.float32)
+    nx = np.asarray(nx, dtype=np.int64)
+    off = (bx - dx / np.float32(2.0)).astype(np.float32)      # the reference's fp32 tensor arithmetic
+    n_vox = int(B * nx[0] * nx[1] * nx[2])
+    if n_vox >= 2 ** 31 - 1 or n_total >= 2 ** 31:
+        raise ValueError("grid too large for int32 rank tables")
+    keys = torch.empty(n_total, dtype=torch.int32, device=geom.device)
+    idx = torch.empty(n_total, dtype=torch.int32, device=geom.device)
+    h_off = (ctypes.c_float * 3)(*off.tolist())
+    h_dx = (ctypes.c_float * 3)(*dx.tolist())
+    h_nx = (ctypes.c_int * 3)(*[int(v) for v in nx])
+    with torch.cuda.device(geom.device):
+        check(lib().omnihd_bev_rank_keys(_ptr(geom), n_total, n_total // B,
+                                         ctypes.cast(h_off, ctypes.c_void_p), ctypes.cast(h_dx, ctypes.c_void_p),
+                                         ctypes.cast(h_nx, ctypes.c_void_p), _ptr(keys), _ptr(idx), n_vox, _stream()),
+              "omnihd_bev_rank_keys")
+    return keys, idx, n_vox
+
+
+def ranks_feat_from_depth(ranks_depth, d, hw):
+    _want(ranks_depth, torch.int32, "ranks_depth")
+    out = torch.empty_like(ranks_depth)
+    with torch.cuda.device(ranks_depth.device):
+        check(lib().omnihd_ranks_feat_from_depth(_ptr(ranks_depth), ranks_depth.numel(), d, hw, _ptr(out), _stream()),
+              "omnihd_ranks_feat_from_depth")
+    return out
+
+
+def csr_from_sorted_keys(sorted_keys, n_rows):
+    _want(sorted_keys, torch.int32, "sorted_keys")
+    row_ptr = torch.empty(n_rows + 1, dtype=torch.int32, device=sorted_keys.device)
+    with torch.cuda.device(sorted_keys.device):
+        check(lib().omnihd_csr_from_sorted_keys(_ptr(sorted_keys), sorted_keys.numel(), n_rows, _ptr(row_ptr), _stream()),
+              "omnihd_csr_from_sorted_keys")
+    return row_ptr
+
+
+def permute_rows_zyx_to_yxz(rows, nz, ny, nx):
+    _want(rows, torch.int32, "rows")
+    out = torch.empty_like(rows)
+    with torch.cuda.device(rows.device):
+        check(lib().omnihd_permute_rows_zyx_to_yxz(_ptr(rows), rows.numel(), nz, ny, nx, _ptr(out), _stream()),
+              "omnihd_permute_rows_zyx_to_yxz")
+    return out
+
+
+def voxel_pooling_prepare_v2(coor, dx, bx, nx):
+    """Device implementation of the reference's ``voxel_pooling_prepare_v2``
+    (cam_stream_lss_bevpoolv2_depthnet.py:302-362): five int32 tables in canonical (stable) order,
+    or five ``None`` when no frustum point falls inside the grid."""
+    B, N, D, H, W, _ = coor.shape
+    keys, idx, sentinel = rank_keys(coor, dx, bx, nx)
+    ranks_bev, (ranks_depth,), starts, lengths = sort_ranks(keys, [idx], _bits_for(sentinel), sentinel)
+    if ranks_bev.numel() == 0:
+        return None, None, None, None, None
+    ranks_feat = ranks_feat_from_depth(ranks_depth.contiguous(), D, H * W)
+    return (ranks_bev.contiguous(), ranks_depth.contiguous(), ranks_feat, starts.contiguous(),
+            lengths.contiguous())
+
+
+def backward_tables(ranks_bev, ranks_depth, ranks_feat, n_feat_rows=None):
+    """The re-sort of QuickCumsumCuda.backward (ops/bev_pool_v2/bev_pool.py:47-57) on the device:
+    stable sort by ranks_feat; returns (ranks_bev, ranks_depth, ranks_feat, starts, lengths)."""
+    if n_feat_rows is None:
+        n_feat_rows = int(ranks_feat.max().item()) + 1 if ranks_feat.numel() else 1
+    rf, (rd, rb), starts, lengths = sort_ranks(ranks_feat.contiguous(), [ranks_depth.contiguous(), ranks_bev.contiguous()],
+                                               _bits_for(n_feat_rows))
+    return rb.contiguous(), rd.contiguous(), rf.contiguous(), starts.contiguous(), lengths.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# radar: hard voxelisation + pillar scatter
+# ---------------------------------------------------------------------------------------------
+def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels):
+    """One sample: points (N,F) fp32 -> (voxels (M,max_points,F), coors (M,3)=(z,y,x) int32,
+    num_points (M,) int32).  mmdet3d Voxelization semantics (see include/omnihd_hip.h)."""
+    _want(points, torch.float32, "points")
+    n, f = points.shape
+    dev = points.device
+    voxels = torch.empty((max_voxels, max_points, f), dtype=torch.float32, device=dev)
+    coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+    num_points = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+    voxel_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    h_num = ctypes.c_int(0)
+    h_vs = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in voxel_size])
+    h_rg = (ctypes.c_float * 6)(*[float(np.float32(v)) for v in point_cloud_range])
+    with torch.cuda.device(dev):
+        ws_bytes = lib().omnihd_voxelize_workspace_bytes(n)
+        if ws_bytes == 0:
+            check(-4, "omnihd_voxelize_workspace_bytes")
+        ws = _workspace(ws_bytes, dev)
+        check(lib().omnihd_voxelize_hard(_ptr(points), n, f, ctypes.cast(h_vs, ctypes.c_void_p),
+                                         ctypes.cast(h_rg, ctypes.c_void_p), max_points, max_voxels,
+                                         _ptr(voxels), _ptr(coors), _ptr(num_points), _ptr(voxel_num),
+                                         ctypes.cast(ctypes.pointer(h_num), ctypes.c_void_p),
+                                         _ptr(ws), ws.numel(), _stream()), "omnihd_voxelize_hard")
+    m = int(h_num.value)
+    return voxels[:m], coors[:m], num_points[:m]
+
+
+class _PillarScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, coors, batch, ny, nx, channels_last):
+        feats = feats.contiguous().float()
+        coors = coors.contiguous().int()
+        m, c = feats.shape
+        dev = feats.device
+        shape = (batch, ny, nx, c) if channels_last else (batch, c, ny, nx)
+        canvas = torch.empty(shape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = _workspace(lib().omnihd_pillar_scatter_workspace_bytes(batch, ny, nx), dev)
+            check(lib().omnihd_pillar_scatter(_ptr(feats), _ptr(coors), m, c, batch, ny, nx,
+                                              1 if channels_last else 0, _ptr(canvas), _ptr(ws), ws.numel(),
+                                              _stream()), "omnihd_pillar_scatter")
+        ctx.save_for_backward(coors)
+        ctx.meta = (m, c, batch, ny, nx, channels_last)
+        if channels_last:
+            canvas = canvas.permute(0, 3, 1, 2)   # logical NCHW view over NHWC memory
+        return canvas
+
+    @staticmethod
+    def backward(ctx, g):
+        (coors,) = ctx.saved_tensors
+        m, c, batch, ny, nx, channels_last = ctx.meta
+        if channels_last:
+            g = g.permute(0, 2, 3, 1)
+        g = g.contiguous().float()
+        fg = torch.empty((m, c), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib().omnihd_pillar_gather(_ptr(g), _ptr(coors), m, c, batch, ny, nx,
+                                             1 if channels_last else 0, _ptr(fg), _stream()),
+                  "omnihd_pillar_gather")
+        return fg, None, None, None, None, None
+
+
+def pillar_scatter(feats, coors, batch, ny, nx, channels_last=False):
+    """(M,C) pillar features + (M,4)=(b,z,y,x) coords -> dense (B,C,ny,nx) canvas (differentiable
+    w.r.t. feats).  With ``channels_last`` the memory layout is NHWC under an NCHW-shaped view."""
+    if not feats.is_cuda:
+        raise RuntimeError("pillar_scatter: CUDA(HIP) tensors only; no CPU path")
+    return _PillarScatter.apply(feats, coors, int(batch), int(ny), int(nx), bool(channels_last))

@@ -1,0 +1,121 @@
+"""Cached pooling plans.
+
+The five rank tables of the reference are a pure function of the camera calibration and the
+grid, yet the reference rebuilds them in every forward
+(cam_stream_lss_bevpoolv2_depthnet.py:281-283) and re-sorts all points in every backward
+(ops/bev_pool_v2/bev_pool.py:47-57).  A ``BevPoolPlan`` holds, on the device,
+
+* the forward tables grouped by OUTPUT ROW in CSR form (``row_ptr``), so the dense forward kernel
+  writes the whole BEV tensor once (no zero-fill, no permute copy, no s2c concat copy), and
+* the backward tables grouped by image-feature pixel,
+
+for one of two row numberings: ``'bzyx'`` (the reference's (B,Z,Y,X,C) buffer) or ``'byxz'``
+((B,Y,X,Z,C) memory = the channels-last layout of the s2c tensor (B, Z*C, Y, X)).
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class BevPoolPlan:
+    layout: str            # 'bzyx' | 'byxz'
+    grid: tuple            # (B, Z, Y, X)
+    n_rows: int            # B*Z*Y*X
+    n_points: int
+    # forward (sorted by row)
+    ranks_row: torch.Tensor     # int32 [n_points]  row index of each point (sorted ascending)
+    ranks_depth: torch.Tensor   # int32 [n_points]
+    ranks_feat: torch.Tensor    # int32 [n_points]
+    row_ptr: torch.Tensor       # int32 [n_rows+1]
+    interval_starts: torch.Tensor
+    interval_lengths: torch.Tensor
+    # backward (sorted by ranks_feat)
+    bp_ranks_row: torch.Tensor
+    bp_ranks_depth: torch.Tensor
+    bp_ranks_feat: torch.Tensor
+    bp_starts: torch.Tensor
+    bp_lengths: torch.Tensor
+
+    @property
+    def n_intervals(self):
+        return int(self.interval_starts.numel())
+
+
+def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows):
+    B, Z, Y, X = grid
+    n_rows = B * Z * Y * X
+    row_ptr = ops.csr_from_sorted_keys(rows, n_rows)
+    bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
+    return BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, starts, lengths,
+                       bp[0], bp[1], bp[2], bp[3], bp[4])
+
+
+def build_plan(coor, dx, bx, nx, layout="byxz"):
+    """Plan from frustum geometry (B,N,D,H,W,3) — one fused key pass + two radix sorts."""
+    if layout not in ("bzyx", "byxz"):
+        raise ValueError(layout)
+    B, N, D, H, W, _ = coor.shape
+    X, Y, Z = int(nx[0]), int(nx[1]), int(nx[2])
+    keys, idx, sentinel = ops.rank_keys(coor.contiguous(), dx, bx, nx)
+    if layout == "byxz":
+        keys = ops.permute_rows_zyx_to_yxz(keys, Z, Y, X)   # the sentinel maps onto itself
+    rows, (rd,), starts, lengths = ops.sort_ranks(keys, [idx], ops._bits_for(sentinel), sentinel)
+    rows, rd = rows.contiguous(), rd.contiguous()
+    rf = ops.ranks_feat_from_depth(rd, D, H * W)
+    return _finish(layout, (B, Z, Y, X), rows, rd, rf, starts.contiguous(), lengths.contiguous(), B * N * H * W)
+
+
+def plan_from_tables(ranks_bev, ranks_depth, ranks_feat, grid, n_feat_rows, layout="bzyx"):
+    """Plan from reference-format tables (sorted by ranks_bev in (b,z,y,x) numbering)."""
+    B, Z, Y, X = grid
+    if layout == "bzyx":
+        rows, (rd, rf), starts, lengths = ops.sort_ranks(
+            ranks_bev.contiguous(), [ranks_depth.contiguous(), ranks_feat.contiguous()],
+            ops._bits_for(B * Z * Y * X))
+    else:
+        keys = ops.permute_rows_zyx_to_yxz(ranks_bev.contiguous(), Z, Y, X)
+        rows, (rd, rf), starts, lengths = ops.sort_ranks(
+            keys, [ranks_depth.contiguous(), ranks_feat.contiguous()], ops._bits_for(B * Z * Y * X))
+    return _finish(layout, grid, rows.contiguous(), rd.contiguous(), rf.contiguous(), starts.contiguous(),
+                   lengths.contiguous(), n_feat_rows)
+
+
+class _PlannedPool(torch.autograd.Function):
+    """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, plan):
+        depth = depth.contiguous().float()
+        feat = feat.contiguous().float()
+        out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
+        ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out)
+        ctx.save_for_backward(depth, feat)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        depth, feat = ctx.saved_tensors
+        plan = ctx.plan
+        out_grad = out_grad.contiguous().float()
+        depth_grad = torch.zeros_like(depth)
+        feat_grad = torch.zeros_like(feat)
+        og5 = out_grad.view(1, 1, 1, plan.n_rows, feat.size(-1))
+        ops.bev_pool_v2_backward(og5, depth_grad, feat_grad, depth, feat, plan.bp_ranks_depth,
+                                 plan.bp_ranks_feat, plan.bp_ranks_row, plan.bp_lengths, plan.bp_starts)
+        return depth_grad, feat_grad, None
+
+
+def planned_pool(depth, feat, plan):
+    """Returns the pooled BEV tensor with logical shape (B, C, Z, Y, X) (what the reference's
+    ``bev_pool_v2`` returns, ops/bev_pool_v2/bev_pool.py:86-92).  For ``layout='byxz'`` it is a
+    zero-copy view over (B,Y,X,Z,C) memory, so ``cat(unbind(dim=2), 1)`` (s2c) is a reshape."""
+    B, Z, Y, X = plan.grid
+    C = feat.size(-1)
+    rows = _PlannedPool.apply(depth, feat, plan)
+    if plan.layout == "bzyx":
+        return rows.view(B, Z, Y, X, C).permute(0, 4, 1, 2, 3)
+    return rows.view(B, Y, X, Z, C).permute(0, 4, 3, 1, 2)

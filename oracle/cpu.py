@@ -1,0 +1,97 @@
+"""oracle/cpu.py — TEST INFRASTRUCTURE, NOT PRODUCT.
+
+numpy-facing wrappers of the C oracle (oracle/liboracle.so, built by oracle/Makefile).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_hard_voxelize.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def bev_pool_v2_fwd(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, starts, lengths,
+                    threads=False):
+    """-> out (B,Z,Y,X,C) fp32, zeros where no interval writes (reference: bev_pool.py:27)."""
+    depth, feat = _f32(depth), _f32(feat)
+    rd, rf, rb, st, ln = map(_i32, (ranks_depth, ranks_feat, ranks_bev, starts, lengths))
+    out = np.zeros(tuple(int(s) for s in bev_feat_shape), dtype=np.float32)
+    fn = lib().oracle_bev_pool_v2_fwd_omp if threads else lib().oracle_bev_pool_v2_fwd
+    fn(ctypes.c_int(feat.shape[-1]), ctypes.c_int(len(st)), _p(depth), _p(feat), _p(rd), _p(rf), _p(rb),
+       _p(st), _p(ln), _p(out))
+    return out
+
+
+def bev_pool_v2_bwd(out_grad, depth, feat, ranks_depth, ranks_feat, ranks_bev, starts, lengths, threads=False):
+    """Backward tables in, (depth_grad, feat_grad) out (zeros where untouched, bev_pool.py:67-68)."""
+    og, depth, feat = _f32(out_grad), _f32(depth), _f32(feat)
+    rd, rf, rb, st, ln = map(_i32, (ranks_depth, ranks_feat, ranks_bev, starts, lengths))
+    dg, fg = np.zeros_like(depth), np.zeros_like(feat)
+    fn = lib().oracle_bev_pool_v2_bwd_omp if threads else lib().oracle_bev_pool_v2_bwd
+    fn(ctypes.c_int(feat.shape[-1]), ctypes.c_int(len(st)), _p(og), _p(depth), _p(feat), _p(rd), _p(rf),
+       _p(rb), _p(st), _p(ln), _p(dg), _p(fg))
+    return dg, fg
+
+
+def bev_pool_v1_fwd(x, geom_feats, starts, lengths, b, d, h, w):
+    x, g, st, ln = _f32(x), _i32(geom_feats), _i32(starts), _i32(lengths)
+    n, c = x.shape
+    out = np.zeros((b, d, h, w, c), dtype=np.float32)
+    lib().oracle_bev_pool_v1_fwd(*[ctypes.c_int(v) for v in (b, d, h, w, n, c, len(st))], _p(x), _p(g),
+                                 _p(st), _p(ln), _p(out))
+    return out
+
+
+def bev_pool_v1_bwd(out_grad, geom_feats, starts, lengths, b, d, h, w):
+    og, g, st, ln = _f32(out_grad), _i32(geom_feats), _i32(starts), _i32(lengths)
+    n, c = g.shape[0], og.shape[-1]
+    xg = np.zeros((n, c), dtype=np.float32)
+    lib().oracle_bev_pool_v1_bwd(*[ctypes.c_int(v) for v in (b, d, h, w, n, c, len(st))], _p(og), _p(g),
+                                 _p(st), _p(ln), _p(xg))
+    return xg
+
+
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    pts = _f32(points)
+    n, f = pts.shape
+    vs, cr = _f32(voxel_size), _f32(coors_range)
+    voxels = np.zeros((max_voxels, max_points, f), dtype=np.float32)
+    coors = np.zeros((max_voxels, 3), dtype=np.int32)
+    num = np.zeros((max_voxels,), dtype=np.int32)
+    m = lib().oracle_hard_voxelize(_p(pts), ctypes.c_int(n), ctypes.c_int(f), _p(vs), _p(cr),
+                                   ctypes.c_int(max_points), ctypes.c_int(max_voxels), _p(voxels), _p(coors), _p(num))
+    return voxels[:m], coors[:m], num[:m]
+
+
+def pillar_scatter(feats, coors, batch, ny, nx):
+    feats, coors = _f32(feats), _i32(coors)
+    m, c = feats.shape
+    canvas = np.empty((batch, c, ny, nx), dtype=np.float32)
+    lib().oracle_pillar_scatter(_p(feats), _p(coors), ctypes.c_int(m), ctypes.c_int(c), ctypes.c_int(batch),
+                                ctypes.c_int(ny), ctypes.c_int(nx), _p(canvas))
+    return canvas

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "omnihd-scenes_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("this test is marked gpu but no GPU is visible (HIP path has no CPU fallback)")
+    import omnihd_amd
+    omnihd_amd.require_gpu()
+    return torch.device("cuda:0")

@@ -1,0 +1,55 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol that include/omnihd_hip.h declares; the host wrappers refuse CPU tensors loudly."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "omnihd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(omnihd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_symbols()
+    for must in ["omnihd_bev_pool_v2_fwd", "omnihd_bev_pool_v2_bwd", "omnihd_bev_pool_v2_fwd_csr",
+                 "omnihd_bev_pool_v1_fwd", "omnihd_bev_pool_v1_bwd", "omnihd_bev_rank_keys", "omnihd_sort_ranks",
+                 "omnihd_voxelize_hard", "omnihd_pillar_scatter", "omnihd_pillar_gather"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    import omnihd_amd
+    from omnihd_amd._lib import PROTOTYPES
+    handle = ctypes.CDLL(omnihd_amd.library_path())
+    names = declared_symbols()
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/omnihd_hip.h but not exported"
+    assert sorted(PROTOTYPES) == names, "python prototypes out of sync with the header"
+    assert omnihd_amd.lib().omnihd_version().decode().startswith("omnihd_hip")
+
+
+def test_plugin_module_paths_and_names():
+    from projects.mmdet3d_plugin.ops.bev_pool_v2 import bev_pool as m2
+    from projects.mmdet3d_plugin.ops.bev_pool_v2 import bev_pool_v2_ext as e2
+    from projects.mmdet3d_plugin.ops import bev_pool as p1
+    from projects.mmdet3d_plugin.ops.bev_pool import bev_pool_ext as e1
+    assert m2.__all__ == ["bev_pool_v2", "TRTBEVPoolv2"]
+    assert callable(e2.bev_pool_v2_forward) and callable(e2.bev_pool_v2_backward)
+    assert callable(p1.bev_pool) and callable(e1.bev_pool_forward) and callable(e1.bev_pool_backward)
+    assert issubclass(m2.QuickCumsumCuda, torch.autograd.Function)
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2
+    depth = torch.rand(1, 1, 2, 2, 2)
+    feat = torch.ones(1, 1, 2, 2, 2)
+    r = torch.zeros(4, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        bev_pool_v2(depth, feat, r, r, r, (1, 1, 2, 2, 2), r[:1], r[:1])

@@ -1,0 +1,155 @@
+"""CPU tests: pin the oracle against the reference's known-answer test and the golden vectors
+captured from the reference Python (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import cpu as OC
+from oracle import lss_oracle as O
+
+
+def kat_tables():
+    # values of the reference's test_bev_pool_v2 (ops/bev_pool_v2/bev_pool.py:145-176)
+    depth = np.array([0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], dtype=np.float32).reshape(1, 1, 2, 2, 2)
+    feat = np.ones((1, 1, 2, 2, 2), dtype=np.float32)
+    rd = np.array([0, 4, 1, 6], dtype=np.int32)
+    rf = np.array([0, 0, 1, 2], dtype=np.int32)
+    rb = np.array([0, 0, 1, 1], dtype=np.int32)
+    st, ln = O.run_length(rb)
+    return depth, feat, rd, rf, rb, st, ln
+
+
+def test_reference_known_answer_forward_backward():
+    depth, feat, rd, rf, rb, st, ln = kat_tables()
+    out = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, (1, 1, 2, 2, 2), st, ln)
+    bev = out.transpose(0, 4, 1, 2, 3)                          # bev_pool.py:91
+    assert np.float32(bev.sum()) == np.float32(4.4)             # reference :169
+    # loss = sum(bev) -> out_grad = ones; backward tables as bev_pool.py:47-57
+    brb, brd, brf, bst, bln = O.backward_tables(rb, rd, rf)
+    dg, fg = OC.bev_pool_v2_bwd(np.ones_like(out), depth, feat, brd, brf, brb, bst, bln)
+    np.testing.assert_allclose(dg.reshape(-1), [2., 2., 0., 0., 2., 0., 2., 0.])            # :170-173
+    np.testing.assert_allclose(fg.reshape(-1), [1.0, 1.0, 0.4, 0.4, 0.8, 0.8, 0., 0.], rtol=1e-6)  # :174-176
+
+
+@pytest.mark.parametrize("tag,final_dim", [("r1", (256, 704)), ("r2", (544, 960)), ("tiny", (32, 48))])
+def test_grid_constants_and_frustum(golden, tag, final_dim):
+    pc = [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
+    dx, bx, nx = O.gen_dx_bx([pc[0], pc[3], 0.5], [pc[1], pc[4], 0.5], [pc[2], pc[5], 0.5])
+    assert np.array_equal(dx, golden[f"g1_{tag}_dx"])
+    assert np.array_equal(bx, golden[f"g1_{tag}_bx"])
+    assert np.array_equal(nx, golden[f"g1_{tag}_nx"])
+    assert nx.tolist() == [240, 160, 16] and bx.tolist() == [-59.75, -39.75, -2.75]
+    xs, ys, ds = O.frustum_axes(final_dim, 4, [1, 60, 1])
+    assert np.array_equal(xs, golden[f"g1_{tag}_xs"])
+    assert np.array_equal(ys, golden[f"g1_{tag}_ys"])
+    assert np.array_equal(ds, golden[f"g1_{tag}_ds"])
+    assert len(ds) == 59
+
+
+def _tiny_setup(golden):
+    pc = golden["g2_pc_range"].tolist()
+    g = float(golden["g2_grid"])
+    dx, bx, nx = O.gen_dx_bx([pc[0], pc[3], g], [pc[1], pc[4], g], [pc[2], pc[5], g])
+    fr = O.create_frustum(tuple(golden["g2_final_dim"].tolist()), 4, golden["g2_dbound"].tolist())
+    return dx, bx, nx, fr
+
+
+def test_geometry_matches_reference(golden):
+    dx, bx, nx, fr = _tiny_setup(golden)
+    geom = O.get_geometry(fr, golden["g2_rots"], golden["g2_trans"])
+    np.testing.assert_allclose(geom, golden["g2_geom"], rtol=0, atol=1e-5)
+
+
+def test_prepare_tables_match_reference(golden):
+    dx, bx, nx, _ = _tiny_setup(golden)
+    tabs = O.voxel_pooling_prepare_v2(golden["g2_geom"], dx, bx, nx)
+    for k, t in zip(["ranks_bev", "ranks_depth", "ranks_feat", "starts", "lengths"], tabs):
+        assert np.array_equal(t, golden[f"g3_{k}"]), k
+
+
+def test_prepare_adversarial_matches_reference(golden):
+    dx, bx, nx = O.gen_dx_bx([-2.0, 2.0, 1.0], [-2.0, 2.0, 1.0], [-1.0, 1.0, 1.0])
+    tabs = O.voxel_pooling_prepare_v2(golden["g3adv_coor"], dx, bx, nx)
+    for k, t in zip(["ranks_bev", "ranks_depth", "ranks_feat", "starts", "lengths"], tabs):
+        assert np.array_equal(t, golden[f"g3adv_{k}"]), k
+    # defect D3: (-2.5,-1.5,-0.5) -> x voxel -0.5 truncates to 0 and is KEPT; NaN / +-1e30 dropped
+    assert 0 in tabs[1] and 9 not in tabs[1] and 10 not in tabs[1] and 11 not in tabs[1]
+
+
+def test_prepare_empty_returns_none():
+    dx, bx, nx = O.gen_dx_bx([-2.0, 2.0, 1.0], [-2.0, 2.0, 1.0], [-1.0, 1.0, 1.0])
+    coor = np.full((1, 1, 2, 2, 2, 3), 100.0, dtype=np.float32)
+    assert O.voxel_pooling_prepare_v2(coor, dx, bx, nx) == (None,) * 5
+
+
+def test_pool_through_reference_autograd_function(golden):
+    """g4_* were produced by the reference's QuickCumsumCuda (python logic) on the tiny rig."""
+    st, ln = golden["g3_starts"], golden["g3_lengths"]
+    depth, feat = golden["g4_depth"], golden["g4_feat"]
+    B, C, Z, Y, X = golden["g4_bev"].shape
+    # (1) with the tables in the order the reference itself produced: bit-identical results
+    rb, rd, rf = golden["g3raw_ranks_bev"], golden["g3raw_ranks_depth"], golden["g3raw_ranks_feat"]
+    out = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, (B, Z, Y, X, C), st, ln)
+    assert np.array_equal(out.transpose(0, 4, 1, 2, 3), golden["g4_bev"])
+    og = np.ascontiguousarray(golden["g4_w"].transpose(0, 2, 3, 4, 1))
+    dg, fg = OC.bev_pool_v2_bwd(og, depth, feat, golden["g4raw_bp_ranks_depth"], golden["g4raw_bp_ranks_feat"],
+                                golden["g4raw_bp_ranks_bev"], golden["g4_bp_starts"], golden["g4_bp_lengths"])
+    assert np.array_equal(dg, golden["g4_depth_grad"])
+    assert np.array_equal(fg, golden["g4_feat_grad"])
+    # (2) canonical (stable) tables: same intervals, summation order inside an interval differs
+    rb, rd, rf = golden["g3_ranks_bev"], golden["g3_ranks_depth"], golden["g3_ranks_feat"]
+    out = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, (B, Z, Y, X, C), st, ln)
+    np.testing.assert_allclose(out.transpose(0, 4, 1, 2, 3), golden["g4_bev"], rtol=1e-5, atol=1e-6)
+    bp = O.backward_tables(rb, rd, rf)
+    for k, t in zip(["ranks_bev", "ranks_depth", "ranks_feat", "starts", "lengths"], bp):
+        assert np.array_equal(t, golden[f"g4_bp_{k}"]), k
+    dg, fg = OC.bev_pool_v2_bwd(og, depth, feat, bp[1], bp[2], bp[0], bp[3], bp[4])
+    np.testing.assert_allclose(dg, golden["g4_depth_grad"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fg, golden["g4_feat_grad"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,H,W,fx", [("r1", 256, 704, 410.0)])
+def test_full_size_checksums(golden, tag, H, W, fx):
+    """Full-size (R1) tables from the oracle equal the reference's, via checksums."""
+    pc = [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
+    dx, bx, nx = O.gen_dx_bx([pc[0], pc[3], 0.5], [pc[1], pc[4], 0.5], [pc[2], pc[5], 0.5])
+    fr = O.create_frustum((H, W), 4, [1, 60, 1])
+    assert np.array_equal(O.synthetic_rig(H, W, fx), golden[f"full_{tag}_lidar2img"])
+    geom = O.get_geometry(fr, golden[f"full_{tag}_rots"], golden[f"full_{tag}_trans"])
+    np.testing.assert_allclose(geom.astype(np.float64).sum(axis=(0, 1, 2, 3, 4)), golden[f"full_{tag}_geom_sum"], rtol=1e-9)
+    tabs = O.voxel_pooling_prepare_v2(geom, dx, bx, nx)
+    cs = [tabs[0].size, tabs[3].size] + [int(t.astype(np.int64).sum()) for t in tabs] + [int(tabs[4].max())]
+    assert cs == golden[f"full_{tag}_checksums"].tolist()
+
+
+# ---- radar side: hand-computed cases (upstream semantics; parity unpinned by the reference) ----
+def test_hard_voxelize_first_occurrence_order_and_caps():
+    vs, rng = [1.0, 1.0, 4.0], [0.0, 0.0, -2.0, 4.0, 4.0, 2.0]
+    pts = np.array([[2.5, 1.5, 0.0, 10],    # voxel (x2,y1) -> id 0
+                    [0.5, 0.5, 0.0, 11],    # voxel (0,0)   -> id 1
+                    [2.6, 1.4, 1.0, 12],    # id 0, slot 1
+                    [9.0, 0.0, 0.0, 13],    # outside
+                    [2.7, 1.3, 0.0, 14],    # id 0, slot 2 -> dropped by max_points=2
+                    [3.5, 3.5, 0.0, 15],    # voxel (3,3)   -> id 2
+                    [0.1, 0.9, -2.0, 16],   # id 1 slot 1 (z = range min is inside)
+                    [1.5, 1.5, 2.0, 17],    # z = range max -> outside
+                    [1.5, 1.5, 0.0, 18]],   # would be id 3 -> refused by max_voxels=3
+                   dtype=np.float32)
+    v, c, n = OC.hard_voxelize(pts, vs, rng, max_points=2, max_voxels=3)
+    assert c.tolist() == [[0, 1, 2], [0, 0, 0], [0, 3, 3]]        # (z,y,x)
+    assert n.tolist() == [2, 2, 1]
+    assert v[0, :, 3].tolist() == [10, 12] and v[1, :, 3].tolist() == [11, 16] and v[2, :, 3].tolist() == [15, 0]
+
+
+def test_hard_voxelize_refused_voxel_does_not_block_existing():
+    vs, rng = [1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 2.0, 2.0, 1.0]
+    pts = np.array([[0.5, 0.5, 0.5], [1.5, 0.5, 0.5], [1.5, 1.5, 0.5], [0.4, 0.4, 0.4]], dtype=np.float32)
+    v, c, n = OC.hard_voxelize(pts, vs, rng, max_points=5, max_voxels=2)
+    assert c.tolist() == [[0, 0, 0], [0, 0, 1]] and n.tolist() == [2, 1]
+
+
+def test_pillar_scatter_index():
+    feats = np.arange(2 * 3, dtype=np.float32).reshape(2, 3) + 1
+    coors = np.array([[0, 0, 1, 2], [1, 0, 0, 3]], dtype=np.int32)
+    canvas = OC.pillar_scatter(feats, coors, batch=2, ny=2, nx=4)
+    assert canvas.shape == (2, 3, 2, 4) and canvas.sum() == feats.sum()
+    assert canvas[0, :, 1, 2].tolist() == [1, 2, 3] and canvas[1, :, 0, 3].tolist() == [4, 5, 6]
