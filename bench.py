@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the camera + 4D-radar BEV-fusion hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM.  Workloads (`--workload`):
+  bev_ops   (round-1 default) the north_star operators at BASELINE resolution R1 (6 x 256x704
+            images -> 6 x 64x176 feature maps, D=59, C=64, BEV 240x160x16; one merged radar
+            cloud): LSS pooling forward (fused dense kernel) + backward, radar hard-voxelise,
+            pillar scatter.  The conv backbone/encoder is not part of this workload; the line
+            says so in config.workload.
+Besides the whole-job rate the line carries
+  roofline      achieved HBM GB/s of the dominant kernel (bev_pool_v2 forward, dense), computed
+                from ALGORITHMIC bytes / mean launch duration measured here with
+                HIP events over back-to-back launches on rotating buffer sets (> Infinity Cache);
+  cpu_baseline  the CPU oracle (a port of the reference algorithm; the reference has no CPU
+                kernels) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "omnihd-scenes_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+RES = {"r1": (256, 704, 410.0), "r2": (544, 960, 560.0)}
+PC_RANGE = [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="bev_ops", choices=["bev_ops"])
+    ap.add_argument("--res", default="r1", choices=list(RES))
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-launches", type=int, default=60)
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic inputs; geometry through the same torch ops the reference uses
+# ---------------------------------------------------------------------------------------------
+def rig(res, batch, dev):
+    """rots (B,6,3,3), trans (B,6,3) exactly as bevf_faster_rcnn_bevdepth.py:121-130 builds them
+    (fp32 inverse of lidar2img on the host, then to the device)."""
+    H, W, fx = RES[res]
+    mats = []
+    for yaw_deg in (0, 60, -60, 180, 120, -120):
+        yaw = np.radians(yaw_deg)
+        R_c2l = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]])
+        t_c2l = np.array([np.cos(yaw), np.sin(yaw), 1.5])
+        R = R_c2l.T
+        E = np.eye(4); E[:3, :3] = R; E[:3, 3] = -R @ t_c2l
+        K = np.eye(4); K[0, 0] = K[1, 1] = fx; K[0, 2] = W / 2; K[1, 2] = H / 2
+        mats.append(K @ E)
+    inv = [torch.Tensor(m).inverse() for m in mats]
+    rots = torch.stack([m[:3, :3] for m in inv]).to(dev)[None].repeat(batch, 1, 1, 1)
+    trans = torch.stack([m[:3, 3] for m in inv]).to(dev)[None].repeat(batch, 1, 1)
+    return rots, trans
+
+
+def lss_constants(res):
+    """dx, bx, nx and frustum as the reference computes them (gen_dx_bx :80-85, create_frustum :222-233)."""
+    H, W, _ = RES[res]
+    rows = [[PC_RANGE[0], PC_RANGE[3], 0.5], [PC_RANGE[1], PC_RANGE[4], 0.5], [PC_RANGE[2], PC_RANGE[5], 0.5]]
+    dx = torch.Tensor([r[2] for r in rows]).numpy()
+    bx = torch.Tensor([r[0] + r[2] / 2.0 for r in rows]).numpy()
+    nx = torch.LongTensor([(r[1] - r[0]) / r[2] for r in rows]).numpy()
+    fH, fW = H // 4, W // 4
+    ds = torch.arange(1, 60, 1, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+    D = ds.shape[0]
+    xs = torch.linspace(0, W - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+    ys = torch.linspace(0, H - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+    return dx, bx, nx, torch.stack((xs, ys, ds), -1)
+
+
+def geometry(frustum, rots, trans):
+    """get_geometry (:235-264) with the same torch ops, on the device."""
+    B, N, _ = trans.shape
+    pts = frustum.to(rots.device).repeat(B, N, 1, 1, 1, 1).unsqueeze(-1)
+    pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
+    pts = rots.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
+    pts += trans.view(B, N, 1, 1, 1, 3)
+    return pts
+
+
+def radar_points(rng, n):
+    pts = np.empty((n, 7), dtype=np.float32)
+    pts[:, 0] = rng.uniform(-60, 60, n); pts[:, 1] = rng.uniform(-40, 40, n); pts[:, 2] = rng.uniform(-3, 5, n)
+    pts[:, 3:5] = rng.normal(0, 5, (n, 2)); pts[:, 5] = rng.uniform(0, 60, n); pts[:, 6] = rng.uniform(0, 40, n)
+    return pts
+
+
+class BevOps:
+    """The north_star operators on one batch, with `sets` rotating input/output buffer sets."""
+
+    def __init__(self, res, batch, dev, seed, sets=4):
+        import omnihd_amd
+        from omnihd_amd import ops
+        omnihd_amd.require_gpu()
+        self.ops, self.omnihd = ops, omnihd_amd
+        self.dev, self.batch = dev, batch
+        H, W, _ = RES[res]
+        self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
+        dx, bx, nx, frustum = lss_constants(res)
+        self.nx = nx
+        rots, trans = rig(res, batch, dev)
+        geom = geometry(frustum, rots, trans).contiguous()
+        self.plan = omnihd_amd.build_plan(geom, dx, bx, nx, layout="byxz")
+        del geom
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.sets = []
+        for _ in range(sets):
+            depth = torch.rand(batch, self.N, self.D, self.fH, self.fW, device=dev, generator=g).softmax(2)
+            feat = torch.randn(batch, self.N, self.fH, self.fW, self.C, device=dev, generator=g)
+            og = torch.randn(self.plan.n_rows, self.C, device=dev, generator=g)
+            out = torch.empty(self.plan.n_rows, self.C, device=dev)
+            # private copies of the tables too, so that nothing is served from the Infinity Cache
+            tabs = [x.clone() for x in (self.plan.ranks_depth, self.plan.ranks_feat, self.plan.row_ptr,
+                                        self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
+                                        self.plan.bp_starts, self.plan.bp_lengths)]
+            self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
+        rng = np.random.default_rng(seed)
+        self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
+        self.i = 0
+
+    def pool_fwd(self, s):
+        depth, feat, og, out, dg, fg, tb = self.sets[s]
+        self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out)
+
+    def pool_bwd(self, s):
+        depth, feat, og, out, dg, fg, tb = self.sets[s]
+        dg.zero_(); fg.zero_()
+        self.ops.bev_pool_v2_backward(og.view(1, 1, 1, -1, self.C), dg, fg, depth, feat, tb[3], tb[4], tb[5], tb[7], tb[6])
+
+    def radar(self):
+        vox, coors, nums = [], [], []
+        for b, pts in enumerate(self.points):
+            v, c, n = self.ops.hard_voxelize(pts, [0.25, 0.25, 8], PC_RANGE, 10, 30000)
+            vox.append(v); nums.append(n)
+            coors.append(torch.nn.functional.pad(c, (1, 0), value=b))
+        v, c = torch.cat(vox), torch.cat(coors)
+        # stand-in pillar feature (the PFN is dense torch work, not part of bev_ops): mean of xyz.. padded to 64
+        feats = v.sum(1)[:, :1].expand(-1, 64).contiguous()
+        return self.ops.pillar_scatter(feats, c, self.batch, 320, 480)
+
+    def step(self):
+        s = self.i % len(self.sets)
+        self.i += 1
+        self.pool_fwd(s)
+        self.pool_bwd(s)
+        self.radar()
+
+    # ---- algorithmic bytes of the dense forward kernel, SURVEY.md 8(d) formula ----------------
+    def fwd_algorithmic_bytes(self):
+        npts, nint = self.plan.n_points, self.plan.n_intervals
+        npix = self.batch * self.N * self.fH * self.fW
+        nvox = self.plan.n_rows
+        return 4 * (2 * npts) + 4 * (3 * nint) + 4 * npts + 4 * self.C * npix + 4 * self.C * nvox
+
+
+def time_kernel(fn, n_sets, launches):
+    """Mean duration of `launches` back-to-back launches (rotating buffer sets), HIP events on the
+    launching stream (= torch's current stream)."""
+    for s in range(n_sets):
+        fn(s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(launches):
+        fn(k % n_sets)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / launches
+
+
+def cpu_baseline(res, budget_s=20.0):
+    """Oracle (port of the reference algorithm) on the host cores: rank tables as the reference
+    builds them every forward + pooling fwd + re-sort + pooling bwd + voxelise + scatter."""
+    from oracle import cpu as OC
+    from oracle import lss_oracle as O
+    H, W, fx = RES[res]
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    dx, bx, nx = O.gen_dx_bx([PC_RANGE[0], PC_RANGE[3], 0.5], [PC_RANGE[1], PC_RANGE[4], 0.5], [PC_RANGE[2], PC_RANGE[5], 0.5])
+    fr = O.create_frustum((H, W), 4, [1, 60, 1])
+    inv = [torch.Tensor(m).inverse() for m in O.synthetic_rig(H, W, fx)]
+    rots = torch.stack([m[:3, :3] for m in inv])[None].numpy()
+    trans = torch.stack([m[:3, 3] for m in inv])[None].numpy()
+    rng = np.random.default_rng(0)
+    D, fH, fW, C = 59, H // 4, W // 4, 64
+    depth = rng.random((1, 6, D, fH, fW), dtype=np.float32)
+    feat = rng.standard_normal((1, 6, fH, fW, C), dtype=np.float32)
+    og = rng.standard_normal((1, 16, 160, 240, C), dtype=np.float32)
+    pts = radar_points(rng, 14000)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        geom = O.get_geometry(fr, rots, trans)
+        rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(geom, dx, bx, nx)
+        OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, (1, 16, 160, 240, C), st, ln, threads=True)
+        bp = O.backward_tables(rb, rd, rf)
+        OC.bev_pool_v2_bwd(og, depth, feat, bp[1], bp[2], bp[0], bp[3], bp[4], threads=True)
+        v, c, n = OC.hard_voxelize(pts, [0.25, 0.25, 8], PC_RANGE, 10, 30000)
+        OC.pillar_scatter(np.ascontiguousarray(np.broadcast_to(v.sum(1)[:, :1], (len(v), 64))), np.pad(c, ((0, 0), (1, 0))), 1, 320, 480)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or frames >= 8:
+            break
+    return {"value": round(frames / el, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frames of the same bev_ops workload at {res}, B=1 (numpy geometry+rank tables per frame, "
+                      f"C/OpenMP pooling fwd+bwd, sequential voxelise, scatter)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    wl = BevOps(a.res, a.batch, dev, seed=1234 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wl.step()
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+
+    if rank == 0:
+        t_fwd = time_kernel(wl.pool_fwd, len(wl.sets), a.kernel_launches)
+        t_bwd = time_kernel(wl.pool_bwd, len(wl.sets), a.kernel_launches)
+        fwd_bytes = wl.fwd_algorithmic_bytes()
+        ach = fwd_bytes / t_fwd / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_bev_pool_fwd.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "frames/sec (6-cam+6-radar BEV fwd+bwd)", "value": round(a.batch * world * a.steps / el, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"bev_ops@{a.res}: LSS bev_pool_v2 fwd(dense)+bwd, radar hard-voxelize + pillar scatter; "
+                                   f"6 cams {RES[a.res][0]}x{RES[a.res][1]} -> fmap {wl.fH}x{wl.fW}, D=59, C=64, BEV 240x160x16; "
+                                   "conv backbone/BEV encoder NOT in this workload",
+                       "frames_per_gpu": a.batch, "n_points": wl.plan.n_points, "n_intervals": wl.plan.n_intervals,
+                       "parallelism": f"dp{world} (independent frames, no data-path collective)"},
+            "roofline": {"kernel": "k_pool_fwd<16,true> (bev_pool_v2 forward, dense CSR)", "bound": "hbm",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_fwd * 1e6, 2),
+                         "bwd_mean_launch_us": round(t_bwd * 1e6, 2)},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.res)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

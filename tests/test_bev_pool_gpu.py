@@ -1,0 +1,215 @@
+"""GPU parity tests of bev_pool_v2 / bev_pool (v1): HIP kernels through the C ABI vs the CPU
+oracle, the reference's known-answer test, the golden vectors, and — when oracle/_ref was built —
+the reference's own kernels compiled by hipcc.
+
+Tolerances: index tables bit-exact; pooled features: bit-exact when the summation order is the
+reference's (intervals <= 512 points), otherwise <= 1e-5 relative (north_star allows 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu as OC
+from oracle import lss_oracle as O
+from tests.helpers import RefKernels, random_tables, t
+
+pytestmark = pytest.mark.gpu
+
+
+def run_fwd(dev, depth, feat, rd, rf, rb, shape, st, ln):
+    from projects.mmdet3d_plugin.ops.bev_pool_v2 import bev_pool_v2_ext as ext
+    out = torch.zeros(shape, dtype=torch.float32, device=dev)
+    ext.bev_pool_v2_forward(t(depth, dev), t(feat, dev), out, t(rd, dev), t(rf, dev), t(rb, dev), t(ln, dev), t(st, dev))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_reference_known_answer(cuda):
+    """The reference's test_bev_pool_v2 (ops/bev_pool_v2/bev_pool.py:145-176), same values."""
+    from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2
+    depth = torch.tensor([0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], device=cuda).view(1, 1, 2, 2, 2).requires_grad_()
+    feat = torch.ones(1, 1, 2, 2, 2, device=cuda).requires_grad_()
+    rd = torch.tensor([0, 4, 1, 6], dtype=torch.int32, device=cuda)
+    rf = torch.tensor([0, 0, 1, 2], dtype=torch.int32, device=cuda)
+    rb = torch.tensor([0, 0, 1, 1], dtype=torch.int32, device=cuda)
+    kept = torch.ones(4, dtype=torch.bool, device=cuda)
+    kept[1:] = rb[1:] != rb[:-1]
+    st = torch.where(kept)[0].int()
+    ln = torch.zeros_like(st)
+    ln[:-1] = st[1:] - st[:-1]
+    ln[-1] = 4 - st[-1]
+    bev = bev_pool_v2(depth, feat, rd, rf, rb, (1, 1, 2, 2, 2), st, ln)
+    loss = bev.sum()
+    loss.backward()
+    assert loss == 4.4
+    assert depth.grad.allclose(torch.tensor([2., 2., 0., 0., 2., 0., 2., 0.], device=cuda).view(1, 1, 2, 2, 2))
+    assert feat.grad.allclose(torch.tensor([1.0, 1.0, 0.4, 0.4, 0.8, 0.8, 0., 0.], device=cuda).view(1, 1, 2, 2, 2))
+
+
+def test_golden_forward_backward_through_plugin_api(cuda, golden):
+    """Tiny rig: same inputs as the reference autograd Function saw; canonical tables."""
+    from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2
+    depth = t(golden["g4_depth"], cuda).requires_grad_()
+    feat = t(golden["g4_feat"], cuda).requires_grad_()
+    B, C, Z, Y, X = golden["g4_bev"].shape
+    args = [t(golden[f"g3_{k}"], cuda) for k in ("ranks_depth", "ranks_feat", "ranks_bev")]
+    nx = torch.tensor([X, Y, Z])          # 0-d tensors in the shape, as the reference passes them
+    bev = bev_pool_v2(depth, feat, *args, (B, nx[2], nx[1], nx[0], C), t(golden["g3_starts"], cuda), t(golden["g3_lengths"], cuda))
+    assert bev.shape == (B, C, Z, Y, X) and bev.is_contiguous()
+    (bev * t(golden["g4_w"], cuda)).sum().backward()
+    np.testing.assert_allclose(bev.detach().cpu().numpy(), golden["g4_bev"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(depth.grad.cpu().numpy(), golden["g4_depth_grad"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), golden["g4_feat_grad"], rtol=1e-5, atol=1e-5)
+
+
+def test_golden_raw_order_is_bit_exact(cuda, golden):
+    """With the tables in the exact order the reference produced, the fma chain is identical."""
+    B, C, Z, Y, X = golden["g4_bev"].shape
+    out = run_fwd(cuda, golden["g4_depth"], golden["g4_feat"], golden["g3raw_ranks_depth"], golden["g3raw_ranks_feat"],
+                  golden["g3raw_ranks_bev"], (B, Z, Y, X, C), golden["g3_starts"], golden["g3_lengths"])
+    assert np.array_equal(out.transpose(0, 4, 1, 2, 3), golden["g4_bev"])
+
+
+@pytest.mark.parametrize("c", [1, 2, 4, 8, 16, 32, 64, 80, 128, 256])
+def test_forward_matches_oracle_all_channel_counts(cuda, c):
+    rng = np.random.default_rng(100 + c)
+    n_vox, n_pix, D = 3 * 7 * 11, 5 * 9, 6
+    rb, rd, rf, st, ln = random_tables(rng, n_vox, n_pix, n_pix * D, 1500)
+    depth = rng.random((1, 1, D, 5, 9), dtype=np.float32)
+    feat = rng.standard_normal((1, 1, 5, 9, c), dtype=np.float32)
+    shape = (1, 3, 7, 11, c)
+    want = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, shape, st, ln)
+    got = run_fwd(cuda, depth, feat, rd, rf, rb, shape, st, ln)
+    assert np.array_equal(got, want)          # same fma chain, same order -> bit-exact
+
+
+def test_forward_long_intervals_split_path(cuda):
+    """Intervals > 512 points take the workgroup-split path: deterministic, ~1e-6 from the oracle."""
+    rng = np.random.default_rng(5)
+    c, n_vox, n_pix, D = 64, 50, 400, 59
+    rb, rd, rf, st, ln = random_tables(rng, n_vox, n_pix, n_pix * D, 20000, long_interval=6000)
+    assert ln.max() > 512
+    depth = rng.random((1, 1, D, 20, 20), dtype=np.float32)
+    feat = rng.standard_normal((1, 1, 20, 20, c), dtype=np.float32)
+    shape = (1, 1, 5, 10, c)
+    want = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, shape, st, ln)
+    got = run_fwd(cuda, depth, feat, rd, rf, rb, shape, st, ln)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4)
+    again = run_fwd(cuda, depth, feat, rd, rf, rb, shape, st, ln)
+    assert np.array_equal(got, again)          # run-to-run identical (no atomics)
+
+
+def test_forward_only_named_rows_are_written_and_empty_tables(cuda):
+    from projects.mmdet3d_plugin.ops.bev_pool_v2 import bev_pool_v2_ext as ext
+    rng = np.random.default_rng(9)
+    rb, rd, rf, st, ln = random_tables(rng, 40, 12, 48, 30)
+    depth = t(rng.random((1, 1, 4, 3, 4), dtype=np.float32), cuda)
+    feat = t(rng.standard_normal((1, 1, 3, 4, 8), dtype=np.float32), cuda)
+    out = torch.full((1, 2, 4, 5, 8), 7.0, device=cuda)
+    ext.bev_pool_v2_forward(depth, feat, out, t(rd, cuda), t(rf, cuda), t(rb, cuda), t(ln, cuda), t(st, cuda))
+    untouched = np.setdiff1d(np.arange(40), rb)
+    assert (out.view(40, 8)[torch.from_numpy(untouched).to(cuda)] == 7.0).all()
+    e = torch.empty(0, dtype=torch.int32, device=cuda)
+    out2 = torch.zeros(1, 2, 4, 5, 8, device=cuda)
+    ext.bev_pool_v2_forward(depth, feat, out2, e, e, e, e, e)          # zero intervals: no-op
+    assert out2.abs().sum() == 0
+
+
+@pytest.mark.parametrize("c", [2, 8, 64, 80])
+def test_backward_matches_oracle(cuda, c):
+    from projects.mmdet3d_plugin.ops.bev_pool_v2 import bev_pool_v2_ext as ext
+    rng = np.random.default_rng(200 + c)
+    n_vox, n_pix, D = 2 * 6 * 9, 4 * 8, 7
+    rb, rd, rf, st, ln = random_tables(rng, n_vox, n_pix, n_pix * D, 180)
+    depth = rng.random((1, 1, D, 4, 8), dtype=np.float32)
+    feat = rng.standard_normal((1, 1, 4, 8, c), dtype=np.float32)
+    og = rng.standard_normal((1, 2, 6, 9, c), dtype=np.float32)
+    brb, brd, brf, bst, bln = O.backward_tables(rb, rd, rf)
+    want_dg, want_fg = OC.bev_pool_v2_bwd(og, depth, feat, brd, brf, brb, bst, bln)
+    dg = torch.zeros(depth.shape, device=cuda)
+    fg = torch.zeros(feat.shape, device=cuda)
+    ext.bev_pool_v2_backward(t(og, cuda), dg, fg, t(depth, cuda), t(feat, cuda), t(brd, cuda), t(brf, cuda), t(brb, cuda),
+                             t(bln, cuda), t(bst, cuda))
+    assert np.array_equal(fg.cpu().numpy(), want_fg)            # same fma chain over points
+    np.testing.assert_allclose(dg.cpu().numpy(), want_dg, rtol=1e-5, atol=1e-5)   # channel sum is a lane tree
+
+
+def test_device_backward_tables_match_oracle(cuda):
+    from omnihd_amd import ops
+    rng = np.random.default_rng(3)
+    rb, rd, rf, st, ln = random_tables(rng, 500, 64, 64 * 9, 400)
+    got = ops.backward_tables(t(rb, cuda), t(rd, cuda), t(rf, cuda), 64)
+    want = O.backward_tables(rb, rd, rf)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.cpu().numpy(), w)
+
+
+def test_csr_dense_forward_and_planned_autograd(cuda, golden):
+    """The fused (dense, CSR) forward + cached-plan autograd path equals the reference-API path."""
+    import omnihd_amd
+    from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2
+    B, C, Z, Y, X = golden["g4_bev"].shape
+    rb, rd, rf = (t(golden[f"g3_{k}"], cuda) for k in ("ranks_bev", "ranks_depth", "ranks_feat"))
+    n_pix = golden["g4_feat"].size // C
+    for layout in ("bzyx", "byxz"):
+        plan = omnihd_amd.plan_from_tables(rb, rd, rf, (B, Z, Y, X), n_pix, layout=layout)
+        depth = t(golden["g4_depth"], cuda).requires_grad_()
+        feat = t(golden["g4_feat"], cuda).requires_grad_()
+        bev = omnihd_amd.plan.planned_pool(depth, feat, plan)
+        assert bev.shape == (B, C, Z, Y, X)
+        (bev * t(golden["g4_w"], cuda)).sum().backward()
+        np.testing.assert_allclose(bev.detach().cpu().numpy(), golden["g4_bev"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(depth.grad.cpu().numpy(), golden["g4_depth_grad"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(feat.grad.cpu().numpy(), golden["g4_feat_grad"], rtol=1e-5, atol=1e-5)
+        if layout == "byxz":   # s2c (cat(unbind(2),1)) is a pure reshape of the channels-last buffer
+            s2c = torch.cat(bev.unbind(dim=2), 1)
+            assert torch.equal(s2c, bev.permute(0, 2, 1, 3, 4).reshape(B, Z * C, Y, X))
+
+
+def test_against_reference_kernels_compiled_by_hipcc(cuda):
+    """oracle/_ref = the reference's bev_pool_cuda.cu compiled unmodified for gfx950."""
+    ref = RefKernels()
+    if not ref.ok:
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    from projects.mmdet3d_plugin.ops.bev_pool_v2 import bev_pool_v2_ext as ext
+    rng = np.random.default_rng(77)
+    c, n_vox, n_pix, D = 64, 16 * 20 * 30, 6 * 16 * 44, 59
+    rb, rd, rf, st, ln = random_tables(rng, n_vox, n_pix, n_pix * D, 120000)
+    depth = t(rng.random((1, 6, D, 16, 44), dtype=np.float32), cuda)
+    feat = t(rng.standard_normal((1, 6, 16, 44, c), dtype=np.float32), cuda)
+    trb, trd, trf, tst, tln = (t(a, cuda) for a in (rb, rd, rf, st, ln))
+    ours = torch.zeros(1, 16, 20, 30, c, device=cuda)
+    theirs = torch.zeros_like(ours)
+    ext.bev_pool_v2_forward(depth, feat, ours, trd, trf, trb, tln, tst)
+    ref.v2_fwd(depth, feat, trd, trf, trb, tst, tln, theirs)
+    assert torch.equal(ours, theirs)                           # bit-exact vs the reference kernel
+    og = t(rng.standard_normal((1, 16, 20, 30, c), dtype=np.float32), cuda)
+    brb, brd, brf, bst, bln = (t(a, cuda) for a in O.backward_tables(rb, rd, rf))
+    dg, fg = torch.zeros_like(depth), torch.zeros_like(feat)
+    dg_r, fg_r = torch.zeros_like(depth), torch.zeros_like(feat)
+    ext.bev_pool_v2_backward(og, dg, fg, depth, feat, brd, brf, brb, bln, bst)
+    ref.v2_bwd(og, depth, feat, brd, brf, brb, bst, bln, dg_r, fg_r)
+    assert torch.equal(fg, fg_r)
+    torch.testing.assert_close(dg, dg_r, rtol=1e-5, atol=1e-5)
+
+
+def test_v1_pool_matches_oracle(cuda):
+    from projects.mmdet3d_plugin.ops.bev_pool import bev_pool
+    rng = np.random.default_rng(21)
+    B, D, H, W, C, n = 2, 3, 5, 7, 16, 900
+    coords = np.stack([rng.integers(0, H, n), rng.integers(0, W, n), rng.integers(0, D, n), rng.integers(0, B, n)], 1)
+    feats = rng.standard_normal((n, C), dtype=np.float32)
+    x = t(feats, cuda).requires_grad_()
+    out = bev_pool(x, t(coords, cuda), B, D, H, W)
+    assert out.shape == (B, C, D, H, W)
+    # oracle on the same (stable) order
+    ranks = coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B) + coords[:, 2] * B + coords[:, 3]
+    order = np.argsort(ranks, kind="stable")
+    st, ln = O.run_length(ranks[order])
+    want = OC.bev_pool_v1_fwd(feats[order], coords[order].astype(np.int32), st, ln, B, D, H, W)
+    assert np.array_equal(out.detach().cpu().numpy(), want.transpose(0, 4, 1, 2, 3))
+    w = rng.standard_normal(out.shape, dtype=np.float32)
+    (out * t(w, cuda)).sum().backward()
+    xg_sorted = OC.bev_pool_v1_bwd(np.ascontiguousarray(w.transpose(0, 2, 3, 4, 1)), coords[order].astype(np.int32), st, ln, B, D, H, W)
+    want_xg = np.empty_like(xg_sorted)
+    want_xg[order] = xg_sorted
+    assert np.array_equal(x.grad.cpu().numpy(), want_xg)

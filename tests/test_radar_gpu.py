@@ -1,0 +1,100 @@
+"""GPU parity tests of the radar-side ops: hard voxelisation (bit-exact voxel assignment) and
+pillar scatter, against the sequential CPU oracle (upstream mmdet3d semantics; see
+oracle/voxelize_oracle.c for the pinning status)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu as OC
+from tests.helpers import t
+
+pytestmark = pytest.mark.gpu
+VS = [0.25, 0.25, 8]
+RNG6 = [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
+
+
+def radar_cloud(rng, n, f=8, spread=1.0):
+    pts = np.empty((n, f), dtype=np.float32)
+    pts[:, 0] = rng.uniform(-60 * spread, 60 * spread, n)
+    pts[:, 1] = rng.uniform(-40 * spread, 40 * spread, n)
+    pts[:, 2] = rng.uniform(-3, 5, n)
+    pts[:, 3:] = rng.standard_normal((n, f - 3))
+    return pts
+
+
+def check(cuda, pts, vs, rng6, max_points, max_voxels):
+    from omnihd_amd import ops
+    want = OC.hard_voxelize(pts, vs, rng6, max_points, max_voxels)
+    got = ops.hard_voxelize(t(pts, cuda), vs, rng6, max_points, max_voxels)
+    assert got[1].dtype == torch.int32 and got[2].dtype == torch.int32
+    assert np.array_equal(got[1].cpu().numpy(), want[1])      # coors (z,y,x), first-occurrence order
+    assert np.array_equal(got[2].cpu().numpy(), want[2])      # points per voxel
+    assert np.array_equal(got[0].cpu().numpy(), want[0])      # point rows, zero padded
+    return want
+
+
+@pytest.mark.parametrize("n,f", [(12000, 8), (20000, 7), (1, 8), (257, 5)])
+def test_voxelize_random_clouds(cuda, n, f):
+    rng = np.random.default_rng(n + f)
+    w = check(cuda, radar_cloud(rng, n, f, spread=1.05), VS, RNG6, 10, 30000)
+    assert len(w[1]) > 0
+
+
+def test_voxelize_dense_clusters_hit_max_points(cuda):
+    rng = np.random.default_rng(1)
+    pts = radar_cloud(rng, 5000)
+    pts[:3000, 0] = rng.uniform(0, 1.0, 3000)       # 3000 points into 4x4 cells
+    pts[:3000, 1] = rng.uniform(0, 1.0, 3000)
+    w = check(cuda, pts, VS, RNG6, 10, 30000)
+    assert w[2].max() == 10
+
+
+def test_voxelize_max_voxels_cap(cuda):
+    rng = np.random.default_rng(2)
+    w = check(cuda, radar_cloud(rng, 20000), VS, RNG6, 10, 500)
+    assert len(w[1]) == 500
+
+
+def test_voxelize_edges_nan_and_all_outside(cuda):
+    from omnihd_amd import ops
+    pts = np.array([[-60.0, -40.0, -3.0, 1], [60.0, 0, 0, 2], [59.99999, 39.99999, 4.99999, 3],
+                    [np.nan, 0, 0, 4], [0, np.inf, 0, 5], [-60.00001, 0, 0, 6], [0, 0, 5.0, 7],
+                    [-59.75, -39.75, 0, 8], [-59.76, -39.76, 1, 9]], dtype=np.float32)
+    check(cuda, pts, VS, RNG6, 10, 100)
+    out = ops.hard_voxelize(t(np.full((50, 4), 1e6, np.float32), cuda), VS, RNG6, 10, 100)
+    assert out[0].shape == (0, 10, 4) and out[1].shape == (0, 3) and out[2].shape == (0,)
+    out = ops.hard_voxelize(torch.empty(0, 4, device=cuda), VS, RNG6, 10, 100)
+    assert out[0].shape[0] == 0
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_pillar_scatter_and_backward(cuda, channels_last):
+    from omnihd_amd import ops
+    rng = np.random.default_rng(4)
+    B, ny, nx, C = 2, 320, 480, 64
+    coors = []
+    for b in range(B):
+        cells = rng.permutation(ny * nx)[:9000]
+        coors.append(np.stack([np.full(9000, b), np.zeros(9000, int), cells // nx, cells % nx], 1))
+    coors = np.concatenate(coors).astype(np.int32)
+    feats = rng.standard_normal((len(coors), C), dtype=np.float32)
+    want = OC.pillar_scatter(feats, coors, B, ny, nx)
+    f = t(feats, cuda).requires_grad_()
+    canvas = ops.pillar_scatter(f, t(coors, cuda), B, ny, nx, channels_last=channels_last)
+    assert canvas.shape == (B, C, ny, nx)
+    assert np.array_equal(canvas.detach().cpu().numpy(), want)
+    w = torch.randn(B, C, ny, nx, device=cuda)
+    (canvas * w).sum().backward()
+    c = torch.from_numpy(coors).long().to(cuda)
+    assert torch.equal(f.grad, w[c[:, 0], :, c[:, 2], c[:, 3]])
+
+
+def test_pillar_scatter_odd_plane_and_empty(cuda):
+    from omnihd_amd import ops
+    feats = torch.arange(6, dtype=torch.float32, device=cuda).view(2, 3) + 1
+    coors = torch.tensor([[0, 0, 1, 2], [1, 0, 0, 0]], dtype=torch.int32, device=cuda)
+    canvas = ops.pillar_scatter(feats, coors, 2, 3, 3)        # plane of 9: scalar path
+    want = OC.pillar_scatter(feats.cpu().numpy(), coors.cpu().numpy(), 2, 3, 3)
+    assert np.array_equal(canvas.cpu().numpy(), want)
+    empty = ops.pillar_scatter(torch.empty(0, 3, device=cuda), torch.empty(0, 4, dtype=torch.int32, device=cuda), 1, 4, 4)
+    assert empty.abs().sum() == 0
