@@ -79,10 +79,20 @@ int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const floa
  * [row_ptr[r], row_ptr[r+1]) of ranks_depth/ranks_feat.  Every one of the n_rows rows is
  * written (zeros for empty rows), so `out` needs no initialisation.  The row numbering is
  * whatever the plan builder chose (reference (b,z,y,x) order, or (b,y,x,z) = channels-last
- * of the s2c tensor).                                                                      */
+ * of the s2c tensor).
+ * tile_row/n_tiles (from omnihd_csr_tiles; may be NULL/0) select the load-balanced tiled
+ * kernel: each workgroup owns a run of whole rows holding ~tile_items points+rows and splits
+ * it evenly over its lanes; rows cut by that split are combined in a fixed order (so a row's
+ * sum may be associated differently from the table order; run-to-run deterministic).       */
 int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                const int* ranks_depth, const int* ranks_feat,
-                               const int* row_ptr, float* out, int c, int n_rows, void* stream);
+                               const int* row_ptr, const int* tile_row, int n_tiles,
+                               float* out, int c, int n_rows, void* stream);
+
+/* tile_row[k] (k in [0,n_tiles]) = first row r with r + row_ptr[r] >= k*tile_items;
+ * n_tiles must equal ceil((n_rows + n_points) / tile_items); 64 <= tile_items <= 2048.     */
+int omnihd_csr_tiles(const int* row_ptr, int n_rows, int n_points, int tile_items,
+                     int* tile_row, int n_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * bev_pool (v1) — imported by the plugin at load time (projects/mmdet3d_plugin/__init__.py:20)

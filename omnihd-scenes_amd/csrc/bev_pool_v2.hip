@@ -166,6 +166,154 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Tiled dense forward ("workgroup merge path").
+//
+// A TILE is a run of whole output rows whose merged item sequence
+//     [points of row r ..., END(r)]  for r = Ra .. Rb-1
+// has about `tile_items` items (tile boundaries come from the plan: tile_row[k] = first row with
+// r + row_ptr[r] >= k * tile_items).  One workgroup owns one tile:
+//   1. row_ptr[Ra..Rb] is staged in LDS with one coalesced read;
+//   2. the item sequence is cut into G equal pieces, one per group of C4 lanes (binary search on
+//      the LDS copy) — every group does the same amount of work no matter how the points are
+//      distributed over rows (near-ego voxels hold thousands of points, 40 % of the rows none);
+//   3. a group streams its points: rank tables are read coalesced C4 points at a time, depth is
+//      gathered by C4 lanes in parallel, 4 feature-row gathers are kept in flight; rows that
+//      start and end inside the piece are stored straight to HBM (one 16 B x C4 = 256 B store);
+//   4. a row cut by a piece boundary leaves a partial in LDS; after one barrier the group that
+//      saw the row's END adds the partials in piece order and stores the row.
+// No atomics, no dependence on dispatch order: results are run-to-run identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxTileItems = 2048;
+
+template <int C4>
+__global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
+    const float* __restrict__ depth, const float4* __restrict__ feat4,
+    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
+    const int* __restrict__ row_ptr, const int* __restrict__ tile_row,
+    float4* __restrict__ out4, int n_tiles, int tiles_per_xcd) {
+  constexpr int G = kBlock / C4;
+  __shared__ int s_rp[kMaxTileItems + 1];
+  __shared__ float4 s_head[kBlock];
+  __shared__ float4 s_tail[kBlock];
+  __shared__ int s_head_row[G];
+  __shared__ int s_tail_row[G];
+
+  // XCD-aware tile choice: workgroup b runs on XCD b % 8 (observed dispatch rule, used for
+  // locality only); give every XCD one contiguous chunk of tiles = one BEV band, so the image
+  // feature rows it gathers stay resident in ITS 4 MiB L2.
+  const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || t >= n_tiles) return;
+
+  const int tid = threadIdx.x;
+  const int sub = tid % C4;
+  const int grp = tid / C4;
+  const int Ra = tile_row[t];
+  const int nrows = tile_row[t + 1] - Ra;
+  for (int i = tid; i <= nrows; i += kBlock) s_rp[i] = row_ptr[Ra + i];
+  if (tid < G) s_head_row[tid] = -1;
+  __syncthreads();
+
+  const int Pa = s_rp[0];
+  const int items = nrows + (s_rp[nrows] - Pa);
+  const int w = (items + G - 1) / G;
+  const int d0 = min(grp * w, items);
+  const int d1 = min(d0 + w, items);
+  // rows whose END lies before item d:  #{k : (s_rp[k+1] - Pa) + k < d}
+  auto split = [&](int d) {
+    int lo = 0, hi = nrows;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_rp[mid + 1] - Pa + mid < d) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  int r = split(d0);
+  const int r1 = split(d1);
+  int p = Pa + d0 - r;
+  const int p1 = Pa + d1 - r1;
+  int cur_end = s_rp[min(r + 1, nrows)];
+  bool head_pending = (r < nrows) && (p > s_rp[r]);   // piece starts inside row r
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto emit = [&]() {   // END(r): the row is complete as far as this piece can tell
+    if (head_pending) {
+      s_head[tid] = acc;
+      if (sub == 0) s_head_row[grp] = r;
+      head_pending = false;
+    } else {
+      store_row(out4 + (size_t)(Ra + r) * C4 + sub, acc, true);
+    }
+    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    ++r;
+    cur_end = s_rp[min(r + 1, nrows)];
+  };
+
+  while (p < p1) {
+    const int n = min(C4, p1 - p);
+    int my_rf = 0;
+    float my_d = 0.f;
+    if (sub < n) {
+      my_rf = ranks_feat[p + sub];
+      my_d = depth[ranks_depth[p + sub]];
+    }
+    for (int j = 0; j < n; j += 4) {
+      float4 v[4];
+      float d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = min(j + u, n - 1);
+        const int f = __shfl(my_rf, jj, C4);
+        d[u] = __shfl(my_d, jj, C4);
+        v[u] = feat4[(size_t)f * C4 + sub];
+      }
+      const int m = min(4, n - j);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < m) {
+          while (p == cur_end && r < r1) emit();
+          acc = fma4(d[u], v[u], acc);
+          ++p;
+        }
+      }
+    }
+  }
+  while (r < r1) emit();
+  s_tail[tid] = acc;
+  if (sub == 0) s_tail_row[grp] = r;
+  __syncthreads();
+
+  const int hr = s_head_row[grp];
+  if (hr >= 0) {
+    int g0 = grp;
+    while (g0 > 0 && s_tail_row[g0 - 1] == hr) --g0;
+    float4 tsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = g0; g < grp; ++g) {
+      const float4 q = s_tail[g * C4 + sub];
+      tsum.x += q.x; tsum.y += q.y; tsum.z += q.z; tsum.w += q.w;
+    }
+    const float4 h = s_head[tid];
+    tsum.x += h.x; tsum.y += h.y; tsum.z += h.z; tsum.w += h.w;
+    store_row(out4 + (size_t)(Ra + hr) * C4 + sub, tsum, true);
+  }
+}
+
+// tile_row[k] = first row r with r + row_ptr[r] >= k * tile_items  (k = 0 .. n_tiles)
+__global__ __launch_bounds__(kBlock) void k_csr_tiles(const int* __restrict__ row_ptr, int n_rows,
+                                                      int tile_items, int n_tiles,
+                                                      int* __restrict__ tile_row) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k <= n_tiles; k += gridDim.x * kBlock) {
+    const long long target = (long long)k * tile_items;
+    int lo = 0, hi = n_rows;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((long long)mid + row_ptr[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    tile_row[k] = (k == n_tiles) ? n_rows : lo;
+  }
+}
+
 // Any channel count / any alignment: one thread per (unit, channel), serial over the points.
 template <bool DENSE>
 __global__ __launch_bounds__(kBlock) void k_pool_fwd_generic(
@@ -345,15 +493,53 @@ extern "C" int omnihd_bev_pool_v2_fwd(const float* depth, const float* feat,
                            interval_lengths, out, c, n_intervals, (hipStream_t)stream);
 }
 
+extern "C" int omnihd_csr_tiles(const int* row_ptr, int n_rows, int n_points, int tile_items,
+                                int* tile_row, int n_tiles, void* stream) {
+  OMNIHD_REQUIRE(n_rows >= 0 && n_points >= 0 && tile_items >= 64 && tile_items <= kMaxTileItems,
+                 "64 <= tile_items <= 2048");
+  OMNIHD_REQUIRE(row_ptr && tile_row, "null pointer");
+  const long long items = (long long)n_rows + n_points;
+  OMNIHD_REQUIRE(n_tiles == (int)((items + tile_items - 1) / tile_items), "n_tiles != ceil((n_rows+n_points)/tile_items)");
+  hipLaunchKernelGGL(k_csr_tiles, dim3(grid_for((int64_t)n_tiles + 1, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, row_ptr, n_rows, tile_items, n_tiles, tile_row);
+  return check_launch("csr_tiles");
+}
+
 extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                           const int* ranks_depth, const int* ranks_feat,
-                                          const int* row_ptr, float* out, int c, int n_rows,
-                                          void* stream) {
-  OMNIHD_REQUIRE(c > 0 && n_rows >= 0, "c > 0 and n_rows >= 0");
+                                          const int* row_ptr, const int* tile_row, int n_tiles,
+                                          float* out, int c, int n_rows, void* stream) {
+  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0, "c > 0 and n_rows >= 0");
   if (n_rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(depth && feat && ranks_depth && ranks_feat && row_ptr && out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (tile_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out)) {
+    const int tiles_per_xcd = (n_tiles + 7) / 8;
+    const dim3 grid(tiles_per_xcd * 8);
+    const float4* f4 = reinterpret_cast<const float4*>(feat);
+    float4* o4 = reinterpret_cast<float4*>(out);
+#define OMNIHD_TILE_CASE(C4)                                                                   \
+  case C4:                                                                                     \
+    hipLaunchKernelGGL((k_pool_fwd_tiles<C4>), grid, dim3(kBlock), 0, st, depth, f4,           \
+                       ranks_depth, ranks_feat, row_ptr, tile_row, o4, n_tiles, tiles_per_xcd); \
+    break;
+    switch (c / 4) {
+      OMNIHD_TILE_CASE(1)
+      OMNIHD_TILE_CASE(2)
+      OMNIHD_TILE_CASE(4)
+      OMNIHD_TILE_CASE(8)
+      OMNIHD_TILE_CASE(16)
+      OMNIHD_TILE_CASE(32)
+      OMNIHD_TILE_CASE(64)
+      default:
+        set_error("unreachable c4=%d", c / 4);
+        return OMNIHD_ERR_ARG;
+    }
+#undef OMNIHD_TILE_CASE
+    return check_launch("bev_pool_v2_fwd_csr(tiles)");
+  }
   return launch_fwd<true>(depth, feat, ranks_depth, ranks_feat, nullptr, nullptr, row_ptr, out, c,
-                          n_rows, (hipStream_t)stream);
+                          n_rows, st);
 }
 
 extern "C" int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth,

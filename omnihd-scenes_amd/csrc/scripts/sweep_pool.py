@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmark of the pooling kernels (not part of the bench contract): tile-size sweep,
+tiled vs untiled dense forward, backward; rotating buffer sets, HIP-event timing."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "omnihd-scenes_amd")]
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from omnihd_amd import ops, plan as P  # noqa: E402
+
+
+def main():
+    res = sys.argv[1] if len(sys.argv) > 1 else "r1"
+    dev = torch.device("cuda:0")
+    wl = bench.BevOps(res, 1, dev, 1234)
+    nbytes = wl.fwd_algorithmic_bytes()
+    print(f"{res}: points {wl.plan.n_points} intervals {wl.plan.n_intervals} rows {wl.plan.n_rows} alg bytes {nbytes/1e6:.1f} MB")
+    wl.tiled = False
+    t = bench.time_kernel(wl.pool_fwd, len(wl.sets), 40)
+    print(f"untiled dense fwd : {t*1e6:8.1f} us  {nbytes/t/1e9:7.0f} GB/s")
+    wl.tiled = True
+    for items in (128, 256, 384, 512, 768, 1024, 1536, 2048):
+        tiles = ops.csr_tiles(wl.plan.row_ptr, wl.plan.n_points, items)
+        for s in wl.sets:
+            s[6][8] = tiles.clone()
+        t = bench.time_kernel(wl.pool_fwd, len(wl.sets), 40)
+        print(f"tiled fwd W={items:5d}: {t*1e6:8.1f} us  {nbytes/t/1e9:7.0f} GB/s  tiles {tiles.numel()-1}")
+    t = bench.time_kernel(wl.pool_bwd, len(wl.sets), 40)
+    print(f"bwd (incl. 2 memsets): {t*1e6:8.1f} us")
+    # plain device copy of the same byte count as a local ceiling
+    a = torch.empty(nbytes // 8, dtype=torch.float32, device=dev)
+    bufs = [(torch.empty_like(a), torch.empty_like(a)) for _ in range(4)]
+    t = bench.time_kernel(lambda k: bufs[k][1].copy_(bufs[k][0]), 4, 40)
+    print(f"torch copy of {nbytes/2e6:.0f} MB -> {nbytes/2e6:.0f} MB: {t*1e6:8.1f} us  {nbytes/t/1e9:7.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,7 @@ class BevPoolPlan:
     ranks_depth: torch.Tensor   # int32 [n_points]
     ranks_feat: torch.Tensor    # int32 [n_points]
     row_ptr: torch.Tensor       # int32 [n_rows+1]
+    tile_row: torch.Tensor      # int32 [n_tiles+1] work partition of the tiled forward kernel
     interval_starts: torch.Tensor
     interval_lengths: torch.Tensor
     # backward (sorted by ranks_feat)
@@ -44,13 +45,17 @@ class BevPoolPlan:
         return int(self.interval_starts.numel())
 
 
+TILE_ITEMS = 512
+
+
 def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows):
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X
     row_ptr = ops.csr_from_sorted_keys(rows, n_rows)
+    tile_row = ops.csr_tiles(row_ptr, int(rows.numel()), TILE_ITEMS)
     bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
-    return BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, starts, lengths,
-                       bp[0], bp[1], bp[2], bp[3], bp[4])
+    return BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, tile_row, starts,
+                       lengths, bp[0], bp[1], bp[2], bp[3], bp[4])
 
 
 def build_plan(coor, dx, bx, nx, layout="byxz"):
@@ -91,7 +96,8 @@ class _PlannedPool(torch.autograd.Function):
         depth = depth.contiguous().float()
         feat = feat.contiguous().float()
         out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
-        ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out)
+        ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
+                                    plan.tile_row)
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan
         return out

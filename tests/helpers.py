@@ -29,16 +29,15 @@ def random_tables(rng, n_vox, n_pix, n_depth, n_points, long_interval=0):
 
 
 def full_size_geometry(tag="r1"):
+    """Geometry of the synthetic rig at full size.  rots/trans come from the golden file (they were
+    produced by the reference's torch.Tensor(mat).inverse() in the authoring container; LAPACK on
+    another host CPU may round the inverse differently, which would move boundary points)."""
     H, W, fx = {"r1": (256, 704, 410.0), "r2": (544, 960, 560.0)}[tag]
     dx, bx, nx = O.gen_dx_bx([PC_RANGE[0], PC_RANGE[3], 0.5], [PC_RANGE[1], PC_RANGE[4], 0.5],
                              [PC_RANGE[2], PC_RANGE[5], 0.5])
     fr = O.create_frustum((H, W), 4, [1, 60, 1])
-    l2i = O.synthetic_rig(H, W, fx)
-    # bevf_faster_rcnn_bevdepth.py:121-124: torch.Tensor(mat).inverse() (fp32) per camera
-    inv = [torch.Tensor(m).inverse() for m in l2i]
-    rots = torch.stack([m[:3, :3] for m in inv])[None].numpy()
-    trans = torch.stack([m[:3, 3] for m in inv])[None].numpy()
-    geom = O.get_geometry(fr, rots, trans)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_golden.npz"))
+    geom = O.get_geometry(fr, gold[f"full_{tag}_rots"], gold[f"full_{tag}_trans"])
     return geom, dx, bx, nx
 
 
