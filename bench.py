@@ -114,6 +114,7 @@ class BevOps:
         omnihd_amd.require_gpu()
         self.ops, self.omnihd = ops, omnihd_amd
         self.dev, self.batch = dev, batch
+        self.tiled = True
         H, W, _ = RES[res]
         self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
         dx, bx, nx, frustum = lss_constants(res)
@@ -132,7 +133,7 @@ class BevOps:
             # private copies of the tables too, so that nothing is served from the Infinity Cache
             tabs = [x.clone() for x in (self.plan.ranks_depth, self.plan.ranks_feat, self.plan.row_ptr,
                                         self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
-                                        self.plan.bp_starts, self.plan.bp_lengths)]
+                                        self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_row)]
             self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
         rng = np.random.default_rng(seed)
         self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
@@ -140,7 +141,7 @@ class BevOps:
 
     def pool_fwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
-        self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out)
+        self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out, tb[8] if self.tiled else None)
 
     def pool_bwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
@@ -274,7 +275,7 @@ def main():
                                    "conv backbone/BEV encoder NOT in this workload",
                        "frames_per_gpu": a.batch, "n_points": wl.plan.n_points, "n_intervals": wl.plan.n_intervals,
                        "parallelism": f"dp{world} (independent frames, no data-path collective)"},
-            "roofline": {"kernel": "k_pool_fwd<16,true> (bev_pool_v2 forward, dense CSR)", "bound": "hbm",
+            "roofline": {"kernel": "k_pool_fwd_tiles<16> (bev_pool_v2 forward, dense CSR, workgroup merge-path tiles)", "bound": "hbm",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_fwd * 1e6, 2),
                          "bwd_mean_launch_us": round(t_bwd * 1e6, 2)},

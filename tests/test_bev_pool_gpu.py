@@ -165,6 +165,60 @@ def test_csr_dense_forward_and_planned_autograd(cuda, golden):
             assert torch.equal(s2c, bev.permute(0, 2, 1, 3, 4).reshape(B, Z * C, Y, X))
 
 
+@pytest.mark.parametrize("tile_items", [64, 200, 512, 2048])
+@pytest.mark.parametrize("c", [64, 8])
+def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
+    """Tiled (workgroup merge-path) dense kernel: rows far longer than a tile, long runs of empty
+    rows, rows cut at every piece boundary.  Checked against the oracle (which only writes named
+    rows into a zero buffer) and against the untiled dense kernel; run-to-run identical."""
+    from omnihd_amd import ops
+    rng = np.random.default_rng(tile_items + c)
+    n_rows, n_pix, D = 3000, 600, 20
+    # heavy tail: a few rows with thousands of points, many singletons, 60 % empty rows
+    rows = np.concatenate([np.full(5000, 7), np.full(2100, 8), np.full(3000, 1500), np.full(700, 2999),
+                           rng.choice(n_rows, 400, replace=False).repeat(rng.integers(1, 9, 400))])
+    rows = np.sort(rows).astype(np.int32)
+    npts = rows.size
+    rd = rng.integers(0, n_pix * D, npts).astype(np.int32)
+    rf = rng.integers(0, n_pix, npts).astype(np.int32)
+    st, ln = O.run_length(rows)
+    depth = rng.random((1, 1, D, 20, 30), dtype=np.float32)
+    feat = rng.standard_normal((1, 1, 20, 30, c), dtype=np.float32)
+    want = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rows, (1, 1, 1, n_rows, c), st, ln).reshape(n_rows, c)
+    row_ptr = ops.csr_from_sorted_keys(t(rows, cuda), n_rows)
+    assert np.array_equal(np.diff(row_ptr.cpu().numpy()), np.bincount(rows, minlength=n_rows))
+    tiles = ops.csr_tiles(row_ptr, npts, tile_items)
+    tr = tiles.cpu().numpy()
+    assert tr[0] == 0 and tr[-1] == n_rows and np.all(np.diff(tr) >= 0)
+    outs = []
+    for tile_arg in (tiles, None, tiles):
+        out = torch.full((n_rows, c), float("nan"), device=cuda)        # every row must be written
+        ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out, tile_arg)
+        outs.append(out.cpu().numpy())
+    np.testing.assert_allclose(outs[0], want, rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(outs[1], want, rtol=1e-5, atol=2e-4)
+    assert np.array_equal(outs[0], outs[2])
+
+
+def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
+    from omnihd_amd import ops
+    depth = torch.rand(1, 1, 2, 2, 2, device=cuda)
+    feat = torch.randn(1, 1, 2, 2, 64, device=cuda)
+    e = torch.empty(0, dtype=torch.int32, device=cuda)
+    row_ptr = ops.csr_from_sorted_keys(e, 1000)
+    out = torch.full((1000, 64), 3.0, device=cuda)
+    ops.bev_pool_v2_forward_csr(depth, feat, e, e, row_ptr, out, ops.csr_tiles(row_ptr, 0, 128))
+    assert out.abs().sum() == 0
+    rows = torch.zeros(5000, dtype=torch.int32, device=cuda)             # one row holds everything
+    rd = torch.randint(0, 8, (5000,), dtype=torch.int32, device=cuda)
+    rf = torch.randint(0, 4, (5000,), dtype=torch.int32, device=cuda)
+    row_ptr = ops.csr_from_sorted_keys(rows, 1)
+    out = torch.empty(1, 64, device=cuda)
+    ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out, ops.csr_tiles(row_ptr, 5000, 256))
+    want = (depth.view(-1)[rd.long()][:, None].double() * feat.view(4, 64)[rf.long()].double()).sum(0)
+    torch.testing.assert_close(out[0].double(), want, rtol=1e-5, atol=1e-4)
+
+
 def test_against_reference_kernels_compiled_by_hipcc(cuda):
     """oracle/_ref = the reference's bev_pool_cuda.cu compiled unmodified for gfx950."""
     ref = RefKernels()
