@@ -511,7 +511,8 @@ extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                           float* out, int c, int n_rows, void* stream) {
   OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0, "c > 0 and n_rows >= 0");
   if (n_rows == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(depth && feat && ranks_depth && ranks_feat && row_ptr && out, "null pointer");
+  // ranks_* may be null when the plan holds no point at all (every row is then written as zeros)
+  OMNIHD_REQUIRE(depth && feat && row_ptr && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (tile_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out)) {
     const int tiles_per_xcd = (n_tiles + 7) / 8;

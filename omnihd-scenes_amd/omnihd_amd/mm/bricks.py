@@ -1,0 +1,101 @@
+"""Layer builders with mmcv's call signatures: build_norm_layer, build_conv_layer, ConvModule."""
+import torch
+from torch import nn
+
+from .registry import NORM_LAYERS
+
+
+def _register_default_norms():
+    from .sync_bn import NaiveSyncBatchNorm1d, NaiveSyncBatchNorm2d, NaiveSyncBatchNorm3d
+    for name, cls in [("BN", nn.BatchNorm2d), ("BN1d", nn.BatchNorm1d), ("BN2d", nn.BatchNorm2d),
+                      ("BN3d", nn.BatchNorm3d), ("SyncBN", nn.SyncBatchNorm), ("GN", nn.GroupNorm),
+                      ("naiveSyncBN1d", NaiveSyncBatchNorm1d), ("naiveSyncBN2d", NaiveSyncBatchNorm2d),
+                      ("naiveSyncBN3d", NaiveSyncBatchNorm3d)]:
+        if name not in NORM_LAYERS:
+            NORM_LAYERS.register_module(name=name, module=cls)
+
+
+_ABBR = {"BN": "bn", "BN1d": "bn", "BN2d": "bn", "BN3d": "bn", "SyncBN": "bn", "GN": "gn",
+         "naiveSyncBN1d": "bn", "naiveSyncBN2d": "bn", "naiveSyncBN3d": "bn"}
+
+
+def build_norm_layer(cfg, num_features, postfix=""):
+    """-> (name, layer); cfg = dict(type=..., requires_grad=True, eps=..., momentum=...)."""
+    _register_default_norms()
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    cls = NORM_LAYERS.get(t)
+    if cls is None:
+        raise KeyError(f"unknown norm layer type {t}")
+    requires_grad = cfg.pop("requires_grad", True)
+    cfg.setdefault("eps", 1e-5)
+    if t == "GN":
+        layer = cls(num_channels=num_features, **cfg)
+    else:
+        layer = cls(num_features, **cfg)
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return _ABBR.get(t, "norm") + str(postfix), layer
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    """cfg None / dict(type='Conv2d') -> nn.Conv2d; dict(type='DCN', ...) -> DeformConv2dPack.
+    Extra keys of cfg are forwarded to the layer, as mmcv does."""
+    if cfg is None:
+        return nn.Conv2d(*args, **kwargs)
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    if t in ("Conv2d", "Conv"):
+        return nn.Conv2d(*args, **kwargs, **cfg)
+    if t == "DCN":
+        from .dcn import DeformConv2dPack
+        return DeformConv2dPack(*args, **kwargs, **cfg)
+    raise KeyError(f"unknown conv layer type {t}")
+
+
+def build_activation(cfg):
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    if t == "ReLU":
+        return nn.ReLU(**cfg)
+    if t == "Sigmoid":
+        return nn.Sigmoid()
+    raise KeyError(f"unknown activation {t}")
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> act with mmcv's attribute names (``.conv``, ``.bn``, ``.activate``) so that
+    state-dict keys such as ``reduc_conv.conv.weight`` / ``reduc_conv.bn.weight`` match."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias="auto", conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), inplace=True):
+        super().__init__()
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == "auto":
+            bias = not self.with_norm
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation, groups=groups, bias=bias)
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            a = dict(act_cfg)
+            if a["type"] == "ReLU":
+                a.setdefault("inplace", inplace)
+            self.activate = build_activation(a)
+        nn.init.kaiming_normal_(self.conv.weight, mode="fan_out", nonlinearity="relu")
+        if getattr(self.conv, "bias", None) is not None:
+            nn.init.zeros_(self.conv.bias)
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.with_norm else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.norm(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
