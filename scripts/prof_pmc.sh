@@ -15,3 +15,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum
 done
 python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# keep only small artefacts (gpurun copies back at most 64 MiB)
+find "$OUT" -type f -size +2M -delete
+find "$OUT" -name "*.db" -delete
+du -sh "$OUT"
