@@ -115,6 +115,7 @@ class BevOps:
         self.ops, self.omnihd = ops, omnihd_amd
         self.dev, self.batch = dev, batch
         self.tiled = True
+        self.scheduled = True
         H, W, _ = RES[res]
         self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
         dx, bx, nx, frustum = lss_constants(res)
@@ -133,7 +134,7 @@ class BevOps:
             # private copies of the tables too, so that nothing is served from the Infinity Cache
             tabs = [x.clone() for x in (self.plan.ranks_depth, self.plan.ranks_feat, self.plan.row_ptr,
                                         self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
-                                        self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_row)]
+                                        self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_row, self.plan.tile_order)]
             self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
         rng = np.random.default_rng(seed)
         self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
@@ -141,7 +142,8 @@ class BevOps:
 
     def pool_fwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
-        self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out, tb[8] if self.tiled else None)
+        self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out, tb[8] if self.tiled else None,
+                                         tb[9] if (self.tiled and self.scheduled) else None)
 
     def pool_bwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]

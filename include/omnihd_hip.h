@@ -83,11 +83,14 @@ int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const floa
  * tile_row/n_tiles (from omnihd_csr_tiles; may be NULL/0) select the load-balanced tiled
  * kernel: each workgroup owns a run of whole rows holding ~tile_items points+rows and splits
  * it evenly over its lanes; rows cut by that split are combined in a fixed order (so a row's
- * sum may be associated differently from the table order; run-to-run deterministic).       */
+ * sum may be associated differently from the table order; run-to-run deterministic).
+ * tile_order (may be NULL) is the launch schedule: 8 * ceil(n_tiles/8) ints; entry
+ * [x * ceil(n_tiles/8) + i] names the i-th tile worked on by XCD x (-1 = idle slot).  Each
+ * tile must appear exactly once.  It only affects speed (L2 locality), never results.       */
 int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                const int* ranks_depth, const int* ranks_feat,
-                               const int* row_ptr, const int* tile_row, int n_tiles,
-                               float* out, int c, int n_rows, void* stream);
+                               const int* row_ptr, const int* tile_row, const int* tile_order,
+                               int n_tiles, float* out, int c, int n_rows, void* stream);
 
 /* tile_row[k] (k in [0,n_tiles]) = first row r with r + row_ptr[r] >= k*tile_items;
  * n_tiles must equal ceil((n_rows + n_points) / tile_items); 64 <= tile_items <= 2048.     */

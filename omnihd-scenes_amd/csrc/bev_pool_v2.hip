@@ -79,12 +79,13 @@ __device__ __forceinline__ float4 pool_range(const float* __restrict__ depth,
   return acc;
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void store_row(float4* p, float4 v, bool streaming) {
   if (streaming) {
-    __builtin_nontemporal_store(v.x, &p->x);
-    __builtin_nontemporal_store(v.y, &p->y);
-    __builtin_nontemporal_store(v.z, &p->z);
-    __builtin_nontemporal_store(v.w, &p->w);
+    // one global_store_dwordx4 ... nt: the BEV tensor is written once and never re-read here
+    f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
   } else {
     *p = v;
   }
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     const float* __restrict__ depth, const float4* __restrict__ feat4,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
     const int* __restrict__ row_ptr, const int* __restrict__ tile_row,
-    float4* __restrict__ out4, int n_tiles, int tiles_per_xcd) {
+    const int* __restrict__ tile_order, float4* __restrict__ out4, int n_tiles,
+    int tiles_per_xcd) {
   constexpr int G = kBlock / C4;
   __shared__ int s_rp[kMaxTileItems + 1];
   __shared__ float4 s_head[kBlock];
@@ -201,10 +203,13 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   __shared__ int s_tail_row[G];
 
   // XCD-aware tile choice: workgroup b runs on XCD b % 8 (observed dispatch rule, used for
-  // locality only); give every XCD one contiguous chunk of tiles = one BEV band, so the image
-  // feature rows it gathers stay resident in ITS 4 MiB L2.
-  const int t = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd || t >= n_tiles) return;
+  // locality only).  Slot (xcd, i) of the schedule names the tile; the plan orders the schedule
+  // so that one XCD works on tiles that gather from the same image columns (its 4 MiB L2 then
+  // holds the feature rows it needs).  Without a schedule: contiguous chunk of tiles per XCD.
+  const int slot = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+  const int t = tile_order ? tile_order[slot] : slot;
+  if (t < 0 || t >= n_tiles) return;
 
   const int tid = threadIdx.x;
   const int sub = tid % C4;
@@ -250,27 +255,34 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     cur_end = s_rp[min(r + 1, nrows)];
   };
 
+  // 3-stage software pipeline over chunks of C4 points:
+  //   chunk k+2: rank loads issued;  chunk k+1: depth gather issued;  chunk k: feature gathers.
+  auto load_rd = [&](int q) { return q < p1 ? ranks_depth[q] : 0; };
+  auto load_rf = [&](int q) { return q < p1 ? ranks_feat[q] : 0; };
+  int rf_cur = load_rf(p + sub);
+  int rd_cur = load_rd(p + sub);
+  int rf_n1 = load_rf(p + C4 + sub);
+  int rd_n1 = load_rd(p + C4 + sub);
+  float d_cur = (p + sub < p1) ? depth[rd_cur] : 0.f;
+
   while (p < p1) {
     const int n = min(C4, p1 - p);
-    int my_rf = 0;
-    float my_d = 0.f;
-    if (sub < n) {
-      my_rf = ranks_feat[p + sub];
-      my_d = depth[ranks_depth[p + sub]];
-    }
-    for (int j = 0; j < n; j += 4) {
-      float4 v[4];
-      float d[4];
+    const int rf_n2 = load_rf(p + 2 * C4 + sub);
+    const int rd_n2 = load_rd(p + 2 * C4 + sub);
+    const float d_n1 = (p + C4 + sub < p1) ? depth[rd_n1] : 0.f;
+    for (int j = 0; j < n; j += 8) {
+      float4 v[8];
+      float d[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int jj = min(j + u, n - 1);
-        const int f = __shfl(my_rf, jj, C4);
-        d[u] = __shfl(my_d, jj, C4);
+        const int f = __shfl(rf_cur, jj, C4);
+        d[u] = __shfl(d_cur, jj, C4);
         v[u] = feat4[(size_t)f * C4 + sub];
       }
-      const int m = min(4, n - j);
+      const int m = min(8, n - j);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         if (u < m) {
           while (p == cur_end && r < r1) emit();
           acc = fma4(d[u], v[u], acc);
@@ -278,6 +290,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
         }
       }
     }
+    rf_cur = rf_n1; d_cur = d_n1;
+    rf_n1 = rf_n2; rd_n1 = rd_n2;
   }
   while (r < r1) emit();
   s_tail[tid] = acc;
@@ -507,8 +521,9 @@ extern "C" int omnihd_csr_tiles(const int* row_ptr, int n_rows, int n_points, in
 
 extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                           const int* ranks_depth, const int* ranks_feat,
-                                          const int* row_ptr, const int* tile_row, int n_tiles,
-                                          float* out, int c, int n_rows, void* stream) {
+                                          const int* row_ptr, const int* tile_row,
+                                          const int* tile_order, int n_tiles, float* out, int c,
+                                          int n_rows, void* stream) {
   OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0, "c > 0 and n_rows >= 0");
   if (n_rows == 0) return OMNIHD_OK;
   // ranks_* may be null when the plan holds no point at all (every row is then written as zeros)
@@ -522,7 +537,8 @@ extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
 #define OMNIHD_TILE_CASE(C4)                                                                   \
   case C4:                                                                                     \
     hipLaunchKernelGGL((k_pool_fwd_tiles<C4>), grid, dim3(kBlock), 0, st, depth, f4,           \
-                       ranks_depth, ranks_feat, row_ptr, tile_row, o4, n_tiles, tiles_per_xcd); \
+                       ranks_depth, ranks_feat, row_ptr, tile_row, tile_order, o4, n_tiles,    \
+                       tiles_per_xcd);                                                         \
     break;
     switch (c / 4) {
       OMNIHD_TILE_CASE(1)

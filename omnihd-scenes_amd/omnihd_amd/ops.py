@@ -79,7 +79,7 @@ def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_dep
               "omnihd_bev_pool_v2_bwd")
 
 
-def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, tile_row=None):
+def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, tile_row=None, tile_order=None):
     """Dense forward: every row of ``out`` (n_rows = row_ptr.numel()-1, C = feat.size(-1)) is written.
     With ``tile_row`` (from :func:`csr_tiles`) the load-balanced tiled kernel is used."""
     _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
@@ -93,10 +93,17 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
     if tile_row is not None:
         _want(tile_row, torch.int32, "tile_row")
         n_tiles = tile_row.numel() - 1
+        if tile_order is not None:
+            _want(tile_order, torch.int32, "tile_order")
+            if tile_order.numel() != 8 * ((n_tiles + 7) // 8):
+                raise ValueError("tile_order must have 8*ceil(n_tiles/8) entries")
+    else:
+        tile_order = None
     dev = _same_device(depth, feat, out, ranks_depth, ranks_feat, row_ptr)
     with torch.cuda.device(dev):
         check(lib().omnihd_bev_pool_v2_fwd_csr(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat),
-                                               _ptr(row_ptr), _ptr(tile_row), n_tiles, _ptr(out), c, n_rows, _stream()),
+                                               _ptr(row_ptr), _ptr(tile_row), _ptr(tile_order), n_tiles, _ptr(out),
+                                               c, n_rows, _stream()),
               "omnihd_bev_pool_v2_fwd_csr")
 
 

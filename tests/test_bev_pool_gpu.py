@@ -190,14 +190,20 @@ def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
     tiles = ops.csr_tiles(row_ptr, npts, tile_items)
     tr = tiles.cpu().numpy()
     assert tr[0] == 0 and tr[-1] == n_rows and np.all(np.diff(tr) >= 0)
+    from omnihd_amd.plan import tile_schedule
+    order = tile_schedule(row_ptr, tiles, t(rf, cuda), (20, 30))
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o[o >= 0]), np.arange(tiles.numel() - 1))     # every tile exactly once
     outs = []
-    for tile_arg in (tiles, None, tiles):
+    for tile_arg, order_arg in ((tiles, None), (None, None), (tiles, None), (tiles, order)):
         out = torch.full((n_rows, c), float("nan"), device=cuda)        # every row must be written
-        ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out, tile_arg)
+        ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out, tile_arg,
+                                    order_arg)
         outs.append(out.cpu().numpy())
     np.testing.assert_allclose(outs[0], want, rtol=1e-5, atol=2e-4)
     np.testing.assert_allclose(outs[1], want, rtol=1e-5, atol=2e-4)
-    assert np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[2])          # run-to-run identical
+    assert np.array_equal(outs[0], outs[3])          # the schedule never changes results
 
 
 def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
