@@ -72,7 +72,7 @@ int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const floa
                            float* depth_grad, float* feat_grad, int c, int n_intervals,
                            void* stream);
 
-/* Fused forward used by our own LSS module (no reference counterpart: it removes the
+/* Fused dense forward used by our own LSS module (no reference counterpart: it removes the
  * reference's zero-fill (bev_pool.py:27), permute copy (:91) and s2c concat copy
  * (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:374-376)).
  * The points are grouped by OUTPUT ROW in CSR form: row r owns points
@@ -80,22 +80,29 @@ int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const floa
  * written (zeros for empty rows), so `out` needs no initialisation.  The row numbering is
  * whatever the plan builder chose (reference (b,z,y,x) order, or (b,y,x,z) = channels-last
  * of the s2c tensor).
- * tile_row/n_tiles (from omnihd_csr_tiles; may be NULL/0) select the load-balanced tiled
- * kernel: each workgroup owns a run of whole rows holding ~tile_items points+rows and splits
- * it evenly over its lanes; rows cut by that split are combined in a fixed order (so a row's
- * sum may be associated differently from the table order; run-to-run deterministic).
- * tile_order (may be NULL) is the launch schedule: 8 * ceil(n_tiles/8) ints; entry
- * [x * ceil(n_tiles/8) + i] names the i-th tile worked on by XCD x (-1 = idle slot).  Each
- * tile must appear exactly once.  It only affects speed (L2 locality), never results.       */
+ *   ranks_row[p]  (n_points ints) output row of point p (the sorted keys of omnihd_sort_ranks);
+ *   tile_row      (n_tiles+1 ints, from omnihd_csr_tiles) work partition into runs of whole rows;
+ *   tile_order    (8*ceil(n_tiles/8) ints or NULL) launch schedule: entry [x*ceil(n_tiles/8)+i]
+ *                 names the i-th tile worked on by XCD x (-1 = idle slot); every tile must appear
+ *                 exactly once; it only affects speed (L2 locality), never results.
+ * With ranks_row and tile_row the load-balanced tiled kernel runs (rows cut by the in-tile work
+ * split are combined in a fixed order: a row's sum may be associated differently from table
+ * order, run-to-run deterministic).  With either NULL a simple row-per-lane-group kernel runs. */
 int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                const int* ranks_depth, const int* ranks_feat,
-                               const int* row_ptr, const int* tile_row, const int* tile_order,
-                               int n_tiles, float* out, int c, int n_rows, void* stream);
+                               const int* ranks_row, const int* row_ptr,
+                               const int* tile_row, const int* tile_order, int n_tiles,
+                               float* out, int c, int n_rows, int n_points, void* stream);
 
-/* tile_row[k] (k in [0,n_tiles]) = first row r with r + row_ptr[r] >= k*tile_items;
- * n_tiles must equal ceil((n_rows + n_points) / tile_items); 64 <= tile_items <= 2048.     */
-int omnihd_csr_tiles(const int* row_ptr, int n_rows, int n_points, int tile_items,
-                     int* tile_row, int n_tiles, void* stream);
+/* Work partition for the tiled forward: tile_row[0..n_tiles] (capacity n_rows+1 ints) with
+ * tile k = rows [tile_row[k], tile_row[k+1]).  A tile closes when rows+points reach a multiple
+ * of tile_items; a row with more than long_len points is a tile of its own.  The kernel needs
+ * tile_items + long_len <= 1280 for its fast path.  count (device int) = n_tiles; h_count, if
+ * non-null, receives it after a stream synchronisation.                                      */
+size_t omnihd_csr_tiles_workspace_bytes(int n_rows);
+int omnihd_csr_tiles(const int* row_ptr, int n_rows, int tile_items, int long_len,
+                     int* tile_row, int* count, int* h_count, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * bev_pool (v1) — imported by the plugin at load time (projects/mmdet3d_plugin/__init__.py:20)

@@ -20,6 +20,7 @@
 // Arithmetic: one fmaf per (point, channel) in table order, i.e. the same rounding chain as
 // the reference's `psum += feat * depth` under nvcc's default contraction.
 #include "common.h"
+#include <stdlib.h>
 
 namespace omnihd {
 namespace {
@@ -169,34 +170,39 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd(
 
 
 // ---------------------------------------------------------------------------------------------
-// Tiled dense forward ("workgroup merge path").
+// Tiled dense forward.
 //
-// A TILE is a run of whole output rows whose merged item sequence
-//     [points of row r ..., END(r)]  for r = Ra .. Rb-1
-// has about `tile_items` items (tile boundaries come from the plan: tile_row[k] = first row with
-// r + row_ptr[r] >= k * tile_items).  One workgroup owns one tile:
-//   1. row_ptr[Ra..Rb] is staged in LDS with one coalesced read;
-//   2. the item sequence is cut into G equal pieces, one per group of C4 lanes (binary search on
-//      the LDS copy) — every group does the same amount of work no matter how the points are
-//      distributed over rows (near-ego voxels hold thousands of points, 40 % of the rows none);
-//   3. a group streams its points: rank tables are read coalesced C4 points at a time, depth is
-//      gathered by C4 lanes in parallel, 4 feature-row gathers are kept in flight; rows that
-//      start and end inside the piece are stored straight to HBM (one 16 B x C4 = 256 B store);
-//   4. a row cut by a piece boundary leaves a partial in LDS; after one barrier the group that
-//      saw the row's END adds the partials in piece order and stores the row.
+// A TILE is a run of whole output rows (tile_row[t] .. tile_row[t+1]) that holds at most kCap
+// points, or one single row of any length; the plan builds tiles of ~tile_items points+rows so
+// every workgroup gets the same amount of work although 40 % of the BEV rows are empty and a few
+// near-ego rows hold thousands of points.  One workgroup per tile, three phases:
+//   Z  empty rows of the tile are zero-filled (row_ptr read coalesced, 16 B x C4 stores);
+//   L  ALL 256 lanes stage the tile's points in LDS as 16-byte records
+//        { pixel row index, depth value (gathered here), output row, last-point-of-row flag }
+//      -> rank tables are read once, coalesced; the dependent depth gather runs 256-wide;
+//   P  the points are cut into G equal pieces, one per group of C4 lanes.  A group reads one
+//      record (one broadcast ds_read_b128), gathers the 16 B x C4 feature row (8 gathers kept in
+//      flight), accumulates, and on a last-point flag stores the finished row (256 B for C=64).
+//      A row cut by a piece boundary leaves partials in LDS which are added in piece order after
+//      one barrier.
 // No atomics, no dependence on dispatch order: results are run-to-run identical.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxTileItems = 2048;
+constexpr int kCap = 1280;   // LDS point records per workgroup (20 KiB)
 
-template <int C4>
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+template <int C4, int U>
 __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     const float* __restrict__ depth, const float4* __restrict__ feat4,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
-    const int* __restrict__ row_ptr, const int* __restrict__ tile_row,
-    const int* __restrict__ tile_order, float4* __restrict__ out4, int n_tiles,
-    int tiles_per_xcd) {
+    const int* __restrict__ ranks_row, const int* __restrict__ row_ptr,
+    const int* __restrict__ tile_row, const int* __restrict__ tile_order,
+    float4* __restrict__ out4, int n_tiles, int tiles_per_xcd, int n_points_total) {
   constexpr int G = kBlock / C4;
-  __shared__ int s_rp[kMaxTileItems + 1];
+  constexpr int GPW = 64 / C4;   // groups per wavefront
+  __shared__ int4 s_rec[kCap];
   __shared__ float4 s_head[kBlock];
   __shared__ float4 s_tail[kBlock];
   __shared__ int s_head_row[G];
@@ -216,115 +222,135 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   const int grp = tid / C4;
   const int Ra = tile_row[t];
   const int nrows = tile_row[t + 1] - Ra;
-  for (int i = tid; i <= nrows; i += kBlock) s_rp[i] = row_ptr[Ra + i];
+  const int Pa = row_ptr[Ra];
+  const int npts = row_ptr[Ra + nrows] - Pa;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- phase Z: zero-fill the empty rows ------------------------------------------------------
+  if (npts < nrows || nrows > 1) {
+    const int lane = tid & 63;
+    const int gw = lane / C4;
+    for (int base = 0; base < nrows; base += kBlock) {
+      const int i = base + tid;
+      bool empty = false;
+      if (i < nrows) empty = row_ptr[Ra + i + 1] == row_ptr[Ra + i];
+      const unsigned long long m = __ballot(empty);
+      if (m == 0ull) continue;
+      const int wave_row0 = Ra + base + (tid & ~63);
+      for (int k = 0; k < 64; k += GPW) {
+        const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
+        if (window == 0ull) continue;
+        if ((m >> (k + gw)) & 1ull)
+          store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
+      }
+    }
+  }
+  if (npts == 0) return;
+
+  float4 acc = zero4;
+
+  // ---- a single long row: windows of kCap points, every group accumulates, one combine --------
+  if (nrows == 1 && npts > kCap) {
+    for (int base = 0; base < npts; base += kCap) {
+      const int n = min(kCap, npts - base);
+      for (int i = tid; i < n; i += kBlock) {
+        const int q = Pa + base + i;
+        s_rec[i] = make_int4(ranks_feat[q], __float_as_int(depth[ranks_depth[q]]), 0, 0);
+      }
+      __syncthreads();
+      const int cw = (n + G - 1) / G;
+      const int j0 = min(grp * cw, n), j1 = min(j0 + cw, n);
+      for (int j = j0; j < j1; j += U) {
+        float4 v[U];
+        float d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int4 rc = s_rec[min(j + u, j1 - 1)];
+          d[u] = (j + u < j1) ? __int_as_float(rc.y) : 0.f;
+          v[u] = feat4[(size_t)rc.x * C4 + sub];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fma4(d[u], v[u], acc);
+      }
+      __syncthreads();
+    }
+    s_tail[tid] = acc;
+    __syncthreads();
+    if (grp == 0) {
+      float4 tsum = s_tail[sub];
+      for (int g = 1; g < G; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
+      store_row(out4 + (size_t)Ra * C4 + sub, tsum, true);
+    }
+    return;
+  }
+
+  // ---- a tile that does not fit the LDS window (only for foreign tile tables): row by row -----
+  if (npts > kCap) {
+    for (int r = Ra + grp; r < Ra + nrows; r += G) {
+      const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
+      if (len > 0)
+        store_row(out4 + (size_t)r * C4 + sub,
+                  pool_range<C4>(depth, feat4, ranks_depth, ranks_feat, s0, len, sub), true);
+    }
+    return;
+  }
+
+  // ---- phase L: stage the tile's point records in LDS ------------------------------------------
+  for (int i = tid; i < npts; i += kBlock) {
+    const int q = Pa + i;
+    const int row = ranks_row[q];
+    const int nxt = (q + 1 < n_points_total) ? ranks_row[q + 1] : -1;
+    s_rec[i] = make_int4(ranks_feat[q], __float_as_int(depth[ranks_depth[q]]), row, row != nxt);
+  }
   if (tid < G) s_head_row[tid] = -1;
   __syncthreads();
 
-  const int Pa = s_rp[0];
-  const int items = nrows + (s_rp[nrows] - Pa);
-  const int w = (items + G - 1) / G;
-  const int d0 = min(grp * w, items);
-  const int d1 = min(d0 + w, items);
-  // rows whose END lies before item d:  #{k : (s_rp[k+1] - Pa) + k < d}
-  auto split = [&](int d) {
-    int lo = 0, hi = nrows;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (s_rp[mid + 1] - Pa + mid < d) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-  };
-  int r = split(d0);
-  const int r1 = split(d1);
-  int p = Pa + d0 - r;
-  const int p1 = Pa + d1 - r1;
-  int cur_end = s_rp[min(r + 1, nrows)];
-  bool head_pending = (r < nrows) && (p > s_rp[r]);   // piece starts inside row r
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  auto emit = [&]() {   // END(r): the row is complete as far as this piece can tell
-    if (head_pending) {
-      s_head[tid] = acc;
-      if (sub == 0) s_head_row[grp] = r;
-      head_pending = false;
-    } else {
-      store_row(out4 + (size_t)(Ra + r) * C4 + sub, acc, true);
-    }
-    acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    ++r;
-    cur_end = s_rp[min(r + 1, nrows)];
-  };
-
-  // 3-stage software pipeline over chunks of C4 points:
-  //   chunk k+2: rank loads issued;  chunk k+1: depth gather issued;  chunk k: feature gathers.
-  auto load_rd = [&](int q) { return q < p1 ? ranks_depth[q] : 0; };
-  auto load_rf = [&](int q) { return q < p1 ? ranks_feat[q] : 0; };
-  int rf_cur = load_rf(p + sub);
-  int rd_cur = load_rd(p + sub);
-  int rf_n1 = load_rf(p + C4 + sub);
-  int rd_n1 = load_rd(p + C4 + sub);
-  float d_cur = (p + sub < p1) ? depth[rd_cur] : 0.f;
-
-  while (p < p1) {
-    const int n = min(C4, p1 - p);
-    const int rf_n2 = load_rf(p + 2 * C4 + sub);
-    const int rd_n2 = load_rd(p + 2 * C4 + sub);
-    const float d_n1 = (p + C4 + sub < p1) ? depth[rd_n1] : 0.f;
-    for (int j = 0; j < n; j += 8) {
-      float4 v[8];
-      float d[8];
+  // ---- phase P: equal pieces of the point list, one per group ----------------------------------
+  const int w = (npts + G - 1) / G;
+  const int i0 = min(grp * w, npts);
+  const int i1 = min(i0 + w, npts);
+  // my first point continues a row that an earlier piece started
+  bool head_pending = (i0 > 0) && (i0 < i1) && (s_rec[i0 - 1].w == 0);
+  for (int i = i0; i < i1; i += U) {
+    float4 v[U];
+    float d[U];
+    int rw[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int jj = min(j + u, n - 1);
-        const int f = __shfl(rf_cur, jj, C4);
-        d[u] = __shfl(d_cur, jj, C4);
-        v[u] = feat4[(size_t)f * C4 + sub];
-      }
-      const int m = min(8, n - j);
+    for (int u = 0; u < U; ++u) {
+      const int4 rc = s_rec[min(i + u, i1 - 1)];
+      d[u] = __int_as_float(rc.y);
+      rw[u] = rc.w ? rc.z : -1;          // output row if this point closes it
+      v[u] = feat4[(size_t)rc.x * C4 + sub];
+    }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (u < m) {
-          while (p == cur_end && r < r1) emit();
-          acc = fma4(d[u], v[u], acc);
-          ++p;
+    for (int u = 0; u < U; ++u) {
+      if (i + u < i1) {
+        acc = fma4(d[u], v[u], acc);
+        if (rw[u] >= 0) {
+          if (head_pending) {
+            s_head[tid] = acc;
+            if (sub == 0) s_head_row[grp] = rw[u];
+            head_pending = false;
+          } else {
+            store_row(out4 + (size_t)rw[u] * C4 + sub, acc, true);
+          }
+          acc = zero4;
         }
       }
     }
-    rf_cur = rf_n1; d_cur = d_n1;
-    rf_n1 = rf_n2; rd_n1 = rd_n2;
   }
-  while (r < r1) emit();
   s_tail[tid] = acc;
-  if (sub == 0) s_tail_row[grp] = r;
+  if (sub == 0) s_tail_row[grp] = (i1 > i0 && s_rec[i1 - 1].w == 0) ? s_rec[i1 - 1].z : -2;
   __syncthreads();
 
   const int hr = s_head_row[grp];
   if (hr >= 0) {
     int g0 = grp;
     while (g0 > 0 && s_tail_row[g0 - 1] == hr) --g0;
-    float4 tsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g = g0; g < grp; ++g) {
-      const float4 q = s_tail[g * C4 + sub];
-      tsum.x += q.x; tsum.y += q.y; tsum.z += q.z; tsum.w += q.w;
-    }
-    const float4 h = s_head[tid];
-    tsum.x += h.x; tsum.y += h.y; tsum.z += h.z; tsum.w += h.w;
-    store_row(out4 + (size_t)(Ra + hr) * C4 + sub, tsum, true);
-  }
-}
-
-// tile_row[k] = first row r with r + row_ptr[r] >= k * tile_items  (k = 0 .. n_tiles)
-__global__ __launch_bounds__(kBlock) void k_csr_tiles(const int* __restrict__ row_ptr, int n_rows,
-                                                      int tile_items, int n_tiles,
-                                                      int* __restrict__ tile_row) {
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k <= n_tiles; k += gridDim.x * kBlock) {
-    const long long target = (long long)k * tile_items;
-    int lo = 0, hi = n_rows;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((long long)mid + row_ptr[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    tile_row[k] = (k == n_tiles) ? n_rows : lo;
+    float4 tsum = zero4;
+    for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
+    tsum = add4(tsum, s_head[tid]);
+    store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
   }
 }
 
@@ -507,38 +533,34 @@ extern "C" int omnihd_bev_pool_v2_fwd(const float* depth, const float* feat,
                            interval_lengths, out, c, n_intervals, (hipStream_t)stream);
 }
 
-extern "C" int omnihd_csr_tiles(const int* row_ptr, int n_rows, int n_points, int tile_items,
-                                int* tile_row, int n_tiles, void* stream) {
-  OMNIHD_REQUIRE(n_rows >= 0 && n_points >= 0 && tile_items >= 64 && tile_items <= kMaxTileItems,
-                 "64 <= tile_items <= 2048");
-  OMNIHD_REQUIRE(row_ptr && tile_row, "null pointer");
-  const long long items = (long long)n_rows + n_points;
-  OMNIHD_REQUIRE(n_tiles == (int)((items + tile_items - 1) / tile_items), "n_tiles != ceil((n_rows+n_points)/tile_items)");
-  hipLaunchKernelGGL(k_csr_tiles, dim3(grid_for((int64_t)n_tiles + 1, kBlock)), dim3(kBlock), 0,
-                     (hipStream_t)stream, row_ptr, n_rows, tile_items, n_tiles, tile_row);
-  return check_launch("csr_tiles");
-}
-
 extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                           const int* ranks_depth, const int* ranks_feat,
-                                          const int* row_ptr, const int* tile_row,
-                                          const int* tile_order, int n_tiles, float* out, int c,
-                                          int n_rows, void* stream) {
+                                          const int* ranks_row, const int* row_ptr,
+                                          const int* tile_row, const int* tile_order, int n_tiles,
+                                          float* out, int c, int n_rows, int n_points,
+                                          void* stream) {
   OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0, "c > 0 and n_rows >= 0");
   if (n_rows == 0) return OMNIHD_OK;
   // ranks_* may be null when the plan holds no point at all (every row is then written as zeros)
   OMNIHD_REQUIRE(depth && feat && row_ptr && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (tile_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out)) {
+  OMNIHD_REQUIRE(n_points >= 0, "n_points >= 0");
+  if (tile_row != nullptr && ranks_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out)) {
     const int tiles_per_xcd = (n_tiles + 7) / 8;
     const dim3 grid(tiles_per_xcd * 8);
+    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); return (e && atoi(e) == 8) ? 8 : 4; }();
     const float4* f4 = reinterpret_cast<const float4*>(feat);
     float4* o4 = reinterpret_cast<float4*>(out);
 #define OMNIHD_TILE_CASE(C4)                                                                   \
   case C4:                                                                                     \
-    hipLaunchKernelGGL((k_pool_fwd_tiles<C4>), grid, dim3(kBlock), 0, st, depth, f4,           \
-                       ranks_depth, ranks_feat, row_ptr, tile_row, tile_order, o4, n_tiles,    \
-                       tiles_per_xcd);                                                         \
+    if (unroll == 8)                                                                           \
+      hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 8>), grid, dim3(kBlock), 0, st, depth, f4,      \
+                         ranks_depth, ranks_feat, ranks_row, row_ptr, tile_row, tile_order,    \
+                         o4, n_tiles, tiles_per_xcd, n_points);                                \
+    else                                                                                       \
+      hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 4>), grid, dim3(kBlock), 0, st, depth, f4,      \
+                         ranks_depth, ranks_feat, ranks_row, row_ptr, tile_row, tile_order,    \
+                         o4, n_tiles, tiles_per_xcd, n_points);                                \
     break;
     switch (c / 4) {
       OMNIHD_TILE_CASE(1)

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/functional.hpp>
@@ -147,6 +148,23 @@ __global__ __launch_bounds__(kBlock) void k_perm_zyx_yxz(const int* __restrict__
     out[i] = ((b * ny + y) * nx + x) * nz + z;
   }
 }
+
+// A new tile starts at row r when the running item count (r + row_ptr[r] = rows + points before
+// r) crosses a multiple of tile_items, and around every LONG row (more than long_len points),
+// which always forms a tile of its own.
+struct TileStart {
+  const int* row_ptr;
+  int tile_items;
+  int long_len;
+  __host__ __device__ bool is_long(int r) const { return row_ptr[r + 1] - row_ptr[r] > long_len; }
+  __host__ __device__ int operator()(int r) const {
+    if (r == 0) return 1;
+    if (is_long(r) || is_long(r - 1)) return 1;
+    return ((long long)r + row_ptr[r]) / tile_items != ((long long)r - 1 + row_ptr[r - 1]) / tile_items;
+  }
+};
+
+__global__ void k_close_tiles(int* tile_row, const int* count, int n_rows) { tile_row[*count] = n_rows; }
 
 struct SortWs {
   size_t tmp_bytes;   // rocprim temporary storage (max over the calls we make)
@@ -285,4 +303,44 @@ extern "C" int omnihd_permute_rows_zyx_to_yxz(const int* rows_in, int64_t n, int
   hipLaunchKernelGGL(k_perm_zyx_yxz, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0,
                      (hipStream_t)stream, rows_in, n, nz, ny, nx, rows_out);
   return check_launch("permute_rows_zyx_to_yxz");
+}
+
+extern "C" size_t omnihd_csr_tiles_workspace_bytes(int n_rows) {
+  if (n_rows <= 0) return 256;
+  size_t b = 0;
+  TileStart ts{nullptr, 1, 1};
+  auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ts);
+  int* o = nullptr;
+  hipError_t e = rocprim::select(nullptr, b, rocprim::make_counting_iterator<int>(0), flags, o, o,
+                                 (size_t)n_rows, 0, false);
+  if (e != hipSuccess) { set_error("csr_tiles: size query: %s", hipGetErrorString(e)); return 0; }
+  return align_up(b, 256) + 256;
+}
+
+extern "C" int omnihd_csr_tiles(const int* row_ptr, int n_rows, int tile_items, int long_len,
+                                int* tile_row, int* count, int* h_count, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  OMNIHD_REQUIRE(n_rows > 0 && tile_items >= 16 && long_len >= 1, "sizes");
+  OMNIHD_REQUIRE(row_ptr && tile_row && count && workspace, "null pointer");
+  TileStart ts{row_ptr, tile_items, long_len};
+  auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ts);
+  size_t need = 0;
+  int* o = nullptr;
+  OMNIHD_HIP_TRY(rocprim::select(nullptr, need, rocprim::make_counting_iterator<int>(0), flags, o, o,
+                                 (size_t)n_rows, st, false));
+  if (workspace_bytes < need) {
+    set_error("csr_tiles: workspace %zu < required %zu", workspace_bytes, need);
+    return OMNIHD_ERR_WORKSPACE;
+  }
+  OMNIHD_HIP_TRY(rocprim::select(workspace, need, rocprim::make_counting_iterator<int>(0), flags,
+                                 tile_row, count, (size_t)n_rows, st, false));
+  hipLaunchKernelGGL(k_close_tiles, dim3(1), dim3(1), 0, st, tile_row, count, n_rows);
+  int rc = check_launch("csr_tiles");
+  if (rc != OMNIHD_OK) return rc;
+  if (h_count) {
+    OMNIHD_HIP_TRY(hipMemcpyAsync(h_count, count, sizeof(int), hipMemcpyDeviceToHost, st));
+    OMNIHD_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return OMNIHD_OK;
 }

@@ -79,9 +79,10 @@ def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_dep
               "omnihd_bev_pool_v2_bwd")
 
 
-def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, tile_row=None, tile_order=None):
+def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, ranks_row=None, tile_row=None,
+                            tile_order=None):
     """Dense forward: every row of ``out`` (n_rows = row_ptr.numel()-1, C = feat.size(-1)) is written.
-    With ``tile_row`` (from :func:`csr_tiles`) the load-balanced tiled kernel is used."""
+    With ``ranks_row`` + ``tile_row`` (from :func:`csr_tiles`) the load-balanced tiled kernel is used."""
     _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
     _want(ranks_depth, torch.int32, "ranks_depth"); _want(ranks_feat, torch.int32, "ranks_feat")
     _want(row_ptr, torch.int32, "row_ptr")
@@ -90,33 +91,37 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
     if out.numel() != n_rows * c:
         raise ValueError(f"out has {out.numel()} elements, expected {n_rows}*{c}")
     n_tiles = 0
-    if tile_row is not None:
-        _want(tile_row, torch.int32, "tile_row")
+    if tile_row is not None and ranks_row is not None:
+        _want(tile_row, torch.int32, "tile_row"); _want(ranks_row, torch.int32, "ranks_row")
         n_tiles = tile_row.numel() - 1
         if tile_order is not None:
             _want(tile_order, torch.int32, "tile_order")
             if tile_order.numel() != 8 * ((n_tiles + 7) // 8):
                 raise ValueError("tile_order must have 8*ceil(n_tiles/8) entries")
     else:
-        tile_order = None
+        tile_row = tile_order = ranks_row = None
     dev = _same_device(depth, feat, out, ranks_depth, ranks_feat, row_ptr)
     with torch.cuda.device(dev):
         check(lib().omnihd_bev_pool_v2_fwd_csr(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat),
-                                               _ptr(row_ptr), _ptr(tile_row), _ptr(tile_order), n_tiles, _ptr(out),
-                                               c, n_rows, _stream()),
+                                               _ptr(ranks_row), _ptr(row_ptr), _ptr(tile_row), _ptr(tile_order),
+                                               n_tiles, _ptr(out), c, n_rows, ranks_depth.numel(), _stream()),
               "omnihd_bev_pool_v2_fwd_csr")
 
 
-def csr_tiles(row_ptr, n_points, tile_items=512):
-    """Tile table for the tiled dense forward (see include/omnihd_hip.h)."""
+def csr_tiles(row_ptr, tile_items=768, long_len=512):
+    """Tile table for the tiled dense forward (see include/omnihd_hip.h): int32 [n_tiles+1]."""
     _want(row_ptr, torch.int32, "row_ptr")
     n_rows = row_ptr.numel() - 1
-    n_tiles = (n_rows + n_points + tile_items - 1) // tile_items
-    tile_row = torch.empty(n_tiles + 1, dtype=torch.int32, device=row_ptr.device)
-    with torch.cuda.device(row_ptr.device):
-        check(lib().omnihd_csr_tiles(_ptr(row_ptr), n_rows, n_points, tile_items, _ptr(tile_row), n_tiles, _stream()),
+    dev = row_ptr.device
+    tile_row = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    h = ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        ws = _workspace(lib().omnihd_csr_tiles_workspace_bytes(n_rows), dev)
+        check(lib().omnihd_csr_tiles(_ptr(row_ptr), n_rows, tile_items, long_len, _ptr(tile_row), _ptr(count),
+                                     ctypes.cast(ctypes.pointer(h), ctypes.c_void_p), _ptr(ws), ws.numel(), _stream()),
               "omnihd_csr_tiles")
-    return tile_row
+    return tile_row[:h.value + 1].clone()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -46,7 +46,8 @@ class BevPoolPlan:
         return int(self.interval_starts.numel())
 
 
-TILE_ITEMS = 512
+TILE_ITEMS = 768     # rows+points per tile of the tiled forward
+LONG_LEN = 512       # a row with more points is a tile of its own (TILE_ITEMS + LONG_LEN <= 1280)
 
 
 def tile_schedule(row_ptr, tile_row, ranks_feat, feat_hw=None, n_xcd=8):
@@ -98,7 +99,7 @@ def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=No
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X
     row_ptr = ops.csr_from_sorted_keys(rows, n_rows)
-    tile_row = ops.csr_tiles(row_ptr, int(rows.numel()), TILE_ITEMS)
+    tile_row = ops.csr_tiles(row_ptr, TILE_ITEMS, LONG_LEN)
     tile_order = tile_schedule(row_ptr, tile_row, rf, feat_hw)
     bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
     return BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, tile_row, tile_order,
@@ -145,7 +146,7 @@ class _PlannedPool(torch.autograd.Function):
         feat = feat.contiguous().float()
         out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
         ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
-                                    plan.tile_row, plan.tile_order)
+                                    plan.ranks_row, plan.tile_row, plan.tile_order)
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan
         return out

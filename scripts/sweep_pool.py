@@ -22,8 +22,8 @@ def main():
     t = bench.time_kernel(wl.pool_fwd, len(wl.sets), 40)
     print(f"untiled dense fwd : {t*1e6:8.1f} us  {nbytes/t/1e9:7.0f} GB/s")
     wl.tiled = True
-    for items in (256, 384, 512, 768, 1024, 1536, 2048):
-        tiles = ops.csr_tiles(wl.plan.row_ptr, wl.plan.n_points, items)
+    for items, long_len in ((256, 256), (384, 384), (512, 512), (768, 512), (1024, 256), (896, 384), (640, 640)):
+        tiles = ops.csr_tiles(wl.plan.row_ptr, items, long_len)
         order = P.tile_schedule(wl.plan.row_ptr, tiles, wl.plan.ranks_feat, (wl.fH, wl.fW))
         for s in wl.sets:
             s[6][8] = tiles.clone()
@@ -32,7 +32,7 @@ def main():
         for sched in (False, True):
             wl.scheduled = sched
             res_t.append(bench.time_kernel(wl.pool_fwd, len(wl.sets), 40))
-        print(f"tiled fwd W={items:5d}: banded {res_t[0]*1e6:7.1f} us {nbytes/res_t[0]/1e9:6.0f} GB/s | "
+        print(f"tiled fwd W={items:5d} L={long_len:4d}: banded {res_t[0]*1e6:7.1f} us {nbytes/res_t[0]/1e9:6.0f} GB/s | "
               f"column-scheduled {res_t[1]*1e6:7.1f} us {nbytes/res_t[1]/1e9:6.0f} GB/s  tiles {tiles.numel()-1}")
     t = bench.time_kernel(wl.pool_bwd, len(wl.sets), 40)
     print(f"bwd (incl. 2 memsets): {t*1e6:8.1f} us")

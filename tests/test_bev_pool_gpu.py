@@ -165,7 +165,7 @@ def test_csr_dense_forward_and_planned_autograd(cuda, golden):
             assert torch.equal(s2c, bev.permute(0, 2, 1, 3, 4).reshape(B, Z * C, Y, X))
 
 
-@pytest.mark.parametrize("tile_items", [64, 200, 512, 2048])
+@pytest.mark.parametrize("tile_items", [64, 200, 512, 1000])
 @pytest.mark.parametrize("c", [64, 8])
 def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
     """Tiled (workgroup merge-path) dense kernel: rows far longer than a tile, long runs of empty
@@ -187,9 +187,13 @@ def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
     want = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rows, (1, 1, 1, n_rows, c), st, ln).reshape(n_rows, c)
     row_ptr = ops.csr_from_sorted_keys(t(rows, cuda), n_rows)
     assert np.array_equal(np.diff(row_ptr.cpu().numpy()), np.bincount(rows, minlength=n_rows))
-    tiles = ops.csr_tiles(row_ptr, npts, tile_items)
+    tiles = ops.csr_tiles(row_ptr, tile_items, 256)
     tr = tiles.cpu().numpy()
-    assert tr[0] == 0 and tr[-1] == n_rows and np.all(np.diff(tr) >= 0)
+    assert tr[0] == 0 and tr[-1] == n_rows and np.all(np.diff(tr) > 0)
+    rp = row_ptr.cpu().numpy()
+    lens, tpts = np.diff(rp), rp[tr[1:]] - rp[tr[:-1]]
+    assert np.all((tpts <= tile_items + 256) | (np.diff(tr) == 1))      # long rows are tiles of their own
+    assert all(np.diff(tr)[np.searchsorted(tr, r, side="right") - 1] == 1 for r in np.nonzero(lens > 256)[0])
     from omnihd_amd.plan import tile_schedule
     order = tile_schedule(row_ptr, tiles, t(rf, cuda), (20, 30))
     o = order.cpu().numpy()
@@ -197,8 +201,8 @@ def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
     outs = []
     for tile_arg, order_arg in ((tiles, None), (None, None), (tiles, None), (tiles, order)):
         out = torch.full((n_rows, c), float("nan"), device=cuda)        # every row must be written
-        ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out, tile_arg,
-                                    order_arg)
+        ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out,
+                                    t(rows, cuda), tile_arg, order_arg)
         outs.append(out.cpu().numpy())
     np.testing.assert_allclose(outs[0], want, rtol=1e-5, atol=2e-4)
     np.testing.assert_allclose(outs[1], want, rtol=1e-5, atol=2e-4)
@@ -213,14 +217,14 @@ def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
     e = torch.empty(0, dtype=torch.int32, device=cuda)
     row_ptr = ops.csr_from_sorted_keys(e, 1000)
     out = torch.full((1000, 64), 3.0, device=cuda)
-    ops.bev_pool_v2_forward_csr(depth, feat, e, e, row_ptr, out, ops.csr_tiles(row_ptr, 0, 128))
+    ops.bev_pool_v2_forward_csr(depth, feat, e, e, row_ptr, out, e, ops.csr_tiles(row_ptr, 128, 64))
     assert out.abs().sum() == 0
     rows = torch.zeros(5000, dtype=torch.int32, device=cuda)             # one row holds everything
     rd = torch.randint(0, 8, (5000,), dtype=torch.int32, device=cuda)
     rf = torch.randint(0, 4, (5000,), dtype=torch.int32, device=cuda)
     row_ptr = ops.csr_from_sorted_keys(rows, 1)
     out = torch.empty(1, 64, device=cuda)
-    ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out, ops.csr_tiles(row_ptr, 5000, 256))
+    ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out, rows, ops.csr_tiles(row_ptr, 256, 256))
     want = (depth.view(-1)[rd.long()][:, None].double() * feat.view(4, 64)[rf.long()].double()).sum(0)
     torch.testing.assert_close(out[0].double(), want, rtol=1e-5, atol=1e-4)
 
