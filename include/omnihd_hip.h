@@ -81,18 +81,24 @@ int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const floa
  * whatever the plan builder chose (reference (b,z,y,x) order, or (b,y,x,z) = channels-last
  * of the s2c tensor).
  *   ranks_row[p]  (n_points ints) output row of point p (the sorted keys of omnihd_sort_ranks);
- *   tile_row      (n_tiles+1 ints, from omnihd_csr_tiles) work partition into runs of whole rows;
- *   tile_order    (8*ceil(n_tiles/8) ints or NULL) launch schedule: entry [x*ceil(n_tiles/8)+i]
- *                 names the i-th tile worked on by XCD x (-1 = idle slot); every tile must appear
- *                 exactly once; it only affects speed (L2 locality), never results.
- * With ranks_row and tile_row the load-balanced tiled kernel runs (rows cut by the in-tile work
+ *   tile_desc     (8*ceil(n_tiles/8) x 4 ints, 16-byte aligned, from omnihd_tile_desc) launch
+ *                 schedule: entry [x*ceil(n_tiles/8)+i] = {first row, #rows, first point, #points}
+ *                 of the i-th tile worked on by XCD x (#rows = 0: idle slot).  Tiles must be runs
+ *                 of whole rows covering every row exactly once; their ORDER only affects speed
+ *                 (L2 locality), never results.
+ * With ranks_row and tile_desc the load-balanced tiled kernel runs (rows cut by the in-tile work
  * split are combined in a fixed order: a row's sum may be associated differently from table
  * order, run-to-run deterministic).  With either NULL a simple row-per-lane-group kernel runs. */
 int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                const int* ranks_depth, const int* ranks_feat,
                                const int* ranks_row, const int* row_ptr,
-                               const int* tile_row, const int* tile_order, int n_tiles,
-                               float* out, int c, int n_rows, int n_points, void* stream);
+                               const int* tile_desc, int n_tiles, float* out, int c,
+                               int n_rows, int n_points, void* stream);
+
+/* Schedule descriptors for the call above from a tile table (omnihd_csr_tiles) and an optional
+ * tile order (8*ceil(n_tiles/8) ints, -1 = idle slot, NULL = tiles in index order).          */
+int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const int* tile_order,
+                     int n_tiles, int* tile_desc, void* stream);
 
 /* Work partition for the tiled forward: tile_row[0..n_tiles] (capacity n_rows+1 ints) with
  * tile k = rows [tile_row[k], tile_row[k+1]).  A tile closes when rows+points reach a multiple

@@ -172,22 +172,27 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd(
 // ---------------------------------------------------------------------------------------------
 // Tiled dense forward.
 //
-// A TILE is a run of whole output rows (tile_row[t] .. tile_row[t+1]) that holds at most kCap
-// points, or one single row of any length; the plan builds tiles of ~tile_items points+rows so
-// every workgroup gets the same amount of work although 40 % of the BEV rows are empty and a few
-// near-ego rows hold thousands of points.  One workgroup per tile, three phases:
-//   Z  empty rows of the tile are zero-filled (row_ptr read coalesced, 16 B x C4 stores);
-//   L  ALL 256 lanes stage the tile's points in LDS as 16-byte records
-//        { pixel row index, depth value (gathered here), output row, last-point-of-row flag }
-//      -> rank tables are read once, coalesced; the dependent depth gather runs 256-wide;
+// A TILE is a run of whole output rows that holds at most kCap points, or one single row of any
+// length; the plan builds tiles of ~tile_items points+rows so every workgroup gets the same
+// amount of work although 40 % of the BEV rows are empty and a few near-ego rows hold thousands
+// of points.  The launch schedule is an array of 16-byte descriptors {first row, #rows, first
+// point, #points}, one per (XCD, slot): workgroup b runs on XCD b % 8 (observed dispatch rule,
+// used for locality only), and the plan orders the schedule so that one XCD works on tiles that
+// gather from the same image columns — its 4 MiB L2 then holds the feature rows it needs
+// (measured: 24 TB/s of 256-byte row gathers from an L2-resident table vs 9 TB/s from the
+// Infinity Cache).  One workgroup per tile, phases:
+//   L  ALL 256 lanes read the tile's rank tables coalesced and gather the depth values 256-wide;
+//      they land in LDS as { pixel-row index | last-point-of-row flag, depth, output row };
+//   Z  meanwhile the empty rows of the tile are zero-filled (row_ptr read coalesced);
 //   P  the points are cut into G equal pieces, one per group of C4 lanes.  A group reads one
-//      record (one broadcast ds_read_b128), gathers the 16 B x C4 feature row (8 gathers kept in
-//      flight), accumulates, and on a last-point flag stores the finished row (256 B for C=64).
+//      record (broadcast LDS read), gathers the 16 B x C4 feature row (U gathers in flight),
+//      accumulates, and on a last-point flag stores the finished row (256 B for C=64).
 //      A row cut by a piece boundary leaves partials in LDS which are added in piece order after
 //      one barrier.
+// 19 KiB of LDS and <= 64 VGPRs: 8 workgroups (32 waves) per CU hide the dependent latencies.
 // No atomics, no dependence on dispatch order: results are run-to-run identical.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCap = 1280;   // LDS point records per workgroup (20 KiB)
+constexpr int kCap = 1280;   // LDS point records per workgroup
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
@@ -198,36 +203,52 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     const float* __restrict__ depth, const float4* __restrict__ feat4,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
     const int* __restrict__ ranks_row, const int* __restrict__ row_ptr,
-    const int* __restrict__ tile_row, const int* __restrict__ tile_order,
-    float4* __restrict__ out4, int n_tiles, int tiles_per_xcd, int n_points_total) {
+    const int4* __restrict__ tile_desc, float4* __restrict__ out4, int tiles_per_xcd,
+    int n_points_total) {
   constexpr int G = kBlock / C4;
   constexpr int GPW = 64 / C4;   // groups per wavefront
-  __shared__ int4 s_rec[kCap];
+  constexpr int kRecInts = kCap * 3;
+  // s_mem: [0, 2*kCap) int2 {rf|last, depth}; [2*kCap, 3*kCap) output row; the tail partials
+  // (kBlock float4 = 1024 ints) reuse the front of the record area after a barrier.
+  __shared__ int s_mem[kRecInts > kBlock * 4 ? kRecInts : kBlock * 4];
   __shared__ float4 s_head[kBlock];
-  __shared__ float4 s_tail[kBlock];
   __shared__ int s_head_row[G];
   __shared__ int s_tail_row[G];
+  int2* s_rfd = reinterpret_cast<int2*>(s_mem);
+  int* s_row = s_mem + 2 * kCap;
+  float4* s_tail = reinterpret_cast<float4*>(s_mem);
 
-  // XCD-aware tile choice: workgroup b runs on XCD b % 8 (observed dispatch rule, used for
-  // locality only).  Slot (xcd, i) of the schedule names the tile; the plan orders the schedule
-  // so that one XCD works on tiles that gather from the same image columns (its 4 MiB L2 then
-  // holds the feature rows it needs).  Without a schedule: contiguous chunk of tiles per XCD.
-  const int slot = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
-  const int t = tile_order ? tile_order[slot] : slot;
-  if (t < 0 || t >= n_tiles) return;
+  const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
+  const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
+  if (nrows <= 0) return;
 
   const int tid = threadIdx.x;
   const int sub = tid % C4;
   const int grp = tid / C4;
-  const int Ra = tile_row[t];
-  const int nrows = tile_row[t + 1] - Ra;
-  const int Pa = row_ptr[Ra];
-  const int npts = row_ptr[Ra + nrows] - Pa;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool long_row = (nrows == 1 && npts > kCap);
+  const bool staged = (npts > 0 && npts <= kCap);
 
-  // ---- phase Z: zero-fill the empty rows ------------------------------------------------------
-  if (npts < nrows || nrows > 1) {
+  // ---- phase L (issue): rank tables -> registers ------------------------------------------------
+  constexpr int kPer = (kCap + kBlock - 1) / kBlock;   // records per lane
+  int l_rf[kPer], l_rd[kPer], l_row[kPer], l_nxt[kPer];
+  if (staged) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = tid + k * kBlock;
+      if (i < npts) {
+        const int q = Pa + i;
+        l_rf[k] = ranks_feat[q];
+        l_rd[k] = ranks_depth[q];
+        l_row[k] = ranks_row[q];
+        l_nxt[k] = (q + 1 < n_points_total) ? ranks_row[q + 1] : -1;
+      }
+    }
+  }
+
+  // ---- phase Z: zero-fill the empty rows (stores only; overlaps the loads above) ---------------
+  if (!(nrows == 1 && npts > 0)) {
     const int lane = tid & 63;
     const int gw = lane / C4;
     for (int base = 0; base < nrows; base += kBlock) {
@@ -250,12 +271,12 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   float4 acc = zero4;
 
   // ---- a single long row: windows of kCap points, every group accumulates, one combine --------
-  if (nrows == 1 && npts > kCap) {
+  if (long_row) {
     for (int base = 0; base < npts; base += kCap) {
       const int n = min(kCap, npts - base);
       for (int i = tid; i < n; i += kBlock) {
         const int q = Pa + base + i;
-        s_rec[i] = make_int4(ranks_feat[q], __float_as_int(depth[ranks_depth[q]]), 0, 0);
+        s_rfd[i] = make_int2(ranks_feat[q], __float_as_int(depth[ranks_depth[q]]));
       }
       __syncthreads();
       const int cw = (n + G - 1) / G;
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
         float d[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int4 rc = s_rec[min(j + u, j1 - 1)];
+          const int2 rc = s_rfd[min(j + u, j1 - 1)];
           d[u] = (j + u < j1) ? __int_as_float(rc.y) : 0.f;
           v[u] = feat4[(size_t)rc.x * C4 + sub];
         }
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   }
 
   // ---- a tile that does not fit the LDS window (only for foreign tile tables): row by row -----
-  if (npts > kCap) {
+  if (!staged) {
     for (int r = Ra + grp; r < Ra + nrows; r += G) {
       const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
       if (len > 0)
@@ -295,12 +316,16 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     return;
   }
 
-  // ---- phase L: stage the tile's point records in LDS ------------------------------------------
-  for (int i = tid; i < npts; i += kBlock) {
-    const int q = Pa + i;
-    const int row = ranks_row[q];
-    const int nxt = (q + 1 < n_points_total) ? ranks_row[q + 1] : -1;
-    s_rec[i] = make_int4(ranks_feat[q], __float_as_int(depth[ranks_depth[q]]), row, row != nxt);
+  // ---- phase L (finish): depth gather, records -> LDS -------------------------------------------
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = tid + k * kBlock;
+    if (i < npts) {
+      const float dv = depth[l_rd[k]];
+      const int last = (l_row[k] != l_nxt[k]) ? (int)0x80000000 : 0;
+      s_rfd[i] = make_int2(l_rf[k] | last, __float_as_int(dv));
+      s_row[i] = l_row[k];
+    }
   }
   if (tid < G) s_head_row[tid] = -1;
   __syncthreads();
@@ -310,37 +335,40 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   const int i0 = min(grp * w, npts);
   const int i1 = min(i0 + w, npts);
   // my first point continues a row that an earlier piece started
-  bool head_pending = (i0 > 0) && (i0 < i1) && (s_rec[i0 - 1].w == 0);
+  bool head_pending = (i0 > 0) && (i0 < i1) && (s_rfd[i0 - 1].x >= 0);
   for (int i = i0; i < i1; i += U) {
     float4 v[U];
     float d[U];
-    int rw[U];
+    int fl[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int4 rc = s_rec[min(i + u, i1 - 1)];
+      const int2 rc = s_rfd[min(i + u, i1 - 1)];
       d[u] = __int_as_float(rc.y);
-      rw[u] = rc.w ? rc.z : -1;          // output row if this point closes it
-      v[u] = feat4[(size_t)rc.x * C4 + sub];
+      fl[u] = rc.x;
+      v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (i + u < i1) {
         acc = fma4(d[u], v[u], acc);
-        if (rw[u] >= 0) {
+        if (fl[u] < 0) {   // this point closes its output row
+          const int row = s_row[i + u];
           if (head_pending) {
             s_head[tid] = acc;
-            if (sub == 0) s_head_row[grp] = rw[u];
+            if (sub == 0) s_head_row[grp] = row;
             head_pending = false;
           } else {
-            store_row(out4 + (size_t)rw[u] * C4 + sub, acc, true);
+            store_row(out4 + (size_t)row * C4 + sub, acc, true);
           }
           acc = zero4;
         }
       }
     }
   }
+  const int tail_row = (i1 > i0 && s_rfd[i1 - 1].x >= 0) ? s_row[i1 - 1] : -2;
+  __syncthreads();   // every group is done with the records: their LDS is reused for the tails
   s_tail[tid] = acc;
-  if (sub == 0) s_tail_row[grp] = (i1 > i0 && s_rec[i1 - 1].w == 0) ? s_rec[i1 - 1].z : -2;
+  if (sub == 0) s_tail_row[grp] = tail_row;
   __syncthreads();
 
   const int hr = s_head_row[grp];
@@ -351,6 +379,23 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
     tsum = add4(tsum, s_head[tid]);
     store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
+  }
+}
+
+// schedule slot -> {first row, #rows, first point, #points}; idle slots get #rows = 0
+__global__ __launch_bounds__(kBlock) void k_tile_desc(const int* __restrict__ row_ptr,
+                                                      const int* __restrict__ tile_row,
+                                                      const int* __restrict__ tile_order,
+                                                      int n_slots, int n_tiles,
+                                                      int4* __restrict__ desc) {
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < n_slots; s += gridDim.x * kBlock) {
+    const int t = tile_order ? tile_order[s] : (s < n_tiles ? s : -1);
+    int4 d = make_int4(0, 0, 0, 0);
+    if (t >= 0 && t < n_tiles) {
+      const int ra = tile_row[t], rb = tile_row[t + 1];
+      d = make_int4(ra, rb - ra, row_ptr[ra], row_ptr[rb] - row_ptr[ra]);
+    }
+    desc[s] = d;
   }
 }
 
@@ -533,34 +578,44 @@ extern "C" int omnihd_bev_pool_v2_fwd(const float* depth, const float* feat,
                            interval_lengths, out, c, n_intervals, (hipStream_t)stream);
 }
 
+extern "C" int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const int* tile_order,
+                                int n_tiles, int* tile_desc, void* stream) {
+  OMNIHD_REQUIRE(n_tiles > 0 && row_ptr && tile_row && tile_desc, "arguments");
+  const int n_slots = 8 * ((n_tiles + 7) / 8);
+  hipLaunchKernelGGL(k_tile_desc, dim3(grid_for(n_slots, kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, row_ptr, tile_row, tile_order, n_slots, n_tiles,
+                     reinterpret_cast<int4*>(tile_desc));
+  return check_launch("tile_desc");
+}
+
 extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                           const int* ranks_depth, const int* ranks_feat,
                                           const int* ranks_row, const int* row_ptr,
-                                          const int* tile_row, const int* tile_order, int n_tiles,
-                                          float* out, int c, int n_rows, int n_points,
-                                          void* stream) {
-  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0, "c > 0 and n_rows >= 0");
+                                          const int* tile_desc, int n_tiles, float* out, int c,
+                                          int n_rows, int n_points, void* stream) {
+  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0 && n_points >= 0, "sizes");
   if (n_rows == 0) return OMNIHD_OK;
   // ranks_* may be null when the plan holds no point at all (every row is then written as zeros)
   OMNIHD_REQUIRE(depth && feat && row_ptr && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
-  OMNIHD_REQUIRE(n_points >= 0, "n_points >= 0");
-  if (tile_row != nullptr && ranks_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out)) {
+  if (tile_desc != nullptr && ranks_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out) &&
+      (reinterpret_cast<uintptr_t>(tile_desc) & 15u) == 0) {
     const int tiles_per_xcd = (n_tiles + 7) / 8;
     const dim3 grid(tiles_per_xcd * 8);
-    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); return (e && atoi(e) == 8) ? 8 : 4; }();
     const float4* f4 = reinterpret_cast<const float4*>(feat);
+    const int4* td = reinterpret_cast<const int4*>(tile_desc);
     float4* o4 = reinterpret_cast<float4*>(out);
+    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); return (e && atoi(e) == 8) ? 8 : 4; }();
 #define OMNIHD_TILE_CASE(C4)                                                                   \
   case C4:                                                                                     \
     if (unroll == 8)                                                                           \
       hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 8>), grid, dim3(kBlock), 0, st, depth, f4,      \
-                         ranks_depth, ranks_feat, ranks_row, row_ptr, tile_row, tile_order,    \
-                         o4, n_tiles, tiles_per_xcd, n_points);                                \
+                         ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
+                         n_points);                                                            \
     else                                                                                       \
       hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 4>), grid, dim3(kBlock), 0, st, depth, f4,      \
-                         ranks_depth, ranks_feat, ranks_row, row_ptr, tile_row, tile_order,    \
-                         o4, n_tiles, tiles_per_xcd, n_points);                                \
+                         ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
+                         n_points);                                                            \
     break;
     switch (c / 4) {
       OMNIHD_TILE_CASE(1)

@@ -79,10 +79,9 @@ def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_dep
               "omnihd_bev_pool_v2_bwd")
 
 
-def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, ranks_row=None, tile_row=None,
-                            tile_order=None):
+def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, ranks_row=None, tile_desc=None):
     """Dense forward: every row of ``out`` (n_rows = row_ptr.numel()-1, C = feat.size(-1)) is written.
-    With ``ranks_row`` + ``tile_row`` (from :func:`csr_tiles`) the load-balanced tiled kernel is used."""
+    With ``ranks_row`` + ``tile_desc`` (from :func:`tile_descriptors`) the load-balanced tiled kernel runs."""
     _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
     _want(ranks_depth, torch.int32, "ranks_depth"); _want(ranks_feat, torch.int32, "ranks_feat")
     _want(row_ptr, torch.int32, "row_ptr")
@@ -91,21 +90,35 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
     if out.numel() != n_rows * c:
         raise ValueError(f"out has {out.numel()} elements, expected {n_rows}*{c}")
     n_tiles = 0
-    if tile_row is not None and ranks_row is not None:
-        _want(tile_row, torch.int32, "tile_row"); _want(ranks_row, torch.int32, "ranks_row")
-        n_tiles = tile_row.numel() - 1
-        if tile_order is not None:
-            _want(tile_order, torch.int32, "tile_order")
-            if tile_order.numel() != 8 * ((n_tiles + 7) // 8):
-                raise ValueError("tile_order must have 8*ceil(n_tiles/8) entries")
+    if tile_desc is not None and ranks_row is not None:
+        _want(tile_desc, torch.int32, "tile_desc"); _want(ranks_row, torch.int32, "ranks_row")
+        if tile_desc.dim() != 2 or tile_desc.size(1) != 4 or tile_desc.size(0) % 8:
+            raise ValueError("tile_desc must be (8*k, 4) int32")
+        n_tiles = tile_desc.size(0)      # number of schedule slots; idle slots carry #rows = 0
     else:
-        tile_row = tile_order = ranks_row = None
+        tile_desc = ranks_row = None
     dev = _same_device(depth, feat, out, ranks_depth, ranks_feat, row_ptr)
     with torch.cuda.device(dev):
         check(lib().omnihd_bev_pool_v2_fwd_csr(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat),
-                                               _ptr(ranks_row), _ptr(row_ptr), _ptr(tile_row), _ptr(tile_order),
-                                               n_tiles, _ptr(out), c, n_rows, ranks_depth.numel(), _stream()),
+                                               _ptr(ranks_row), _ptr(row_ptr), _ptr(tile_desc), n_tiles, _ptr(out),
+                                               c, n_rows, ranks_depth.numel(), _stream()),
               "omnihd_bev_pool_v2_fwd_csr")
+
+
+def tile_descriptors(row_ptr, tile_row, tile_order=None):
+    """(8*ceil(n_tiles/8), 4) int32 launch schedule {first row, #rows, first point, #points}."""
+    _want(row_ptr, torch.int32, "row_ptr"); _want(tile_row, torch.int32, "tile_row")
+    n_tiles = tile_row.numel() - 1
+    n_slots = 8 * ((n_tiles + 7) // 8)
+    if tile_order is not None:
+        _want(tile_order, torch.int32, "tile_order")
+        if tile_order.numel() != n_slots:
+            raise ValueError("tile_order must have 8*ceil(n_tiles/8) entries")
+    desc = torch.empty((n_slots, 4), dtype=torch.int32, device=row_ptr.device)
+    with torch.cuda.device(row_ptr.device):
+        check(lib().omnihd_tile_desc(_ptr(row_ptr), _ptr(tile_row), _ptr(tile_order), n_tiles, _ptr(desc), _stream()),
+              "omnihd_tile_desc")
+    return desc
 
 
 def csr_tiles(row_ptr, tile_items=768, long_len=512):

@@ -32,6 +32,7 @@ class BevPoolPlan:
     row_ptr: torch.Tensor       # int32 [n_rows+1]
     tile_row: torch.Tensor      # int32 [n_tiles+1] work partition of the tiled forward kernel
     tile_order: torch.Tensor    # int32 [8*ceil(n_tiles/8)] launch schedule (XCD x slot -> tile, -1 idle)
+    tile_desc: torch.Tensor     # int32 [8*ceil(n_tiles/8), 4] the schedule as kernel descriptors
     interval_starts: torch.Tensor
     interval_lengths: torch.Tensor
     # backward (sorted by ranks_feat)
@@ -101,9 +102,10 @@ def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=No
     row_ptr = ops.csr_from_sorted_keys(rows, n_rows)
     tile_row = ops.csr_tiles(row_ptr, TILE_ITEMS, LONG_LEN)
     tile_order = tile_schedule(row_ptr, tile_row, rf, feat_hw)
+    tile_desc = ops.tile_descriptors(row_ptr, tile_row, tile_order)
     bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
     return BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, tile_row, tile_order,
-                       starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4])
+                       tile_desc, starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4])
 
 
 def build_plan(coor, dx, bx, nx, layout="byxz"):
@@ -146,7 +148,7 @@ class _PlannedPool(torch.autograd.Function):
         feat = feat.contiguous().float()
         out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
         ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
-                                    plan.ranks_row, plan.tile_row, plan.tile_order)
+                                    plan.ranks_row, plan.tile_desc)
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan
         return out

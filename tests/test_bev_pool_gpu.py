@@ -199,10 +199,14 @@ def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
     o = order.cpu().numpy()
     assert np.array_equal(np.sort(o[o >= 0]), np.arange(tiles.numel() - 1))     # every tile exactly once
     outs = []
-    for tile_arg, order_arg in ((tiles, None), (None, None), (tiles, None), (tiles, order)):
+    d_plain = ops.tile_descriptors(row_ptr, tiles)
+    d_sched = ops.tile_descriptors(row_ptr, tiles, order)
+    dn = d_sched.cpu().numpy()
+    assert dn[:, 1].sum() == n_rows and dn[:, 3].sum() == npts
+    for desc in (d_plain, None, d_plain, d_sched):
         out = torch.full((n_rows, c), float("nan"), device=cuda)        # every row must be written
         ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out,
-                                    t(rows, cuda), tile_arg, order_arg)
+                                    t(rows, cuda), desc)
         outs.append(out.cpu().numpy())
     np.testing.assert_allclose(outs[0], want, rtol=1e-5, atol=2e-4)
     np.testing.assert_allclose(outs[1], want, rtol=1e-5, atol=2e-4)
@@ -217,14 +221,16 @@ def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
     e = torch.empty(0, dtype=torch.int32, device=cuda)
     row_ptr = ops.csr_from_sorted_keys(e, 1000)
     out = torch.full((1000, 64), 3.0, device=cuda)
-    ops.bev_pool_v2_forward_csr(depth, feat, e, e, row_ptr, out, e, ops.csr_tiles(row_ptr, 128, 64))
+    ops.bev_pool_v2_forward_csr(depth, feat, e, e, row_ptr, out, e,
+                                ops.tile_descriptors(row_ptr, ops.csr_tiles(row_ptr, 128, 64)))
     assert out.abs().sum() == 0
     rows = torch.zeros(5000, dtype=torch.int32, device=cuda)             # one row holds everything
     rd = torch.randint(0, 8, (5000,), dtype=torch.int32, device=cuda)
     rf = torch.randint(0, 4, (5000,), dtype=torch.int32, device=cuda)
     row_ptr = ops.csr_from_sorted_keys(rows, 1)
     out = torch.empty(1, 64, device=cuda)
-    ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out, rows, ops.csr_tiles(row_ptr, 256, 256))
+    ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out, rows,
+                                ops.tile_descriptors(row_ptr, ops.csr_tiles(row_ptr, 256, 256)))
     want = (depth.view(-1)[rd.long()][:, None].double() * feat.view(4, 64)[rf.long()].double()).sum(0)
     torch.testing.assert_close(out[0].double(), want, rtol=1e-5, atol=1e-4)
 
