@@ -115,6 +115,7 @@ class BevOps:
         self.ops, self.omnihd = ops, omnihd_amd
         self.dev, self.batch = dev, batch
         self.tiled = True
+        self.sched_bwd = True
         self.scheduled = True
         H, W, _ = RES[res]
         self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
@@ -134,7 +135,8 @@ class BevOps:
             # private copies of the tables too, so that nothing is served from the Infinity Cache
             tabs = [x.clone() for x in (self.plan.ranks_depth, self.plan.ranks_feat, self.plan.row_ptr,
                                         self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
-                                        self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_desc, self.plan.ranks_row)]
+                                        self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_desc, self.plan.ranks_row,
+                                        self.plan.pix_desc)]
             self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
         rng = np.random.default_rng(seed)
         self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
@@ -146,8 +148,12 @@ class BevOps:
 
     def pool_bwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
-        dg.zero_(); fg.zero_()
-        self.ops.bev_pool_v2_backward(og.view(1, 1, 1, -1, self.C), dg, fg, depth, feat, tb[3], tb[4], tb[5], tb[7], tb[6])
+        dg.zero_()
+        if self.sched_bwd:
+            self.ops.bev_pool_v2_backward_sched(og, depth, feat, tb[3], tb[5], tb[10], dg, fg)
+        else:
+            fg.zero_()
+            self.ops.bev_pool_v2_backward(og.view(1, 1, 1, -1, self.C), dg, fg, depth, feat, tb[3], tb[4], tb[5], tb[7], tb[6])
 
     def radar(self):
         vox, coors, nums = [], [], []

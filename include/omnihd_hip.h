@@ -100,6 +100,18 @@ int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
 int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const int* tile_order,
                      int n_tiles, int* tile_desc, void* stream);
 
+/* Scheduled backward used by our own LSS module (same arithmetic as omnihd_bev_pool_v2_bwd).
+ * pix_desc: 8 * groups_per_xcd descriptors of 4 ints {pixel row f, first point, #points, 0},
+ * 16-byte aligned; entry [x*groups_per_xcd + i] is the i-th pixel handled on XCD x; f = -1 marks
+ * an idle slot.  Points [first, first+#points) of ranks_depth / ranks_row (the backward tables:
+ * sorted by pixel) belong to pixel f.  EVERY pixel should be listed exactly once (also pixels
+ * without points): feat_grad is then written densely and needs no zero-fill.  depth_grad is
+ * only written at the listed points (the caller zero-fills it).  C in {4,8,16,32,64}.        */
+int omnihd_bev_pool_v2_bwd_sched(const float* out_grad, const float* depth, const float* feat,
+                                 const int* ranks_depth, const int* ranks_row,
+                                 const int* pix_desc, int groups_per_xcd, float* depth_grad,
+                                 float* feat_grad, int c, void* stream);
+
 /* Work partition for the tiled forward: tile_row[0..n_tiles] (capacity n_rows+1 ints) with
  * tile k = rows [tile_row[k], tile_row[k+1]).  A tile closes when rows+points reach a multiple
  * of tile_items; a row with more than long_len points is a tile of its own.  The kernel needs

@@ -479,6 +479,89 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Scheduled backward: one group of C4 lanes per image-feature pixel, pixels taken from a plan-made
+// schedule of 16-byte descriptors {pixel row, first point, #points, -}.
+//   * the schedule lists EVERY pixel (also those without points), so feat_grad is written densely
+//     and needs no zero-fill; it walks the image in 4x4 pixel patches and gives each XCD one
+//     contiguous run of patches: neighbouring pixels hit the same BEV rows (a voxel collects its
+//     points from adjacent pixels), so an out_grad row fetched once is reused from L1/L2;
+//   * per chunk of C4 points the three tables are read coalesced, depth is gathered C4-wide,
+//     U out_grad rows (16 B x C4 lanes) are in flight per group;
+//   * depth_grad needs a dot product over the C channels for every point: each lane keeps its
+//     4-channel partial for the C4 points of the chunk and ONE log2(C4)-stage butterfly
+//     (C4-1 exchanges instead of C4*log2(C4)) leaves lane j with the sum of point j, which
+//     it then scatters to depth_grad.
+// feat_grad: fg += depth * g in table order (same fma chain as the reference kernel).
+// ---------------------------------------------------------------------------------------------
+template <int C4, int U>
+__global__ __launch_bounds__(kBlock) void k_pool_bwd_sched(
+    const float4* __restrict__ og4, const float* __restrict__ depth,
+    const float4* __restrict__ feat4, const int* __restrict__ ranks_depth,
+    const int* __restrict__ ranks_row, const int4* __restrict__ pix_desc,
+    float* __restrict__ depth_grad, float4* __restrict__ feat_grad4, int groups_per_xcd) {
+  constexpr int G = kBlock / C4;
+  const int sub = threadIdx.x % C4;
+  const int grp = threadIdx.x / C4;
+  const int gi = (int)(blockIdx.x >> 3) * G + grp;     // group slot inside this XCD's run
+  if (gi >= groups_per_xcd) return;
+  const int4 desc = pix_desc[(size_t)(blockIdx.x & 7) * groups_per_xcd + gi];
+  const int f = desc.x, s = desc.y, len = desc.z;
+  if (f < 0) return;
+  float4 fg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (len > 0) {
+    const float4 x = feat4[(size_t)f * C4 + sub];
+    for (int cb = 0; cb < len; cb += C4) {
+      const int n = min(C4, len - cb);
+      int my_rb = 0, my_rd = 0;
+      float my_d = 0.f;
+      if (sub < n) {
+        my_rb = ranks_row[s + cb + sub];
+        my_rd = ranks_depth[s + cb + sub];
+        my_d = depth[my_rd];
+      }
+      float part[C4];
+#pragma unroll
+      for (int j = 0; j < C4; ++j) part[j] = 0.f;
+#pragma unroll
+      for (int j = 0; j < C4; j += U) {
+        if (j < n) {
+          float4 g[U];
+          float d[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int jj = min(j + u, n - 1);
+            const int v = __shfl(my_rb, jj, C4);
+            d[u] = (j + u < n) ? __shfl(my_d, jj, C4) : 0.f;
+            g[u] = og4[(size_t)v * C4 + sub];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            part[j + u] = (j + u < n)
+                              ? fmaf(g[u].w, x.w, fmaf(g[u].z, x.z, fmaf(g[u].y, x.y, g[u].x * x.x)))
+                              : 0.f;
+            fg = fma4(d[u], g[u], fg);
+          }
+        }
+      }
+      // butterfly: after the stage with mask m a lane keeps the m partials whose point index
+      // has the same bit m as the lane; at the end lane j holds the full sum of point j.
+#pragma unroll
+      for (int m = C4 / 2; m >= 1; m >>= 1) {
+        const bool hi = (sub & m) != 0;
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+          const float send = hi ? part[k] : part[k + m];
+          const float keep = hi ? part[k + m] : part[k];
+          part[k] = keep + __shfl_xor(send, m, C4);
+        }
+      }
+      if (sub < n) depth_grad[my_rd] = part[0];
+    }
+  }
+  feat_grad4[(size_t)f * C4 + sub] = fg;
+}
+
 __global__ __launch_bounds__(kBlock) void k_pool_bwd_generic(
     const float* __restrict__ og, const float* __restrict__ depth, const float* __restrict__ feat,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
@@ -681,4 +764,42 @@ extern "C" int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth,
                        depth_grad, feat_grad, c, n_intervals);
   }
   return check_launch("bev_pool_v2_bwd");
+}
+
+extern "C" int omnihd_bev_pool_v2_bwd_sched(const float* out_grad, const float* depth,
+                                            const float* feat, const int* ranks_depth,
+                                            const int* ranks_row, const int* pix_desc,
+                                            int groups_per_xcd, float* depth_grad,
+                                            float* feat_grad, int c, void* stream) {
+  OMNIHD_REQUIRE(c > 0 && groups_per_xcd >= 0, "sizes");
+  if (groups_per_xcd == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(out_grad && depth && feat && pix_desc && depth_grad && feat_grad, "null pointer");
+  OMNIHD_REQUIRE(c % 4 == 0 && (c / 4 == 16 || c / 4 == 8 || c / 4 == 4 || c / 4 == 2 || c / 4 == 1),
+                 "scheduled backward supports C in {4,8,16,32,64}");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(out_grad) | reinterpret_cast<uintptr_t>(feat) |
+                   reinterpret_cast<uintptr_t>(feat_grad) | reinterpret_cast<uintptr_t>(pix_desc)) & 15u) == 0,
+                 "16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const float4* og4 = reinterpret_cast<const float4*>(out_grad);
+  const float4* f4 = reinterpret_cast<const float4*>(feat);
+  float4* fg4 = reinterpret_cast<float4*>(feat_grad);
+  const int4* pd = reinterpret_cast<const int4*>(pix_desc);
+#define OMNIHD_BWDS_CASE(C4, U)                                                                 \
+  case C4: {                                                                                    \
+    const int G = kBlock / C4;                                                                  \
+    const dim3 grid(8 * ((groups_per_xcd + G - 1) / G));                                        \
+    hipLaunchKernelGGL((k_pool_bwd_sched<C4, U>), grid, dim3(kBlock), 0, st, og4, depth, f4,    \
+                       ranks_depth, ranks_row, pd, depth_grad, fg4, groups_per_xcd);            \
+  } break;
+  switch (c / 4) {
+    OMNIHD_BWDS_CASE(1, 1)
+    OMNIHD_BWDS_CASE(2, 2)
+    OMNIHD_BWDS_CASE(4, 4)
+    OMNIHD_BWDS_CASE(8, 4)
+    OMNIHD_BWDS_CASE(16, 4)
+    default:
+      return OMNIHD_ERR_ARG;
+  }
+#undef OMNIHD_BWDS_CASE
+  return check_launch("bev_pool_v2_bwd_sched");
 }

@@ -105,6 +105,23 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
               "omnihd_bev_pool_v2_fwd_csr")
 
 
+def bev_pool_v2_backward_sched(out_grad, depth, feat, ranks_depth, ranks_row, pix_desc, depth_grad, feat_grad):
+    """Scheduled backward (see include/omnihd_hip.h): ``pix_desc`` (8*k, 4) int32 lists every pixel once."""
+    for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad),
+                 ("feat_grad", feat_grad)):
+        _want(t, torch.float32, n)
+    _want(ranks_depth, torch.int32, "ranks_depth"); _want(ranks_row, torch.int32, "ranks_row")
+    _want(pix_desc, torch.int32, "pix_desc")
+    if pix_desc.dim() != 2 or pix_desc.size(1) != 4 or pix_desc.size(0) % 8:
+        raise ValueError("pix_desc must be (8*k, 4) int32")
+    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, ranks_depth, ranks_row, pix_desc)
+    with torch.cuda.device(dev):
+        check(lib().omnihd_bev_pool_v2_bwd_sched(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(ranks_depth),
+                                                 _ptr(ranks_row), _ptr(pix_desc), pix_desc.size(0) // 8,
+                                                 _ptr(depth_grad), _ptr(feat_grad), feat.size(-1), _stream()),
+              "omnihd_bev_pool_v2_bwd_sched")
+
+
 def tile_descriptors(row_ptr, tile_row, tile_order=None):
     """(8*ceil(n_tiles/8), 4) int32 launch schedule {first row, #rows, first point, #points}."""
     _want(row_ptr, torch.int32, "row_ptr"); _want(tile_row, torch.int32, "tile_row")

@@ -41,6 +41,7 @@ class BevPoolPlan:
     bp_ranks_feat: torch.Tensor
     bp_starts: torch.Tensor
     bp_lengths: torch.Tensor
+    pix_desc: torch.Tensor = None   # int32 [8*k, 4] schedule of the scheduled backward (every pixel once)
 
     @property
     def n_intervals(self):
@@ -96,6 +97,38 @@ def tile_schedule(row_ptr, tile_row, ranks_feat, feat_hw=None, n_xcd=8):
     return flat.int().contiguous()
 
 
+def pixel_schedule(bp_ranks_feat, bp_starts, bp_lengths, n_feat_rows, feat_hw=None, n_xcd=8):
+    """Schedule of the scheduled backward: one descriptor {pixel row, first point, #points, 0} per
+    image-feature pixel (pixels without points included, so feat_grad is written densely), walked
+    in 4x4 pixel patches (neighbouring pixels hit the same BEV rows -> out_grad rows are reused from
+    L1/L2) and cut into ``n_xcd`` contiguous runs, one per XCD.  Host-side planning, once per
+    calibration; only the ORDER is a performance choice."""
+    dev = bp_ranks_feat.device
+    start = torch.zeros(n_feat_rows, dtype=torch.int32, device=dev)
+    length = torch.zeros(n_feat_rows, dtype=torch.int32, device=dev)
+    if bp_starts.numel():
+        pix = bp_ranks_feat[bp_starts.long()].long()
+        start[pix] = bp_starts
+        length[pix] = bp_lengths
+    f = torch.arange(n_feat_rows, device=dev)
+    if feat_hw is not None:
+        fH, fW = feat_hw
+        img, h, w = f // (fH * fW), (f // fW) % fH, f % fW
+        key = ((img * ((fH + 3) // 4) + h // 4) * ((fW + 3) // 4) + w // 4) * 16 + (h % 4) * 4 + (w % 4)
+        f = f[torch.argsort(key, stable=True)]
+    per = (n_feat_rows + n_xcd - 1) // n_xcd
+    desc = torch.zeros((n_xcd * per, 4), dtype=torch.int32, device=dev)
+    desc[:, 0] = -1
+    # equal pixel counts per XCD; run k of the walk -> rows [k*per, k*per + count)
+    bounds = [(n_feat_rows * k) // n_xcd for k in range(n_xcd + 1)]
+    for k in range(n_xcd):
+        run = f[bounds[k]:bounds[k + 1]]
+        desc[k * per:k * per + run.numel(), 0] = run.int()
+        desc[k * per:k * per + run.numel(), 1] = start[run]
+        desc[k * per:k * per + run.numel(), 2] = length[run]
+    return desc.contiguous()
+
+
 def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=None):
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X
@@ -104,8 +137,9 @@ def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=No
     tile_order = tile_schedule(row_ptr, tile_row, rf, feat_hw)
     tile_desc = ops.tile_descriptors(row_ptr, tile_row, tile_order)
     bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
+    pix_desc = pixel_schedule(bp[2], bp[3], bp[4], n_feat_rows, feat_hw)
     return BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, tile_row, tile_order,
-                       tile_desc, starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4])
+                       tile_desc, starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4], pix_desc)
 
 
 def build_plan(coor, dx, bx, nx, layout="byxz"):
@@ -159,10 +193,16 @@ class _PlannedPool(torch.autograd.Function):
         plan = ctx.plan
         out_grad = out_grad.contiguous().float()
         depth_grad = torch.zeros_like(depth)
-        feat_grad = torch.zeros_like(feat)
-        og5 = out_grad.view(1, 1, 1, plan.n_rows, feat.size(-1))
-        ops.bev_pool_v2_backward(og5, depth_grad, feat_grad, depth, feat, plan.bp_ranks_depth,
-                                 plan.bp_ranks_feat, plan.bp_ranks_row, plan.bp_lengths, plan.bp_starts)
+        c = feat.size(-1)
+        if plan.pix_desc is not None and c in (4, 8, 16, 32, 64):
+            feat_grad = torch.empty_like(feat)          # written densely by the scheduled kernel
+            ops.bev_pool_v2_backward_sched(out_grad.view(plan.n_rows, c), depth, feat, plan.bp_ranks_depth,
+                                           plan.bp_ranks_row, plan.pix_desc, depth_grad, feat_grad)
+        else:
+            feat_grad = torch.zeros_like(feat)
+            og5 = out_grad.view(1, 1, 1, plan.n_rows, c)
+            ops.bev_pool_v2_backward(og5, depth_grad, feat_grad, depth, feat, plan.bp_ranks_depth,
+                                     plan.bp_ranks_feat, plan.bp_ranks_row, plan.bp_lengths, plan.bp_starts)
         return depth_grad, feat_grad, None
 
 

@@ -33,8 +33,17 @@ def main():
             res_t.append(bench.time_kernel(wl.pool_fwd, len(wl.sets), 40))
         print(f"tiled fwd W={items:5d} L={long_len:4d}: banded {res_t[0]*1e6:7.1f} us {nbytes/res_t[0]/1e9:6.0f} GB/s | "
               f"column-scheduled {res_t[1]*1e6:7.1f} us {nbytes/res_t[1]/1e9:6.0f} GB/s  tiles {tiles.numel()-1}")
+    wl.sched_bwd = False
     t = bench.time_kernel(wl.pool_bwd, len(wl.sets), 40)
-    print(f"bwd (incl. 2 memsets): {t*1e6:8.1f} us")
+    print(f"bwd reference-API kernel (incl. 2 memsets): {t*1e6:8.1f} us")
+    wl.sched_bwd = True
+    t = bench.time_kernel(wl.pool_bwd, len(wl.sets), 40)
+    print(f"bwd scheduled kernel (incl. depth_grad memset): {t*1e6:8.1f} us")
+    lin = P.pixel_schedule(wl.plan.bp_ranks_feat, wl.plan.bp_starts, wl.plan.bp_lengths, wl.N * wl.fH * wl.fW, None)
+    for s in wl.sets:
+        s[6][10] = lin.clone()
+    t = bench.time_kernel(wl.pool_bwd, len(wl.sets), 40)
+    print(f"bwd scheduled kernel, linear pixel order      : {t*1e6:8.1f} us")
     # plain device copy of the same byte count as a local ceiling
     a = torch.empty(nbytes // 8, dtype=torch.float32, device=dev)
     bufs = [(torch.empty_like(a), torch.empty_like(a)) for _ in range(4)]
