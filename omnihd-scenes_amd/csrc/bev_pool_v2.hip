@@ -500,6 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_sched(
     const float4* __restrict__ feat4, const int* __restrict__ ranks_depth,
     const int* __restrict__ ranks_row, const int4* __restrict__ pix_desc,
     float* __restrict__ depth_grad, float4* __restrict__ feat_grad4, int groups_per_xcd) {
+  static_assert(U >= 1 && U <= C4 && (C4 % U) == 0 && (U & (U - 1)) == 0, "U: power of two dividing C4");
   constexpr int G = kBlock / C4;
   const int sub = threadIdx.x % C4;
   const int grp = threadIdx.x / C4;
@@ -520,43 +521,43 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_sched(
         my_rd = ranks_depth[s + cb + sub];
         my_d = depth[my_rd];
       }
-      float part[C4];
+      for (int j = 0; j < n; j += U) {
+        float4 g[U];
+        float d[U];
+        float part[U];
 #pragma unroll
-      for (int j = 0; j < C4; ++j) part[j] = 0.f;
+        for (int u = 0; u < U; ++u) {
+          const int jj = min(j + u, n - 1);
+          const int v = __shfl(my_rb, jj, C4);
+          d[u] = (j + u < n) ? __shfl(my_d, jj, C4) : 0.f;
+          g[u] = og4[(size_t)v * C4 + sub];
+        }
 #pragma unroll
-      for (int j = 0; j < C4; j += U) {
-        if (j < n) {
-          float4 g[U];
-          float d[U];
+        for (int u = 0; u < U; ++u) {
+          part[u] = fmaf(g[u].w, x.w, fmaf(g[u].z, x.z, fmaf(g[u].y, x.y, g[u].x * x.x)));
+          fg = fma4(d[u], g[u], fg);
+        }
+        // Channel sums of the U points: log2(U) halving stages over the TOP lane bits (a lane keeps
+        // the partials whose index matches its bits), then a plain xor-reduction over the remaining
+        // low bits.  Afterwards every lane with (sub / (C4/U)) == u holds the full dot of point j+u.
+        int m = C4 / 2;
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int jj = min(j + u, n - 1);
-            const int v = __shfl(my_rb, jj, C4);
-            d[u] = (j + u < n) ? __shfl(my_d, jj, C4) : 0.f;
-            g[u] = og4[(size_t)v * C4 + sub];
-          }
+        for (int h = U / 2; h >= 1; h >>= 1, m >>= 1) {
+          const bool hi = (sub & m) != 0;
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            part[j + u] = (j + u < n)
-                              ? fmaf(g[u].w, x.w, fmaf(g[u].z, x.z, fmaf(g[u].y, x.y, g[u].x * x.x)))
-                              : 0.f;
-            fg = fma4(d[u], g[u], fg);
+          for (int k = 0; k < h; ++k) {
+            const float send = hi ? part[k] : part[k + h];
+            const float keep = hi ? part[k + h] : part[k];
+            part[k] = keep + __shfl_xor(send, m, C4);
           }
         }
-      }
-      // butterfly: after the stage with mask m a lane keeps the m partials whose point index
-      // has the same bit m as the lane; at the end lane j holds the full sum of point j.
 #pragma unroll
-      for (int m = C4 / 2; m >= 1; m >>= 1) {
-        const bool hi = (sub & m) != 0;
-#pragma unroll
-        for (int k = 0; k < m; ++k) {
-          const float send = hi ? part[k] : part[k + m];
-          const float keep = hi ? part[k + m] : part[k];
-          part[k] = keep + __shfl_xor(send, m, C4);
-        }
+        for (; m >= 1; m >>= 1) part[0] += __shfl_xor(part[0], m, C4);
+        constexpr int kLanesPerPoint = C4 / U;
+        const int u_mine = sub / kLanesPerPoint;
+        const int rd_mine = __shfl(my_rd, min(j + u_mine, n - 1), C4);
+        if ((sub % kLanesPerPoint) == 0 && j + u_mine < n) depth_grad[rd_mine] = part[0];
       }
-      if (sub < n) depth_grad[my_rd] = part[0];
     }
   }
   feat_grad4[(size_t)f * C4 + sub] = fg;

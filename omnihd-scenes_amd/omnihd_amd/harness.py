@@ -1,0 +1,168 @@
+"""Synthetic-input training-step harness for the camera + 4D-radar BEV-fusion detector.
+
+Builds the detector from the REFERENCE's config dict (projects/configs/bevfusion_NewScenes/
+bevfusion.py, loaded unchanged when the file is available, otherwise from the equivalent dict kept
+here) and runs forward + backward + AdamW on seeded synthetic inputs of the shapes SURVEY.md 8(d)
+specifies.  The reference drives the same step through mmcv's EpochBasedRunner
+(projects/mmdet3d_plugin/bevformer/apis/mmdet_train.py:76-207: MMDistributedDataParallel with
+broadcast_buffers=False, AdamW lr 2e-4 wd 0.05, grad-clip 35); the runner itself is out of scope.
+"""
+import copy
+import math
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+POINT_CLOUD_RANGE = [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
+RES = {"r1": (256, 704, 410.0), "r2": (544, 960, 560.0)}
+ANCHOR_SIZES = [[1.9768212501227105, 4.637021209998035, 1.6647611354273741],
+                [0.796163784946599, 0.8183815295280997, 1.6895737765415433],
+                [0.912318683145357, 1.9201067650572057, 1.620921669034068],
+                [2.6724696700336494, 8.184714524976142, 3.0254503871391982]]
+ANCHOR_Z = [0.9104247242165809, 1.1421614665993767, 0.9059764319390522, 1.5158325603046292]
+
+
+def reference_model_cfg():
+    """The ``model=dict(...)`` of projects/configs/bevfusion_NewScenes/bevfusion.py:30-155, restated as
+    data (used when the reference checkout is not on the machine, e.g. the GPU box)."""
+    pcr, vs = POINT_CLOUD_RANGE, [0.25, 0.25, 8]
+    sync1, sync2 = (dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), dict(type="naiveSyncBN2d", eps=1e-3, momentum=0.01))
+    return dict(
+        type="BEVFUSION_depth", freeze_img=False, se=True, lc_fusion=True, camera_stream=True, lss=False, grid=0.5,
+        num_views=6, final_dim=(544, 960), pc_range=pcr, downsample=4, camera_depth_range=[1, 60, 1],
+        img_depth_loss_method="kld", img_depth_loss_weight=1.0,
+        pts_voxel_layer=dict(max_num_points=10, point_cloud_range=pcr, voxel_size=vs, max_voxels=(30000, 40000)),
+        pts_voxel_encoder=dict(type="PillarFeatureNetV1", in_channels=8, feat_channels=[64], with_distance=False,
+                               voxel_size=vs, point_cloud_range=pcr, norm_cfg=sync1),
+        pts_middle_encoder=dict(type="PointPillarsScatter", in_channels=64, output_shape=[320, 480]),
+        pts_backbone=dict(type="SECOND", in_channels=64, norm_cfg=sync2, layer_nums=[3, 5, 5], layer_strides=[2, 2, 2],
+                          out_channels=[64, 128, 256]),
+        pts_neck=dict(type="SECONDFPN", norm_cfg=sync2, in_channels=[64, 128, 256], upsample_strides=[1, 2, 4],
+                      out_channels=[128, 128, 128]),
+        img_backbone=dict(type="ResNet", depth=50, num_stages=4, out_indices=(1, 2, 3), frozen_stages=1,
+                          norm_cfg=dict(type="BN", requires_grad=False), norm_eval=True, style="pytorch"),
+        img_neck=dict(type="FPNC", final_dim=(544, 960), downsample=4, in_channels=[512, 1024, 2048], out_channels=256,
+                      use_adp=True, num_outs=4),
+        pts_bbox_head=dict(
+            type="Anchor3DHead", num_classes=4, in_channels=384, feat_channels=384, use_direction_classifier=True,
+            anchor_generator=dict(type="AlignedAnchor3DRangeGenerator",
+                                  ranges=[[-60, -40, z, 60, 40, z] for z in ANCHOR_Z], sizes=ANCHOR_SIZES,
+                                  custom_values=[0, 0], rotations=[0, 1.57], reshape_out=True),
+            assigner_per_size=False, diff_rad_by_sin=True, dir_offset=0.7854, dir_limit_offset=0,
+            bbox_coder=dict(type="DeltaXYZWLHRBBoxCoder", code_size=9),
+            loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+            loss_bbox=dict(type="SmoothL1Loss", beta=1.0 / 9.0, loss_weight=1.0),
+            loss_dir=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.2)),
+        train_cfg=dict(pts=dict(assigner=dict(type="MaxIoUAssigner", iou_calculator=dict(type="BboxOverlapsNearest3D"),
+                                              pos_iou_thr=0.6, neg_iou_thr=0.3, min_pos_iou=0.3, ignore_iof_thr=-1),
+                                allowed_border=0, code_weight=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2],
+                                pos_weight=-1, debug=False)),
+        test_cfg=dict(pts=dict(use_rotate_nms=True, nms_across_levels=False, nms_pre=1000, nms_thr=0.2, score_thr=0.05,
+                               min_bbox_size=0, max_num=500)))
+
+
+def model_cfg_for(res, radar_dims):
+    """Reference config with only the input geometry adapted: final_dim (R1 = the BASELINE metric's
+    256x704; R2 = the repo's 544x960) and the number of radar channels (7 in BASELINE.json, 8 in the
+    repo config)."""
+    ref = "/root/reference/projects/configs/bevfusion_NewScenes/bevfusion.py"
+    if os.path.exists(ref):
+        from .mm.config import load_config
+        cfg = copy.deepcopy(load_config(ref)["model"])
+    else:
+        cfg = reference_model_cfg()
+    H, W, _ = RES[res]
+    cfg["final_dim"] = (H, W)
+    cfg["img_neck"]["final_dim"] = (H, W)
+    cfg["pts_voxel_encoder"]["in_channels"] = radar_dims
+    return cfg
+
+
+def synthetic_lidar2img(res):
+    """Six pinhole cameras on a ring: float64 4x4 lidar2img per camera."""
+    H, W, fx = RES[res]
+    mats = []
+    for yaw_deg in (0, 60, -60, 180, 120, -120):
+        yaw = math.radians(yaw_deg)
+        R_c2l = np.array([[math.sin(yaw), 0, math.cos(yaw)], [-math.cos(yaw), 0, math.sin(yaw)], [0, -1, 0]])
+        t_c2l = np.array([math.cos(yaw), math.sin(yaw), 1.5])
+        R = R_c2l.T
+        E = np.eye(4); E[:3, :3] = R; E[:3, 3] = -R @ t_c2l
+        K = np.eye(4); K[0, 0] = K[1, 1] = fx; K[0, 2] = W / 2; K[1, 2] = H / 2
+        mats.append(K @ E)
+    return mats
+
+
+def synthetic_batch(res, batch, radar_dims, device, seed):
+    """Inputs of one training step, resident on ``device``."""
+    H, W, _ = RES[res]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    img = torch.randn(batch, 6, 3, H, W, generator=g)
+    img_depth = torch.zeros(batch, 6, H, W)
+    mask = torch.rand(batch, 6, H, W, generator=g) < 0.02
+    img_depth[mask] = torch.rand(int(mask.sum()), generator=g) * 59 + 1
+    points, gt_boxes, gt_labels = [], [], []
+    for _ in range(batch):
+        n = int(rng.integers(8000, 20001))
+        p = np.empty((n, radar_dims), dtype=np.float32)
+        p[:, 0] = rng.uniform(-60, 60, n); p[:, 1] = rng.uniform(-40, 40, n); p[:, 2] = rng.uniform(-3, 5, n)
+        p[:, 3:5] = rng.normal(0, 5, (n, 2)); p[:, 5] = rng.uniform(0, 60, n); p[:, 6] = rng.uniform(0, 40, n)
+        if radar_dims > 7:
+            p[:, 7] = rng.choice([0.0, 0.1, 0.2], n)
+        points.append(torch.from_numpy(p).to(device))
+        k = 30
+        cls = rng.integers(0, 4, k)
+        sz = np.asarray(ANCHOR_SIZES)[cls] * rng.uniform(0.8, 1.2, (k, 3))
+        box = np.concatenate([rng.uniform(-58, 58, (k, 1)), rng.uniform(-38, 38, (k, 1)),
+                              np.asarray(ANCHOR_Z)[cls][:, None] - sz[:, 2:3] / 2 + rng.normal(0, 0.2, (k, 1)), sz,
+                              rng.uniform(-math.pi, math.pi, (k, 1)), rng.normal(0, 3, (k, 2))], 1).astype(np.float32)
+        gt_boxes.append(torch.from_numpy(box).to(device))
+        gt_labels.append(torch.from_numpy(cls).long().to(device))
+    metas = [dict(lidar2img=synthetic_lidar2img(res)) for _ in range(batch)]
+    return dict(points=points, img=img.to(device), img_depth=img_depth.to(device), img_metas=metas,
+                gt_bboxes_3d=gt_boxes, gt_labels_3d=gt_labels)
+
+
+class FusionTrainStep:
+    """forward_train -> sum of losses -> backward -> grad-clip 35 -> AdamW (the reference recipe,
+    bevfusion.py:257-261), optionally under DistributedDataParallel (RCCL) and bf16 autocast for the
+    dense convolutions (pooling, voxelisation and the losses stay fp32)."""
+
+    def __init__(self, res="r1", batch=1, radar_dims=7, device="cuda:0", seed=0, dtype="bf16", ddp=False,
+                 channels_last=True, sets=2):
+        from .mm.config import build_detector
+        self.device = torch.device(device)
+        torch.manual_seed(0)                         # identical initial weights on every rank
+        model = build_detector(model_cfg_for(res, radar_dims)).to(self.device)
+        if channels_last:
+            model = model.to(memory_format=torch.channels_last)
+        model.train()
+        self.raw_model = model
+        self.model = model
+        if ddp:
+            self.model = nn.parallel.DistributedDataParallel(model, device_ids=[self.device.index],
+                                                             broadcast_buffers=False, bucket_cap_mb=25,
+                                                             gradient_as_bucket_view=True)
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=self.device.type == "cuda")
+        self.params = params
+        self.autocast = dtype == "bf16"
+        self.batches = [synthetic_batch(res, batch, radar_dims, self.device, seed + 1000 * i) for i in range(sets)]
+        self.i = 0
+        self.last_losses = None
+
+    def step(self):
+        b = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        self.opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
+            losses = self.model(return_loss=True, **b)
+        total = sum(v if torch.is_tensor(v) else sum(v) for v in losses.values())
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(self.params, max_norm=35, norm_type=2)
+        self.opt.step()
+        self.last_losses = losses
+        return total

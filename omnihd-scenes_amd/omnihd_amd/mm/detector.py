@@ -1,0 +1,76 @@
+"""``MVXFasterRCNN`` skeleton (mmdet3d v0.17.1 MVXTwoStageDetector subset) — the base class of the
+reference's fusion detectors (bevfusion/detectors/bevf_faster_rcnn_bevdepth.py:33).  Only what the
+camera + radar BEV-fusion path uses is restated: sub-module construction from the config dict with
+the upstream attribute names (``pts_voxel_layer``, ``pts_voxel_encoder``, ``pts_middle_encoder``,
+``pts_backbone``, ``pts_neck``, ``img_backbone``, ``img_neck``, ``pts_bbox_head``), ``voxelize``,
+``extract_img_feat`` and ``forward_pts_train``."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import BACKBONES, HEADS, MIDDLE_ENCODERS, NECKS, VOXEL_ENCODERS
+from .second import Voxelization
+from . import anchor_head, fpn, resnet, second  # noqa: F401  (register upstream type names)
+
+
+class MVXFasterRCNN(nn.Module):
+    def __init__(self, pts_voxel_layer=None, pts_voxel_encoder=None, pts_middle_encoder=None, pts_fusion_layer=None,
+                 img_backbone=None, pts_backbone=None, img_neck=None, pts_neck=None, pts_bbox_head=None,
+                 img_roi_head=None, img_rpn_head=None, train_cfg=None, test_cfg=None, pretrained=None, **_):
+        super().__init__()
+        if pts_voxel_layer:
+            self.pts_voxel_layer = Voxelization(**pts_voxel_layer)
+        if pts_voxel_encoder:
+            self.pts_voxel_encoder = VOXEL_ENCODERS.build(pts_voxel_encoder)
+        if pts_middle_encoder:
+            self.pts_middle_encoder = MIDDLE_ENCODERS.build(pts_middle_encoder)
+        if pts_backbone:
+            self.pts_backbone = BACKBONES.build(pts_backbone)
+        if pts_neck is not None:
+            self.pts_neck = NECKS.build(pts_neck)
+        if pts_bbox_head:
+            head = dict(pts_bbox_head)
+            head.update(train_cfg=train_cfg["pts"] if train_cfg else None, test_cfg=test_cfg["pts"] if test_cfg else None)
+            self.pts_bbox_head = HEADS.build(head)
+        if img_backbone:
+            self.img_backbone = BACKBONES.build(img_backbone)
+        if img_neck is not None:
+            self.img_neck = NECKS.build(img_neck)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    with_pts_backbone = property(lambda self: hasattr(self, "pts_backbone"))
+    with_pts_neck = property(lambda self: hasattr(self, "pts_neck"))
+    with_img_backbone = property(lambda self: hasattr(self, "img_backbone"))
+    with_img_neck = property(lambda self: hasattr(self, "img_neck"))
+    with_pts_bbox = property(lambda self: hasattr(self, "pts_bbox_head"))
+    with_img_bbox = property(lambda self: False)
+
+    def extract_img_feat(self, img, img_metas):
+        """(B, N, C, H, W) images -> list of (B*N, C', h, w) neck outputs."""
+        if not self.with_img_backbone or img is None:
+            return None
+        if img.dim() == 5:
+            B, N, C, H, W = img.shape
+            img = img.view(B * N, C, H, W)
+        feats = self.img_backbone(img)
+        if self.with_img_neck:
+            feats = self.img_neck(feats)
+        return feats
+
+    @torch.no_grad()
+    def voxelize(self, points):
+        """Per-sample hard voxelisation (HIP kernel), concatenated, batch index prepended to coors."""
+        voxels, coors, nums = [], [], []
+        for i, res in enumerate(points):
+            v, c, n = self.pts_voxel_layer(res)
+            voxels.append(v)
+            nums.append(n)
+            coors.append(F.pad(c, (1, 0), mode="constant", value=i))
+        return torch.cat(voxels, dim=0), torch.cat(nums, dim=0), torch.cat(coors, dim=0)
+
+    def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore=None):
+        outs = self.pts_bbox_head(pts_feats)
+        return self.pts_bbox_head.loss(*outs, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+
+    def forward_img_train(self, x, img_metas, **kwargs):
+        return dict()     # no image head in the fusion configs

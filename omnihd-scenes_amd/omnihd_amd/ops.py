@@ -373,4 +373,4 @@ def pillar_scatter(feats, coors, batch, ny, nx, channels_last=False):
     w.r.t. feats).  With ``channels_last`` the memory layout is NHWC under an NCHW-shaped view."""
     if not feats.is_cuda:
         raise RuntimeError("pillar_scatter: CUDA(HIP) tensors only; no CPU path")
-    return _PillarScatter.apply(feats, coors, int(batch), int(ny), int(nx), bool(channels_last))
+    return _PillarScatter.apply(feats.float(), coors, int(batch), int(ny), int(nx), bool(channels_last))

@@ -212,7 +212,8 @@ def planned_pool(depth, feat, plan):
     zero-copy view over (B,Y,X,Z,C) memory, so ``cat(unbind(dim=2), 1)`` (s2c) is a reshape."""
     B, Z, Y, X = plan.grid
     C = feat.size(-1)
-    rows = _PlannedPool.apply(depth, feat, plan)
+    # fp32 like the reference (bev_pool.py:20-21); the casts are autograd ops so bf16 callers get bf16 grads
+    rows = _PlannedPool.apply(depth.float(), feat.float(), plan)
     if plan.layout == "bzyx":
         return rows.view(B, Z, Y, X, C).permute(0, 4, 1, 2, 3)
     return rows.view(B, Y, X, Z, C).permute(0, 4, 3, 1, 2)

@@ -1,0 +1,126 @@
+"""``BEVFUSION_depth`` — camera + 4D-radar BEV-fusion detector, host-side mirror of
+projects/mmdet3d_plugin/bevfusion/detectors/bevf_faster_rcnn_bevdepth.py (class :33-232, SE_Block
+:21-30).  Same registry name, constructor arguments, attribute / state-dict names
+(``lift_splat_shot_vis``, ``reduc_conv.conv``, ``reduc_conv.bn``, ``seblock.att.1``) and the same
+``forward_train`` signature and loss keys (``loss_cls``, ``loss_bbox``, ``loss_dir``,
+``img_depth_loss``).
+
+Hot-path differences: radar voxelisation / pillar scatter and the LSS pooling run in the HIP
+kernels; the pooled BEV tensor arrives channels-last and zero-copy; ``batch_size`` comes from the
+host (``len(img_metas)``) instead of the reference's device->host ``coors[-1, 0] + 1`` sync (:100);
+camera inverses are computed in one batched fp32 ``inverse`` on the host (:116-130 builds 12 tiny
+tensors per sample).  ``simple_test`` does not render debug figures (reference defect D7)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from omnihd_amd.mm import DETECTORS, ConvModule
+from omnihd_amd.mm.detector import MVXFasterRCNN
+
+from .cam_stream_lss_bevpoolv2_depthnet import LiftSplatShoot_Depth
+
+__all__ = ["BEVFUSION_depth", "SE_Block"]
+
+
+class SE_Block(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.att = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(c, c, kernel_size=1, stride=1), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.att(x)
+
+
+@DETECTORS.register_module()
+class BEVFUSION_depth(MVXFasterRCNN):
+    def __init__(self, freeze_img=False, lss=False, lc_fusion=False, camera_stream=False,
+                 camera_depth_range=[4.0, 45.0, 1.0], img_depth_loss_weight=1.0, img_depth_loss_method="kld",
+                 grid=0.6, num_views=6, se=False, final_dim=(900, 1600), pc_range=[-50, -50, -5, 50, 50, 3],
+                 downsample=4, imc=256, lic=384, norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), **kwargs):
+        super().__init__(**kwargs)
+        self.num_views, self.lc_fusion = num_views, lc_fusion
+        self.img_depth_loss_weight, self.img_depth_loss_method = img_depth_loss_weight, img_depth_loss_method
+        self.camera_depth_range = camera_depth_range
+        self.lift, self.se = camera_stream, se
+        if camera_stream:
+            self.lift_splat_shot_vis = LiftSplatShoot_Depth(lss=lss, grid=grid, inputC=imc, camC=64, pc_range=pc_range,
+                                                            camera_depth_range=camera_depth_range, final_dim=final_dim,
+                                                            downsample=downsample, norm_cfg=norm_cfg)
+        if lc_fusion:
+            if se:
+                self.seblock = SE_Block(lic)
+            self.reduc_conv = ConvModule(lic + imc, lic, 3, padding=1, conv_cfg=None, norm_cfg=norm_cfg,
+                                         act_cfg=dict(type="ReLU"), inplace=False)
+        self.freeze_img = freeze_img
+        self.freeze()
+
+    def freeze(self):
+        if not self.freeze_img:
+            return
+        mods = [getattr(self, n) for n in ("img_backbone", "img_neck") if hasattr(self, n)]
+        if self.lift:
+            mods.append(self.lift_splat_shot_vis)
+        for m in mods:
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def extract_pts_feat(self, pts, img_feats, img_metas):
+        if not self.with_pts_backbone:
+            return None
+        voxels, num_points, coors = self.voxelize(pts)
+        voxel_features = self.pts_voxel_encoder(voxels, num_points, coors)
+        x = self.pts_middle_encoder(voxel_features, coors, len(pts))
+        x = self.pts_backbone(x)
+        if self.with_pts_neck:
+            x = self.pts_neck(x)
+        return x
+
+    @staticmethod
+    def _cam_inverse(img_metas, device):
+        """rots (B,N,3,3), trans (B,N,3) = blocks of inverse(lidar2img) in fp32 (reference :116-130)."""
+        mats = torch.Tensor(np.stack([np.stack([np.asarray(m) for m in meta["lidar2img"]]) for meta in img_metas]))
+        inv = mats.inverse()
+        return inv[..., :3, :3].to(device), inv[..., :3, 3].to(device)
+
+    def extract_feat(self, points, img, img_metas, gt_bboxes_3d=None):
+        img_feats = self.extract_img_feat(img, img_metas)
+        pts_feats = self.extract_pts_feat(points, img_feats, img_metas)
+        depth_dist = None
+        if self.lift:
+            BN, C, H, W = img_feats[0].shape
+            batch_size = BN // self.num_views
+            view = img_feats[0].view(batch_size, self.num_views, C, H, W)
+            rots, trans = self._cam_inverse(img_metas, view.device)
+            img_bev_feat, depth_dist = self.lift_splat_shot_vis(view, rots, trans, lidar2img_rt=None,
+                                                                img_metas=img_metas)
+            if pts_feats is None:
+                pts_feats = [img_bev_feat]
+            elif self.lc_fusion:
+                if img_bev_feat.shape[2:] != pts_feats[0].shape[2:]:
+                    img_bev_feat = F.interpolate(img_bev_feat, pts_feats[0].shape[2:], mode="bilinear",
+                                                 align_corners=True)
+                pts_feats = [self.reduc_conv(torch.cat([img_bev_feat, pts_feats[0]], dim=1))]
+                if self.se:
+                    pts_feats = [self.seblock(pts_feats[0])]
+        return dict(img_feats=img_feats, pts_feats=pts_feats, depth_dist=depth_dist)
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_labels=None,
+                      gt_bboxes=None, img=None, img_depth=None, proposals=None, gt_bboxes_ignore=None):
+        fd = self.extract_feat(points, img=img, img_metas=img_metas, gt_bboxes_3d=gt_bboxes_3d)
+        img_feats, pts_feats, depth_dist = fd["img_feats"], fd["pts_feats"], fd["depth_dist"]
+        losses = dict()
+        if pts_feats:
+            losses.update(self.forward_pts_train(pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore))
+        if img_feats:
+            if img_depth is not None:
+                loss_depth, _ = self.lift_splat_shot_vis.get_depth_loss(depth_labels=img_depth, depth_preds=depth_dist,
+                                                                        loss_depth_type=self.img_depth_loss_method)
+                losses.update(img_depth_loss=self.img_depth_loss_weight * loss_depth)
+            losses.update(self.forward_img_train(img_feats, img_metas=img_metas))
+        return losses
+
+    def forward(self, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(**kwargs)
+        raise NotImplementedError("test-time decoding (rotate-NMS, box export) is a 'next' row of SURVEY.md 8(f)")

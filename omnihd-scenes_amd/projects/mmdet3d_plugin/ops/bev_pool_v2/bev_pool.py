@@ -74,7 +74,7 @@ class QuickCumsumCuda(torch.autograd.Function):
 def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
                 interval_lengths):
     """Returns the pooled feature as a contiguous (B, C, Z, Y, X) tensor."""
-    x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+    x = QuickCumsumCuda.apply(depth.float(), feat.float(), ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
                               interval_starts, interval_lengths)
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
