@@ -30,15 +30,19 @@ class DeformConv2dPack(nn.Module):
         nn.init.zeros_(self.conv_offset.bias)
 
     def forward(self, x):
+        offset = self.conv_offset(x)                                   # (B, dg*2*k*k, Ho, Wo)
+        with torch.autocast(x.device.type, enabled=False):             # sampling positions need fp32
+            return self._sample_and_contract(x.float(), offset.float()).to(x.dtype)
+
+    def _sample_and_contract(self, x, offset):
         B, C, H, W = x.shape
         k, s, p, d = self.k, self.stride, self.padding, self.dilation
-        offset = self.conv_offset(x)                                   # (B, dg*2*k*k, Ho, Wo)
         Ho, Wo = offset.shape[-2:]
         dg = self.deform_groups
         offset = offset.view(B, dg, k * k, 2, Ho, Wo)
         ys = torch.arange(Ho, device=x.device, dtype=x.dtype).view(1, 1, Ho, 1) * s - p
         xs = torch.arange(Wo, device=x.device, dtype=x.dtype).view(1, 1, 1, Wo) * s - p
-        xg = x.view(B * dg, C // dg, H, W)
+        xg = x.reshape(B * dg, C // dg, H, W)
         cols = []
         for t in range(k * k):
             ky, kx = divmod(t, k)
@@ -51,7 +55,7 @@ class DeformConv2dPack(nn.Module):
                         .view(B, C, Ho, Wo))
         col = torch.stack(cols, dim=2)                                 # (B, C, k*k, Ho, Wo)
         g = self.groups
-        col = col.view(B, g, (C // g) * k * k, Ho * Wo)
-        w = self.weight.view(g, self.out_channels // g, (C // g) * k * k)
+        col = col.reshape(B, g, (C // g) * k * k, Ho * Wo)
+        w = self.weight.float().reshape(g, self.out_channels // g, (C // g) * k * k)
         out = torch.einsum("gok,bgkn->bgon", w, col)
         return out.reshape(B, self.out_channels, Ho, Wo)
