@@ -242,11 +242,8 @@ def cpu_baseline_fusion(res, radar_dims, budget_s=30.0):
     """The same training step on the host CPU: torch-CPU dense layers + the oracle (port of the
     reference algorithm) for the ops that have no reference CPU kernels.  As in the reference, the
     rank tables are rebuilt every forward and re-sorted every backward (no plan cache)."""
-    import omnihd_amd
-    from omnihd_amd import harness, ops as gops
-    from oracle import cpu as OC
-    from oracle import lss_oracle as O
-    from projects.mmdet3d_plugin.bevfusion.detectors import cam_stream_lss_bevpoolv2_depthnet as lssmod
+    from omnihd_amd import harness
+    from oracle.torch_shim import oracle_ops
 
     # More threads than ~32 make torch-CPU convolutions at batch 6 slower, not faster (measured on the
     # 256-core GPU host: 435 s/step with 256 threads); the thread count actually used is reported.
@@ -254,69 +251,18 @@ def cpu_baseline_fusion(res, radar_dims, budget_s=30.0):
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
 
-    class CpuPlan:
-        pass
-
-    def cpu_build_plan(coor, dx, bx, nx, layout="bzyx"):
-        p = CpuPlan()
-        p.tabs = O.voxel_pooling_prepare_v2(coor.numpy(), dx, bx, nx)
-        p.n_points = 0 if p.tabs[0] is None else len(p.tabs[0])
-        p.nx = [int(v) for v in nx]
-        return p
-
-    class CpuPool(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, depth, feat, plan):
-            rb, rd, rf, st, ln = plan.tabs
-            B, C = depth.shape[0], feat.shape[-1]
-            X, Y, Z = plan.nx
-            out = OC.bev_pool_v2_fwd(depth.numpy(), feat.numpy(), rd, rf, rb, (B, Z, Y, X, C), st, ln, threads=True)
-            ctx.save_for_backward(depth, feat)
-            ctx.plan = plan
-            return torch.from_numpy(out)
-
-        @staticmethod
-        def backward(ctx, g):
-            depth, feat = ctx.saved_tensors
-            rb, rd, rf, st, ln = ctx.plan.tabs
-            bp = O.backward_tables(rb, rd, rf)
-            dg, fg = OC.bev_pool_v2_bwd(g.contiguous().numpy(), depth.numpy(), feat.numpy(), bp[1], bp[2], bp[0],
-                                        bp[3], bp[4], threads=True)
-            return torch.from_numpy(dg), torch.from_numpy(fg), None
-
-    def cpu_planned_pool(depth, feat, plan):
-        out = CpuPool.apply(depth.float().contiguous(), feat.float().contiguous(), plan)
-        return out.permute(0, 4, 1, 2, 3).contiguous()          # bev_pool.py:91
-
-    def cpu_voxelize(points, voxel_size, pcr, max_points, max_voxels):
-        v, c, n = OC.hard_voxelize(points.numpy(), voxel_size, pcr, max_points, max_voxels)
-        return torch.from_numpy(v), torch.from_numpy(c), torch.from_numpy(n)
-
-    def cpu_scatter(feats, coors, batch, ny, nx, channels_last=False):
-        canvas = feats.new_zeros(batch, feats.shape[1], ny * nx)
-        c = coors.long()
-        for b in range(batch):                                   # PointPillarsScatter.forward_batch
-            m = c[:, 0] == b
-            canvas[b][:, c[m, 2] * nx + c[m, 3]] = feats[m].t()
-        return canvas.view(batch, -1, ny, nx)
-
-    saved = (omnihd_amd.build_plan, lssmod.planned_pool, gops.hard_voxelize, gops.pillar_scatter)
-    omnihd_amd.build_plan, lssmod.planned_pool = cpu_build_plan, cpu_planned_pool
-    gops.hard_voxelize, gops.pillar_scatter = cpu_voxelize, cpu_scatter
-    try:
+    with oracle_ops():
         st = harness.FusionTrainStep(res=res, batch=1, radar_dims=radar_dims, device="cpu", dtype="fp32",
                                      channels_last=False, sets=1)
         lss = st.raw_model.lift_splat_shot_vis
         steps, t0 = 0, time.perf_counter()
         while True:
-            lss._plans.clear()
+            lss._plans.clear()                     # the reference rebuilds the tables every forward
             st.step()
             steps += 1
             el = time.perf_counter() - t0
             if el > budget_s or steps >= 2:
                 break
-    finally:
-        omnihd_amd.build_plan, lssmod.planned_pool, gops.hard_voxelize, gops.pillar_scatter = saved
     return {"value": round(steps / el, 4), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{steps} training step(s) of the same fusion workload at {res}, B=1, fp32: torch-CPU dense layers; "
                       "numpy rank tables rebuilt every forward, C/OpenMP pooling fwd+bwd with per-backward re-sort, "

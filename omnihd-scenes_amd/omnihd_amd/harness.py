@@ -80,14 +80,39 @@ def model_cfg_for(res, radar_dims):
     return cfg
 
 
+TINY = dict(H=32, W=48, fx=30.0, pc_range=[-8.0, -6.0, -1.0, 8.0, 6.0, 1.0], grid=1.0, voxel_size=[0.5, 0.5, 2.0],
+            canvas=[24, 32], depth_range=[1.0, 9.0, 1.0], radius=0.3, height=0.2, n_points=(300, 600), n_boxes=6,
+            anchor_sizes=[[0.8, 1.6, 0.8], [0.4, 0.4, 0.9]], anchor_z=[-0.4, -0.45])
+
+
+def tiny_model_cfg(radar_dims=7):
+    """A scaled-down copy of the reference model config (same module graph: R50, FPNC, DepthNet with
+    DCN, LSS, pillars, SECOND/FPN, fusion conv + SE, Anchor3DHead) for tests and smoke runs."""
+    cfg = reference_model_cfg()
+    t = TINY
+    cfg.update(final_dim=(t["H"], t["W"]), pc_range=t["pc_range"], grid=t["grid"], camera_depth_range=t["depth_range"])
+    cfg["img_neck"]["final_dim"] = (t["H"], t["W"])
+    cfg["pts_voxel_layer"].update(point_cloud_range=t["pc_range"], voxel_size=t["voxel_size"], max_voxels=(400, 500))
+    cfg["pts_voxel_encoder"].update(in_channels=radar_dims, voxel_size=t["voxel_size"], point_cloud_range=t["pc_range"])
+    cfg["pts_middle_encoder"]["output_shape"] = t["canvas"]
+    r = t["pc_range"]
+    cfg["pts_bbox_head"].update(num_classes=2)
+    cfg["pts_bbox_head"]["anchor_generator"].update(
+        ranges=[[r[0], r[1], z, r[3], r[4], z] for z in t["anchor_z"]], sizes=t["anchor_sizes"])
+    return cfg
+
+
 def synthetic_lidar2img(res):
     """Six pinhole cameras on a ring: float64 4x4 lidar2img per camera."""
-    H, W, fx = RES[res]
+    if res == "tiny":
+        H, W, fx, radius, height = TINY["H"], TINY["W"], TINY["fx"], TINY["radius"], TINY["height"]
+    else:
+        (H, W, fx), radius, height = RES[res], 1.0, 1.5
     mats = []
     for yaw_deg in (0, 60, -60, 180, 120, -120):
         yaw = math.radians(yaw_deg)
         R_c2l = np.array([[math.sin(yaw), 0, math.cos(yaw)], [-math.cos(yaw), 0, math.sin(yaw)], [0, -1, 0]])
-        t_c2l = np.array([math.cos(yaw), math.sin(yaw), 1.5])
+        t_c2l = np.array([radius * math.cos(yaw), radius * math.sin(yaw), height])
         R = R_c2l.T
         E = np.eye(4); E[:3, :3] = R; E[:3, 3] = -R @ t_c2l
         K = np.eye(4); K[0, 0] = K[1, 1] = fx; K[0, 2] = W / 2; K[1, 2] = H / 2
@@ -97,6 +122,8 @@ def synthetic_lidar2img(res):
 
 def synthetic_batch(res, batch, radar_dims, device, seed):
     """Inputs of one training step, resident on ``device``."""
+    if res == "tiny":
+        return _tiny_batch(batch, radar_dims, device, seed)
     H, W, _ = RES[res]
     g = torch.Generator(device="cpu").manual_seed(seed)
     rng = np.random.default_rng(seed)
@@ -126,6 +153,35 @@ def synthetic_batch(res, batch, radar_dims, device, seed):
                 gt_bboxes_3d=gt_boxes, gt_labels_3d=gt_labels)
 
 
+def _tiny_batch(batch, radar_dims, device, seed):
+    t = TINY
+    H, W, r = t["H"], t["W"], t["pc_range"]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    img = torch.randn(batch, 6, 3, H, W, generator=g)
+    img_depth = torch.zeros(batch, 6, H, W)
+    mask = torch.rand(batch, 6, H, W, generator=g) < 0.1
+    img_depth[mask] = torch.rand(int(mask.sum()), generator=g) * 8 + 1
+    points, gt_boxes, gt_labels = [], [], []
+    for _ in range(batch):
+        n = int(rng.integers(*t["n_points"]))
+        p = rng.normal(0, 2, (n, radar_dims)).astype(np.float32)
+        p[:, 0] = rng.uniform(r[0] - 0.5, r[3] + 0.5, n); p[:, 1] = rng.uniform(r[1] - 0.5, r[4] + 0.5, n)
+        p[:, 2] = rng.uniform(r[2], r[5], n)
+        points.append(torch.from_numpy(p).to(device))
+        k = t["n_boxes"]
+        cls = rng.integers(0, 2, k)
+        sz = np.asarray(t["anchor_sizes"])[cls] * rng.uniform(0.9, 1.1, (k, 3))
+        box = np.concatenate([rng.uniform(r[0] + 1, r[3] - 1, (k, 1)), rng.uniform(r[1] + 1, r[4] - 1, (k, 1)),
+                              np.asarray(t["anchor_z"])[cls][:, None] - sz[:, 2:3] / 2, sz,
+                              rng.uniform(-math.pi, math.pi, (k, 1)), rng.normal(0, 1, (k, 2))], 1).astype(np.float32)
+        gt_boxes.append(torch.from_numpy(box).to(device))
+        gt_labels.append(torch.from_numpy(cls).long().to(device))
+    metas = [dict(lidar2img=synthetic_lidar2img("tiny")) for _ in range(batch)]
+    return dict(points=points, img=img.to(device), img_depth=img_depth.to(device), img_metas=metas,
+                gt_bboxes_3d=gt_boxes, gt_labels_3d=gt_labels)
+
+
 class FusionTrainStep:
     """forward_train -> sum of losses -> backward -> grad-clip 35 -> AdamW (the reference recipe,
     bevfusion.py:257-261), optionally under DistributedDataParallel (RCCL) and bf16 autocast for the
@@ -136,16 +192,17 @@ class FusionTrainStep:
         from .mm.config import build_detector
         self.device = torch.device(device)
         torch.manual_seed(0)                         # identical initial weights on every rank
-        model = build_detector(model_cfg_for(res, radar_dims)).to(self.device)
+        cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)
+        model = build_detector(cfg).to(self.device)
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
         model.train()
         self.raw_model = model
         self.model = model
         if ddp:
-            self.model = nn.parallel.DistributedDataParallel(model, device_ids=[self.device.index],
-                                                             broadcast_buffers=False, bucket_cap_mb=25,
-                                                             gradient_as_bucket_view=True)
+            self.model = nn.parallel.DistributedDataParallel(
+                model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
+                broadcast_buffers=False, bucket_cap_mb=25, gradient_as_bucket_view=True)
         params = [p for p in model.parameters() if p.requires_grad]
         self.opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=self.device.type == "cuda")
         self.params = params
@@ -158,7 +215,7 @@ class FusionTrainStep:
         b = self.batches[self.i % len(self.batches)]
         self.i += 1
         self.opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
+        with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.autocast):
             losses = self.model(return_loss=True, **b)
         total = sum(v if torch.is_tensor(v) else sum(v) for v in losses.values())
         total.backward()
