@@ -231,6 +231,23 @@ int omnihd_pillar_gather(const float* canvas_grad, const int* coors, int m, int 
                          int batch, int ny, int nx, int channels_last, float* feats_grad,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dense BEV convolutions (matrix cores)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution, bf16 inputs, fp32 accumulate/output.
+ * ref: the backward of the nn.Conv2d layers of LiftSplatShoot_Depth.bevencode
+ * (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:201-214) and of reduc_conv
+ * (bevf_faster_rcnn_bevdepth.py:61-72), which the reference leaves to cuDNN.
+ *   x_nhwc    [batch, h, w, cin]  bf16 (channels-last activations of the forward pass)
+ *   gout_nhwc [batch, h, w, cout] bf16 (gradient of the conv output)
+ *   dw        [cout, 3, 3, cin]   fp32 (= the memory of a channels-last (cout,cin,3,3) weight)
+ * cin, cout multiples of 128; w a multiple of 8.  Deterministic (fixed split-K order).        */
+size_t omnihd_conv3x3_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout);
+int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw,
+                              int batch, int h, int w, int cin, int cout,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

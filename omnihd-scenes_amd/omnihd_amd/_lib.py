@@ -35,6 +35,8 @@ PROTOTYPES = {
     "omnihd_pillar_scatter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "omnihd_pillar_scatter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "omnihd_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
+    "omnihd_conv3x3_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "omnihd_pillar_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p]),
 }

@@ -63,6 +63,30 @@ def build_activation(cfg):
     raise KeyError(f"unknown activation {t}")
 
 
+class BevConv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state-dict keys) whose 3x3 s1 p1 bf16 training path takes its weight
+    gradient from the hand-written MFMA kernel (omnihd_conv3x3_wgrad_bf16); everything else is MIOpen."""
+
+    def forward(self, x):
+        from .. import ops
+        if (self.training and torch.is_autocast_enabled() and x.is_cuda and self.bias is None
+                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1):
+            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            wb = self.weight.to(torch.bfloat16)
+            if ops.conv3x3_wgrad_supported(xb, wb):
+                return ops.conv3x3(xb, wb)
+        return super().forward(x)
+
+
+def use_bev_conv(module):
+    """Switch every eligible nn.Conv2d under ``module`` to BevConv2d in place (parameters are kept)."""
+    for m in module.modules():
+        if type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) \
+                and m.groups == 1 and m.bias is None and m.in_channels % 128 == 0 and m.out_channels % 128 == 0:
+            m.__class__ = BevConv2d
+
+
 class ConvModule(nn.Module):
     """conv -> norm -> act with mmcv's attribute names (``.conv``, ``.bn``, ``.activate``) so that
     state-dict keys such as ``reduc_conv.conv.weight`` / ``reduc_conv.bn.weight`` match."""

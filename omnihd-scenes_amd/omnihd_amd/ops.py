@@ -374,3 +374,67 @@ def pillar_scatter(feats, coors, batch, ny, nx, channels_last=False):
     if not feats.is_cuda:
         raise RuntimeError("pillar_scatter: CUDA(HIP) tensors only; no CPU path")
     return _PillarScatter.apply(feats.float(), coors, int(batch), int(ny), int(nx), bool(channels_last))
+
+
+# ---------------------------------------------------------------------------------------------
+# dense BEV convolutions: hand-written MFMA weight gradient
+# ---------------------------------------------------------------------------------------------
+_WGRAD_WS = {}
+
+
+def conv3x3_wgrad(x, grad_out):
+    """x (B,Cin,H,W) bf16 channels-last, grad_out (B,Cout,H,W) bf16 channels-last ->
+    dW (Cout,Cin,3,3) fp32 in channels-last memory (3x3, stride 1, pad 1)."""
+    _want_cl(x, "x"); _want_cl(grad_out, "grad_out")
+    B, cin, H, W = x.shape
+    cout = grad_out.shape[1]
+    dev = x.device
+    dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib().omnihd_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
+        key = (str(dev), torch.cuda.current_stream().cuda_stream)
+        ws = _WGRAD_WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _workspace(nbytes, dev)
+            _WGRAD_WS[key] = ws
+        check(lib().omnihd_conv3x3_wgrad_bf16(_ptr(x), _ptr(grad_out), _ptr(dw), B, H, W, cin, cout, _ptr(ws),
+                                              ws.numel(), _stream()), "omnihd_conv3x3_wgrad_bf16")
+    return dw.permute(0, 3, 1, 2)
+
+
+def _want_cl(t, name):
+    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4:
+        raise TypeError(f"{name} must be a 4-D bf16 CUDA(HIP) tensor")
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError(f"{name} must be channels-last contiguous")
+
+
+def conv3x3_wgrad_supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and weight.shape[2:] == (3, 3)
+            and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0 and x.shape[3] % 8 == 0)
+
+
+class _Conv3x3(torch.autograd.Function):
+    """3x3/s1/p1 convolution: forward and data gradient on MIOpen, WEIGHT gradient on the hand-written
+    MFMA kernel (the slowest dense kernel of the training step under MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = None
+        g = g.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = conv3x3_wgrad(x.contiguous(memory_format=torch.channels_last), g).to(weight.dtype)
+        return gx, gw
+
+
+def conv3x3(x, weight):
+    return _Conv3x3.apply(x, weight)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from omnihd_amd.mm import DETECTORS, ConvModule
+from omnihd_amd.mm.bricks import use_bev_conv
 from omnihd_amd.mm.detector import MVXFasterRCNN
 
 from .cam_stream_lss_bevpoolv2_depthnet import LiftSplatShoot_Depth
@@ -52,6 +53,11 @@ class BEVFUSION_depth(MVXFasterRCNN):
                 self.seblock = SE_Block(lic)
             self.reduc_conv = ConvModule(lic + imc, lic, 3, padding=1, conv_cfg=None, norm_cfg=norm_cfg,
                                          act_cfg=dict(type="ReLU"), inplace=False)
+        # dense BEV convolutions (BEV encoder, fusion conv): weight gradient on the hand-written MFMA kernel
+        if camera_stream:
+            use_bev_conv(self.lift_splat_shot_vis.bevencode)
+        if lc_fusion:
+            use_bev_conv(self.reduc_conv)
         self.freeze_img = freeze_img
         self.freeze()
 
