@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma(const unsigned short* __r
       rb[i] = ok ? *reinterpret_cast<const uint4*>(b_src + (size_t)(32 * i) * Mp + k) : make_uint4(0, 0, 0, 0);
     }
     px += kBK;
-    if (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
+    while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
   };
   auto stash = [&](int buf) {
 #pragma unroll
