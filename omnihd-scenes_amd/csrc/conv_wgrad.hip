@@ -110,7 +110,13 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma(const unsigned short* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ra[i] = *reinterpret_cast<const uint4*>(a_src + (size_t)(32 * i) * Mp + k);
-      rb[i] = ok ? *reinterpret_cast<const uint4*>(b_src + (size_t)(32 * i) * Mp + k) : make_uint4(0, 0, 0, 0);
+      rb[i] = *reinterpret_cast<const uint4*>(b_src + (size_t)(32 * i) * Mp + k);   // always in bounds (guards)
+    }
+    // mask AFTER the loads: a load behind a runtime condition would be branched around and waited for
+    // one by one (4 dependent memory round trips per K-step)
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = make_uint4(0, 0, 0, 0);
     }
     px += kBK;
     while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
