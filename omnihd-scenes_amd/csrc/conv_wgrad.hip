@@ -18,6 +18,7 @@
 // one step ahead, fp32 accumulation, split-K over pixel ranges into fp32 slabs that a second tiny
 // kernel adds in a fixed order (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace omnihd {
 namespace {
@@ -192,6 +193,16 @@ __global__ __launch_bounds__(kBlock) void k_sum_slabs(const float* __restrict__ 
   }
 }
 
+// Row pitch of the pixel-major operands.  A pitch that is a multiple of 1 KiB (38400 px * 2 B = 75 KiB)
+// maps every row of a tile onto the same few L2 channels; an ODD number of 128-byte lines per row
+// rotates the rows over all channels.
+int padded_pixels(size_t m) {
+  size_t mp = (m + kBK - 1) / kBK * kBK;
+  static const int extra = [] { const char* e = getenv("OMNIHD_WGRAD_PAD"); return e ? atoi(e) : 1; }();
+  if (extra > 0 && (mp / 64) % 2 == 0) mp += 64 * (size_t)extra;
+  return (int)mp;
+}
+
 int pick_split(int cout, int cin, int mp) {
   const int tiles = (cout / kTile) * (cin / kTile) * 9;
   int s = (3 * kCUs + tiles - 1) / tiles;          // aim at >= 3 workgroups per CU
@@ -210,7 +221,7 @@ using namespace omnihd;
 extern "C" size_t omnihd_conv3x3_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout) {
   if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 256;
   const size_t M = (size_t)batch * h * w;
-  const size_t Mp = (M + kBK - 1) / kBK * kBK;
+  const size_t Mp = padded_pixels(M);
   const int S = pick_split(cout, cin, (int)Mp);
   // [pad row of W pixels] Gt [Cout][Mp] | guard | Xt [3][Cin][Mp] | guard | slabs
   return align_up((size_t)cout * Mp * 2, 256) + align_up((size_t)3 * cin * Mp * 2, 256) +
@@ -231,7 +242,7 @@ extern "C" int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nh
     return OMNIHD_ERR_WORKSPACE;
   }
   const int M = batch * h * w;
-  const int Mp = (M + kBK - 1) / kBK * kBK;
+  const int Mp = padded_pixels(M);
   const int S = pick_split(cout, cin, Mp);
   int k_per_split = ((Mp / kBK + S - 1) / S) * kBK;
   const size_t guard = align_up((size_t)w * 2 + 256, 256);   // a dy = -1 read at k = 0 lands here, masked anyway
