@@ -69,22 +69,61 @@ class BevConv2d(nn.Conv2d):
 
     def forward(self, x):
         from .. import ops
-        if (self.training and torch.is_autocast_enabled() and x.is_cuda and self.bias is None
+        if (self.training and self.weight.requires_grad and torch.is_autocast_enabled() and x.is_cuda
                 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
                 and self.dilation == (1, 1) and self.groups == 1):
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             wb = self.weight.to(torch.bfloat16)
             if ops.conv3x3_wgrad_supported(xb, wb):
-                return ops.conv3x3(xb, wb)
+                return ops.conv3x3(xb, wb, None if self.bias is None else self.bias.to(torch.bfloat16))
         return super().forward(x)
 
 
 def use_bev_conv(module):
-    """Switch every eligible nn.Conv2d under ``module`` to BevConv2d in place (parameters are kept)."""
+    """Switch every eligible nn.Conv2d under ``module`` (3x3, stride 1, pad 1, channels % 128 == 0) to
+    BevConv2d in place; parameters and state-dict keys are kept.  Layers whose feature-map width is not a
+    multiple of 8 simply take the MIOpen path at run time."""
+    n = 0
     for m in module.modules():
         if type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) \
-                and m.groups == 1 and m.bias is None and m.in_channels % 128 == 0 and m.out_channels % 128 == 0:
+                and m.dilation == (1, 1) and m.groups == 1 and m.in_channels % 128 == 0 and m.out_channels % 128 == 0:
             m.__class__ = BevConv2d
+            n += 1
+    return n
+
+
+class BilinearResize(nn.Module):
+    """``nn.Upsample(size, mode='bilinear', align_corners=True)`` as two small matrix products
+    (out = Rh @ x @ Rw^T; bilinear resampling is separable and linear).  Same values up to fp rounding;
+    forward AND backward are GEMMs instead of the slow gather/scatter interpolation kernels."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.size = tuple(size)
+        self._cache = {}
+
+    @staticmethod
+    def _matrix(n_out, n_in, device, dtype):
+        m = torch.zeros(n_out, n_in, device=device, dtype=torch.float32)
+        if n_in == 1 or n_out == 1:
+            m[:, 0] = 1.0
+            return m.to(dtype)
+        pos = torch.arange(n_out, device=device, dtype=torch.float32) * ((n_in - 1) / (n_out - 1))
+        lo = pos.floor().clamp(max=n_in - 1).long()
+        hi = (lo + 1).clamp(max=n_in - 1)
+        w = pos - lo.float()
+        idx = torch.arange(n_out, device=device)
+        m[idx, lo] += 1 - w
+        m[idx, hi] += w
+        return m.to(dtype)
+
+    def forward(self, x):
+        H, W = x.shape[-2:]
+        key = (H, W, str(x.device), x.dtype)
+        if key not in self._cache:
+            self._cache[key] = (self._matrix(self.size[0], H, x.device, x.dtype), self._matrix(self.size[1], W, x.device, x.dtype))
+        rh, rw = self._cache[key]
+        return torch.einsum("ih,bchw,jw->bcij", rh, x, rw)
 
 
 class ConvModule(nn.Module):

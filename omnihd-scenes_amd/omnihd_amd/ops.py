@@ -419,22 +419,25 @@ class _Conv3x3(torch.autograd.Function):
     MFMA kernel (the slowest dense kernel of the training step under MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.conv2d(x, weight, bias, 1, 1)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        gx = gw = None
+        gx = gw = gb = None
         g = g.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
             gx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             gw = conv3x3_wgrad(x.contiguous(memory_format=torch.channels_last), g).to(weight.dtype)
-        return gx, gw
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=(0, 2, 3), dtype=torch.float32).to(g.dtype)
+        return gx, gw, gb
 
 
-def conv3x3(x, weight):
-    return _Conv3x3.apply(x, weight)
+def conv3x3(x, weight, bias=None):
+    return _Conv3x3.apply(x, weight, bias)

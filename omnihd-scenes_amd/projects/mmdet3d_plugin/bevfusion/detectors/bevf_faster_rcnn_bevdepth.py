@@ -53,11 +53,9 @@ class BEVFUSION_depth(MVXFasterRCNN):
                 self.seblock = SE_Block(lic)
             self.reduc_conv = ConvModule(lic + imc, lic, 3, padding=1, conv_cfg=None, norm_cfg=norm_cfg,
                                          act_cfg=dict(type="ReLU"), inplace=False)
-        # dense BEV convolutions (BEV encoder, fusion conv): weight gradient on the hand-written MFMA kernel
-        if camera_stream:
-            use_bev_conv(self.lift_splat_shot_vis.bevencode)
-        if lc_fusion:
-            use_bev_conv(self.reduc_conv)
+        # 3x3 convolutions with channel counts that are multiples of 128 (BEV encoder, fusion conv, FPNC,
+        # DepthNet, SECOND, ResNet stages): weight gradient on the hand-written MFMA kernel
+        use_bev_conv(self)
         self.freeze_img = freeze_img
         self.freeze()
 

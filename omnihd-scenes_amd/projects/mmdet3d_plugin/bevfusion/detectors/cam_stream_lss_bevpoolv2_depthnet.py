@@ -83,7 +83,8 @@ class ASPP(nn.Module):
     def forward(self, x):
         branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x)]
         pooled = self.global_avg_pool(x)
-        branches.append(F.interpolate(pooled, size=x.shape[2:], mode="bilinear", align_corners=True))
+        # bilinear (align_corners) up-sampling of a 1x1 map is a broadcast (reference :537-541)
+        branches.append(pooled.expand(-1, -1, x.shape[2], x.shape[3]))
         x = self.relu(self.bn1(self.conv1(torch.cat(branches, dim=1))))
         return self.dropout(x)
 

@@ -7,6 +7,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from omnihd_amd.mm import NECKS, ConvModule
+from omnihd_amd.mm.bricks import BilinearResize
 from omnihd_amd.mm.fpn import FPN
 
 __all__ = ["FPNC"]
@@ -22,8 +23,8 @@ class FPNC(FPN):
         if use_adp:
             adp = []
             for i in range(self.num_outs):
-                resize = (nn.AdaptiveAvgPool2d(self.target_size) if i == 0 else
-                          nn.Upsample(size=self.target_size, mode="bilinear", align_corners=True))
+                # (the reference uses nn.Upsample(bilinear, align_corners=True): same map, as two GEMMs)
+                resize = (nn.AdaptiveAvgPool2d(self.target_size) if i == 0 else BilinearResize(self.target_size))
                 adp.append(nn.Sequential(resize, ConvModule(self.out_channels, self.out_channels, 1, padding=0,
                                                             conv_cfg=fuse_conv_cfg, norm_cfg=norm_cfg,
                                                             act_cfg=act_cfg, inplace=False)))
