@@ -105,30 +105,28 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma(const unsigned short* __r
   int px = (k0 + lcol * 8) % W;
   int py = ((k0 + lcol * 8) / W) % H;
 
-  // Two register stages: the loads of K-steps k+1 and k+2 are in flight while step k is multiplied
-  // (memory latency under load is several microseconds; one stage ahead leaves the matrix cores idle).
-  uint4 ra[2][4], rb[2][4];
-  auto issue = [&](int k, uint4 (&va)[4], uint4 (&vb)[4]) {
+  uint4 ra[4], rb[4];
+  auto issue = [&](int k) {
     const bool ok = (k + lcol * 8 < M) && (py + dy >= 0) && (py + dy < H);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      va[i] = *reinterpret_cast<const uint4*>(a_src + (size_t)(32 * i) * Mp + k);
-      vb[i] = *reinterpret_cast<const uint4*>(b_src + (size_t)(32 * i) * Mp + k);   // always in bounds (guards)
+      ra[i] = *reinterpret_cast<const uint4*>(a_src + (size_t)(32 * i) * Mp + k);
+      rb[i] = *reinterpret_cast<const uint4*>(b_src + (size_t)(32 * i) * Mp + k);   // always in bounds (guards)
     }
     // mask AFTER the loads: a load behind a runtime condition would be branched around and waited for
     // one by one (4 dependent memory round trips per K-step)
     if (!ok) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vb[i] = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) rb[i] = make_uint4(0, 0, 0, 0);
     }
     px += kBK;
     while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
   };
-  auto stash = [&](int buf, const uint4 (&va)[4], const uint4 (&vb)[4]) {
+  auto stash = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(&sA[buf][lrow + 32 * i][lcol * 8]) = va[i];
-      *reinterpret_cast<uint4*>(&sB[buf][lrow + 32 * i][lcol * 8]) = vb[i];
+      *reinterpret_cast<uint4*>(&sA[buf][lrow + 32 * i][lcol * 8]) = ra[i];
+      *reinterpret_cast<uint4*>(&sB[buf][lrow + 32 * i][lcol * 8]) = rb[i];
     }
   };
 
@@ -144,41 +142,31 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma(const unsigned short* __r
   const int frow = lane & 31;
   const int fk = (lane >> 5) * 8;
 
-  auto multiply = [&](int buf) {
-#pragma unroll
-    for (int ks = 0; ks < kBK / 16; ++ks) {
-      bf16x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][wm * 64 + i * 32 + frow][ks * 16 + fk]);
-        b[i] = *reinterpret_cast<const bf16x8*>(&sB[buf][wn * 64 + i * 32 + frow][ks * 16 + fk]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
   if (k0 < k1) {
-    issue(k0, ra[0], rb[0]);
-    stash(0, ra[0], rb[0]);
-    if (k0 + kBK < k1) issue(k0 + kBK, ra[0], rb[0]);          // step k0+1 -> stage 0
+    issue(k0);
+    stash(0);
     __syncthreads();
-    // loop over PAIRS of K-steps so that the register stage of each load is a compile-time index
-    for (int k = k0; k < k1; k += 2 * kBK) {
-      // ---- step k (LDS buffer 0); stage 0 holds k+1, stage 1 receives k+2
-      if (k + 2 * kBK < k1) issue(k + 2 * kBK, ra[1], rb[1]);
-      multiply(0);
-      if (k + kBK < k1) stash(1, ra[0], rb[0]);
+    int buf = 0;
+    for (int k = k0; k < k1; k += kBK) {
+      const bool more = k + kBK < k1;
+      if (more) issue(k + kBK);
+#pragma unroll
+      for (int ks = 0; ks < kBK / 16; ++ks) {
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][wm * 64 + i * 32 + frow][ks * 16 + fk]);
+          b[i] = *reinterpret_cast<const bf16x8*>(&sB[buf][wn * 64 + i * 32 + frow][ks * 16 + fk]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) stash(buf ^ 1);
       __syncthreads();
-      if (k + kBK >= k1) break;
-      // ---- step k+1 (LDS buffer 1); stage 1 holds k+2, stage 0 receives k+3
-      if (k + 3 * kBK < k1) issue(k + 3 * kBK, ra[0], rb[0]);
-      multiply(1);
-      if (k + 2 * kBK < k1) stash(0, ra[1], rb[1]);
-      __syncthreads();
+      buf ^= 1;
     }
   }
 
