@@ -891,10 +891,14 @@ extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
     const float4* f4 = reinterpret_cast<const float4*>(feat);
     const int4* td = reinterpret_cast<const int4*>(tile_desc);
     float4* o4 = reinterpret_cast<float4*>(out);
-    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 8 || u == 16) ? u : 4; }();
 #define OMNIHD_TILE_CASE(C4)                                                                   \
   case C4:                                                                                     \
-    if (unroll == 8)                                                                           \
+    if (unroll == 16)                                                                          \
+      hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 16>), grid, dim3(kBlock), 0, st, depth, f4,     \
+                         ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
+                         n_points);                                                            \
+    else if (unroll == 8)                                                                      \
       hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 8>), grid, dim3(kBlock), 0, st, depth, f4,      \
                          ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
                          n_points);                                                            \
