@@ -186,3 +186,58 @@ def test_detector_refuses_cpu_tensors_without_the_oracle_shim():
     st = FusionTrainStep(res="tiny", batch=1, radar_dims=7, device="cpu", dtype="fp32", channels_last=False, sets=1)
     with pytest.raises(RuntimeError, match="no CPU p"):
         st.step()
+
+
+def test_rcfusion_config_builds_and_trains_tiny_step():
+    """the RCFusion variant (RadarPillarFeatureNet + Cross_Modal_Fusion)."""
+    from omnihd_amd import harness
+    from omnihd_amd.mm.config import build_detector, load_config
+    from oracle.torch_shim import oracle_ops
+    ref = "/root/reference/projects/configs/RCFusion_NewScenes/rcfusion_lss.py"
+    if os.path.exists(ref):
+        m = build_detector(load_config(ref)["model"])
+        keys = set(m.state_dict())
+        for k in ["cross_attention.att_img.0.weight", "cross_attention.att_radar.0.weight", "cross_attention.reduce_mixBEV.conv.weight",
+                  "cross_attention.reduce_mixBEV.bn.weight", "pts_voxel_encoder.pfn_layers.0.linear1.weight",
+                  "pts_voxel_encoder.pfn_layers.0.norm3.weight"]:
+            assert k in keys, k
+        assert "reduc_conv.conv.weight" not in keys
+    c = harness.tiny_model_cfg(7)
+    c["type"] = "RCFusion_FasterRCNN"
+    c.pop("lc_fusion")
+    c["rc_fusion"] = "cross_attention"
+    c["pts_voxel_encoder"].update(type="RadarPillarFeatureNet", with_velocity_snr_center=True)
+    torch.set_num_threads(4)
+    with oracle_ops():
+        model = build_detector(c)
+        model.train()
+        losses = model(return_loss=True, **harness.synthetic_batch("tiny", 2, 7, "cpu", 0))
+        total = sum(v[0] if isinstance(v, list) else v for v in losses.values())
+        total.backward()
+    assert set(losses) == {"loss_cls", "loss_bbox", "loss_dir", "img_depth_loss"} and math.isfinite(float(total.detach()))
+    assert model.cross_attention.att_img[0].weight.grad is not None
+
+
+def test_bilinear_resize_equals_interpolate():
+    from omnihd_amd.mm.bricks import BilinearResize
+    x = torch.randn(2, 3, 8, 22)
+    for size in [(64, 176), (16, 44), (8, 22), (5, 7)]:
+        torch.testing.assert_close(BilinearResize(size)(x), F.interpolate(x, size=size, mode="bilinear", align_corners=True),
+                                   rtol=1e-5, atol=1e-5)
+
+
+def test_dcn_gather_formulation_matches_grid_sample_formulation():
+    from omnihd_amd.mm.dcn import DeformConv2dPack
+    torch.manual_seed(0)
+    m = DeformConv2dPack(16, 32, 3, padding=1, groups=4)
+    torch.nn.init.normal_(m.conv_offset.weight, std=0.3)
+    torch.nn.init.normal_(m.conv_offset.bias, std=1.5)          # offsets well beyond one pixel, some outside the image
+    x = torch.randn(2, 16, 9, 11, requires_grad=True)
+    off = m.conv_offset(x)
+    a = m._gather_and_gemm(x, off, torch.float32)
+    b = m._sample_and_contract(x, off)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    ga = torch.autograd.grad(a.square().sum(), [x, m.weight, m.conv_offset.weight], retain_graph=True)
+    gb = torch.autograd.grad(b.square().sum(), [x, m.weight, m.conv_offset.weight])
+    for u, v in zip(ga, gb):
+        torch.testing.assert_close(u, v, rtol=1e-3, atol=1e-3 * float(v.abs().max()))
