@@ -86,10 +86,6 @@ int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const floa
  *                 of the i-th tile worked on by XCD x (#rows = 0: idle slot).  Tiles must be runs
  *                 of whole rows covering every row exactly once; their ORDER only affects speed
  *                 (L2 locality), never results.
- * depth_bins_x_hw = D*fH*fW and hw = fH*fW (or 0, 0): when given (and C = 64) the kernel derives
- * ranks_feat[p] = (ranks_depth[p] / (D*HW)) * HW + ranks_depth[p] % HW itself (the LSS relation,
- * cam_stream_lss_bevpoolv2_depthnet.py:316-322) and finds the output row of a point in row_ptr, so
- * ranks_feat and ranks_row are not read at all (they may be NULL).
  * With ranks_row and tile_desc the load-balanced tiled kernel runs (rows cut by the in-tile work
  * split are combined in a fixed order: a row's sum may be associated differently from table
  * order, run-to-run deterministic).  With either NULL a simple row-per-lane-group kernel runs. */
@@ -97,7 +93,7 @@ int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                const int* ranks_depth, const int* ranks_feat,
                                const int* ranks_row, const int* row_ptr,
                                const int* tile_desc, int n_tiles, float* out, int c,
-                               int n_rows, int n_points, int depth_bins_x_hw, int hw, void* stream);
+                               int n_rows, int n_points, void* stream);
 
 /* Schedule descriptors for the call above from a tile table (omnihd_csr_tiles) and an optional
  * tile order (8*ceil(n_tiles/8) ints, -1 = idle slot, NULL = tiles in index order).          */

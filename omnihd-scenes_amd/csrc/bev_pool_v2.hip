@@ -383,197 +383,6 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lean tiled forward: the same tiling/phases as k_pool_fwd_tiles, but the only per-point table it
-// reads is ranks_depth (4 B per point).  The pixel row of a frustum point follows from its depth
-// index (ranks_feat = (rd / (D*HW)) * HW + rd % HW, reference cam_stream_lss_bevpoolv2_depthnet.py
-// :316-322), and the output row / last-point flag follow from the tile's row_ptr slice, which is
-// staged in LDS anyway (binary search in LDS per point).  HBM reads per frame @R1 drop from
-// 16.2 (rd+rf) + 8.1 (ranks_row) MB to 8.1 MB.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int div_by(int n, int d, float inv_d) {
-  int q = (int)((float)n * inv_d);
-  const int r = n - q * d;
-  if (r < 0) --q; else if (r >= d) ++q;
-  return q;
-}
-
-template <int C4, int U>
-__global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles_lean(
-    const float* __restrict__ depth, const float4* __restrict__ feat4,
-    const int* __restrict__ ranks_depth, const int* __restrict__ row_ptr,
-    const int4* __restrict__ tile_desc, float4* __restrict__ out4, int tiles_per_xcd, int dhw, int hw,
-    float inv_dhw, float inv_hw) {
-  constexpr int G = kBlock / C4;
-  constexpr int GPW = 64 / C4;
-  constexpr int kRecInts = kCap * 3;
-  __shared__ int s_mem[kRecInts > kBlock * 4 ? kRecInts : kBlock * 4];
-  __shared__ int s_rp[kCap + 4];
-  __shared__ float4 s_head[kBlock];
-  __shared__ int s_head_row[G];
-  __shared__ int s_tail_row[G];
-  int2* s_rfd = reinterpret_cast<int2*>(s_mem);
-  int* s_row = s_mem + 2 * kCap;
-  float4* s_tail = reinterpret_cast<float4*>(s_mem);
-
-  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
-  const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
-  const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
-  if (nrows <= 0) return;
-
-  const int tid = threadIdx.x;
-  const int sub = tid % C4;
-  const int grp = tid / C4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto feat_row = [&](int rd) {
-    const int cam = div_by(rd, dhw, inv_dhw);
-    const int rem = rd - cam * dhw;
-    return cam * hw + (rem - div_by(rem, hw, inv_hw) * hw);
-  };
-
-  // ---- a single long row, or a tile too large for LDS (foreign tile tables): direct paths --------
-  if (npts > kCap || nrows > kCap) {
-    if (nrows == 1) {
-      float4 acc = zero4;
-      const int cw = (npts + G - 1) / G;
-      const int j0 = min(grp * cw, npts), j1 = min(j0 + cw, npts);
-      for (int base = j0; base < j1; base += C4) {
-        const int n = min(C4, j1 - base);
-        int my_rf = 0;
-        float my_d = 0.f;
-        if (sub < n) {
-          const int rd = ranks_depth[Pa + base + sub];
-          my_rf = feat_row(rd);
-          my_d = depth[rd];
-        }
-        for (int j = 0; j < n; ++j)
-          acc = fma4(__shfl(my_d, j, C4), feat4[(size_t)__shfl(my_rf, j, C4) * C4 + sub], acc);
-      }
-      s_tail[tid] = acc;
-      __syncthreads();
-      if (grp == 0) {
-        float4 tsum = s_tail[sub];
-        for (int g = 1; g < G; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-        store_row(out4 + (size_t)Ra * C4 + sub, tsum, true);
-      }
-    } else {
-      for (int r = Ra + grp; r < Ra + nrows; r += G) {
-        const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
-        float4 acc = zero4;
-        for (int i = 0; i < len; ++i) {
-          const int rd = ranks_depth[s0 + i];
-          acc = fma4(depth[rd], feat4[(size_t)feat_row(rd) * C4 + sub], acc);
-        }
-        store_row(out4 + (size_t)r * C4 + sub, acc, true);
-      }
-    }
-    return;
-  }
-
-  // ---- stage the tile's row_ptr slice; issue the rank loads ---------------------------------------
-  for (int i = tid; i <= nrows; i += kBlock) s_rp[i] = row_ptr[Ra + i];
-  constexpr int kPer = (kCap + kBlock - 1) / kBlock;
-  int l_rd[kPer];
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int i = tid + k * kBlock;
-    l_rd[k] = (i < npts) ? ranks_depth[Pa + i] : 0;
-  }
-  if (tid < G) s_head_row[tid] = -1;
-  __syncthreads();
-
-  // ---- phase Z: zero-fill the empty rows (from the LDS copy) --------------------------------------
-  if (!(nrows == 1 && npts > 0)) {
-    const int lane = tid & 63;
-    const int gw = lane / C4;
-    for (int base = 0; base < nrows; base += kBlock) {
-      const int i = base + tid;
-      const bool empty = (i < nrows) && (s_rp[i + 1] == s_rp[i]);
-      const unsigned long long m = __ballot(empty);
-      if (m == 0ull) continue;
-      const int wave_row0 = Ra + base + (tid & ~63);
-      for (int k = 0; k < 64; k += GPW) {
-        const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
-        if (window == 0ull) continue;
-        if ((m >> (k + gw)) & 1ull)
-          store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
-      }
-    }
-  }
-  if (npts == 0) return;
-
-  // ---- phase L: depth gather, pixel row, output row + last flag -> LDS records --------------------
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int i = tid + k * kBlock;
-    if (i < npts) {
-      const int rd = l_rd[k];
-      const float dv = depth[rd];
-      const int q = Pa + i;
-      int lo = 0, hi = nrows;            // last r with s_rp[r] <= q
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_rp[mid] <= q) lo = mid; else hi = mid;
-      }
-      const int last = (q + 1 == s_rp[lo + 1]) ? (int)0x80000000 : 0;
-      s_rfd[i] = make_int2(feat_row(rd) | last, __float_as_int(dv));
-      s_row[i] = Ra + lo;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase P: equal pieces of the point list, one per group -------------------------------------
-  float4 acc = zero4;
-  const int w = (npts + G - 1) / G;
-  const int i0 = min(grp * w, npts);
-  const int i1 = min(i0 + w, npts);
-  bool head_pending = (i0 > 0) && (i0 < i1) && (s_rfd[i0 - 1].x >= 0);
-  for (int i = i0; i < i1; i += U) {
-    float4 v[U];
-    float d[U];
-    int fl[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int2 rc = s_rfd[min(i + u, i1 - 1)];
-      d[u] = __int_as_float(rc.y);
-      fl[u] = rc.x;
-      v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (i + u < i1) {
-        acc = fma4(d[u], v[u], acc);
-        if (fl[u] < 0) {
-          const int row = s_row[i + u];
-          if (head_pending) {
-            s_head[tid] = acc;
-            if (sub == 0) s_head_row[grp] = row;
-            head_pending = false;
-          } else {
-            store_row(out4 + (size_t)row * C4 + sub, acc, true);
-          }
-          acc = zero4;
-        }
-      }
-    }
-  }
-  const int tail_row = (i1 > i0 && s_rfd[i1 - 1].x >= 0) ? s_row[i1 - 1] : -2;
-  __syncthreads();
-  s_tail[tid] = acc;
-  if (sub == 0) s_tail_row[grp] = tail_row;
-  __syncthreads();
-
-  const int hr = s_head_row[grp];
-  if (hr >= 0) {
-    int g0 = grp;
-    while (g0 > 0 && s_tail_row[g0 - 1] == hr) --g0;
-    float4 tsum = zero4;
-    for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-    tsum = add4(tsum, s_head[tid]);
-    store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Persistent, software-pipelined tiled forward.
 //
 // Measured on k_pool_fwd_tiles (ablation builds): of ~52 us per launch only ~13 us are feature
@@ -1115,23 +924,12 @@ extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
                                           const int* ranks_depth, const int* ranks_feat,
                                           const int* ranks_row, const int* row_ptr,
                                           const int* tile_desc, int n_tiles, float* out, int c,
-                                          int n_rows, int n_points, int depth_bins_x_hw, int hw,
-                                          void* stream) {
+                                          int n_rows, int n_points, void* stream) {
   OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0 && n_points >= 0, "sizes");
   if (n_rows == 0) return OMNIHD_OK;
   // ranks_* may be null when the plan holds no point at all (every row is then written as zeros)
   OMNIHD_REQUIRE(depth && feat && row_ptr && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (tile_desc != nullptr && depth_bins_x_hw > 0 && hw > 0 && c == 64 && n_tiles > 0 && vec_ok(c, feat, out) &&
-      (reinterpret_cast<uintptr_t>(tile_desc) & 15u) == 0) {
-    // lean variant: ranks_feat / ranks_row are derived in the kernel (LSS layout of ranks_depth)
-    const int tiles_per_xcd = (n_tiles + 7) / 8;
-    hipLaunchKernelGGL((k_pool_fwd_tiles_lean<16, 4>), dim3(tiles_per_xcd * 8), dim3(kBlock), 0, st, depth,
-                       reinterpret_cast<const float4*>(feat), ranks_depth, row_ptr,
-                       reinterpret_cast<const int4*>(tile_desc), reinterpret_cast<float4*>(out), tiles_per_xcd,
-                       depth_bins_x_hw, hw, 1.0f / (float)depth_bins_x_hw, 1.0f / (float)hw);
-    return check_launch("bev_pool_v2_fwd_csr(lean tiles)");
-  }
   if (tile_desc != nullptr && ranks_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out) &&
       (reinterpret_cast<uintptr_t>(tile_desc) & 15u) == 0) {
     const int tiles_per_xcd = (n_tiles + 7) / 8;

@@ -79,11 +79,9 @@ def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_dep
               "omnihd_bev_pool_v2_bwd")
 
 
-def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, ranks_row=None, tile_desc=None,
-                            lss_dims=None):
+def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, ranks_row=None, tile_desc=None):
     """Dense forward: every row of ``out`` (n_rows = row_ptr.numel()-1, C = feat.size(-1)) is written.
-    With ``ranks_row`` + ``tile_desc`` (from :func:`tile_descriptors`) the load-balanced tiled kernel runs;
-    with ``lss_dims=(D, fH*fW)`` in addition (and C = 64) its lean variant derives ranks_feat / ranks_row itself."""
+    With ``ranks_row`` + ``tile_desc`` (from :func:`tile_descriptors`) the load-balanced tiled kernel runs."""
     _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
     _want(ranks_depth, torch.int32, "ranks_depth"); _want(ranks_feat, torch.int32, "ranks_feat")
     _want(row_ptr, torch.int32, "row_ptr")
@@ -103,9 +101,7 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
     with torch.cuda.device(dev):
         check(lib().omnihd_bev_pool_v2_fwd_csr(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat),
                                                _ptr(ranks_row), _ptr(row_ptr), _ptr(tile_desc), n_tiles, _ptr(out),
-                                               c, n_rows, ranks_depth.numel(),
-                                               int(lss_dims[0] * lss_dims[1]) if (lss_dims and n_tiles) else 0,
-                                               int(lss_dims[1]) if (lss_dims and n_tiles) else 0, _stream()),
+                                               c, n_rows, ranks_depth.numel(), _stream()),
               "omnihd_bev_pool_v2_fwd_csr")
 
 

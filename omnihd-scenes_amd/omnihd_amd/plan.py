@@ -42,7 +42,6 @@ class BevPoolPlan:
     bp_starts: torch.Tensor
     bp_lengths: torch.Tensor
     pix_desc: torch.Tensor = None   # int32 [8*k, 4] schedule of the scheduled backward (every pixel once)
-    lss_dims: tuple = None          # (D, fH*fW) when ranks_feat is the LSS function of ranks_depth
 
     @property
     def n_intervals(self):
@@ -155,10 +154,8 @@ def build_plan(coor, dx, bx, nx, layout="byxz"):
     rows, (rd,), starts, lengths = ops.sort_ranks(keys, [idx], ops._bits_for(sentinel), sentinel)
     rows, rd = rows.contiguous(), rd.contiguous()
     rf = ops.ranks_feat_from_depth(rd, D, H * W)
-    plan = _finish(layout, (B, Z, Y, X), rows, rd, rf, starts.contiguous(), lengths.contiguous(), B * N * H * W,
+    return _finish(layout, (B, Z, Y, X), rows, rd, rf, starts.contiguous(), lengths.contiguous(), B * N * H * W,
                    feat_hw=(H, W))
-    plan.lss_dims = (D, H * W)
-    return plan
 
 
 def plan_from_tables(ranks_bev, ranks_depth, ranks_feat, grid, n_feat_rows, layout="bzyx", feat_hw=None):
@@ -185,7 +182,7 @@ class _PlannedPool(torch.autograd.Function):
         feat = feat.contiguous().float()
         out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
         ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
-                                    plan.ranks_row, plan.tile_desc, plan.lss_dims)
+                                    plan.ranks_row, plan.tile_desc)
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan
         return out

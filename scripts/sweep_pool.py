@@ -33,13 +33,6 @@ def main():
             res_t.append(bench.time_kernel(wl.pool_fwd, len(wl.sets), 40))
         print(f"tiled fwd W={items:5d} L={long_len:4d}: banded {res_t[0]*1e6:7.1f} us {nbytes/res_t[0]/1e9:6.0f} GB/s | "
               f"column-scheduled {res_t[1]*1e6:7.1f} us {nbytes/res_t[1]/1e9:6.0f} GB/s  tiles {tiles.numel()-1}")
-    for lean in (False, True):
-        wl.lean = lean
-        desc = wl.plan.tile_desc
-        for s in wl.sets:
-            s[6][8] = desc.clone()
-        t = bench.time_kernel(wl.pool_fwd, len(wl.sets), 40)
-        print(f"plan tiles (W=768,L=512) lean={lean}: {t*1e6:7.1f} us {nbytes/t/1e9:6.0f} GB/s")
     wl.sched_bwd = False
     t = bench.time_kernel(wl.pool_bwd, len(wl.sets), 40)
     print(f"bwd reference-API kernel (incl. 2 memsets): {t*1e6:8.1f} us")

@@ -235,34 +235,6 @@ def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
     torch.testing.assert_close(out[0].double(), want, rtol=1e-5, atol=1e-4)
 
 
-def test_lean_tiled_forward_equals_table_driven_kernel(cuda, golden):
-    """The lean kernel derives ranks_feat / output rows itself; same plan, same results (bit-exact: the
-    summation order is identical), at the tiny rig (C=64) and at full size R1."""
-    import omnihd_amd
-    from omnihd_amd import ops
-    from tests.helpers import full_size_geometry
-    pc, g = golden["g2_pc_range"].tolist(), float(golden["g2_grid"])
-    dx, bx, nx = O.gen_dx_bx([pc[0], pc[3], g], [pc[1], pc[4], g], [pc[2], pc[5], g])
-    cases = [(t(golden["g2_geom"], cuda), dx, bx, nx)]
-    geom, dx1, bx1, nx1 = full_size_geometry("r1")
-    cases.append((t(geom, cuda), dx1, bx1, nx1))
-    for geom_t, dx_, bx_, nx_ in cases:
-        plan = omnihd_amd.build_plan(geom_t, dx_, bx_, nx_, layout="byxz")
-        B, N, D, H, W = geom_t.shape[:5]
-        assert plan.lss_dims == (D, H * W)
-        gen = torch.Generator(device=cuda).manual_seed(1)
-        depth = torch.rand(B, N, D, H, W, device=cuda, generator=gen)
-        feat = torch.randn(B, N, H, W, 64, device=cuda, generator=gen)
-        outs = []
-        for dims in (None, plan.lss_dims):
-            out = torch.full((plan.n_rows, 64), float("nan"), device=cuda)
-            ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out, plan.ranks_row,
-                                        plan.tile_desc, dims)
-            outs.append(out)
-        assert torch.equal(outs[0], outs[1])
-        assert not torch.isnan(outs[1]).any()
-
-
 def test_against_reference_kernels_compiled_by_hipcc(cuda):
     """oracle/_ref = the reference's bev_pool_cuda.cu compiled unmodified for gfx950."""
     ref = RefKernels()
