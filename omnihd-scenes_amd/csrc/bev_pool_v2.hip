@@ -382,254 +382,6 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Persistent, software-pipelined tiled forward.
-//
-// Measured on k_pool_fwd_tiles (ablation builds): of ~52 us per launch only ~13 us are feature
-// gathers and ~11 us row stores; ~30 us are the DEPENDENT memory round trips every tile pays before
-// it can start (descriptor -> rank tables -> depth gather -> LDS) — under load each costs 2-3 us and
-// a workgroup sits idle through them.  Here a workgroup is persistent (4 per CU) and walks a strided
-// list of its XCD's tiles with a 3-deep pipeline:
-//     tile t+2: rank-table / row_ptr loads are in flight
-//     tile t+1: depth gathers are in flight
-//     tile t  : records are in LDS -> phase P (gathers + accumulate + row stores)
-// so the round trips of the next tiles hide under the work of the current one.  Two LDS record
-// buffers (39 KiB total).  Tiles, schedule order and arithmetic are those of k_pool_fwd_tiles:
-// results are bit-identical to it.
-// ---------------------------------------------------------------------------------------------
-template <int C4, int U>
-__global__ __launch_bounds__(kBlock) void k_pool_fwd_stream(
-    const float* __restrict__ depth, const float4* __restrict__ feat4,
-    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
-    const int* __restrict__ ranks_row, const int* __restrict__ row_ptr,
-    const int4* __restrict__ tile_desc, float4* __restrict__ out4, int tiles_per_xcd,
-    int blocks_per_xcd, int n_points_total) {
-  constexpr int G = kBlock / C4;
-  constexpr int GPW = 64 / C4;
-  constexpr int kPer = (kCap + kBlock - 1) / kBlock;
-  constexpr int kRowsPer = 3;                       // empty-row flags per lane (tiles of <= 768 rows)
-  __shared__ int2 s_rfd[2][kCap];
-  __shared__ int s_row[2][kCap];
-  __shared__ float4 s_head[kBlock];
-  __shared__ float4 s_tail[kBlock];
-  __shared__ int s_head_row[2][G];
-  __shared__ int s_tail_row[G];
-
-  const int xcd = blockIdx.x & 7;
-  const int j = blockIdx.x >> 3;
-  if (j >= blocks_per_xcd) return;
-  const int tid = threadIdx.x;
-  const int sub = tid % C4;
-  const int grp = tid / C4;
-  const int lane = tid & 63;
-  const int gw = lane / C4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  auto desc_of = [&](int t) {
-    const int i = j + t * blocks_per_xcd;
-    return (i < tiles_per_xcd) ? tile_desc[xcd * tiles_per_xcd + i] : make_int4(0, 0, 0, 0);
-  };
-  auto staged = [](const int4& d) { return d.w > 0 && d.w <= kCap; };
-
-  struct Ranks { int rf[kPer], rd[kPer], row[kPer], nxt[kPer], rp0[kRowsPer], rp1[kRowsPer]; };
-  struct Gath { int rf[kPer]; float d[kPer]; int row[kPer]; unsigned z; };
-
-  auto load_ranks = [&](const int4& d, Ranks& r) {
-    if (staged(d)) {
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int i = tid + k * kBlock;
-        if (i < d.w) {
-          const int q = d.z + i;
-          r.rf[k] = ranks_feat[q];
-          r.rd[k] = ranks_depth[q];
-          r.row[k] = ranks_row[q];
-          r.nxt[k] = (q + 1 < n_points_total) ? ranks_row[q + 1] : -1;
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kRowsPer; ++k) {
-      const int i = tid + k * kBlock;
-      r.rp0[k] = 0; r.rp1[k] = 1;
-      if (i < d.y) { r.rp0[k] = row_ptr[d.x + i]; r.rp1[k] = row_ptr[d.x + i + 1]; }
-    }
-  };
-  auto gather = [&](const int4& d, const Ranks& r, Gath& g) {
-    if (staged(d)) {
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int i = tid + k * kBlock;
-        if (i < d.w) {
-          g.d[k] = depth[r.rd[k]];
-          g.rf[k] = r.rf[k] | ((r.row[k] != r.nxt[k]) ? (int)0x80000000 : 0);
-          g.row[k] = r.row[k];
-        }
-      }
-    }
-    g.z = 0u;
-#pragma unroll
-    for (int k = 0; k < kRowsPer; ++k) g.z |= (r.rp0[k] == r.rp1[k]) ? (1u << k) : 0u;
-  };
-  auto write_records = [&](int buf, const int4& d, const Gath& g) {
-    if (staged(d)) {
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int i = tid + k * kBlock;
-        if (i < d.w) {
-          s_rfd[buf][i] = make_int2(g.rf[k], __float_as_int(g.d[k]));
-          s_row[buf][i] = g.row[k];
-        }
-      }
-    }
-  };
-
-  auto process = [&](int buf, const int4& d, unsigned z) {
-    const int Ra = d.x, nrows = d.y, Pa = d.z, npts = d.w;
-    // ---- phase Z: zero-fill the empty rows -----------------------------------------------------
-    if (!(nrows == 1 && npts > 0)) {
-      if (nrows <= kRowsPer * kBlock) {
-#pragma unroll
-        for (int k = 0; k < kRowsPer; ++k) {
-          if (k * kBlock >= nrows) break;
-          const unsigned long long m = __ballot((z >> k) & 1u);
-          if (m == 0ull) continue;
-          const int wave_row0 = Ra + k * kBlock + (tid & ~63);
-          for (int q = 0; q < 64; q += GPW) {
-            const unsigned long long window = (GPW >= 64) ? m : ((m >> q) & ((1ull << GPW) - 1ull));
-            if (window == 0ull) continue;
-            if ((m >> (q + gw)) & 1ull) store_row(out4 + (size_t)(wave_row0 + q + gw) * C4 + sub, zero4, true);
-          }
-        }
-      } else {
-        for (int r = Ra + grp; r < Ra + nrows; r += G)
-          if (row_ptr[r + 1] == row_ptr[r]) store_row(out4 + (size_t)r * C4 + sub, zero4, true);
-      }
-    }
-    if (npts == 0) return;
-    float4 acc = zero4;
-    if (!staged(d)) {
-      if (nrows == 1) {   // one long row: windows of kCap points through this tile's (unused) record buffer
-        for (int base = 0; base < npts; base += kCap) {
-          const int n = min(kCap, npts - base);
-          for (int i = tid; i < n; i += kBlock) {
-            const int q = Pa + base + i;
-            s_rfd[buf][i] = make_int2(ranks_feat[q], __float_as_int(depth[ranks_depth[q]]));
-          }
-          __syncthreads();
-          const int cw = (n + G - 1) / G;
-          const int j0 = min(grp * cw, n), j1 = min(j0 + cw, n);
-          for (int jj = j0; jj < j1; jj += U) {
-            float4 v[U];
-            float dd[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int2 rc = s_rfd[buf][min(jj + u, j1 - 1)];
-              dd[u] = (jj + u < j1) ? __int_as_float(rc.y) : 0.f;
-              v[u] = feat4[(size_t)rc.x * C4 + sub];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc = fma4(dd[u], v[u], acc);
-          }
-          __syncthreads();
-        }
-        s_tail[tid] = acc;
-        __syncthreads();
-        if (grp == 0) {
-          float4 tsum = s_tail[sub];
-          for (int g = 1; g < G; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-          store_row(out4 + (size_t)Ra * C4 + sub, tsum, true);
-        }
-        __syncthreads();
-      } else {            // oversize multi-row tile (foreign tile tables only)
-        for (int r = Ra + grp; r < Ra + nrows; r += G) {
-          const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
-          if (len > 0)
-            store_row(out4 + (size_t)r * C4 + sub,
-                      pool_range<C4>(depth, feat4, ranks_depth, ranks_feat, s0, len, sub), true);
-        }
-      }
-      return;
-    }
-    // ---- phase P ---------------------------------------------------------------------------------
-    const int w = (npts + G - 1) / G;
-    const int i0 = min(grp * w, npts);
-    const int i1 = min(i0 + w, npts);
-    bool head_pending = (i0 > 0) && (i0 < i1) && (s_rfd[buf][i0 - 1].x >= 0);
-    for (int i = i0; i < i1; i += U) {
-      float4 v[U];
-      float dd[U];
-      int fl[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int2 rc = s_rfd[buf][min(i + u, i1 - 1)];
-        dd[u] = __int_as_float(rc.y);
-        fl[u] = rc.x;
-        v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (i + u < i1) {
-          acc = fma4(dd[u], v[u], acc);
-          if (fl[u] < 0) {
-            const int row = s_row[buf][i + u];
-            if (head_pending) {
-              s_head[tid] = acc;
-              if (sub == 0) s_head_row[buf][grp] = row;
-              head_pending = false;
-            } else {
-              store_row(out4 + (size_t)row * C4 + sub, acc, true);
-            }
-            acc = zero4;
-          }
-        }
-      }
-    }
-    s_tail[tid] = acc;
-    if (sub == 0) s_tail_row[grp] = (i1 > i0 && s_rfd[buf][i1 - 1].x >= 0) ? s_row[buf][i1 - 1] : -2;
-    __syncthreads();
-    const int hr = s_head_row[buf][grp];
-    if (hr >= 0) {
-      int g0 = grp;
-      while (g0 > 0 && s_tail_row[g0 - 1] == hr) --g0;
-      float4 tsum = zero4;
-      for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-      tsum = add4(tsum, s_head[tid]);
-      store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
-    }
-  };
-
-  // ---- prologue ------------------------------------------------------------------------------------
-  int4 d0 = desc_of(0);
-  if (d0.y <= 0) return;
-  int4 d1 = desc_of(1), d2 = desc_of(2);
-  Ranks rk;
-  Gath g0v, g1v;
-  if (tid < G) { s_head_row[0][tid] = -1; s_head_row[1][tid] = -1; }
-  load_ranks(d0, rk);
-  gather(d0, rk, g0v);
-  load_ranks(d1, rk);
-  write_records(0, d0, g0v);
-  __syncthreads();
-
-  int cur = 0;
-  unsigned zcur = g0v.z;
-  for (int t = 0;; ++t) {
-    // buf[cur] holds tile t (d0); rk holds the rank loads of tile t+1 (d1); d2 = tile t+2
-    gather(d1, rk, g1v);             // depth gathers of tile t+1 go out
-    load_ranks(d2, rk);              // rank loads of tile t+2 go out
-    const int4 d3 = desc_of(t + 3);
-    process(cur, d0, zcur);
-    if (d1.y <= 0) break;
-    if (tid < G) s_head_row[cur][tid] = -1;        // this buffer's heads were consumed above (after a barrier)
-    write_records(cur ^ 1, d1, g1v);
-    zcur = g1v.z;
-    __syncthreads();
-    cur ^= 1;
-    d0 = d1; d1 = d2; d2 = d3;
-  }
-}
-
 // schedule slot -> {first row, #rows, first point, #points}; idle slots get #rows = 0
 __global__ __launch_bounds__(kBlock) void k_tile_desc(const int* __restrict__ row_ptr,
                                                       const int* __restrict__ tile_row,
@@ -937,22 +689,10 @@ extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
     const float4* f4 = reinterpret_cast<const float4*>(feat);
     const int4* td = reinterpret_cast<const int4*>(tile_desc);
     float4* o4 = reinterpret_cast<float4*>(out);
-    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 8 || u == 16) ? u : 4; }();
-    static const int stream_bpc = [] { const char* e = getenv("OMNIHD_FWD_STREAM"); return e ? atoi(e) : 4; }();
-    if (stream_bpc > 0 && c == 64) {
-      // persistent pipelined variant: stream_bpc workgroups per CU, 32 CUs per XCD
-      const int bpx = min(tiles_per_xcd, 32 * stream_bpc);
-      hipLaunchKernelGGL((k_pool_fwd_stream<16, 4>), dim3(bpx * 8), dim3(kBlock), 0, st, depth, f4, ranks_depth,
-                         ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd, bpx, n_points);
-      return check_launch("bev_pool_v2_fwd_csr(stream)");
-    }
+    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 8) ? 8 : 4; }();
 #define OMNIHD_TILE_CASE(C4)                                                                   \
   case C4:                                                                                     \
-    if (unroll == 16)                                                                          \
-      hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 16>), grid, dim3(kBlock), 0, st, depth, f4,     \
-                         ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
-                         n_points);                                                            \
-    else if (unroll == 8)                                                                      \
+    if (unroll == 8)                                                                           \
       hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 8>), grid, dim3(kBlock), 0, st, depth, f4,      \
                          ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
                          n_points);                                                            \
