@@ -199,7 +199,7 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
 }
 
 template <int C4, int U>
-__global__ __launch_bounds__(kBlock, (C4 == 16 && U == 4) ? 8 : 1) void k_pool_fwd_tiles(
+__global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     const float* __restrict__ depth, const float4* __restrict__ feat4,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
     const int* __restrict__ ranks_row, const int* __restrict__ row_ptr,
