@@ -10,7 +10,7 @@ wl = bench.BevOps("r1", 1, torch.device("cuda:0"), 1234)
 n = 128 * 1024 * 1024 // 4                                  # 128 MiB
 bufs = [(torch.randn(n, device="cuda"), torch.empty(n, device="cuda")) for _ in range(4)]
 for k in range(8):
-    bufs[k % 4][1].copy_(bufs[k % 4][0])
+    torch.mul(bufs[k % 4][0], 1.5, out=bufs[k % 4][1])          # reads 128 MiB, writes 128 MiB, 16 B per lane
     wl.pool_fwd(k % len(wl.sets))
 torch.cuda.synchronize()
 print("copy_bytes", n * 4, "alg_bytes", wl.fwd_algorithmic_bytes())
