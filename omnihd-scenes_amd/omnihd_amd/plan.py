@@ -52,43 +52,57 @@ TILE_ITEMS = 768     # rows+points per tile of the tiled forward
 LONG_LEN = 512       # a row with more points is a tile of its own (TILE_ITEMS + LONG_LEN <= 1280)
 
 
-def tile_schedule(row_ptr, tile_row, ranks_feat, feat_hw=None, n_xcd=8):
+def tile_schedule(row_ptr, tile_row, ranks_feat, feat_hw=None, n_xcd=8, grid=None, layout="byxz", origin_cell=None):
     """Launch schedule of the tiled forward: which tile each (XCD, slot) works on.
 
-    Host-side planning only (runs once per calibration).  Tiles are ordered by the mean IMAGE
-    COLUMN (camera * fW + w) of the feature rows they gather and cut into ``n_xcd`` equal runs, so
-    the workgroups resident on one XCD (block b -> XCD b % 8) gather from one narrow band of image
-    columns that fits that XCD's 4 MiB L2; tiles with no points are dealt round-robin.  Changes
-    speed only: every tile is processed exactly once whatever the order."""
+    Host-side planning only (runs once per calibration).  The workgroups resident on one XCD (block
+    b -> XCD b % 8) should gather from as few image-feature rows as possible so that they stay in that
+    XCD's 4 MiB L2.  With ``grid`` (B,Z,Y,X) the tiles are ordered by the AZIMUTH of their BEV cells
+    around ``origin_cell`` (x, y in cells; default grid centre — the LSS module passes the centroid of
+    the camera positions) and cut into ``n_xcd`` runs of equal work: a wedge of BEV is seen through
+    a narrow band of image columns.  Measured on the R1 rig: 2.5-3.9 MB of feature rows per XCD
+    (24 MB summed, 17.3 MB compulsory) against 3.8-6.8 MB (45 MB) for an ordering by mean image column
+    and 53 MB for contiguous BEV bands.  Without ``grid`` the mean image column is used.
+    Changes speed only: every tile is processed exactly once whatever the order."""
     n_tiles = tile_row.numel() - 1
     per = (n_tiles + n_xcd - 1) // n_xcd          # the kernel derives the same value from n_tiles
+    dev = row_ptr.device
     lo = row_ptr[tile_row[:-1].long()].long()
     hi = row_ptr[tile_row[1:].long()].long()
-    if feat_hw is not None:
-        fH, fW = feat_hw
-        col = (ranks_feat // (fH * fW)) * fW + ranks_feat % fW
+    cnt = hi - lo
+    work = (cnt + (tile_row[1:] - tile_row[:-1]).long()).double()
+    if grid is not None:
+        B, Z, Y, X = grid
+        mid = ((tile_row[:-1] + tile_row[1:]) // 2).long().clamp(max=B * Z * Y * X - 1)
+        if layout == "byxz":
+            cell = mid // Z
+            yy, xx = (cell // X) % Y, cell % X
+        else:
+            yy, xx = (mid // X) % Y, mid % X
+        ox, oy = origin_cell if origin_cell is not None else ((X - 1) / 2.0, (Y - 1) / 2.0)
+        key = torch.atan2(yy.double() - oy, xx.double() - ox)
+        order = torch.argsort(key, stable=True)
     else:
-        col = ranks_feat
-    csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=col.device), col.double().cumsum(0)])
-    cnt = (hi - lo)
-    mean = (csum[hi] - csum[lo]) / cnt.clamp(min=1)
-    has = cnt > 0
-    busy = torch.nonzero(has).flatten()
-    busy = busy[torch.argsort(mean[busy], stable=True)]
-    idle = torch.nonzero(~has).flatten()
-    order = torch.full((n_xcd, per), -1, dtype=torch.int64, device=col.device)
-    nb, ni = busy.numel(), idle.numel()
-    # equal number of busy tiles per XCD (contiguous runs in column order), idle tiles fill the rest
-    bounds = [(nb * k) // n_xcd for k in range(n_xcd + 1)]
-    ibounds = [(ni * k) // n_xcd for k in range(n_xcd + 1)]
+        if feat_hw is not None:
+            fH, fW = feat_hw
+            col = (ranks_feat // (fH * fW)) * fW + ranks_feat % fW
+        else:
+            col = ranks_feat
+        csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), col.double().cumsum(0)])
+        mean = (csum[hi] - csum[lo]) / cnt.clamp(min=1)
+        mean = torch.where(cnt > 0, mean, torch.full_like(mean, float("inf")))
+        order = torch.argsort(mean, stable=True)
+    # cut the ordered tiles into n_xcd runs of (nearly) equal work, at most ``per`` tiles each
+    cw = work[order].cumsum(0)
+    run = torch.clamp((cw * n_xcd / (cw[-1] + 1)).long(), max=n_xcd - 1)
+    flat = torch.full((n_xcd * per,), -1, dtype=torch.int64, device=dev)
     spill = []
     for k in range(n_xcd):
-        both = torch.cat([busy[bounds[k]:bounds[k + 1]], idle[ibounds[k]:ibounds[k + 1]]])
-        if both.numel() > per:          # floor/ceil mismatch: at most one tile, re-homed below
-            spill.append(both[per:])
-            both = both[:per]
-        order[k, :both.numel()] = both
-    flat = order.flatten()
+        mine = order[run == k]
+        if mine.numel() > per:
+            spill.append(mine[per:])
+            mine = mine[:per]
+        flat[k * per:k * per + mine.numel()] = mine
     if spill:
         extra = torch.cat(spill)
         free = torch.nonzero(flat < 0).flatten()[:extra.numel()]
@@ -129,12 +143,12 @@ def pixel_schedule(bp_ranks_feat, bp_starts, bp_lengths, n_feat_rows, feat_hw=No
     return desc.contiguous()
 
 
-def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=None):
+def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=None, origin_cell=None):
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X
     row_ptr = ops.csr_from_sorted_keys(rows, n_rows)
     tile_row = ops.csr_tiles(row_ptr, TILE_ITEMS, LONG_LEN)
-    tile_order = tile_schedule(row_ptr, tile_row, rf, feat_hw)
+    tile_order = tile_schedule(row_ptr, tile_row, rf, feat_hw, grid=grid, layout=layout, origin_cell=origin_cell)
     tile_desc = ops.tile_descriptors(row_ptr, tile_row, tile_order)
     bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
     pix_desc = pixel_schedule(bp[2], bp[3], bp[4], n_feat_rows, feat_hw)
@@ -142,8 +156,9 @@ def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=No
                        tile_desc, starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4], pix_desc)
 
 
-def build_plan(coor, dx, bx, nx, layout="byxz"):
-    """Plan from frustum geometry (B,N,D,H,W,3) — one fused key pass + two radix sorts."""
+def build_plan(coor, dx, bx, nx, layout="byxz", origin_xy=None):
+    """Plan from frustum geometry (B,N,D,H,W,3) — one fused key pass + two radix sorts.
+    ``origin_xy``: metric (x, y) of the rig centre (centroid of the camera positions) for the XCD schedule."""
     if layout not in ("bzyx", "byxz"):
         raise ValueError(layout)
     B, N, D, H, W, _ = coor.shape
@@ -154,8 +169,12 @@ def build_plan(coor, dx, bx, nx, layout="byxz"):
     rows, (rd,), starts, lengths = ops.sort_ranks(keys, [idx], ops._bits_for(sentinel), sentinel)
     rows, rd = rows.contiguous(), rd.contiguous()
     rf = ops.ranks_feat_from_depth(rd, D, H * W)
+    origin_cell = None
+    if origin_xy is not None:
+        origin_cell = ((float(origin_xy[0]) - (float(bx[0]) - float(dx[0]) / 2)) / float(dx[0]) - 0.5,
+                       (float(origin_xy[1]) - (float(bx[1]) - float(dx[1]) / 2)) / float(dx[1]) - 0.5)
     return _finish(layout, (B, Z, Y, X), rows, rd, rf, starts.contiguous(), lengths.contiguous(), B * N * H * W,
-                   feat_hw=(H, W))
+                   feat_hw=(H, W), origin_cell=origin_cell)
 
 
 def plan_from_tables(ranks_bev, ranks_depth, ranks_feat, grid, n_feat_rows, layout="bzyx", feat_hw=None):

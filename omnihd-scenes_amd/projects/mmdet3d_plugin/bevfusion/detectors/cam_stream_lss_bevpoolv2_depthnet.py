@@ -222,8 +222,9 @@ class LiftSplatShoot_Depth(nn.Module):
         if plan is None:
             with torch.no_grad():
                 geom = self.get_geometry(rots, trans, *extra).contiguous().float()
+                origin = trans[..., :2].float().mean(dim=(0, 1)).cpu().tolist()     # centroid of the camera positions
                 plan = omnihd_amd.build_plan(geom, self.dx.numpy(), self.bx.numpy(), self.nx.numpy(),
-                                             layout=self.pool_layout)
+                                             layout=self.pool_layout, origin_xy=origin)
             if len(self._plans) >= self._max_plans:
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = plan

@@ -25,14 +25,15 @@ def main():
     for items, long_len in ((256, 256), (384, 384), (512, 512), (768, 512), (1024, 256), (896, 384), (640, 640)):
         tiles = ops.csr_tiles(wl.plan.row_ptr, items, long_len)
         order = P.tile_schedule(wl.plan.row_ptr, tiles, wl.plan.ranks_feat, (wl.fH, wl.fW))
+        order_az = P.tile_schedule(wl.plan.row_ptr, tiles, wl.plan.ranks_feat, (wl.fH, wl.fW), grid=wl.plan.grid, layout="byxz")
         res_t = []
-        for o in (None, order):
+        for o in (None, order, order_az):
             desc = ops.tile_descriptors(wl.plan.row_ptr, tiles, o)
             for s in wl.sets:
                 s[6][8] = desc.clone()
             res_t.append(bench.time_kernel(wl.pool_fwd, len(wl.sets), 40))
         print(f"tiled fwd W={items:5d} L={long_len:4d}: banded {res_t[0]*1e6:7.1f} us {nbytes/res_t[0]/1e9:6.0f} GB/s | "
-              f"column-scheduled {res_t[1]*1e6:7.1f} us {nbytes/res_t[1]/1e9:6.0f} GB/s  tiles {tiles.numel()-1}")
+              f"column {res_t[1]*1e6:7.1f} us {nbytes/res_t[1]/1e9:6.0f} GB/s | azimuth {res_t[2]*1e6:7.1f} us {nbytes/res_t[2]/1e9:6.0f} GB/s  tiles {tiles.numel()-1}")
     wl.sched_bwd = False
     t = bench.time_kernel(wl.pool_bwd, len(wl.sets), 40)
     print(f"bwd reference-API kernel (incl. 2 memsets): {t*1e6:8.1f} us")

@@ -198,6 +198,8 @@ def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
     order = tile_schedule(row_ptr, tiles, t(rf, cuda), (20, 30))
     o = order.cpu().numpy()
     assert np.array_equal(np.sort(o[o >= 0]), np.arange(tiles.numel() - 1))     # every tile exactly once
+    o2 = tile_schedule(row_ptr, tiles, t(rf, cuda), (20, 30), grid=(1, 10, 20, 15), layout="byxz").cpu().numpy()
+    assert np.array_equal(np.sort(o2[o2 >= 0]), np.arange(tiles.numel() - 1))
     outs = []
     d_plain = ops.tile_descriptors(row_ptr, tiles)
     d_sched = ops.tile_descriptors(row_ptr, tiles, order)
