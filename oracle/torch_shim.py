@@ -69,7 +69,7 @@ def oracle_ops():
     from omnihd_amd import ops as gops
     from projects.mmdet3d_plugin.bevfusion.detectors import cam_stream_lss_bevpoolv2_depthnet as lssmod
     saved = (omnihd_amd.build_plan, lssmod.planned_pool, gops.hard_voxelize, gops.pillar_scatter)
-    omnihd_amd.build_plan = lambda coor, dx, bx, nx, layout="bzyx": CpuPlan(coor, dx, bx, nx)
+    omnihd_amd.build_plan = lambda coor, dx, bx, nx, layout="bzyx", **_kw: CpuPlan(coor, dx, bx, nx)
     lssmod.planned_pool = planned_pool
     gops.hard_voxelize, gops.pillar_scatter = hard_voxelize, pillar_scatter
     try:
