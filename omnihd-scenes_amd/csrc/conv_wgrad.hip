@@ -184,6 +184,126 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma(const unsigned short* __r
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant of the NT GEMM.  The register-staged kernel above keeps only 64 KB of operands in
+// flight per CU (2 workgroups x one K-step) against a loaded-memory latency of several microseconds
+// -> 13 % MFMA utilisation (profiles/round1: SQ_WAIT_ANY 54 %).  Here operands go global -> LDS with
+// `global_load_lds` (no VGPR round trip, 16 B per lane, 1 KiB per wave instruction) into a ring of
+// kStages K-steps, three of which are in flight while the fourth is multiplied: 96 KB in flight per CU
+// with one 4-wave workgroup per CU.  LDS-DMA writes lane-linear images, so rows are unpadded (128 B
+// pitch) and the 16-byte chunks of a row are XOR-swizzled by ((row >> 1) & 7) — applied to the GLOBAL
+// source chunk a lane fetches and again when a fragment is read: conflict-free ds_read_b128.
+// Waits are counted by hand (s_waitcnt vmcnt(16) leaves two K-steps in flight) and the barrier is the
+// raw s_barrier: __syncthreads() would drain the DMA queue.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStages = 4;
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef __attribute__((address_space(1))) const void gbl_ptr_t;
+
+__global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short* __restrict__ Gt,
+                                                            const unsigned short* __restrict__ Xt,
+                                                            const unsigned short* __restrict__ zero_page,
+                                                            float* __restrict__ slab, int Cout, int Cin,
+                                                            int M, int Mp, int H, int W, int n_split,
+                                                            int k_per_split) {
+  // one LDS object only (a second one makes hipcc drain the DMA queue before every ds_read)
+  __shared__ __attribute__((aligned(16))) unsigned short sm[kStages][2][kTile][kBK];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tiles_c = Cin / kTile, tiles_n = Cout / kTile;
+  int bid = blockIdx.x;
+  const int ct = bid % tiles_c; bid /= tiles_c;
+  const int nt = bid % tiles_n; bid /= tiles_n;
+  const int tap = bid % 9;
+  const int split = bid / 9;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int k0 = split * k_per_split;
+  const int k1 = min(k0 + k_per_split, Mp);
+
+  // loader: wave w owns rows [32w, 32w+32) of both operands, 4 DMA calls of 8 rows each per operand.
+  const int lr = lane >> 3;                       // row inside the 8-row call
+  const int pos = lane & 7;                       // 16-byte slot inside the LDS row
+  const int c_even = pos ^ ((lane >> 4) & 7);     // global chunk for calls 0,2 ; calls 1,3 use c_even ^ 4
+  const unsigned short* a_row = Gt + (size_t)(nt * kTile + wave * 32 + lr) * Mp;
+  const unsigned short* b_row = Xt + ((size_t)(dx + 1) * Cin + ct * kTile + wave * 32 + lr) * Mp + dy * W;
+  // image row of this lane's two chunk positions at K-step k0 (chunks never straddle rows: W % 8 == 0)
+  int px0 = (k0 + c_even * 8) % W, py0 = ((k0 + c_even * 8) / W) % H;
+  int px1 = (k0 + (c_even ^ 4) * 8) % W, py1 = ((k0 + (c_even ^ 4) * 8) / W) % H;
+
+  auto issue = [&](int k, int stage) {
+    const bool real = k < k1;
+    const bool ok0 = real && (k + c_even * 8 < M) && (py0 + dy >= 0) && (py0 + dy < H);
+    const bool ok1 = real && (k + (c_even ^ 4) * 8 < M) && (py1 + dy >= 0) && (py1 + dy < H);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (i & 1) ? (c_even ^ 4) : c_even;
+      const bool ok = (i & 1) ? ok1 : ok0;
+      const unsigned short* ga = real ? a_row + (size_t)(8 * i) * Mp + k + c * 8 : zero_page;
+      const unsigned short* gb = ok ? b_row + (size_t)(8 * i) * Mp + k + c * 8 : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)ga, (lds_ptr_t*)&sm[stage][0][wave * 32 + 8 * i][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)gb, (lds_ptr_t*)&sm[stage][1][wave * 32 + 8 * i][0], 16, 0, 0);
+    }
+    px0 += kBK; while (px0 >= W) { px0 -= W; py0 = (py0 + 1 == H) ? 0 : py0 + 1; }
+    px1 += kBK; while (px1 >= W) { px1 -= W; py1 = (py1 + 1 == H) ? 0 : py1 + 1; }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+
+  // prologue: three K-steps in flight
+  issue(k0, 0);
+  issue(k0 + kBK, 1);
+  issue(k0 + 2 * kBK, 2);
+  int stage = 0;
+  for (int k = k0; k < k1; k += kBK) {
+    // the oldest K-step (8 DMA calls per wave) has landed when at most 16 younger calls are outstanding
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(k + 3 * kBK, (stage + 3) % kStages);      // its buffer was last read two barriers ago
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + frow;
+        const int rb = wn * 64 + i * 32 + frow;
+        const int c = ks * 2 + fhalf;
+        a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+        b[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1][rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    stage = (stage + 1) % kStages;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail loads before the epilogue stores
+
+  float* dst = slab + (size_t)split * Cout * 9 * Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = nt * kTile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int c = ct * kTile + wn * 64 + j * 32 + (lane & 31);
+        dst[((size_t)n * 9 + tap) * Cin + c] = acc[i][j][r];
+      }
+}
+
 __global__ __launch_bounds__(kBlock) void k_sum_slabs(const float* __restrict__ slab, int n_split,
                                                       size_t n, float* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
@@ -224,7 +344,7 @@ extern "C" size_t omnihd_conv3x3_wgrad_workspace_bytes(int batch, int h, int w, 
   const size_t Mp = padded_pixels(M);
   const int S = pick_split(cout, cin, (int)Mp);
   // [pad row of W pixels] Gt [Cout][Mp] | guard | Xt [3][Cin][Mp] | guard | slabs
-  return align_up((size_t)cout * Mp * 2, 256) + align_up((size_t)3 * cin * Mp * 2, 256) +
+  return 256 + align_up((size_t)cout * Mp * 2, 256) + align_up((size_t)3 * cin * Mp * 2, 256) +
          align_up((size_t)S * cout * 9 * cin * 4, 256) + 4 * align_up((size_t)w * 2 + 256, 256);
 }
 
@@ -246,7 +366,9 @@ extern "C" int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nh
   const int S = pick_split(cout, cin, Mp);
   int k_per_split = ((Mp / kBK + S - 1) / S) * kBK;
   const size_t guard = align_up((size_t)w * 2 + 256, 256);   // a dy = -1 read at k = 0 lands here, masked anyway
-  char* p = static_cast<char*>(workspace) + guard;
+  unsigned short* zero_page = static_cast<unsigned short*>(workspace);       // 256 zero bytes
+  OMNIHD_HIP_TRY(hipMemsetAsync(zero_page, 0, 256, st));
+  char* p = static_cast<char*>(workspace) + 256 + guard;
   unsigned short* Gt = reinterpret_cast<unsigned short*>(p);
   p += align_up((size_t)cout * Mp * 2, 256) + guard;
   unsigned short* Xt = reinterpret_cast<unsigned short*>(p);
@@ -259,8 +381,13 @@ extern "C" int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nh
   hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, static_cast<const unsigned short*>(x_nhwc), M, cin,
                      w, Mp, 3, Xt);
   const int blocks = (cin / kTile) * (cout / kTile) * 9 * S;
-  hipLaunchKernelGGL(k_wgrad_mfma, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, S > 1 ? slab : dw, cout, cin, M,
-                     Mp, h, w, S, k_per_split);
+  static const int use_glds = [] { const char* e = getenv("OMNIHD_WGRAD_GLDS"); return e ? atoi(e) : 1; }();
+  if (use_glds)
+    hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, S > 1 ? slab : dw,
+                       cout, cin, M, Mp, h, w, S, k_per_split);
+  else
+    hipLaunchKernelGGL(k_wgrad_mfma, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, S > 1 ? slab : dw, cout, cin, M,
+                       Mp, h, w, S, k_per_split);
   if (S > 1) {
     const size_t n = (size_t)cout * 9 * cin;
     hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, S, n, dw);
