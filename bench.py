@@ -335,10 +335,12 @@ def main():
         fwd_bytes = ops_wl.fwd_algorithmic_bytes()
         wl = ops_wl
         ach = fwd_bytes / t_fwd / 1e9
+        # HBM-side bytes per launch from rocprofv3 PMC passes (scripts/pmc_traffic.sh): FETCH_SIZE x the factor
+        # calibrated on a 128 MiB read of the same width (2.0 on gfx950, as the microarch guide says) + WRITE_SIZE
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_bev_pool_fwd.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        if os.path.exists(pmc) and a.res == "r1" and a.batch == 1:
+            traffic = round(json.load(open(pmc)).get("hbm_bytes_per_launch"))
         line = {
             "metric": "frames/sec (6-cam+6-radar BEV fwd+bwd)", "value": round(a.batch * world * a.steps / el, 3),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -356,7 +358,7 @@ def main():
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
                                        "overlapped with backward) + naiveSyncBN stat exchange" if a.workload == "fusion"
                                        else f"dp{world} (independent frames, no data-path collective)")},
-            "roofline": {"kernel": "k_pool_fwd_tiles<16> (bev_pool_v2 forward, dense CSR, workgroup merge-path tiles)", "bound": "hbm",
+            "roofline": {"kernel": "k_pool_fwd_tiles<16,4> (bev_pool_v2 forward, dense, balanced tiles, azimuth XCD schedule)", "bound": "hbm",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_fwd * 1e6, 2),
                          "bwd_mean_launch_us": round(t_bwd * 1e6, 2)},
