@@ -300,6 +300,17 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     radar_dims = 7 if a.res == "r1" else 8
+    # Dominant north_star kernel (bev_pool_v2 forward): timed FIRST, on the same frame geometry with rotating buffer
+    # sets, before the training loop heats the chip (the same kernel inside the step runs ~15 % slower: DVFS
+    # after MFMA-heavy convolutions and a polluted L2 — see profiles/ for the in-step rocprofv3 average).
+    kernel_times = None
+    if rank == 0:
+        ops_wl = BevOps(a.res, a.batch, dev, seed=1234)
+        kernel_times = (time_kernel(ops_wl.pool_fwd, len(ops_wl.sets), a.kernel_launches),
+                        time_kernel(ops_wl.pool_bwd, len(ops_wl.sets), a.kernel_launches),
+                        ops_wl.fwd_algorithmic_bytes(), ops_wl.plan.n_points, ops_wl.plan.n_intervals, ops_wl.fH, ops_wl.fW)
+        del ops_wl
+        torch.cuda.empty_cache()
     if a.workload == "fusion":
         from omnihd_amd.harness import FusionTrainStep
         wl = FusionTrainStep(res=a.res, batch=a.batch, radar_dims=radar_dims, device=f"cuda:{local}", seed=1234 + rank,
@@ -325,15 +336,7 @@ def main():
     el = float(el.item())
 
     if rank == 0:
-        if a.workload == "fusion":
-            del wl
-            torch.cuda.empty_cache()
-        # dominant north_star kernel, timed on the same frame geometry with rotating buffer sets
-        ops_wl = BevOps(a.res, a.batch, dev, seed=1234)
-        t_fwd = time_kernel(ops_wl.pool_fwd, len(ops_wl.sets), a.kernel_launches)
-        t_bwd = time_kernel(ops_wl.pool_bwd, len(ops_wl.sets), a.kernel_launches)
-        fwd_bytes = ops_wl.fwd_algorithmic_bytes()
-        wl = ops_wl
+        t_fwd, t_bwd, fwd_bytes, n_points, n_intervals, fH, fW = kernel_times
         ach = fwd_bytes / t_fwd / 1e9
         # HBM-side bytes per launch from rocprofv3 PMC passes (scripts/pmc_traffic.sh): FETCH_SIZE x the factor
         # calibrated on a 128 MiB read of the same width (2.0 on gfx950, as the microarch guide says) + WRITE_SIZE
@@ -352,9 +355,9 @@ def main():
                                     f"radar N~U(8k,20k)x{radar_dims}, 30 GT boxes; random-init weights"
                                     if a.workload == "fusion" else
                                     f"bev_ops@{a.res}: LSS bev_pool_v2 fwd(dense)+bwd, radar hard-voxelize + pillar scatter; "
-                                    f"6 cams {RES[a.res][0]}x{RES[a.res][1]} -> fmap {wl.fH}x{wl.fW}, D=59, C=64, BEV 240x160x16; "
+                                    f"6 cams {RES[a.res][0]}x{RES[a.res][1]} -> fmap {fH}x{fW}, D=59, C=64, BEV 240x160x16; "
                                     "conv backbone/BEV encoder NOT in this workload"),
-                       "frames_per_gpu": a.batch, "n_points": wl.plan.n_points, "n_intervals": wl.plan.n_intervals,
+                       "frames_per_gpu": a.batch, "n_points": n_points, "n_intervals": n_intervals,
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
                                        "overlapped with backward) + naiveSyncBN stat exchange" if a.workload == "fusion"
                                        else f"dp{world} (independent frames, no data-path collective)")},
