@@ -248,6 +248,20 @@ int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* 
                               int batch, int h, int w, int cin, int cout,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Bilinear sampling ("deformable im2col") of the 3x3 deformable convolution of DepthNet, deform_groups = 1.
+ * ref: build_conv_layer(dict(type='DCN', ...)) at cam_stream_lss_bevpoolv2_depthnet.py:587-595 (mmcv
+ * DeformConv2dPack, un-vendored).  x [batch,h,w,c] bf16 channels-last; offset [batch,ho,wo,18] fp32 with
+ * channel = tap*2 + (0: dy, 1: dx); col / gcol [batch*ho*wo, 9, c] bf16; c in {32,64,128,256}.
+ * fwd:  col[p][t][:] = zero-padded bilinear sample of x at (yo*stride - pad + ky*dil + dy, ...).
+ * bwd:  gx (same layout as x, may be NULL) and goffset (same layout as offset, may be NULL) from gcol;
+ *       max_abs_offset_ceil is a DEVICE int >= ceil(max |offset|) (bounds the gather window of gx;
+ *       no atomics, deterministic); stride must be 1 for gx.                                        */
+int omnihd_dcn3x3_sample_fwd(const void* x_nhwc_bf16, const float* offset_nhwc, void* col_bf16, int batch,
+                             int h, int w, int c, int stride, int pad, int dil, void* stream);
+int omnihd_dcn3x3_sample_bwd(const void* x_nhwc_bf16, const float* offset_nhwc, const void* gcol_bf16,
+                             const int* max_abs_offset_ceil, void* gx_nhwc_bf16, float* goffset_nhwc,
+                             int batch, int h, int w, int c, int stride, int pad, int dil, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,223 @@
+// Bilinear sampling of the deformable 3x3 convolution in DepthNet (deform_groups = 1) on gfx950.
+//
+// Reference: build_conv_layer(dict(type='DCN', groups=4, ...)) at
+// bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:587-595; the op itself is mmcv's
+// DeformConv2dPack (an un-vendored extension: deformable im2col + grouped GEMM, its backward scatters
+// with atomicAdd).  Here the im2col is a ROW gather — the same access pattern as bev_pool: a feature
+// row (C bf16 channels of one pixel, 512 B for C=256) is owned by C/8 lanes with 16 B each:
+//
+//   fwd      col[p][t][:]  = sum_{4 corners k} w_k(p,t) * x[corner_k(p,t)][:]        (p = output pixel, t = tap)
+//   bwd-off  d off[p][t]   = chain rule over  D_k = <gcol[p][t][:], x[corner_k][:]>      (4 dot products)
+//   bwd-in   gx[q][:]      = sum over the (p,t) whose sample lies within one pixel of q of
+//                            (1-|py-qy|)(1-|px-qx|) * gcol[p][t][:]
+//
+// bwd-in is a GATHER over a bounded window of candidate output pixels (window radius from the largest
+// |offset| of this call, read from device memory): deterministic, no atomics.  The contraction with
+// the (grouped) weight stays a bf16 GEMM in the caller.  Zero padding outside the image, offset
+// channel order (tap, (dy, dx)) as in mmcv.
+#include "common.h"
+
+namespace omnihd {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);       // round to nearest even
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = bf2f(v.x & 0xffff); f[1] = bf2f(v.x >> 16); f[2] = bf2f(v.y & 0xffff); f[3] = bf2f(v.y >> 16);
+  f[4] = bf2f(v.z & 0xffff); f[5] = bf2f(v.z >> 16); f[6] = bf2f(v.w & 0xffff); f[7] = bf2f(v.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 v;
+  v.x = f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16); v.y = f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+  v.z = f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16); v.w = f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+  return v;
+}
+
+struct Geo { int B, H, W, Ho, Wo, stride, pad, dil; };
+
+struct Sample {        // bilinear footprint of one (output pixel, tap)
+  bool any;
+  int row[4];          // flat input pixel index of the 4 corners, -1 = outside
+  float w[4];
+  float hh, lh, hw, lw;
+};
+
+__device__ __forceinline__ Sample make_sample(const Geo& g, const float* __restrict__ off, long p, int t) {
+  Sample s;
+  const int hw_o = g.Ho * g.Wo;
+  const int b = (int)(p / hw_o);
+  const int rem = (int)(p % hw_o);
+  const int yo = rem / g.Wo, xo = rem % g.Wo;
+  const float py = (float)(yo * g.stride - g.pad + (t / 3) * g.dil) + off[p * 18 + 2 * t];
+  const float px = (float)(xo * g.stride - g.pad + (t % 3) * g.dil) + off[p * 18 + 2 * t + 1];
+  s.any = py > -1.f && px > -1.f && py < (float)g.H && px < (float)g.W;
+  const float fy = floorf(py), fx = floorf(px);
+  const int y0 = (int)fy, x0 = (int)fx;
+  s.lh = py - fy; s.lw = px - fx; s.hh = 1.f - s.lh; s.hw = 1.f - s.lw;
+  const float wy[2] = {s.hh, s.lh}, wx[2] = {s.hw, s.lw};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+    const bool ok = s.any && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+    s.row[k] = ok ? (b * g.H + yy) * g.W + xx : -1;
+    s.w[k] = ok ? wy[k >> 1] * wx[k & 1] : 0.f;
+  }
+  return s;
+}
+
+template <int C8>
+__global__ __launch_bounds__(kBlock) void k_dcn_fwd(const uint4* __restrict__ x8, const float* __restrict__ off,
+                                                    Geo g, long n_bags, uint4* __restrict__ col8) {
+  constexpr int G = kBlock / C8;
+  const int sub = threadIdx.x % C8, grp = threadIdx.x / C8;
+  for (long bag = (long)blockIdx.x * G + grp; bag < n_bags; bag += (long)gridDim.x * G) {
+    const Sample s = make_sample(g, off, bag / 9, (int)(bag % 9));
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x8[(size_t)max(s.row[k], 0) * C8 + sub];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float f[8];
+      unpack8(v[k], f);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(s.w[k], f[c], acc[c]);
+    }
+    col8[(size_t)bag * C8 + sub] = pack8(acc);
+  }
+}
+
+template <int C8>
+__global__ __launch_bounds__(kBlock) void k_dcn_bwd_off(const uint4* __restrict__ x8, const float* __restrict__ off,
+                                                        const uint4* __restrict__ gcol8, Geo g, long n_bags,
+                                                        float* __restrict__ goff) {
+  constexpr int G = kBlock / C8;
+  const int sub = threadIdx.x % C8, grp = threadIdx.x / C8;
+  for (long bag = (long)blockIdx.x * G + grp; bag < n_bags; bag += (long)gridDim.x * G) {
+    const long p = bag / 9;
+    const int t = (int)(bag % 9);
+    const Sample s = make_sample(g, off, p, t);
+    float gc[8];
+    unpack8(gcol8[(size_t)bag * C8 + sub], gc);
+    float d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float f[8];
+      unpack8(x8[(size_t)max(s.row[k], 0) * C8 + sub], f);
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) a = fmaf(gc[c], f[c], a);
+      d[k] = s.row[k] >= 0 ? a : 0.f;
+    }
+#pragma unroll
+    for (int o = C8 / 2; o > 0; o >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] += __shfl_xor(d[k], o, C8);
+    }
+    if (sub == 0) {
+      // corners: 0 = (y0,x0) hh*hw, 1 = (y0,x1) hh*lw, 2 = (y1,x0) lh*hw, 3 = (y1,x1) lh*lw
+      goff[p * 18 + 2 * t] = -s.hw * d[0] - s.lw * d[1] + s.hw * d[2] + s.lw * d[3];
+      goff[p * 18 + 2 * t + 1] = -s.hh * d[0] + s.hh * d[1] - s.lh * d[2] + s.lh * d[3];
+    }
+  }
+}
+
+template <int C8>
+__global__ __launch_bounds__(kBlock) void k_dcn_bwd_in(const float* __restrict__ off, const uint4* __restrict__ gcol8,
+                                                       Geo g, const int* __restrict__ radius_ptr, long n_in,
+                                                       uint4* __restrict__ gx8) {
+  constexpr int G = kBlock / C8;
+  const int sub = threadIdx.x % C8, grp = threadIdx.x / C8;
+  const int R = *radius_ptr + 1;                      // candidate window half-width
+  for (long q = (long)blockIdx.x * G + grp; q < n_in; q += (long)gridDim.x * G) {
+    const int b = (int)(q / (g.H * g.W));
+    const int rem = (int)(q % (g.H * g.W));
+    const int y = rem / g.W, x = rem % g.W;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 9; ++t) {
+      const int ky = t / 3, kx = t % 3;
+      // stride 1: the undeformed sample of output pixel (yo, xo) sits at (yo - pad + ky*dil, ...)
+      const int cy = y + g.pad - ky * g.dil, cx = x + g.pad - kx * g.dil;
+      for (int yo = max(cy - R, 0); yo <= min(cy + R, g.Ho - 1); ++yo) {
+        for (int xo = max(cx - R, 0); xo <= min(cx + R, g.Wo - 1); ++xo) {
+          const long p = ((long)b * g.Ho + yo) * g.Wo + xo;
+          const float py = (float)(yo * g.stride - g.pad + ky * g.dil) + off[p * 18 + 2 * t];
+          const float px = (float)(xo * g.stride - g.pad + kx * g.dil) + off[p * 18 + 2 * t + 1];
+          const float ay = fabsf(py - (float)y), ax = fabsf(px - (float)x);
+          if (ay < 1.f && ax < 1.f) {
+            const float w = (1.f - ay) * (1.f - ax);
+            float f[8];
+            unpack8(gcol8[(size_t)(p * 9 + t) * C8 + sub], f);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = fmaf(w, f[c], acc[c]);
+          }
+        }
+      }
+    }
+    gx8[(size_t)q * C8 + sub] = pack8(acc);
+  }
+}
+
+bool c8_ok(int c) { return c == 256 || c == 128 || c == 64 || c == 32; }
+
+}  // namespace
+}  // namespace omnihd
+
+using namespace omnihd;
+
+#define OMNIHD_DCN_DISPATCH(KERNEL, GRID, ...)                                                        \
+  switch (c / 8) {                                                                                     \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;         \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;         \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;           \
+    default: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;          \
+  }
+
+static int dcn_geo(Geo* g, int b, int h, int w, int stride, int pad, int dil) {
+  g->B = b; g->H = h; g->W = w; g->stride = stride; g->pad = pad; g->dil = dil;
+  g->Ho = (h + 2 * pad - dil * 2 - 1) / stride + 1;
+  g->Wo = (w + 2 * pad - dil * 2 - 1) / stride + 1;
+  return g->Ho > 0 && g->Wo > 0;
+}
+
+extern "C" int omnihd_dcn3x3_sample_fwd(const void* x_nhwc_bf16, const float* offset_nhwc, void* col_bf16, int batch,
+                                        int h, int w, int c, int stride, int pad, int dil, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Geo g;
+  OMNIHD_REQUIRE(batch > 0 && c8_ok(c) && dcn_geo(&g, batch, h, w, stride, pad, dil), "shape (C in {32,64,128,256})");
+  OMNIHD_REQUIRE(x_nhwc_bf16 && offset_nhwc && col_bf16, "null pointer");
+  const long n_bags = (long)batch * g.Ho * g.Wo * 9;
+  const dim3 grid(grid_for(n_bags, kBlock / (c / 8) * 4));
+  OMNIHD_DCN_DISPATCH(k_dcn_fwd, grid, static_cast<const uint4*>(x_nhwc_bf16), offset_nhwc, g, n_bags,
+                      static_cast<uint4*>(col_bf16))
+  return check_launch("dcn3x3_sample_fwd");
+}
+
+extern "C" int omnihd_dcn3x3_sample_bwd(const void* x_nhwc_bf16, const float* offset_nhwc, const void* gcol_bf16,
+                                        const int* max_abs_offset_ceil, void* gx_nhwc_bf16, float* goffset_nhwc,
+                                        int batch, int h, int w, int c, int stride, int pad, int dil, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Geo g;
+  OMNIHD_REQUIRE(batch > 0 && c8_ok(c) && dcn_geo(&g, batch, h, w, stride, pad, dil), "shape (C in {32,64,128,256})");
+  OMNIHD_REQUIRE(stride == 1, "the input-gradient gather assumes stride 1");
+  OMNIHD_REQUIRE(x_nhwc_bf16 && offset_nhwc && gcol_bf16 && max_abs_offset_ceil, "null pointer");
+  const long n_bags = (long)batch * g.Ho * g.Wo * 9;
+  const long n_in = (long)batch * h * w;
+  if (goffset_nhwc) {
+    const dim3 grid(grid_for(n_bags, kBlock / (c / 8) * 4));
+    OMNIHD_DCN_DISPATCH(k_dcn_bwd_off, grid, static_cast<const uint4*>(x_nhwc_bf16), offset_nhwc,
+                        static_cast<const uint4*>(gcol_bf16), g, n_bags, goffset_nhwc)
+  }
+  if (gx_nhwc_bf16) {
+    const dim3 grid(grid_for(n_in, kBlock / (c / 8)));
+    OMNIHD_DCN_DISPATCH(k_dcn_bwd_in, grid, offset_nhwc, static_cast<const uint4*>(gcol_bf16), g, max_abs_offset_ceil,
+                        n_in, static_cast<uint4*>(gx_nhwc_bf16))
+  }
+  return check_launch("dcn3x3_sample_bwd");
+}

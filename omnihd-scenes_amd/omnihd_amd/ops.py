@@ -441,3 +441,48 @@ class _Conv3x3(torch.autograd.Function):
 
 def conv3x3(x, weight, bias=None):
     return _Conv3x3.apply(x, weight, bias)
+
+
+# ---------------------------------------------------------------------------------------------
+# deformable 3x3 sampling (DepthNet's DCN)
+# ---------------------------------------------------------------------------------------------
+class _DcnSample(torch.autograd.Function):
+    """x (B,H,W,C) bf16, offset (B,Ho,Wo,18) fp32 -> col (B*Ho*Wo, 9*C) bf16 (row gathers, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, stride, pad, dil):
+        B, H, W, C = x.shape
+        Ho, Wo = offset.shape[1:3]
+        col = torch.empty((B * Ho * Wo, 9 * C), dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib().omnihd_dcn3x3_sample_fwd(_ptr(x), _ptr(offset), _ptr(col), B, H, W, C, stride, pad, dil, _stream()),
+                  "omnihd_dcn3x3_sample_fwd")
+        ctx.save_for_backward(x, offset)
+        ctx.geo = (stride, pad, dil)
+        return col
+
+    @staticmethod
+    def backward(ctx, gcol):
+        x, offset = ctx.saved_tensors
+        stride, pad, dil = ctx.geo
+        B, H, W, C = x.shape
+        gcol = gcol.contiguous().to(torch.bfloat16)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        goff = torch.empty_like(offset) if ctx.needs_input_grad[1] else None
+        radius = offset.abs().amax().ceil().to(torch.int32).reshape(1)          # stays on the device
+        with torch.cuda.device(x.device):
+            check(lib().omnihd_dcn3x3_sample_bwd(_ptr(x), _ptr(offset), _ptr(gcol), _ptr(radius), _ptr(gx), _ptr(goff),
+                                                 B, H, W, C, stride, pad, dil, _stream()), "omnihd_dcn3x3_sample_bwd")
+        return gx, goff, None, None, None
+
+
+def dcn3x3_sample(x_nhwc, offset_nhwc, stride=1, pad=1, dil=1):
+    if not (x_nhwc.is_cuda and x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous()):
+        raise TypeError("x must be a contiguous (B,H,W,C) bf16 CUDA(HIP) tensor")
+    if not (offset_nhwc.dtype == torch.float32 and offset_nhwc.is_contiguous() and offset_nhwc.shape[-1] == 18):
+        raise TypeError("offset must be a contiguous (B,Ho,Wo,18) fp32 tensor")
+    return _DcnSample.apply(x_nhwc, offset_nhwc, int(stride), int(pad), int(dil))
+
+
+def dcn3x3_supported(x, k, stride, deform_groups):
+    return (x.is_cuda and x.dim() == 4 and k == 3 and stride == 1 and deform_groups == 1 and x.shape[1] in (32, 64, 128, 256))
