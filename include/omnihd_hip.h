@@ -248,6 +248,13 @@ int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* 
                               int batch, int h, int w, int cin, int cout,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight gradient of a 1x1 convolution: dw [cout, cin] fp32 = gout^T x with x_rows [m, cin] and
+ * gout_rows [m, cout] bf16 (m = batch*ho*wo rows; a strided 1x1 conv passes the sub-sampled input).
+ * Same matrix-core kernel as the 3x3 case with a single tap.  cin, cout multiples of 128.        */
+size_t omnihd_conv1x1_wgrad_workspace_bytes(int m, int cin, int cout);
+int omnihd_conv1x1_wgrad_bf16(const void* x_rows, const void* gout_rows, float* dw, int m, int cin, int cout,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Bilinear sampling ("deformable im2col") of the 3x3 deformable convolution of DepthNet, deform_groups = 1.
  * ref: build_conv_layer(dict(type='DCN', ...)) at cam_stream_lss_bevpoolv2_depthnet.py:587-595 (mmcv
  * DeformConv2dPack, un-vendored).  x [batch,h,w,c] bf16 channels-last; offset [batch,ho,wo,18] fp32 with

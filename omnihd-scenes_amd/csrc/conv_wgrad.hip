@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
                                                             const unsigned short* __restrict__ zero_page,
                                                             float* __restrict__ slab, int Cout, int Cin,
                                                             int M, int Mp, int H, int W, int n_split,
-                                                            int k_per_split) {
+                                                            int k_per_split, int taps) {
   // one LDS object only (a second one makes hipcc drain the DMA queue before every ds_read)
   __shared__ __attribute__((aligned(16))) unsigned short sm[kStages][2][kTile][kBK];
   const int tid = threadIdx.x;
@@ -215,9 +215,9 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
   int bid = blockIdx.x;
   const int ct = bid % tiles_c; bid /= tiles_c;
   const int nt = bid % tiles_n; bid /= tiles_n;
-  const int tap = bid % 9;
-  const int split = bid / 9;
-  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int tap = bid % taps;
+  const int split = bid / taps;
+  const int dy = (taps == 9) ? tap / 3 - 1 : 0, dx = (taps == 9) ? tap % 3 - 1 : 0;
   const int k0 = split * k_per_split;
   const int k1 = min(k0 + k_per_split, Mp);
 
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
   const int pos = lane & 7;                       // 16-byte slot inside the LDS row
   const int c_even = pos ^ ((lane >> 4) & 7);     // global chunk for calls 0,2 ; calls 1,3 use c_even ^ 4
   const unsigned short* a_row = Gt + (size_t)(nt * kTile + wave * 32 + lr) * Mp;
-  const unsigned short* b_row = Xt + ((size_t)(dx + 1) * Cin + ct * kTile + wave * 32 + lr) * Mp + dy * W;
+  const unsigned short* b_row = Xt + ((size_t)((taps == 9) ? dx + 1 : 0) * Cin + ct * kTile + wave * 32 + lr) * Mp + dy * W;
   // image row of this lane's two chunk positions at K-step k0 (chunks never straddle rows: W % 8 == 0)
   int px0 = (k0 + c_even * 8) % W, py0 = ((k0 + c_even * 8) / W) % H;
   int px1 = (k0 + (c_even ^ 4) * 8) % W, py1 = ((k0 + (c_even ^ 4) * 8) / W) % H;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail loads before the epilogue stores
 
-  float* dst = slab + (size_t)split * Cout * 9 * Cin;
+  float* dst = slab + (size_t)split * Cout * taps * Cin;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
       for (int r = 0; r < 16; ++r) {
         const int n = nt * kTile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int c = ct * kTile + wn * 64 + j * 32 + (lane & 31);
-        dst[((size_t)n * 9 + tap) * Cin + c] = acc[i][j][r];
+        dst[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
       }
 }
 
@@ -323,8 +323,8 @@ int padded_pixels(size_t m) {
   return (int)mp;
 }
 
-int pick_split(int cout, int cin, int mp) {
-  const int tiles = (cout / kTile) * (cin / kTile) * 9;
+int pick_split(int cout, int cin, int mp, int taps = 9) {
+  const int tiles = (cout / kTile) * (cin / kTile) * taps;
   int s = (3 * kCUs + tiles - 1) / tiles;          // aim at >= 3 workgroups per CU
   const int max_s = mp / (kBK * 8);                 // at least 8 K-steps per split
   if (s > max_s) s = max_s;
@@ -384,7 +384,7 @@ extern "C" int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nh
   static const int use_glds = [] { const char* e = getenv("OMNIHD_WGRAD_GLDS"); return e ? atoi(e) : 1; }();
   if (use_glds)
     hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, S > 1 ? slab : dw,
-                       cout, cin, M, Mp, h, w, S, k_per_split);
+                       cout, cin, M, Mp, h, w, S, k_per_split, 9);
   else
     hipLaunchKernelGGL(k_wgrad_mfma, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, S > 1 ? slab : dw, cout, cin, M,
                        Mp, h, w, S, k_per_split);
@@ -393,4 +393,47 @@ extern "C" int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nh
     hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, S, n, dw);
   }
   return check_launch("conv3x3_wgrad_bf16");
+}
+
+// 1x1 convolution (taps = 1): dW[n][c] = sum_m G[m][n] * X[m][c]; x and gout are [m, c] / [m, cout] bf16 rows.
+extern "C" size_t omnihd_conv1x1_wgrad_workspace_bytes(int m, int cin, int cout) {
+  if (m <= 0 || cin <= 0 || cout <= 0) return 256;
+  const size_t Mp = padded_pixels((size_t)m);
+  const int S = pick_split(cout, cin, (int)Mp, 1);
+  return 256 + align_up((size_t)cout * Mp * 2, 256) + align_up((size_t)cin * Mp * 2, 256) +
+         align_up((size_t)S * cout * cin * 4, 256) + 4 * 1024;
+}
+
+extern "C" int omnihd_conv1x1_wgrad_bf16(const void* x_rows, const void* gout_rows, float* dw, int m, int cin,
+                                         int cout, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  OMNIHD_REQUIRE(m > 0 && cin % kTile == 0 && cout % kTile == 0, "Cin and Cout must be multiples of 128");
+  OMNIHD_REQUIRE(x_rows && gout_rows && dw && workspace, "null pointer");
+  if (workspace_bytes < omnihd_conv1x1_wgrad_workspace_bytes(m, cin, cout)) {
+    set_error("conv1x1_wgrad: workspace too small");
+    return OMNIHD_ERR_WORKSPACE;
+  }
+  const int Mp = padded_pixels((size_t)m);
+  const int S = pick_split(cout, cin, Mp, 1);
+  const int k_per_split = ((Mp / kBK + S - 1) / S) * kBK;
+  unsigned short* zero_page = static_cast<unsigned short*>(workspace);
+  OMNIHD_HIP_TRY(hipMemsetAsync(zero_page, 0, 256, st));
+  char* p = static_cast<char*>(workspace) + 256 + 1024;
+  unsigned short* Gt = reinterpret_cast<unsigned short*>(p);
+  p += align_up((size_t)cout * Mp * 2, 256) + 1024;
+  unsigned short* Xt = reinterpret_cast<unsigned short*>(p);
+  p += align_up((size_t)cin * Mp * 2, 256) + 1024;
+  float* slab = reinterpret_cast<float*>(p);
+  const dim3 gG(Mp / 64, cout / 64), gX(Mp / 64, cin / 64);
+  // W = Mp: no image-row wrap, so the (single) dx = 0 shift never masks anything
+  hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, static_cast<const unsigned short*>(gout_rows), m, cout, Mp, Mp, 1, Gt);
+  hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, static_cast<const unsigned short*>(x_rows), m, cin, Mp, Mp, 1, Xt);
+  const int blocks = (cin / kTile) * (cout / kTile) * S;
+  hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, S > 1 ? slab : dw, cout, cin,
+                     m, Mp, 1 << 30, 64, S, k_per_split, 1);
+  if (S > 1) {
+    const size_t n = (size_t)cout * cin;
+    hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, S, n, dw);
+  }
+  return check_launch("conv1x1_wgrad_bf16");
 }

@@ -64,29 +64,35 @@ def build_activation(cfg):
 
 
 class BevConv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters / state-dict keys) whose 3x3 s1 p1 bf16 training path takes its weight
-    gradient from the hand-written MFMA kernel (omnihd_conv3x3_wgrad_bf16); everything else is MIOpen."""
+    """nn.Conv2d (same parameters / state-dict keys) whose bf16 training path takes its weight gradient from
+    the hand-written MFMA kernels (omnihd_conv3x3_wgrad_bf16 / omnihd_conv1x1_wgrad_bf16); forward and
+    data gradient stay on MIOpen."""
 
     def forward(self, x):
         from .. import ops
         if (self.training and self.weight.requires_grad and torch.is_autocast_enabled() and x.is_cuda
-                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
                 and self.dilation == (1, 1) and self.groups == 1):
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             wb = self.weight.to(torch.bfloat16)
-            if ops.conv3x3_wgrad_supported(xb, wb):
-                return ops.conv3x3(xb, wb, None if self.bias is None else self.bias.to(torch.bfloat16))
+            if ops.conv_wgrad_supported(xb, wb, self.stride, self.padding):
+                return ops.conv_hip_wgrad(xb, wb, None if self.bias is None else self.bias.to(torch.bfloat16),
+                                          self.stride, self.padding)
         return super().forward(x)
 
 
 def use_bev_conv(module):
-    """Switch every eligible nn.Conv2d under ``module`` (3x3, stride 1, pad 1, channels % 128 == 0) to
-    BevConv2d in place; parameters and state-dict keys are kept.  Layers whose feature-map width is not a
-    multiple of 8 simply take the MIOpen path at run time."""
+    """Switch every eligible nn.Conv2d under ``module`` (3x3 s1 p1, or 1x1 p0 with stride 1/2; channel counts
+    multiples of 128) to BevConv2d in place; parameters and state-dict keys are kept.  Layers whose run-time
+    shapes do not fit (e.g. 3x3 with a feature-map width not divisible by 8) simply take the MIOpen path."""
     n = 0
     for m in module.modules():
-        if type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) \
-                and m.dilation == (1, 1) and m.groups == 1 and m.in_channels % 128 == 0 and m.out_channels % 128 == 0:
+        if type(m) is not nn.Conv2d or m.groups != 1 or m.dilation != (1, 1):
+            continue
+        if m.in_channels % 128 or m.out_channels % 128:
+            continue
+        k3 = m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+        k1 = m.kernel_size == (1, 1) and m.padding == (0, 0) and m.stride in ((1, 1), (2, 2))
+        if k3 or k1:
             m.__class__ = BevConv2d
             n += 1
     return n

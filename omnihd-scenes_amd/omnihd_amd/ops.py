@@ -409,38 +409,83 @@ def _want_cl(t, name):
         raise ValueError(f"{name} must be channels-last contiguous")
 
 
+def conv1x1_wgrad(x, grad_out):
+    """x (B,Cin,H,W) bf16 channels-last (already sub-sampled for a strided conv), grad_out (B,Cout,H,W) bf16
+    channels-last -> dW (Cout,Cin,1,1) fp32."""
+    _want_cl(x, "x"); _want_cl(grad_out, "grad_out")
+    B, cin, H, W = x.shape
+    cout = grad_out.shape[1]
+    m = B * H * W
+    dev = x.device
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nbytes = lib().omnihd_conv1x1_wgrad_workspace_bytes(m, cin, cout)
+        key = (str(dev), torch.cuda.current_stream().cuda_stream)
+        ws = _WGRAD_WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _workspace(nbytes, dev)
+            _WGRAD_WS[key] = ws
+        check(lib().omnihd_conv1x1_wgrad_bf16(_ptr(x), _ptr(grad_out), _ptr(dw), m, cin, cout, _ptr(ws), ws.numel(),
+                                              _stream()), "omnihd_conv1x1_wgrad_bf16")
+    return dw.view(cout, cin, 1, 1)
+
+
+def conv_wgrad_supported(x, weight, stride, padding):
+    """3x3/s1/p1 (feature-map width % 8 == 0) or 1x1/p0 with stride 1 or 2; channels multiples of 128; bf16."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4):
+        return False
+    if weight.shape[0] % 128 or weight.shape[1] % 128:
+        return False
+    k = tuple(weight.shape[2:])
+    if k == (3, 3):
+        return stride == (1, 1) and padding == (1, 1) and x.shape[3] % 8 == 0
+    if k == (1, 1):
+        return padding == (0, 0) and stride in ((1, 1), (2, 2))
+    return False
+
+
 def conv3x3_wgrad_supported(x, weight):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and weight.shape[2:] == (3, 3)
-            and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0 and x.shape[3] % 8 == 0)
+    return conv_wgrad_supported(x, weight, (1, 1), (1, 1))
 
 
-class _Conv3x3(torch.autograd.Function):
-    """3x3/s1/p1 convolution: forward and data gradient on MIOpen, WEIGHT gradient on the hand-written
-    MFMA kernel (the slowest dense kernel of the training step under MIOpen)."""
+class _ConvHipWgrad(torch.autograd.Function):
+    """Convolution whose forward and data gradient run on MIOpen and whose WEIGHT gradient runs on the
+    hand-written MFMA kernel (the slowest dense kernels of the training step under MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stride, padding):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.conv2d(x, weight, bias, 1, 1)
+        ctx.conv = (list(stride), list(padding))
+        return torch.nn.functional.conv2d(x, weight, bias, stride, padding)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
+        stride, padding = ctx.conv
         gx = gw = gb = None
         g = g.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+            gx = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            gw = conv3x3_wgrad(x.contiguous(memory_format=torch.channels_last), g).to(weight.dtype)
+            if weight.shape[2] == 3:
+                gw = conv3x3_wgrad(x.contiguous(memory_format=torch.channels_last), g)
+            else:
+                xs = x if stride[0] == 1 else x[:, :, ::stride[0], ::stride[1]]
+                gw = conv1x1_wgrad(xs.contiguous(memory_format=torch.channels_last), g)
+            gw = gw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=(0, 2, 3), dtype=torch.float32).to(g.dtype)
-        return gx, gw, gb
+        return gx, gw, gb, None, None
 
 
 def conv3x3(x, weight, bias=None):
-    return _Conv3x3.apply(x, weight, bias)
+    return _ConvHipWgrad.apply(x, weight, bias, (1, 1), (1, 1))
+
+
+def conv_hip_wgrad(x, weight, bias, stride, padding):
+    return _ConvHipWgrad.apply(x, weight, bias, tuple(stride), tuple(padding))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -79,3 +79,19 @@ def test_dcn_hip_sampling_matches_torch_formulation(cuda):
         assert float((u - v).abs().max()) <= 3e-2 * float(v.abs().max()), name
     again = m._hip_sample_and_gemm(x, off)
     assert torch.equal(a, again)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,stride", [(2, 8, 22, 512, 128, 1), (6, 16, 44, 256, 1024, 1), (1, 9, 13, 128, 256, 2), (3, 7, 5, 2048, 512, 1)])
+def test_wgrad_1x1_matches_fp32_reference(cuda, B, H, W, cin, cout, stride):
+    from omnihd_amd import ops
+    torch.manual_seed(cin + H)
+    x = torch.randn(B, cin, H, W, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, device=cuda) * 0.05).to(torch.bfloat16).requires_grad_()
+    y = ops.conv_hip_wgrad(x, w, None, (stride, stride), (0, 0))
+    g = (torch.randn_like(y.float()) * 0.1).to(torch.bfloat16)
+    (gw,) = torch.autograd.grad(y, w, g)
+    wr = w.detach().float().requires_grad_()
+    yr = F.conv2d(x.float(), wr, None, stride)
+    (want,) = torch.autograd.grad(yr, wr, g.float())
+    assert gw.shape == want.shape
+    assert float((gw.float() - want).abs().max()) <= 1e-2 * float(want.abs().max())      # bf16 output rounding
