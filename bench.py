@@ -189,8 +189,8 @@ class BevOps:
 def time_kernel(fn, n_sets, launches):
     """Mean duration of `launches` back-to-back launches (rotating buffer sets), HIP events on the
     launching stream (= torch's current stream)."""
-    for s in range(n_sets):
-        fn(s)
+    for k in range(max(4 * launches, 200)):          # bring the clocks up: a fresh process starts in a low power state
+        fn(k % n_sets)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
