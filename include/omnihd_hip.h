@@ -269,6 +269,28 @@ int omnihd_dcn3x3_sample_bwd(const void* x_nhwc_bf16, const float* offset_nhwc, 
                              const int* max_abs_offset_ceil, void* gx_nhwc_bf16, float* goffset_nhwc,
                              int batch, int h, int w, int c, int stride, int pad, int dil, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Test-time post-process: rotated BEV NMS
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces mmdet3d v0.17.1 `iou3d_cuda.nms_gpu(boxes, keep, thresh, device_id)`
+ * (mmdet3d/ops/iou3d/src/iou3d.cpp + iou3d_kernel.cu, un-vendored), reached from the reference via
+ * Anchor3DHead.get_bboxes -> box3d_multiclass_nms with test_cfg
+ * projects/configs/bevfusion_NewScenes/bevfusion.py:147-155.
+ *   boxes    [n,5] f32 (x1, y1, x2, y2, angle), ALREADY in descending score order (the Python wrapper
+ *            sorts, as upstream's does);  n <= 4096
+ *   keep     [n] i64: positions (into the sorted order) of the surviving boxes, ascending
+ *   num_out  [1] i32 on the device: number of survivors (upstream returns it to the host; here the
+ *            mask reduction also runs on the device, the caller reads the count when it needs it)
+ *   workspace >= omnihd_nms_rotated_workspace_bytes(n)                                              */
+size_t omnihd_nms_rotated_workspace_bytes(int n);
+int omnihd_nms_rotated(const float* boxes, int n, float thresh, long long* keep, int* num_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[i*nb+j] = rotated BEV IoU(boxes_a[i], boxes_b[j]) with the same arithmetic as the NMS
+ * (upstream `boxes_iou_bev_gpu`).                                                                   */
+int omnihd_iou_bev_matrix(const float* boxes_a, int na, const float* boxes_b, int nb, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 """ctypes binding of libomnihd_hip.so — one prototype per symbol of include/omnihd_hip.h."""
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libomnihd_hip.so")
@@ -43,6 +43,9 @@ PROTOTYPES = {
     "omnihd_dcn3x3_sample_bwd": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "omnihd_pillar_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p]),
+    "omnihd_nms_rotated_workspace_bytes": (c_size_t, [c_int]),
+    "omnihd_nms_rotated": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "omnihd_iou_bev_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -351,3 +351,50 @@ class Anchor3DHead(nn.Module):
             loss_bbox = pos_pred.sum()
             loss_dir = pos_dir_pred.sum()
         return dict(loss_cls=[loss_cls], loss_bbox=[loss_bbox], loss_dir=[loss_dir])
+
+    # ---- test time --------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, dir_cls_preds, input_metas, cfg=None, rescale=False):
+        """Decode + per-class rotated NMS per sample (vendored twin: det_anchor3d_head.py:374-423).
+        Returns a list of (LiDARInstance3DBoxes, scores, labels) per sample."""
+        assert len(cls_scores) == len(bbox_preds) == len(dir_cls_preds)
+        sizes = [c.shape[-2:] for c in cls_scores]
+        anchors = [a.reshape(-1, self.box_code_size)
+                   for a in self.anchor_generator.grid_anchors(sizes, device=cls_scores[0].device)]
+        return [self.get_bboxes_single([c[b].detach() for c in cls_scores], [r[b].detach() for r in bbox_preds],
+                                       [d[b].detach() for d in dir_cls_preds], anchors, input_metas[b], cfg, rescale)
+                for b in range(len(input_metas))]
+
+    def get_bboxes_single(self, cls_scores, bbox_preds, dir_cls_preds, mlvl_anchors, input_meta, cfg=None,
+                          rescale=False):
+        """det_anchor3d_head.py:425-516: sigmoid scores, top-``nms_pre`` anchors by best class score per
+        level, box decoding, background slot, ``box3d_multiclass_nms``, direction-bin yaw fix-up."""
+        from .boxes import LiDARInstance3DBoxes, box3d_multiclass_nms, xywhr2xyxyr
+        cfg = self.test_cfg if cfg is None else cfg
+        box_type = input_meta.get("box_type_3d", LiDARInstance3DBoxes) if isinstance(input_meta, dict) \
+            else LiDARInstance3DBoxes
+        boxes, scores, dirs = [], [], []
+        for cls_score, bbox_pred, dir_pred, anchors in zip(cls_scores, bbox_preds, dir_cls_preds, mlvl_anchors):
+            assert cls_score.shape[-2:] == bbox_pred.shape[-2:] == dir_pred.shape[-2:]
+            dir_bin = dir_pred.float().permute(1, 2, 0).reshape(-1, 2).max(dim=-1)[1]
+            logits = cls_score.float().permute(1, 2, 0).reshape(-1, self.num_classes)
+            sc = logits.sigmoid() if self.use_sigmoid_cls else logits.softmax(-1)
+            deltas = bbox_pred.float().permute(1, 2, 0).reshape(-1, self.box_code_size)
+            nms_pre = cfg.get("nms_pre", -1)
+            if 0 < nms_pre < sc.shape[0]:
+                best = sc.max(dim=1)[0] if self.use_sigmoid_cls else sc[:, :-1].max(dim=1)[0]
+                top = best.topk(nms_pre)[1]
+                anchors, deltas, sc, dir_bin = anchors[top], deltas[top], sc[top], dir_bin[top]
+            boxes.append(self.bbox_coder.decode(anchors, deltas))
+            scores.append(sc)
+            dirs.append(dir_bin)
+        boxes, scores, dirs = torch.cat(boxes), torch.cat(scores), torch.cat(dirs)
+        for_nms = xywhr2xyxyr(box_type(boxes, box_dim=self.box_code_size).bev)
+        if self.use_sigmoid_cls:
+            scores = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
+        boxes, scores, labels, dirs = box3d_multiclass_nms(boxes, for_nms, scores, cfg.get("score_thr", 0),
+                                                           cfg["max_num"], cfg, dirs)
+        if boxes.shape[0] > 0:
+            rot = limit_period(boxes[..., 6] - self.dir_offset, self.dir_limit_offset, np.pi)
+            boxes[..., 6] = rot + self.dir_offset + np.pi * dirs.to(boxes.dtype)
+        return box_type(boxes, box_dim=self.box_code_size), scores, labels

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .registry import BACKBONES, HEADS, MIDDLE_ENCODERS, NECKS, VOXEL_ENCODERS
+from .boxes import bbox3d2result
 from .second import Voxelization
 from . import anchor_head, fpn, resnet, second  # noqa: F401  (register upstream type names)
 
@@ -74,3 +75,20 @@ class MVXFasterRCNN(nn.Module):
 
     def forward_img_train(self, x, img_metas, **kwargs):
         return dict()     # no image head in the fusion configs
+
+    # ---- test time (mmdet3d MVXTwoStageDetector.simple_test_pts / forward_test / Base3DDetector.forward) ----
+    def simple_test_pts(self, x, img_metas, rescale=False):
+        outs = self.pts_bbox_head(x)
+        bbox_list = self.pts_bbox_head.get_bboxes(*outs, img_metas, rescale=rescale)
+        return [bbox3d2result(b, s, l) for b, s, l in bbox_list]
+
+    def forward_test(self, points=None, img_metas=None, img=None, **kwargs):
+        """Upstream wraps every test input in a list of augmentations; the configs use one (no TTA)."""
+        for var, name in [(points, "points"), (img_metas, "img_metas")]:
+            if not isinstance(var, list):
+                raise TypeError(f"{name} must be a list, but got {type(var)}")
+        if len(points) != len(img_metas):
+            raise ValueError(f"num of augmentations ({len(points)}) != num of image meta ({len(img_metas)})")
+        if len(points) != 1:
+            raise NotImplementedError("test-time augmentation is not part of the reference configs")
+        return self.simple_test(points[0], img_metas[0], None if img is None else img[0], **kwargs)

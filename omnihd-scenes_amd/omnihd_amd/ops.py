@@ -531,3 +531,42 @@ def dcn3x3_sample(x_nhwc, offset_nhwc, stride=1, pad=1, dil=1):
 
 def dcn3x3_supported(x, k, stride, deform_groups):
     return (x.is_cuda and x.dim() == 4 and k == 3 and stride == 1 and deform_groups == 1 and x.shape[1] in (32, 64, 128, 256))
+
+
+# --------------------------------------------------------------------------------------------
+# Test-time post-process: rotated BEV NMS (mmdet3d v0.17.1 `nms_gpu` / `boxes_iou_bev`)
+# --------------------------------------------------------------------------------------------
+def nms_rotated(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
+    """mmdet3d `nms_gpu(boxes, scores, thresh, pre_maxsize, post_max_size)`: boxes (N,5) fp32
+    (x1, y1, x2, y2, ry), scores (N,) -> int64 indices of the kept boxes in descending score
+    order.  Sorting stays on torch (as upstream); masks and their reduction run in the HIP library."""
+    _want(boxes, torch.float32, "boxes")
+    _same_device(boxes, scores)
+    order = scores.sort(0, descending=True)[1]
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    sorted_boxes = boxes[order].contiguous()
+    n = sorted_boxes.shape[0]
+    dev = boxes.device
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    num_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _workspace(lib().omnihd_nms_rotated_workspace_bytes(n), dev)
+        check(lib().omnihd_nms_rotated(_ptr(sorted_boxes), n, float(thresh), _ptr(keep), _ptr(num_out), _ptr(ws),
+                                       ws.numel(), _stream()), "omnihd_nms_rotated")
+    kept = order[keep[:int(num_out.item())]].contiguous()
+    if post_max_size is not None:
+        kept = kept[:post_max_size]
+    return kept
+
+
+def iou_bev_matrix(boxes_a, boxes_b):
+    """(Na,5) x (Nb,5) (x1,y1,x2,y2,ry) -> (Na,Nb) rotated BEV IoU (mmdet3d `boxes_iou_bev`)."""
+    _want(boxes_a, torch.float32, "boxes_a")
+    _want(boxes_b, torch.float32, "boxes_b")
+    _same_device(boxes_a, boxes_b)
+    out = torch.empty((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    with torch.cuda.device(boxes_a.device):
+        check(lib().omnihd_iou_bev_matrix(_ptr(boxes_a), boxes_a.shape[0], _ptr(boxes_b), boxes_b.shape[0],
+                                          _ptr(out), _stream()), "omnihd_iou_bev_matrix")
+    return out

@@ -124,7 +124,17 @@ class BEVFUSION_depth(MVXFasterRCNN):
             losses.update(self.forward_img_train(img_feats, img_metas=img_metas))
         return losses
 
+    @torch.no_grad()
+    def simple_test(self, points, img_metas, img=None, rescale=False):
+        """Reference :153-176 without its debug rendering of the BEV feature (defect D7)."""
+        fd = self.extract_feat(points, img=img, img_metas=img_metas)
+        bbox_list = [dict() for _ in range(len(img_metas))]
+        if fd["pts_feats"] and self.with_pts_bbox:
+            for result, pts_bbox in zip(bbox_list, self.simple_test_pts(fd["pts_feats"], img_metas, rescale=rescale)):
+                result["pts_bbox"] = pts_bbox
+        return bbox_list
+
     def forward(self, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(**kwargs)
-        raise NotImplementedError("test-time decoding (rotate-NMS, box export) is a 'next' row of SURVEY.md 8(f)")
+        return self.forward_test(**kwargs)

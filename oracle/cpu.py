@@ -20,6 +20,7 @@ def lib():
             subprocess.check_call(["make", "-C", _HERE, "-s"])
         _lib = ctypes.CDLL(_SO)
         _lib.oracle_hard_voxelize.restype = ctypes.c_int
+        _lib.oracle_nms_rotated.restype = ctypes.c_int
     return _lib
 
 
@@ -95,3 +96,28 @@ def pillar_scatter(feats, coors, batch, ny, nx):
     lib().oracle_pillar_scatter(_p(feats), _p(coors), ctypes.c_int(m), ctypes.c_int(c), ctypes.c_int(batch),
                                 ctypes.c_int(ny), ctypes.c_int(nx), _p(canvas))
     return canvas
+
+
+def iou_bev_matrix(boxes_a, boxes_b):
+    """(Na,5),(Nb,5) boxes (x1,y1,x2,y2,ry) -> (Na,Nb) rotated BEV IoU (oracle/nms_oracle.c)."""
+    a, b = _f32(boxes_a).reshape(-1, 5), _f32(boxes_b).reshape(-1, 5)
+    out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    lib().oracle_iou_bev_matrix(_p(a), ctypes.c_int(a.shape[0]), _p(b), ctypes.c_int(b.shape[0]), _p(out))
+    return out
+
+
+def nms_rotated_sorted(sorted_boxes, thresh):
+    """Boxes already in descending score order -> kept positions (int64, ascending)."""
+    b = _f32(sorted_boxes).reshape(-1, 5)
+    keep = np.zeros(max(b.shape[0], 1), dtype=np.int64)
+    n = lib().oracle_nms_rotated(_p(b), ctypes.c_int(b.shape[0]), ctypes.c_float(thresh), _p(keep))
+    return keep[:n]
+
+
+def nms_rotated(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
+    """mmdet3d `nms_gpu` semantics on numpy arrays; the score sort is a STABLE descending sort."""
+    order = np.argsort(-np.asarray(scores, dtype=np.float32), kind="stable")
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    kept = order[nms_rotated_sorted(np.asarray(boxes)[order], thresh)]
+    return kept if post_max_size is None else kept[:post_max_size]

@@ -2,7 +2,7 @@
 
 Lets the detector's Python host code run on CPU tensors by temporarily routing the four HIP-backed
 operators to the CPU oracle (numpy rank tables, C pooling kernels, sequential voxelise, index
-scatter).  Used ONLY by tests (CPU-side checks of the host logic, world_size-2 gloo runs) and by
+scatter, sequential rotated NMS).  Used ONLY by tests (CPU-side checks of the host logic, world_size-2 gloo runs) and by
 bench.py's cpu_baseline leg; the product never imports it and has no CPU path of its own.
 """
 import contextlib
@@ -62,17 +62,27 @@ def pillar_scatter(feats, coors, batch, ny, nx, channels_last=False):
     return canvas.view(batch, -1, ny, nx)
 
 
+def nms_rotated(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
+    order = scores.sort(0, descending=True)[1]                   # torch's order, as the product wrapper uses
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    keep = OC.nms_rotated_sorted(boxes[order].detach().numpy(), float(thresh))
+    kept = order[torch.from_numpy(keep)]
+    return kept if post_max_size is None else kept[:post_max_size]
+
+
 @contextlib.contextmanager
 def oracle_ops():
     """Inside the block ``omnihd_amd`` ops used by the detector run on the CPU oracle."""
     import omnihd_amd
     from omnihd_amd import ops as gops
     from projects.mmdet3d_plugin.bevfusion.detectors import cam_stream_lss_bevpoolv2_depthnet as lssmod
-    saved = (omnihd_amd.build_plan, lssmod.planned_pool, gops.hard_voxelize, gops.pillar_scatter)
+    saved = (omnihd_amd.build_plan, lssmod.planned_pool, gops.hard_voxelize, gops.pillar_scatter, gops.nms_rotated)
     omnihd_amd.build_plan = lambda coor, dx, bx, nx, layout="bzyx", **_kw: CpuPlan(coor, dx, bx, nx)
     lssmod.planned_pool = planned_pool
-    gops.hard_voxelize, gops.pillar_scatter = hard_voxelize, pillar_scatter
+    gops.hard_voxelize, gops.pillar_scatter, gops.nms_rotated = hard_voxelize, pillar_scatter, nms_rotated
     try:
         yield
     finally:
-        omnihd_amd.build_plan, lssmod.planned_pool, gops.hard_voxelize, gops.pillar_scatter = saved
+        (omnihd_amd.build_plan, lssmod.planned_pool, gops.hard_voxelize, gops.pillar_scatter,
+         gops.nms_rotated) = saved

@@ -241,3 +241,67 @@ def test_dcn_gather_formulation_matches_grid_sample_formulation():
     gb = torch.autograd.grad(b.square().sum(), [x, m.weight, m.conv_offset.weight])
     for u, v in zip(ga, gb):
         torch.testing.assert_close(u, v, rtol=1e-3, atol=1e-3 * float(v.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# Test-time path: box container, multi-class NMS host logic, simple_test
+# ---------------------------------------------------------------------------------------------
+def test_lidar_boxes_container_known_answers():
+    from omnihd_amd.mm.boxes import LiDARInstance3DBoxes, xywhr2xyxyr
+    raw = torch.tensor([[1.0, 2.0, 0.5, 2.0, 4.0, 1.5, 0.3, 0.1, -0.2], [0.0, 0.0, -1.0, 1.0, 1.0, 2.0, -1.0, 0.0, 0.0]])
+    b = LiDARInstance3DBoxes(raw, box_dim=9)
+    assert torch.equal(b.bev, raw[:, [0, 1, 3, 4, 6]]) and torch.equal(b.dims, raw[:, 3:6]) and len(b) == 2
+    torch.testing.assert_close(b.gravity_center, torch.tensor([[1.0, 2.0, 1.25], [0.0, 0.0, 0.0]]))
+    # dataset side (newscenes_dataset.py:273-277): annotations carry the gravity centre -> bottom centre
+    c = LiDARInstance3DBoxes(raw, box_dim=9, origin=(0.5, 0.5, 0.5))
+    torch.testing.assert_close(c.tensor[:, 2], torch.tensor([0.5 - 0.75, -1.0 - 1.0]))
+    torch.testing.assert_close(c.gravity_center[:, 2], raw[:, 2])
+    torch.testing.assert_close(xywhr2xyxyr(b.bev), torch.tensor([[0.0, 0.0, 2.0, 4.0, 0.3], [-0.5, -0.5, 0.5, 0.5, -1.0]]))
+    assert len(b[1]) == 1 and len(b[torch.tensor([True, False])]) == 1 and len(LiDARInstance3DBoxes(torch.zeros(0, 9), box_dim=9)) == 0
+
+
+def test_multiclass_nms_host_logic_over_the_oracle():
+    from omnihd_amd.mm.boxes import LiDARInstance3DBoxes, box3d_multiclass_nms, xywhr2xyxyr
+    from oracle.torch_shim import oracle_ops
+    boxes = torch.tensor([[0, 0, 0, 2, 4, 1.5, 0.0], [0.2, 0, 0, 2, 4, 1.5, 0.05], [10, 0, 0, 2, 4, 1.5, 0.0],
+                          [10, 0.1, 0, 2, 4, 1.5, 1.57], [30, 0, 0, 1, 1, 1, 0.0]], dtype=torch.float32)
+    #                      class 0   class 1  background
+    scores = torch.tensor([[0.90, 0.10, 0.0], [0.80, 0.04, 0.0], [0.30, 0.60, 0.0], [0.95, 0.50, 0.0], [0.01, 0.02, 0.0]])
+    dirs = torch.tensor([0, 1, 0, 1, 0])
+    cfg = dict(use_rotate_nms=True, nms_thr=0.2, score_thr=0.05, max_num=500)
+    for_nms = xywhr2xyxyr(LiDARInstance3DBoxes(boxes).bev)
+    with oracle_ops():
+        b, s, l, d = box3d_multiclass_nms(boxes, for_nms, scores, 0.05, 500, cfg, dirs)
+        # class 0: order 3,0,1,2 -> keep 3,0 (1 suppressed by 0, 2 by 3); class 1: candidates 0,2,3 -> keep 2, 0 (3 suppressed by 2)
+        assert s.tolist() == pytest.approx([0.95, 0.90, 0.60, 0.10]) and l.tolist() == [0, 0, 1, 1] and d.tolist() == [1, 0, 0, 0]
+        assert torch.equal(b, boxes[[3, 0, 2, 0]])
+        b, s, l, d = box3d_multiclass_nms(boxes, for_nms, scores, 0.05, 3, cfg, dirs)      # global top-max_num
+        assert s.tolist() == pytest.approx([0.95, 0.90, 0.60]) and l.tolist() == [0, 0, 1]
+        b, s, l = box3d_multiclass_nms(boxes, for_nms, scores, 0.99, 3, cfg)               # nothing above the threshold
+        assert b.shape == (0, 7) and s.shape == (0,) and l.dtype == torch.long
+    with pytest.raises(NotImplementedError):
+        box3d_multiclass_nms(boxes, for_nms, scores, 0.05, 3, dict(use_rotate_nms=False, nms_thr=0.2))
+
+
+def test_tiny_detector_simple_test_on_cpu_with_oracle_ops():
+    from omnihd_amd.harness import FusionTrainStep
+    from oracle.torch_shim import oracle_ops
+    torch.set_num_threads(4)
+    with oracle_ops():
+        st = FusionTrainStep(res="tiny", batch=2, radar_dims=7, device="cpu", dtype="fp32", channels_last=False, sets=1)
+        m, b = st.raw_model, st.batches[0]
+        m.eval()
+        torch.nn.init.constant_(m.pts_bbox_head.conv_cls.bias, 0.0)
+        out = m(return_loss=False, points=[b["points"]], img_metas=[b["img_metas"]], img=[b["img"]])
+        with pytest.raises(TypeError):
+            m(return_loss=False, points=b["points"][0], img_metas=[b["img_metas"]], img=[b["img"]])
+        with pytest.raises(NotImplementedError):       # a list of two "augmentations"
+            m(return_loss=False, points=b["points"], img_metas=b["img_metas"], img=b["img"])
+    assert len(out) == 2
+    for r in out:
+        d = r["pts_bbox"]
+        n = len(d["boxes_3d"])
+        assert 0 < n <= 500 and d["scores_3d"].shape == (n,) and d["labels_3d"].shape == (n,)
+        assert float(d["scores_3d"].min()) > 0.05 and set(d["labels_3d"].tolist()) <= {0, 1}
+        yaw = d["boxes_3d"].yaw                      # direction fix-up: yaw in [dir_offset, dir_offset + 2pi)
+        assert float(yaw.min()) >= 0.7854 - 1e-4 and float(yaw.max()) < 0.7854 + 2 * math.pi + 1e-4

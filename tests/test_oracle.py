@@ -153,3 +153,89 @@ def test_pillar_scatter_index():
     canvas = OC.pillar_scatter(feats, coors, batch=2, ny=2, nx=4)
     assert canvas.shape == (2, 3, 2, 4) and canvas.sum() == feats.sum()
     assert canvas[0, :, 1, 2].tolist() == [1, 2, 3] and canvas[1, :, 0, 3].tolist() == [4, 5, 6]
+
+
+# ---------------------------------------------------------------------------------------------
+# Rotated BEV IoU / NMS oracle (upstream mmdet3d v0.17.1 iou3d; parity unpinned, see nms_oracle.c)
+# ---------------------------------------------------------------------------------------------
+def _xyxyr(cx, cy, w, h, r):
+    return [cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, r]
+
+
+def _clip_area(a, b):
+    """Independent check: Sutherland-Hodgman clipping of polygon a by convex polygon b (float64)."""
+    def corners(bx):
+        cx, cy, w, h, r = (bx[0] + bx[2]) / 2, (bx[1] + bx[3]) / 2, bx[2] - bx[0], bx[3] - bx[1], bx[4]
+        c, s = np.cos(r), np.sin(r)
+        pts = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]])
+        rot = np.array([[c, s], [-s, c]])              # the clockwise convention of the v0.17.1 kernel
+        return pts @ rot.T + [cx, cy]
+    cr = lambda u, v: u[0] * v[1] - u[1] * v[0]
+    poly, clip = corners(np.asarray(a, np.float64)), corners(np.asarray(b, np.float64))
+    if cr(clip[1] - clip[0], clip[2] - clip[1]) < 0:
+        clip = clip[::-1]
+    out = list(poly)
+    for i in range(4):
+        p0, p1 = clip[i], clip[(i + 1) % 4]
+        inp, out = out, []
+        if not inp:
+            break
+        side = lambda q: cr(p1 - p0, q - p0)
+        for j in range(len(inp)):
+            cur, prv = inp[j], inp[j - 1]
+            if side(cur) >= 0:
+                if side(prv) < 0:
+                    out.append(prv + (cur - prv) * side(prv) / (side(prv) - side(cur)))
+                out.append(cur)
+            elif side(prv) >= 0:
+                out.append(prv + (cur - prv) * side(prv) / (side(prv) - side(cur)))
+    if len(out) < 3:
+        return 0.0
+    o = np.array(out)
+    return 0.5 * abs(np.sum(o[:, 0] * np.roll(o[:, 1], -1) - np.roll(o[:, 0], -1) * o[:, 1]))
+
+
+def test_iou_oracle_hand_computed_cases():
+    a = np.array([_xyxyr(0, 0, 2, 2, 0)], np.float32)
+    b = np.array([_xyxyr(1, 0, 2, 2, 0),            # half overlap: 2 / (4 + 4 - 2)
+                  _xyxyr(0, 0, 2, 2, np.pi / 4),    # octagon of area 8(sqrt2 - 1)
+                  _xyxyr(5, 5, 1, 1, 0.3),          # disjoint
+                  _xyxyr(0, 0, 1, 1, 1.0),          # contained at any angle: 1 / 4
+                  _xyxyr(0, 0, 2, 2, 0),            # identical
+                  _xyxyr(0.5, 0.5, 4, 1, np.pi / 2)], np.float32)   # 1x4 bar turned upright: overlap 1 x 1.5 ... see below
+    iou = OC.iou_bev_matrix(a, b)[0]
+    oct_area = 8 * (2 ** 0.5 - 1)
+    np.testing.assert_allclose(iou[:5], [1 / 3, oct_area / (8 - oct_area), 0.0, 0.25, 1.0], atol=1e-6)
+    # bar: centre (0.5, 0.5), after the quarter turn it spans x in [0, 1], y in [-1.5, 2.5]; inside the 2x2
+    # square that is 1 x 2 -> IoU 2 / (4 + 4 - 2)
+    np.testing.assert_allclose(iou[5], 2 / 6, atol=1e-6)
+
+
+def test_iou_oracle_against_independent_polygon_clipping():
+    rng = np.random.default_rng(11)
+    n = 60
+    xy = rng.normal(0, 2.0, (n, 2))
+    wl = np.stack([rng.uniform(0.5, 2.6, n), rng.uniform(0.5, 8.0, n)], 1)
+    boxes = np.concatenate([xy - wl / 2, xy + wl / 2, rng.uniform(-np.pi, np.pi, (n, 1))], 1).astype(np.float32)
+    iou = OC.iou_bev_matrix(boxes, boxes)
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    worst = 0.0
+    for i in range(n):
+        for j in range(n):
+            ov = _clip_area(boxes[i], boxes[j])
+            worst = max(worst, abs(ov / max(area[i] + area[j] - ov, 1e-8) - iou[i, j]))
+    assert (iou > 0.05).sum() > n * 4
+    assert worst < 2e-4, worst
+
+
+def test_nms_oracle_greedy_semantics():
+    boxes = np.array([_xyxyr(0, 0, 2, 4, 0.0), _xyxyr(0.2, 0, 2, 4, 0.05), _xyxyr(10, 0, 2, 4, 0.0),
+                      _xyxyr(10, 0.1, 2, 4, 1.57), _xyxyr(0.1, 0.1, 2, 4, 0.0)], np.float32)
+    scores = np.array([0.9, 0.8, 0.3, 0.95, 0.5], np.float32)
+    # order: 3, 0, 1, 4, 2.  Box 0 suppresses 1 and 4; box 3 (upright vs lying) overlaps box 2 with
+    # IoU = 4 / 12 > 0.2 -> suppressed at 0.2, kept at 0.4
+    assert OC.nms_rotated(boxes, scores, 0.2).tolist() == [3, 0]
+    assert OC.nms_rotated(boxes, scores, 0.4).tolist() == [3, 0, 2]
+    assert OC.nms_rotated(boxes, scores, 0.2, pre_maxsize=2).tolist() == [3, 0]
+    assert OC.nms_rotated(boxes, scores, 0.4, post_max_size=1).tolist() == [3]
+    assert OC.nms_rotated(np.zeros((0, 5), np.float32), np.zeros(0, np.float32), 0.2).tolist() == []
