@@ -1,0 +1,155 @@
+"""Radar input format and loader — mirror of the reference's
+``LoadRadarPointsMultiSweeps`` (projects/mmdet3d_plugin/datasets/pipelines/loading.py:113-316) and
+of the camera-matrix side of ``LoadMultiViewImageFromFiles_newsc`` (:321-400).
+
+On-disk format: one little-endian float32 ``.bin`` per radar sweep, rows of ``load_dim`` = 8 values
+``[x, y, z, v_r, power, motion_state, SNR, valid]`` in the SENSOR frame.  Per frame up to
+``sweeps_num`` sweeps of each of six radars are merged into rows of ten values
+``[x, y, z, vx_comp, vy_comp, power, snr, dt, Vr_comp, radar_id]`` in the LiDAR/ego frame, then
+``use_dim`` selects columns and points outside ``pc_range`` are dropped (strict inequalities).
+
+The arithmetic follows the reference line by line (numpy, float32 inputs promoted exactly where the
+reference promotes them) so that results are bit-identical; ``merge_radar_sweeps`` is the array-level
+core, the class only adds file reading.  Image decoding / undistortion (OpenCV) is dataset IO and
+stays out of scope; the 4x4 matrix bookkeeping that feeds ``img_metas['lidar2img']`` is restated in
+``half_scale_front_back`` / ``scale_lidar2img``.
+"""
+import numpy as np
+import torch
+
+RADAR_ID = {"radar_front": 0, "radar_left_front": 1, "radar_right_front": 2, "radar_back": 3, "radar_left_back": 4,
+            "radar_right_back": 5}
+
+
+def quaternion_rotation_matrix(q_wxyz):
+    """3x3 rotation of a (w, x, y, z) quaternion, normalised first (pyquaternion ``rotation_matrix``)."""
+    q = np.asarray(getattr(q_wxyz, "elements", q_wxyz), dtype=np.float64)
+    n2 = float(np.dot(q, q))
+    if abs(1.0 - n2) >= 1e-14 and n2 > 0:
+        q = q / np.sqrt(n2)
+    w, x, y, z = q
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), w * w - x * x + y * y - z * z, 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), w * w - x * x - y * y + z * z]])
+
+
+def compensate_sweep(points_sweep, sweep, time_diff, radar_id):
+    """One sweep (N, 8) float32 in the sensor frame -> (N, 10) float64 rows in the current LiDAR frame.
+
+    Ego-motion compensation of the radial velocity (reference :262-286): the ego velocity is turned
+    into the sensor frame, projected on each point's line of sight and added to the measured v_r; the
+    compensated radial speed is split into x/y components and rotated into the LiDAR frame."""
+    pts = np.copy(points_sweep)
+    xyz, vr = pts[:, :3], pts[:, 3]
+    r = np.linalg.norm(xyz, axis=1)
+    azimuth = np.arctan2(xyz[:, 1], xyz[:, 0])
+    elevation = np.arcsin(xyz[:, 2] / r)
+    v_ego = np.array(sweep["ego_velocity"]).reshape(-1, 3)
+    v_sensor = v_ego @ np.linalg.inv(quaternion_rotation_matrix(sweep["sensor2ego_rotation"])).T
+    v_sensor = np.repeat(v_sensor, pts.shape[0], axis=0)
+    vr_comp = (v_sensor[:, 0] * np.cos(azimuth) * np.cos(elevation) + v_sensor[:, 1] * np.sin(azimuth) * np.cos(elevation)
+               + v_sensor[:, 2] * np.sin(elevation) + vr)
+    vx = vr_comp * np.cos(elevation) * np.cos(azimuth)
+    vy = vr_comp * np.cos(elevation) * np.sin(azimuth)
+    velo = np.concatenate((vx.reshape(-1, 1), vy.reshape(-1, 1), np.zeros((pts.shape[0], 1))), axis=1)
+    rot = np.asarray(sweep["sensor2lidar_rotation"])
+    velo = (velo @ rot.T)[:, :2]
+    pts[:, :3] = pts[:, :3] @ rot.T                       # float64 product stored back as float32, as upstream
+    pts[:, :3] += sweep["sensor2lidar_translation"]
+    return np.concatenate([pts[:, :3], velo, pts[:, [4, 6]], np.ones((pts.shape[0], 1)) * time_diff,
+                           vr_comp.reshape(-1, 1), np.full((pts.shape[0], 1), radar_id)], axis=1)
+
+
+def merge_radar_sweeps(radars, read_points, sweeps_num=3, load_dim=8):
+    """``radars``: {radar name: [sweep dicts, newest first]} -> (M, 10) float64 (reference :229-300)."""
+    merged = []
+    for key, sweeps in radars.items():
+        use = range(len(sweeps)) if len(sweeps) < sweeps_num else range(sweeps_num)
+        ts = int(sweeps[0]["timestamp"]) * 1e-6
+        for idx in use:
+            sweep = sweeps[idx]
+            pts = np.copy(read_points(sweep["data_path"])).reshape(-1, load_dim)
+            merged.append(compensate_sweep(pts, sweep, ts - int(sweep["timestamp"]) * 1e-6, RADAR_ID[key]))
+    return np.concatenate(merged, axis=0)
+
+
+class RadarPoints:
+    """Minimal point container (reference core/points/radar_points.py:5-28 over mmdet3d BasePoints):
+    float32 tensor (N, points_dim), range test with strict inequalities, boolean indexing."""
+
+    def __init__(self, tensor, points_dim=3, attribute_dims=None):
+        t = torch.as_tensor(np.asarray(tensor) if not isinstance(tensor, torch.Tensor) else tensor, dtype=torch.float32)
+        if t.numel() == 0:
+            t = t.reshape((0, points_dim))
+        assert t.dim() == 2 and t.size(-1) == points_dim, t.size()
+        self.tensor, self.points_dim, self.attribute_dims, self.rotation_axis = t, points_dim, attribute_dims, 2
+
+    def in_range_3d(self, point_range):
+        t = self.tensor
+        return ((t[:, 0] > point_range[0]) & (t[:, 1] > point_range[1]) & (t[:, 2] > point_range[2])
+                & (t[:, 0] < point_range[3]) & (t[:, 1] < point_range[4]) & (t[:, 2] < point_range[5]))
+
+    def __getitem__(self, item):
+        return RadarPoints(self.tensor[item], points_dim=self.points_dim, attribute_dims=self.attribute_dims)
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def shuffle(self):
+        idx = torch.randperm(len(self), device=self.tensor.device)
+        self.tensor = self.tensor[idx]
+        return idx
+
+
+class LoadRadarPointsMultiSweeps:
+    """Same constructor and ``__call__(results)`` contract as the reference class (:116-316);
+    ``file_client_args`` is accepted for config compatibility (only the disk backend exists here)."""
+
+    def __init__(self, load_dim=8, use_dim=(0, 1, 2, 3, 4, 5, 6, 7), sweeps_num=3, file_client_args=None, max_num=300,
+                 pc_range=(-72, -56, -3.0, 72, 56, 5.0), test_mode=False):
+        self.load_dim, self.use_dim, self.sweeps_num = load_dim, list(use_dim), sweeps_num
+        self.max_num, self.pc_range, self.test_mode = max_num, list(pc_range), test_mode
+        if file_client_args and file_client_args.get("backend", "disk") != "disk":
+            raise NotImplementedError("only the disk backend is provided")
+
+    @staticmethod
+    def _load_points(pts_filename):
+        if pts_filename.endswith(".npy"):
+            return np.load(pts_filename)
+        return np.fromfile(pts_filename, dtype=np.float32)
+
+    def __call__(self, results):
+        points = merge_radar_sweeps(results["radars"], self._load_points, self.sweeps_num, self.load_dim)
+        points = points[:, self.use_dim]
+        points = RadarPoints(points, points_dim=points.shape[-1], attribute_dims=None)
+        results["points"] = points[points.in_range_3d(self.pc_range)]
+        return results
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(sweeps_num={self.sweeps_num})"
+
+
+# ---- camera matrices that end up in img_metas['lidar2img'] ------------------------------------
+def half_scale_front_back(img_filenames, lidar2img, cam_intrinsic, factor=0.5):
+    """Front and back cameras are stored at twice the resolution of the side cameras and are halved
+    at load time; their projection matrices are scaled with them (reference :358-372)."""
+    s = np.eye(4)
+    s[0, 0] *= factor
+    s[1, 1] *= factor
+    out_l2i, out_k = [], []
+    for name, l2i, k in zip(img_filenames, lidar2img, cam_intrinsic):
+        if name.split("/")[-2] in ("camera_front", "camera_back"):
+            out_l2i.append(s @ l2i)
+            out_k.append(s @ k)
+        else:
+            out_l2i.append(l2i)
+            out_k.append(k)
+    return out_l2i, out_k
+
+
+def scale_lidar2img(lidar2img, scale):
+    """``RandomScaleImageMultiViewImage`` (pipelines/transform_3d.py:295-330): fx, fy, cx, cy scale with the image."""
+    s = np.eye(4)
+    s[0, 0] *= scale
+    s[1, 1] *= scale
+    return [s @ m for m in lidar2img]

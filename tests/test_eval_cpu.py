@@ -1,0 +1,187 @@
+"""Detection evaluator against (a) golden vectors produced by the reference's
+own devkit code (tests/golden/make_golden_eval.py -> eval_golden.npz) and (b) the known-answer cases
+of the reference's unit tests (newscenes_devkit/eval/detection/tests/test_algo.py:200-428: AP and TP
+values of hand-built scenes), restated here as data."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from newscenes_devkit.eval.common.data_classes import EvalBoxes
+from newscenes_devkit.eval.common.loaders import filter_eval_boxes, yaw_to_wxyz
+from newscenes_devkit.eval.common.utils import angle_diff, center_distance, cummean, quaternion_yaw, scale_iou, yaw_diff
+from newscenes_devkit.eval.detection.algo import accumulate, calc_ap, calc_tp
+from newscenes_devkit.eval.detection.config import config_factory
+from newscenes_devkit.eval.detection.constants import DETECTION_NAMES, TP_METRICS
+from newscenes_devkit.eval.detection.data_classes import (DetectionBox, DetectionConfig, DetectionMetricData,
+                                                          DetectionMetricDataList, DetectionMetrics)
+from newscenes_devkit.eval.detection.evaluate import NewScenesEval
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "eval_golden.npz"))
+
+
+def _boxes(g, case, kind):
+    ns = int(g[f"c{case}_n_samples"])
+    d = {k: g[f"c{case}_{kind}_{k}"] for k in ("sample", "cls", "trans", "size", "rot", "vel", "score", "vis")}
+    eb = EvalBoxes()
+    for s in range(ns):
+        rows = np.nonzero(d["sample"] == s)[0]
+        eb.add_boxes(str(s), [DetectionBox(sample_token=str(s), translation=tuple(d["trans"][i].tolist()),
+                                           size=tuple(d["size"][i].tolist()), rotation=tuple(d["rot"][i].tolist()),
+                                           velocity=tuple(d["vel"][i].tolist()), ego_translation=tuple(d["trans"][i].tolist()),
+                                           detection_name=DETECTION_NAMES[d["cls"][i]], detection_score=float(d["score"][i]),
+                                           visibility=int(d["vis"][i])) for i in rows])
+    return eb
+
+
+def test_config_is_the_reference_json(gold):
+    cfg = config_factory("detection_newsc_config_final")
+    assert list(gold["names"]) == DETECTION_NAMES and list(gold["tp_metrics"]) == TP_METRICS
+    assert cfg.dist_ths == list(gold["cfg_dist_ths"])
+    assert [cfg.dist_th_tp, cfg.min_recall, cfg.min_precision, cfg.max_boxes_per_sample, cfg.mean_ap_weight] == \
+        list(gold["cfg_scalars"])
+    assert np.array_equal(np.array([cfg.class_range[n] for n in DETECTION_NAMES], dtype=float), gold["cfg_class_range"])
+    assert DetectionConfig.deserialize(cfg.serialize()) == cfg
+    with pytest.raises(AssertionError):
+        config_factory("detection_cvpr_2019")
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_accumulate_ap_tp_nos_match_reference_devkit(gold, case):
+    cfg = config_factory("detection_newsc_config_final")
+    gt = filter_eval_boxes(None, _boxes(gold, case, "gt"), cfg.class_range)
+    pred = filter_eval_boxes(None, _boxes(gold, case, "pred"), cfg.class_range)
+    metrics = DetectionMetrics(cfg)
+    for name in cfg.class_names:
+        for th in cfg.dist_ths:
+            md = accumulate(gt, pred, name, cfg.dist_fcn_callable, th, verbose=False)
+            for f in ("recall", "precision", "confidence", "trans_err", "vel_err", "scale_err", "orient_err"):
+                np.testing.assert_allclose(getattr(md, f), gold[f"c{case}_md_{name}_{th}_{f}"], rtol=1e-12, atol=1e-12,
+                                           err_msg=f"{name} {th} {f}")
+            metrics.add_label_ap(name, th, calc_ap(md, cfg.min_recall, cfg.min_precision))
+            if th == cfg.dist_th_tp:
+                for m in TP_METRICS:
+                    metrics.add_label_tp(name, m, calc_tp(md, cfg.min_recall, m))
+    aps = np.array([[metrics.get_label_ap(n, th) for th in cfg.dist_ths] for n in DETECTION_NAMES])
+    tps = np.array([[metrics.get_label_tp(n, m) for m in TP_METRICS] for n in DETECTION_NAMES])
+    np.testing.assert_allclose(aps, gold[f"c{case}_label_aps"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(tps, gold[f"c{case}_label_tps"], rtol=1e-12, atol=1e-14)
+    summary = [metrics.mean_ap, metrics.no_score] + [metrics.tp_errors[m] for m in TP_METRICS]
+    np.testing.assert_allclose(summary, gold[f"c{case}_summary"], rtol=1e-12, atol=1e-14)
+    if case == 0:
+        assert metrics.mean_ap > 0.05
+
+
+def test_driver_on_result_dict_and_files(gold, tmp_path):
+    cfg = config_factory("detection_newsc_config_final")
+    pred = _boxes(gold, 1, "pred")
+    results = {"meta": {"use_camera": True, "use_radar": True}, "results": pred.serialize()}
+    path = tmp_path / "results_newsc.json"
+    path.write_text(json.dumps(results))
+    ev = NewScenesEval(_boxes(gold, 1, "gt"), cfg, str(path), output_dir=str(tmp_path / "out"), verbose=False)
+    summary = ev.main()
+    np.testing.assert_allclose([summary["mean_ap"], summary["NOS"]], gold["c1_summary"][:2], rtol=1e-12)
+    on_disk = json.loads((tmp_path / "out" / "metrics_summary.json").read_text())
+    assert on_disk["NOS"] == summary["NOS"] and set(on_disk["label_aps"]) == set(DETECTION_NAMES)
+    again = DetectionMetrics.deserialize(on_disk)
+    assert abs(again.no_score - summary["NOS"]) < 1e-15
+    details = DetectionMetricDataList.deserialize(json.loads((tmp_path / "out" / "metrics_details.json").read_text()))
+    assert len(details.get_class_data("car")) == 4 and len(details.get_dist_data(2.0)) == 4
+    # too many boxes in one sample is an error, as is a token mismatch
+    with pytest.raises(AssertionError, match="boxes per sample"):
+        NewScenesEval(_boxes(gold, 1, "gt"), DetectionConfig.deserialize({**cfg.serialize(), "max_boxes_per_sample": 3}),
+                      results, verbose=False)
+    fewer = {"meta": {}, "results": {k: v for k, v in results["results"].items() if k != "0"}}
+    with pytest.raises(AssertionError, match="doesn't match"):
+        NewScenesEval(_boxes(gold, 1, "gt"), cfg, fewer, verbose=False)
+
+
+# ---- known-answer scenes of the reference's test_algo.py ---------------------------------------
+_DEF = {"trans": (0, 0, 0), "size": (1, 1, 1), "rot": (0, 0, 0, 0), "vel": (0, 0), "score": -1.0, "name": "car"}
+
+
+def _md(gts, preds, name="car", dist_th=2.0):
+    def eb(d, scored):
+        out = EvalBoxes()
+        for tok, items in d.items():
+            out.add_boxes(tok, [DetectionBox(sample_token=tok, translation=b["trans"], size=b["size"], rotation=b["rot"],
+                                             velocity=b["vel"], detection_name=b["name"],
+                                             detection_score=b["score"] if scored else -1.0)
+                                for b in ({**_DEF, **it} for it in items)])
+        return out
+    return accumulate(eb(gts, False), eb(preds, True), class_name=name, dist_fcn=center_distance, dist_th=dist_th,
+                      verbose=False)
+
+
+CAR1 = {"trans": (1, 1, 1), "name": "car", "score": 1.0}
+CAR2 = {"trans": (3, 3, 1), "name": "car", "score": 0.7}
+RIDER1 = {"trans": (5, 5, 1), "name": "rider", "score": 1.0}
+
+
+@pytest.mark.parametrize("gts,preds,target", [
+    ({"s1": []}, {"s1": [CAR1]}, 0.0),                               # only false positives
+    ({"s1": [CAR1]}, {"s1": []}, 0.0),                               # only false negatives
+    ({"s1": []}, {"s1": []}, 0.0),
+    ({"s1": [CAR1]}, {"s1": [CAR1]}, 1.0),                           # perfect
+    ({"s1": [CAR1, CAR2]}, {"s1": [CAR1]}, 0.4 / 0.9),               # one of two found
+    ({"s1": [CAR1]}, {"s1": [CAR1, CAR2]}, 1.0),                     # FP scored below the TP
+    ({"s1": [CAR2]}, {"s1": [CAR1, CAR2]}, ((0.8 * 0.4) / 2) / (0.9 * 0.9)),   # FP scored above the TP
+    ({"s1": [CAR1]}, {"s1": [CAR1, RIDER1]}, 1.0),                   # FP of another class
+    ({"s1": [CAR1], "s2": [CAR2]}, {"s1": [CAR1], "s2": [CAR2]}, 1.0),
+    ({"s1": [CAR1], "s2": []}, {"s1": [CAR1], "s2": []}, 1.0),
+    ({"s1": [CAR1], "s2": [CAR2]}, {"s1": [CAR1], "s2": []}, 0.4 / 0.9),
+])
+def test_ap_known_answers(gts, preds, target):
+    ap = calc_ap(_md(gts, preds), min_precision=0.1, min_recall=0.1)
+    assert abs(ap - target) <= 0.01
+
+
+def test_tp_known_answers():
+    def tp(gts, preds, metric="trans_err"):
+        return calc_tp(_md(gts, preds, dist_th=2.0), min_recall=0.1, metric_name=metric)
+    gt1, gt2, gt3 = {"trans": (1, 1, 1)}, {"trans": (10, 10, 1), "size": (2, 2, 2)}, {"trans": (20, 20, 1), "size": (2, 4, 2)}
+    p1 = {"trans": (1, 1, 1), "score": 1.0}
+    p2 = {"trans": (11, 10, 1), "size": (2, 2, 2), "score": 0.9}
+    p3 = {"trans": (100, 10, 1), "size": (2, 2, 2), "score": 0.8}
+    p4 = {"trans": (20, 20, 1), "size": (2, 4, 2), "score": 0.7}
+    p5 = {"trans": (21, 20, 1), "size": (2, 4, 2), "score": 0.7}
+    for m in TP_METRICS:                                             # no match at all -> error 1
+        assert tp({"s": [{"trans": (1, 1, 1)}]}, {"s": [{"trans": (3, 3, 1), "score": 1.0}]}, m) == 1.0
+        assert tp({"s": [{"trans": (1, 1, 1)}]}, {"s": [{"trans": (1, 1, 1), "score": 1.0, "name": "rider"}]}, m) == 1.0
+        assert abs(tp({"s": [gt1]}, {"s": [p1]}, m)) <= 0.01         # perfect box
+        assert abs(tp({"s": [gt1]}, {"s": [{"trans": (1, 1, 1), "score": 0.3}]}, m)) <= 0.01
+    assert abs(tp({"s": [gt2]}, {"s": [p2]}) - 1.0) <= 0.01
+    two = ((0 + 0) / 2 + (0 + 0.5) / 2) / (2 * 0.9)
+    assert abs(tp({"s": [gt1, gt2]}, {"s": [p1, p2]}) - two) <= 0.01
+    assert abs(tp({"s": [gt1, gt2]}, {"s": [p1, p2, p3]}) - two) <= 0.01           # extra FP changes nothing
+    three = ((0 + 0) / 2 + (0 + 0.5) / 2 + (0.5 + 0.33) / 2) / (3 * 0.9)
+    assert abs(tp({"s": [gt1, gt2, gt3]}, {"s": [p1, p2, p4]}) - three) <= 0.01
+    assert abs(tp({"s": [gt2, gt3]}, {"s": [p2, p5]}) - 1.0) <= 0.01
+    assert abs(tp({"a": [gt1], "b": [gt2], "c": []}, {"a": [p1], "b": [p2, p3], "c": []}) - two) <= 0.01
+    md = DetectionMetricData.random_md()
+    assert calc_tp(md, min_recall=1, metric_name="trans_err") == 1.0
+    for bad in [(-0.5, 0.4), (0.5, -0.8), (0.7, 1), (1.2, 0)]:
+        with pytest.raises(AssertionError):
+            calc_ap(md, *bad)
+
+
+def test_pair_measures_known_answers():
+    a = DetectionBox(translation=(0, 0, 0), size=(4, 4, 4), rotation=yaw_to_wxyz(0.0), velocity=(1.0, 0.0))
+    b = DetectionBox(translation=(3, 4, 9), size=(2, 4, 8), rotation=yaw_to_wxyz(np.pi / 2), velocity=(1.0, 2.0))
+    assert center_distance(a, b) == 5.0
+    assert abs(scale_iou(a, b) - (2 * 4 * 4) / (64 + 64 - 32)) < 1e-12
+    assert abs(yaw_diff(a, b) - np.pi / 2) < 1e-12 and abs(yaw_diff(a, b, period=np.pi) - np.pi / 2) < 1e-12
+    assert abs(quaternion_yaw(yaw_to_wxyz(-2.5)) + 2.5) < 1e-12 and quaternion_yaw((0, 0, 0, 0)) == 0.0
+    assert abs(quaternion_yaw(tuple(3.0 * np.array(yaw_to_wxyz(1.2)))) - 1.2) < 1e-12      # un-normalised input
+    assert abs(angle_diff(3.1, -3.1, 2 * np.pi) - (6.2 - 2 * np.pi)) < 1e-12
+    np.testing.assert_allclose(cummean(np.array([1.0, np.nan, 3.0])), [1.0, 1.0, 2.0])
+    np.testing.assert_allclose(cummean(np.array([np.nan, np.nan])), [1.0, 1.0])
+    with pytest.raises(AssertionError):
+        DetectionBox(detection_name="bus")
+    assert DetectionBox.deserialize(b.serialize()).ego_translation == b.translation

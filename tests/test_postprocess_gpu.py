@@ -79,6 +79,7 @@ def test_nms_rejects_cpu_tensors_and_oversize(cuda):
 
 def _head_and_outputs(device, seed=0, hw=(20, 30)):
     from omnihd_amd.harness import tiny_model_cfg
+    from omnihd_amd.mm import anchor_head  # noqa: F401  (registers Anchor3DHead)
     from omnihd_amd.mm.registry import HEADS
     cfg = tiny_model_cfg()
     head_cfg = dict(cfg["pts_bbox_head"])
