@@ -291,6 +291,21 @@ int omnihd_nms_rotated(const float* boxes, int n, float thresh, long long* keep,
  * (upstream `boxes_iou_bev_gpu`).                                                                   */
 int omnihd_iou_bev_matrix(const float* boxes_a, int na, const float* boxes_b, int nb, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Frozen-BatchNorm epilogue of a convolution (image backbone, bevfusion.py:76-85)
+ * ---------------------------------------------------------------------------------------- */
+
+/* y = act(x * scale[c] + shift[c] (+ res)) on channels-last bf16 rows: x, res, y [n_rows, c] bf16
+ * (res may be NULL), scale/shift [c] f32 (= gamma/sqrt(var+eps), beta - mean*scale of a BatchNorm in
+ * eval mode, mmcv/torch `F.batch_norm(training=False)` followed by `+ identity` and `ReLU`);
+ * relu != 0 applies max(., 0).  c % 8 == 0.                                                        */
+int omnihd_affine_act_fwd(const void* x, const float* scale, const float* shift, const void* res, void* y,
+                          long long n_rows, int c, int relu, void* stream);
+/* Backward of the above for constant scale/shift: gres = gy * [y > 0] (all ones when relu == 0),
+ * gx = gres * scale[c].  y is the forward output (only read when relu != 0); gres may be NULL.       */
+int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gres,
+                          long long n_rows, int c, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,8 @@ PROTOTYPES = {
                                      c_void_p, c_void_p]),
     "omnihd_nms_rotated_workspace_bytes": (c_size_t, [c_int]),
     "omnihd_nms_rotated": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "omnihd_affine_act_fwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
+    "omnihd_affine_act_bwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "omnihd_iou_bev_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }
 

@@ -1,5 +1,6 @@
 """Layer builders with mmcv's call signatures: build_norm_layer, build_conv_layer, ConvModule."""
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .registry import NORM_LAYERS
@@ -61,6 +62,36 @@ def build_activation(cfg):
     if t == "Sigmoid":
         return nn.Sigmoid()
     raise KeyError(f"unknown activation {t}")
+
+
+def frozen_bn_constants(bn):
+    """(scale, shift) fp32 of a BatchNorm that is in eval mode with constant affine parameters:
+    y = x * scale + shift.  Cached on the module; rebuilt when any of its tensors is written to."""
+    tensors = (bn.running_mean, bn.running_var, bn.weight, bn.bias)
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    cached = getattr(bn, "_omnihd_affine", None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            scale = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
+            shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
+        cached = (key, scale, shift)
+        bn._omnihd_affine = cached
+    return cached[1], cached[2]
+
+
+def bn_act(x, bn, relu=True, residual=None, inplace=True):
+    """``relu(bn(x) + residual)``.  A frozen BatchNorm (eval mode, affine parameters without gradient) on a
+    bf16 device tensor is an affine map with constant coefficients: that case runs as ONE fused
+    channels-last pass each way (csrc/affine_act.hip); everything else is the plain torch composition."""
+    from .. import ops
+    if (isinstance(bn, nn.modules.batchnorm._BatchNorm) and not bn.training and bn.track_running_stats and bn.affine
+            and not bn.weight.requires_grad and not bn.bias.requires_grad and ops.affine_act_supported(x, residual)):
+        scale, shift = frozen_bn_constants(bn)
+        return ops.affine_act(x, scale, shift, residual, relu)
+    out = bn(x)
+    if residual is not None:
+        out = out + residual
+    return F.relu(out, inplace=inplace) if relu else out
 
 
 class BevConv2d(nn.Conv2d):

@@ -6,8 +6,15 @@ Dense convolutions: executed by MIOpen through torch (channels-last bf16 when th
 import torch
 from torch import nn
 
-from .bricks import build_norm_layer
+from .bricks import bn_act, build_norm_layer
 from .registry import BACKBONES
+
+
+def _downsample(seq, x):
+    """``downsample`` is Sequential(conv, norm) (mmdet naming downsample.0 / downsample.1)."""
+    if isinstance(seq, nn.Sequential) and len(seq) == 2:
+        return bn_act(seq[0](x), seq[1], relu=False)
+    return seq(x)
 
 
 class BasicBlock(nn.Module):
@@ -26,11 +33,10 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.relu(getattr(self, self.norm1_name)(self.conv1(x)))
-        out = getattr(self, self.norm2_name)(self.conv2(out))
+        out = bn_act(self.conv1(x), getattr(self, self.norm1_name))
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+            identity = _downsample(self.downsample, x)
+        return bn_act(self.conv2(out), getattr(self, self.norm2_name), residual=identity)
 
 
 class Bottleneck(nn.Module):
@@ -54,12 +60,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.relu(getattr(self, self.norm1_name)(self.conv1(x)))
-        out = self.relu(getattr(self, self.norm2_name)(self.conv2(out)))
-        out = getattr(self, self.norm3_name)(self.conv3(out))
+        out = bn_act(self.conv1(x), getattr(self, self.norm1_name))
+        out = bn_act(self.conv2(out), getattr(self, self.norm2_name))
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+            identity = _downsample(self.downsample, x)
+        return bn_act(self.conv3(out), getattr(self, self.norm3_name), residual=identity)
 
 
 @BACKBONES.register_module()
@@ -113,7 +118,7 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        x = self.maxpool(self.relu(getattr(self, self.norm1_name)(self.conv1(x))))
+        x = self.maxpool(bn_act(self.conv1(x), getattr(self, self.norm1_name)))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

@@ -570,3 +570,46 @@ def iou_bev_matrix(boxes_a, boxes_b):
         check(lib().omnihd_iou_bev_matrix(_ptr(boxes_a), boxes_a.shape[0], _ptr(boxes_b), boxes_b.shape[0],
                                           _ptr(out), _stream()), "omnihd_iou_bev_matrix")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# Frozen-BatchNorm epilogue: y = act(x * scale + shift (+ residual)), channels-last bf16
+# --------------------------------------------------------------------------------------------
+class _AffineAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, res, relu):
+        n, c, h, w = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            check(lib().omnihd_affine_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y), n * h * w, c,
+                                              1 if relu else 0, _stream()), "omnihd_affine_act_fwd")
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.relu, ctx.has_res = relu, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, scale = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        n, c, h, w = gy.shape
+        gx = torch.empty_like(gy, memory_format=torch.channels_last)
+        gres = torch.empty_like(gy, memory_format=torch.channels_last) if ctx.has_res and ctx.needs_input_grad[3] else None
+        with torch.cuda.device(gy.device):
+            check(lib().omnihd_affine_act_bwd(_ptr(gy), _ptr(y), _ptr(scale), _ptr(gx), _ptr(gres), n * h * w, c,
+                                              1 if ctx.relu else 0, _stream()), "omnihd_affine_act_bwd")
+        return gx, None, None, gres, None
+
+
+def affine_act_supported(x, res=None):
+    ok = x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0
+    return ok and (res is None or (res.shape == x.shape and res.dtype == x.dtype and res.is_cuda))
+
+
+def affine_act(x, scale, shift, res=None, relu=True):
+    """x, res (N,C,H,W) bf16 (made channels-last if they are not), scale/shift (C,) fp32 constants."""
+    x = x.contiguous(memory_format=torch.channels_last)
+    if res is not None:
+        res = res.contiguous(memory_format=torch.channels_last)
+    _want(scale, torch.float32, "scale")
+    _want(shift, torch.float32, "shift")
+    return _AffineAct.apply(x, scale, shift, res, relu)

@@ -95,3 +95,76 @@ def test_wgrad_1x1_matches_fp32_reference(cuda, B, H, W, cin, cout, stride):
     (want,) = torch.autograd.grad(yr, wr, g.float())
     assert gw.shape == want.shape
     assert float((gw.float() - want).abs().max()) <= 1e-2 * float(want.abs().max())      # bf16 output rounding
+
+
+# ---------------------------------------------------------------------------------------------
+# Frozen-BatchNorm epilogue (csrc/affine_act.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,relu,with_res", [((6, 256, 16, 44), True, True), ((2, 64, 9, 7), True, False),
+                                                 ((1, 8, 3, 5), False, True), ((3, 2048, 8, 22), False, False)])
+def test_affine_act_forward_backward_match_torch(cuda, shape, relu, with_res):
+    from omnihd_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    res = (torch.randn(shape, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+           if with_res else None)
+    scale = (torch.rand(shape[1], generator=g) + 0.5).to(cuda)
+    shift = torch.randn(shape[1], generator=g).to(cuda)
+    gy = torch.randn(shape, generator=g).to(cuda).bfloat16()          # NCHW-contiguous on purpose
+    y = ops.affine_act(x, scale, shift, res, relu)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    ref = x.detach().float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.detach().float()
+    if relu:
+        ref = ref.clamp_min(0)
+    # one bf16 rounding of an fp32 value that may differ in its last fp32 bit (fma vs mul+add)
+    torch.testing.assert_close(y.float(), ref.bfloat16().float(), rtol=2 ** -7, atol=1e-6)
+    assert (y.float() - ref).abs().max() <= ref.abs().max() * 2 ** -8 + 1e-6
+    y.backward(gy)
+    mask = (y.detach().float() > 0) if relu else torch.ones_like(ref, dtype=torch.bool)
+    want_res = (gy.float() * mask).bfloat16()
+    want_x = (want_res.float() * scale.view(1, -1, 1, 1)).bfloat16()
+    assert torch.equal(x.grad, want_x) and x.grad.is_contiguous(memory_format=torch.channels_last)
+    if with_res:
+        assert torch.equal(res.grad, want_res)
+
+
+def test_frozen_bn_blocks_fused_path_matches_torch_composition(cuda, monkeypatch):
+    """A ResNet stage with frozen BatchNorm under bf16 autocast: fused epilogues vs plain torch ops."""
+    from omnihd_amd import ops
+    from omnihd_amd.mm.resnet import ResNet
+    torch.manual_seed(0)
+    net = ResNet(depth=50, num_stages=2, strides=(1, 2), dilations=(1, 1), out_indices=(0, 1), frozen_stages=0,
+                 norm_cfg=dict(type="BN", requires_grad=False), norm_eval=True).to(cuda).to(memory_format=torch.channels_last)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    net.train()
+    x = torch.randn(2, 3, 64, 96, device=cuda).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs = net(x)
+        sum(o.float().square().mean() for o in outs).backward()
+        return [o.detach().float() for o in outs], {n: p.grad.detach().float().clone() for n, p in net.named_parameters()
+                                                    if p.grad is not None}
+    calls = []
+    real = ops.affine_act
+    monkeypatch.setattr(ops, "affine_act", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    fused_out, fused_grad = run()
+    assert len(calls) >= 20                                    # every BN of the two stages took the fused path
+    monkeypatch.setattr(ops, "affine_act_supported", lambda *a, **k: False)
+    plain_out, plain_grad = run()
+    for a, b in zip(fused_out, plain_out):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 0.03 * float(b.abs().max())          # bf16 activations, ~20 layers deep
+    assert fused_grad.keys() == plain_grad.keys() and len(fused_grad) > 10
+    for k in fused_grad:
+        denom = float(plain_grad[k].abs().max()) + 1e-12
+        assert float((fused_grad[k] - plain_grad[k]).abs().max()) / denom < 0.08, k
