@@ -196,6 +196,8 @@ class FusionTrainStep:
         model = build_detector(cfg).to(self.device)
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
+            if hasattr(getattr(model, "pts_middle_encoder", None), "channels_last"):
+                model.pts_middle_encoder.channels_last = True      # radar canvas written NHWC by the scatter kernel
         model.train()
         self.raw_model = model
         self.model = model

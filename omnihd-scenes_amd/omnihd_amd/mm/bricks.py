@@ -104,10 +104,8 @@ class BevConv2d(nn.Conv2d):
         if (self.training and self.weight.requires_grad and torch.is_autocast_enabled() and x.is_cuda
                 and self.dilation == (1, 1) and self.groups == 1):
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            wb = self.weight.to(torch.bfloat16)
-            if ops.conv_wgrad_supported(xb, wb, self.stride, self.padding):
-                return ops.conv_hip_wgrad(xb, wb, None if self.bias is None else self.bias.to(torch.bfloat16),
-                                          self.stride, self.padding)
+            if ops.conv_wgrad_supported(xb, self.weight, self.stride, self.padding):
+                return ops.conv_hip_wgrad(xb, self.weight, self.bias, self.stride, self.padding)
         return super().forward(x)
 
 

@@ -357,13 +357,15 @@ class _PillarScatter(torch.autograd.Function):
     def backward(ctx, g):
         (coors,) = ctx.saved_tensors
         m, c, batch, ny, nx, channels_last = ctx.meta
-        if channels_last:
-            g = g.permute(0, 2, 3, 1)
-        g = g.contiguous().float()
+        # the gather kernel reads either memory layout of the (B,C,ny,nx) gradient: take it as it comes
+        g = g.float()
+        nhwc = g.is_contiguous(memory_format=torch.channels_last) and not g.is_contiguous()
+        if not nhwc:
+            g = g.contiguous()
         fg = torch.empty((m, c), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             check(lib().omnihd_pillar_gather(_ptr(g), _ptr(coors), m, c, batch, ny, nx,
-                                             1 if channels_last else 0, _ptr(fg), _stream()),
+                                             1 if nhwc else 0, _ptr(fg), _stream()),
                   "omnihd_pillar_gather")
         return fg, None, None, None, None, None
 
@@ -454,10 +456,14 @@ class _ConvHipWgrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding):
-        ctx.save_for_backward(x, weight)
+        # ``weight`` / ``bias`` may be the fp32 master parameters: they are rounded to the activation dtype here
+        # and their gradients are returned in THEIR dtype, so autograd adds no cast kernels of its own.
+        wb = weight.detach().to(x.dtype)
+        ctx.save_for_backward(x, wb)
         ctx.has_bias = bias is not None
         ctx.conv = (list(stride), list(padding))
-        return torch.nn.functional.conv2d(x, weight, bias, stride, padding)
+        ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
+        return torch.nn.functional.conv2d(x, wb, None if bias is None else bias.detach().to(x.dtype), stride, padding)
 
     @staticmethod
     def backward(ctx, g):
@@ -474,9 +480,9 @@ class _ConvHipWgrad(torch.autograd.Function):
             else:
                 xs = x if stride[0] == 1 else x[:, :, ::stride[0], ::stride[1]]
                 gw = conv1x1_wgrad(xs.contiguous(memory_format=torch.channels_last), g)
-            gw = gw.to(weight.dtype)
+            gw = gw.to(ctx.param_dtypes[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(dim=(0, 2, 3), dtype=torch.float32).to(g.dtype)
+            gb = g.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.param_dtypes[1])
         return gx, gw, gb, None, None
 
 

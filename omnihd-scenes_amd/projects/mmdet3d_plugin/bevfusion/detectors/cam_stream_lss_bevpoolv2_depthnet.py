@@ -85,7 +85,10 @@ class ASPP(nn.Module):
         pooled = self.global_avg_pool(x)
         # bilinear (align_corners) up-sampling of a 1x1 map is a broadcast (reference :537-541)
         branches.append(pooled.expand(-1, -1, x.shape[2], x.shape[3]))
-        x = self.relu(self.bn1(self.conv1(torch.cat(branches, dim=1))))
+        # concatenate in NHWC: the result is channels-last whatever the layout of the broadcast branch
+        # (torch.cat of mixed layouts falls back to an NCHW result that the next conv has to re-lay out)
+        cat = torch.cat([b.permute(0, 2, 3, 1) for b in branches], dim=3).permute(0, 3, 1, 2)
+        x = self.relu(self.bn1(self.conv1(cat)))
         return self.dropout(x)
 
 
