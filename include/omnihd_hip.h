@@ -235,22 +235,30 @@ int omnihd_pillar_gather(const float* canvas_grad, const int* coors, int m, int 
  * Dense BEV convolutions (matrix cores)
  * ---------------------------------------------------------------------------------------- */
 
-/* Weight gradient of a 3x3 / stride 1 / pad 1 convolution, bf16 inputs, fp32 accumulate/output.
- * ref: the backward of the nn.Conv2d layers of LiftSplatShoot_Depth.bevencode
- * (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:201-214) and of reduc_conv
- * (bevf_faster_rcnn_bevdepth.py:61-72), which the reference leaves to cuDNN.
- *   x_nhwc    [batch, h, w, cin]  bf16 (channels-last activations of the forward pass)
- *   gout_nhwc [batch, h, w, cout] bf16 (gradient of the conv output)
- *   dw        [cout, 3, 3, cin]   fp32 (= the memory of a channels-last (cout,cin,3,3) weight)
- * cin, cout multiples of 128; w a multiple of 8.  Deterministic (fixed split-K order).        */
+/* Weight gradient of a dense 2-D convolution, bf16 inputs, fp32 accumulate/output.
+ * ref: the backward of the nn.Conv2d / ConvModule layers on the path (e.g. LiftSplatShoot_Depth.bevencode,
+ * bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:201-214; reduc_conv,
+ * bevf_faster_rcnn_bevdepth.py:61-72; ASPP :491-561; SECOND / FPN / ResNet through mmcv), which the
+ * reference leaves to cuDNN.
+ *   x_nhwc    [batch, h, w, cin]    bf16 (channels-last activations of the forward pass)
+ *   gout_nhwc [batch, ho, wo, cout] bf16 (gradient of the conv output)
+ *   dw        [cout, kh, kw, cin]   fp32 (= the memory of a channels-last (cout,cin,kh,kw) weight)
+ * kh == kw in {1, 3}; stride, dilation >= 1 (same in both directions), pad >= 0; cin, cout multiples of 8
+ * (padded to 128 internally); ho, wo must be the convolution's output size.  groups == 1.
+ * Deterministic (fixed split-K order).  The workspace query returns 0 for an unsupported geometry.   */
+size_t omnihd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout,
+                                         int kh, int kw, int stride, int pad, int dil);
+int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw, int batch, int h, int w,
+                           int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad, int dil,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* The common 3x3 / stride 1 / pad 1 case under its original name.                                     */
 size_t omnihd_conv3x3_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout);
 int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw,
                               int batch, int h, int w, int cin, int cout,
                               void* workspace, size_t workspace_bytes, void* stream);
 
-/* Weight gradient of a 1x1 convolution: dw [cout, cin] fp32 = gout^T x with x_rows [m, cin] and
- * gout_rows [m, cout] bf16 (m = batch*ho*wo rows; a strided 1x1 conv passes the sub-sampled input).
- * Same matrix-core kernel as the 3x3 case with a single tap.  cin, cout multiples of 128.        */
+/* 1x1 / stride 1 case: dw [cout, cin] fp32 = gout^T x with x_rows [m, cin] and gout_rows [m, cout] bf16.   */
 size_t omnihd_conv1x1_wgrad_workspace_bytes(int m, int cin, int cout);
 int omnihd_conv1x1_wgrad_bf16(const void* x_rows, const void* gout_rows, float* dw, int m, int cin, int cout,
                               void* workspace, size_t workspace_bytes, void* stream);

@@ -1,22 +1,25 @@
-// Weight gradient of the 3x3 / stride 1 / pad 1 BEV convolutions on the gfx950 matrix cores.
+// Weight gradient of the dense convolutions on the gfx950 matrix cores.
 //
 // Where it sits: the BEV encoder of the camera stream (4 convs 1024->1024->512->512->256 at
 // 160x240, reference bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:201-214) and the
 // fusion conv 640->384 (bevf_faster_rcnn_bevdepth.py:61-72) hold ~1.5 of the ~3 TFLOP of a forward
-// pass; their weight gradients are the slowest dense kernels of the training step under MIOpen
-// (154-205 TFLOP/s measured on MI355X, 9 ms of a 70 ms step; scripts/conv_bench.py).
+// pass; their weight gradients were the slowest dense kernels of the training step under MIOpen
+// (154-205 TFLOP/s measured on MI355X, 9 ms of a 70 ms step; scripts/conv_bench.py).  The same kernel
+// now serves every 1x1 / 3x3 convolution of the detector (image backbone, FPN, DepthNet incl. the
+// dilated ASPP branches, SECOND incl. its stride-2 entries, SECONDFPN, head).
 //
-//   dW[n][dy][dx][c] = sum over pixels m=(b,y,x) of  G[m][n] * X[(b, y+dy-1, x+dx-1)][c]
+//   dW[n][ky][kx][c] = sum over output pixels m=(b,y,x) of  G[m][n] * X[(b, y*s+ky*d-p, x*s+kx*d-p)][c]
 //
 // is, per tap, a GEMM whose REDUCTION dimension is the pixel index — the slow dimension of both
-// NHWC operands.  So the operands are first re-laid out pixel-contiguous (k_to_kmajor: one pass
-// through LDS, which also bakes the three dx shifts of X with their zero borders into three
-// copies; a dy shift is then a 16-byte-aligned offset of W pixels), and the GEMM itself is a plain
-// "NT" bf16 MFMA kernel: 128x128 output tile per workgroup, 4 wavefronts each owning a 64x64
-// quadrant as 2x2 v_mfma_f32_32x32x16_bf16 tiles, K (pixels) stepped by 64 through double-buffered
-// LDS (row pitch 144 B: conflict-free ds_read_b128 fragments), register-staged global loads issued
-// one step ahead, fp32 accumulation, split-K over pixel ranges into fp32 slabs that a second tiny
-// kernel adds in a fixed order (deterministic, no atomics).
+// NHWC operands.  So the operands are first re-laid out pixel-contiguous ("k-major") in one pass through
+// LDS.  For stride-1 3x3 convolutions that pass also bakes the three dx shifts of X with their zero
+// borders into three copies (a dy shift is then a 16-byte-aligned offset of dil*Wp pixels, Wp = the row
+// pitch padded to a multiple of 8); strided convolutions get one staged copy per tap.  The GEMM itself
+// is an "NT" bf16 MFMA kernel: 128x128 output tile per workgroup, 4 wavefronts each owning a 64x64
+// quadrant as 2x2 v_mfma_f32_32x32x16_bf16 tiles, K (pixels) stepped by 64 through a 4-stage LDS ring
+// filled by LDS-DMA, fp32 accumulation, split-K over pixel ranges into fp32 slabs that a second tiny
+// kernel adds in a fixed order (deterministic, no atomics).  Channel counts that are not multiples of
+// 128 are zero-padded in the staged operands.
 #include "common.h"
 #include <stdlib.h>
 
@@ -29,26 +32,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBlock = 256;
 constexpr int kTile = 128;     // output tile is kTile x kTile
 constexpr int kBK = 64;        // pixels per K-step
-constexpr int kPitch = 72;     // bf16 elements per LDS row (64 + 8 pad -> 144 B)
 
 // ---------------------------------------------------------------------------------------------
-// NHWC (M, C) bf16  ->  n_shifts x (C, Mp) bf16, pixel-contiguous; shift s in {0} or {-1,0,+1}:
-//   out[s][c][m] = in[m + dx_s][c]  if 0 <= x(m) + dx_s < W  else 0;   m >= M: 0
-// One workgroup: 64 pixels x 64 channels through LDS.
+// NHWC (M, C) bf16  ->  n_shifts x (Cp, Mp) bf16, pixel-contiguous ("k-major").
+// The pixel axis of the output is the PADDED image raster m' = (b*H + y) * Wp + x with Wp = W rounded up
+// to a multiple of 8 (so that a row shift is a 16-byte-aligned offset and an 8-pixel chunk never
+// straddles image rows); pad columns, pixels past the last image and channel rows c >= C are zero.
+// shift s in {0} or {-dil, 0, +dil}:
+//   out[s][c][m'] = in[(row(m'), x(m') + dx_s)][c]   if x(m') < W and 0 <= x(m') + dx_s < W   else 0
+// One workgroup: 64 padded pixels x 64 channels through LDS (halo of `dil` pixels each side).
 // ---------------------------------------------------------------------------------------------
+constexpr int kMaxDil = 18;
+
 __global__ __launch_bounds__(kBlock) void k_to_kmajor(const unsigned short* __restrict__ in, int M,
-                                                      int C, int W, int Mp, int n_shifts,
-                                                      unsigned short* __restrict__ out) {
-  __shared__ unsigned short s[64][66 + 2];   // [channel][pixel + halo], +2 pad
+                                                      int C, int Cp, int W, int Wp, int Mp, int n_shifts,
+                                                      int dil, unsigned short* __restrict__ out) {
+  __shared__ unsigned short s[64][64 + 2 * kMaxDil + 2];   // [channel][pixel + halo]
   const int m0 = blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
-  // load pixels m0-1 .. m0+64 (66 of them), 64 channels each: 8 lanes x 16 B per pixel
-  for (int i = tid; i < 66 * 8; i += kBlock) {
+  const int halo = (n_shifts == 1) ? 0 : dil;
+  const int span = 64 + 2 * halo;
+  const int rows = M / W;                                   // image rows over the whole batch
+  // load padded pixels m0-halo .. m0+63+halo, 64 channels each: 8 lanes x 16 B per pixel
+  for (int i = tid; i < span * 8; i += kBlock) {
     const int p = i / 8, oc = i % 8;
-    const int m = m0 - 1 + p;
+    const int mp = m0 - halo + p;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (m >= 0 && m < M) v = *reinterpret_cast<const uint4*>(in + (size_t)m * C + c0 + oc * 8);
+    if (mp >= 0 && c0 + oc * 8 < C) {
+      const int row = mp / Wp, x = mp - row * Wp;
+      if (row < rows && x < W) v = *reinterpret_cast<const uint4*>(in + ((size_t)row * W + x) * C + c0 + oc * 8);
+    }
     const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[oc * 8 + k][p] = e[k];
@@ -59,142 +73,79 @@ __global__ __launch_bounds__(kBlock) void k_to_kmajor(const unsigned short* __re
     const int sh = i / (64 * 8);
     const int c = (i / 8) % 64;
     const int q = i % 8;
-    const int dx = (n_shifts == 1) ? 0 : sh - 1;
+    const int dx = (n_shifts == 1) ? 0 : (sh - 1) * dil;
     unsigned short e[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int m = m0 + q * 8 + k;
-      const int x = m % W;
-      const bool ok = (m < M) && (x + dx >= 0) && (x + dx < W);
-      e[k] = ok ? s[c][q * 8 + k + 1 + dx] : (unsigned short)0;
+      const int mp = m0 + q * 8 + k;
+      const int x = mp % Wp;
+      const bool ok = (x < W) && (x + dx >= 0) && (x + dx < W);   // rows past the batch were loaded as zeros
+      e[k] = ok ? s[c][q * 8 + k + halo + dx] : (unsigned short)0;
     }
-    *reinterpret_cast<uint4*>(out + ((size_t)sh * C + c0 + c) * Mp + m0 + q * 8) =
+    *reinterpret_cast<uint4*>(out + ((size_t)sh * Cp + c0 + c) * Mp + m0 + q * 8) =
         *reinterpret_cast<const uint4*>(e);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// slab[split][n][tap][c] = sum over the split's pixels of Gt[n][m] * Xt[dx][c][m + dy*W]
+// Per-tap staging for strided convolutions (im2col in k-major form): one copy per tap t = (ky, kx),
+//   out[t][c][m] = in[(b, oy*stride + ky*dil - pad, ox*stride + kx*dil - pad)][c]   or 0 outside,
+// m = (b*Ho + oy)*Wo + ox the OUTPUT raster (the reduction axis of the weight gradient).
+// One workgroup: 64 output pixels x 64 channels of one tap; each pixel's 64 channels are one 128-byte read.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_wgrad_mfma(const unsigned short* __restrict__ Gt,
-                                                       const unsigned short* __restrict__ Xt,
-                                                       float* __restrict__ slab, int Cout, int Cin,
-                                                       int M, int Mp, int H, int W, int n_split,
-                                                       int k_per_split) {
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][kTile][kPitch];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[2][kTile][kPitch];
+__global__ __launch_bounds__(kBlock) void k_taps_kmajor(const unsigned short* __restrict__ in, int B, int H, int W,
+                                                        int C, int Cp, int Ho, int Wo, int Mp, int KW, int stride,
+                                                        int pad, int dil, unsigned short* __restrict__ out) {
+  __shared__ unsigned short s[64][64 + 2];
+  const int m0 = blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tap = blockIdx.z;
+  const int ky = tap / KW, kx = tap % KW;
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int tiles_c = Cin / kTile, tiles_n = Cout / kTile;
-  int bid = blockIdx.x;
-  const int ct = bid % tiles_c; bid /= tiles_c;
-  const int nt = bid % tiles_n; bid /= tiles_n;
-  const int tap = bid % 9;
-  const int split = bid / 9;
-  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-  const int k0 = split * k_per_split;
-  const int k1 = min(k0 + k_per_split, Mp);
-
-  // loader mapping: 8 lanes x 16 B cover the 64 pixels of one row; rows r0 + 32*i
-  const int lrow = tid >> 3;          // 0..31
-  const int lcol = tid & 7;           // chunk of 8 pixels
-  const unsigned short* a_src = Gt + (size_t)(nt * kTile + lrow) * Mp + lcol * 8;
-  const unsigned short* b_src = Xt + ((size_t)(dx + 1) * Cin + ct * kTile + lrow) * Mp + lcol * 8 + dy * W;
-  // image row of this lane's chunk (chunks never straddle rows: W % 8 == 0)
-  int px = (k0 + lcol * 8) % W;
-  int py = ((k0 + lcol * 8) / W) % H;
-
-  uint4 ra[4], rb[4];
-  auto issue = [&](int k) {
-    const bool ok = (k + lcol * 8 < M) && (py + dy >= 0) && (py + dy < H);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const uint4*>(a_src + (size_t)(32 * i) * Mp + k);
-      rb[i] = *reinterpret_cast<const uint4*>(b_src + (size_t)(32 * i) * Mp + k);   // always in bounds (guards)
+  const int M = B * Ho * Wo;
+  for (int i = tid; i < 64 * 8; i += kBlock) {
+    const int p = i / 8, oc = i % 8;
+    const int m = m0 + p;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < M && c0 + oc * 8 < C) {
+      const int ox = m % Wo, t = m / Wo, oy = t % Ho, b = t / Ho;
+      const int iy = oy * stride + ky * dil - pad, ix = ox * stride + kx * dil - pad;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = *reinterpret_cast<const uint4*>(in + (((size_t)b * H + iy) * W + ix) * C + c0 + oc * 8);
     }
-    // mask AFTER the loads: a load behind a runtime condition would be branched around and waited for
-    // one by one (4 dependent memory round trips per K-step)
-    if (!ok) {
+    const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = make_uint4(0, 0, 0, 0);
-    }
-    px += kBK;
-    while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(&sA[buf][lrow + 32 * i][lcol * 8]) = ra[i];
-      *reinterpret_cast<uint4*>(&sB[buf][lrow + 32 * i][lcol * 8]) = rb[i];
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int wm = wave >> 1, wn = wave & 1;
-  const int frow = lane & 31;
-  const int fk = (lane >> 5) * 8;
-
-  if (k0 < k1) {
-    issue(k0);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k = k0; k < k1; k += kBK) {
-      const bool more = k + kBK < k1;
-      if (more) issue(k + kBK);
-#pragma unroll
-      for (int ks = 0; ks < kBK / 16; ++ks) {
-        bf16x8 a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][wm * 64 + i * 32 + frow][ks * 16 + fk]);
-          b[i] = *reinterpret_cast<const bf16x8*>(&sB[buf][wn * 64 + i * 32 + frow][ks * 16 + fk]);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) stash(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
-    }
+    for (int k = 0; k < 8; ++k) s[oc * 8 + k][p] = e[k];
   }
-
-  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  float* dst = slab + (size_t)split * Cout * 9 * Cin;
+  __syncthreads();
+  for (int i = tid; i < 64 * 8; i += kBlock) {
+    const int c = i / 8, q = i % 8;
+    unsigned short e[8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = nt * kTile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int c = ct * kTile + wn * 64 + j * 32 + (lane & 31);
-        dst[((size_t)n * 9 + tap) * Cin + c] = acc[i][j][r];
-      }
+    for (int k = 0; k < 8; ++k) e[k] = s[c][q * 8 + k];
+    *reinterpret_cast<uint4*>(out + ((size_t)tap * Cp + c0 + c) * Mp + m0 + q * 8) = *reinterpret_cast<const uint4*>(e);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA variant of the NT GEMM.  The register-staged kernel above keeps only 64 KB of operands in
-// flight per CU (2 workgroups x one K-step) against a loaded-memory latency of several microseconds
-// -> 13 % MFMA utilisation (profiles/round1: SQ_WAIT_ANY 54 %).  Here operands go global -> LDS with
-// `global_load_lds` (no VGPR round trip, 16 B per lane, 1 KiB per wave instruction) into a ring of
-// kStages K-steps, three of which are in flight while the fourth is multiplied: 96 KB in flight per CU
-// with one 4-wave workgroup per CU.  LDS-DMA writes lane-linear images, so rows are unpadded (128 B
-// pitch) and the 16-byte chunks of a row are XOR-swizzled by ((row >> 1) & 7) — applied to the GLOBAL
-// source chunk a lane fetches and again when a fragment is read: conflict-free ds_read_b128.
-// Waits are counted by hand (s_waitcnt vmcnt(16) leaves two K-steps in flight) and the barrier is the
-// raw s_barrier: __syncthreads() would drain the DMA queue.
+// slab[split][n][tap][c] = sum over the split's pixels of Gt[n][m] * Xt[copy(tap)][c][m + off(tap)]
+//
+// "NT" GEMM on the matrix cores with LDS-DMA operand staging.  A first, register-staged version of this
+// kernel kept only 64 KB of operands in flight per CU against a loaded-memory latency of several
+// microseconds -> 13 % MFMA utilisation (profiles/round1: SQ_WAIT_ANY 54 %).  Here operands go
+// global -> LDS with `global_load_lds` (no VGPR round trip, 16 B per lane, 1 KiB per wave instruction)
+// into a ring of kStages K-steps, three of which are in flight while the fourth is multiplied: 96 KB in
+// flight per CU with one 4-wave workgroup per CU.  LDS-DMA writes lane-linear images, so rows are
+// unpadded (128 B pitch) and the 16-byte chunks of a row are XOR-swizzled by ((row >> 1) & 7) — applied
+// to the GLOBAL source chunk a lane fetches and again when a fragment is read: conflict-free
+// ds_read_b128.  Waits are counted by hand (s_waitcnt vmcnt(16) leaves two K-steps in flight) and the
+// barrier is the raw s_barrier: __syncthreads() would drain the DMA queue.
+//
+// mode 0: taps share three dx-shifted copies of X; tap (ky,kx) reads copy kx at pixel offset
+//         (ky-1)*dil*Wp and masks image rows whose source row is outside [0,H)   (taps = 9 or 1)
+// mode 1: one staged copy per tap, nothing to mask                                (any taps)
+// Channel counts are padded to multiples of 128 in the staged operands (zero rows); only the real
+// [Cout][taps][Cin] block is written.
 // ---------------------------------------------------------------------------------------------
 constexpr int kStages = 4;
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -204,20 +155,23 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
                                                             const unsigned short* __restrict__ Xt,
                                                             const unsigned short* __restrict__ zero_page,
                                                             float* __restrict__ slab, int Cout, int Cin,
-                                                            int M, int Mp, int H, int W, int n_split,
-                                                            int k_per_split, int taps) {
+                                                            int Coutp, int Cinp, int M, int Mp, int H, int W,
+                                                            int n_split, int k_per_split, int taps, int mode,
+                                                            int dil) {
   // one LDS object only (a second one makes hipcc drain the DMA queue before every ds_read)
   __shared__ __attribute__((aligned(16))) unsigned short sm[kStages][2][kTile][kBK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int tiles_c = Cin / kTile, tiles_n = Cout / kTile;
+  const int tiles_c = Cinp / kTile, tiles_n = Coutp / kTile;
   int bid = blockIdx.x;
   const int ct = bid % tiles_c; bid /= tiles_c;
   const int nt = bid % tiles_n; bid /= tiles_n;
   const int tap = bid % taps;
   const int split = bid / taps;
-  const int dy = (taps == 9) ? tap / 3 - 1 : 0, dx = (taps == 9) ? tap % 3 - 1 : 0;
+  const bool shared = (mode == 0) && (taps == 9);
+  const int dy = shared ? (tap / 3 - 1) * dil : 0;
+  const int copy = shared ? tap % 3 : ((mode == 1) ? tap : 0);
   const int k0 = split * k_per_split;
   const int k1 = min(k0 + k_per_split, Mp);
 
@@ -226,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
   const int pos = lane & 7;                       // 16-byte slot inside the LDS row
   const int c_even = pos ^ ((lane >> 4) & 7);     // global chunk for calls 0,2 ; calls 1,3 use c_even ^ 4
   const unsigned short* a_row = Gt + (size_t)(nt * kTile + wave * 32 + lr) * Mp;
-  const unsigned short* b_row = Xt + ((size_t)((taps == 9) ? dx + 1 : 0) * Cin + ct * kTile + wave * 32 + lr) * Mp + dy * W;
+  const unsigned short* b_row = Xt + ((size_t)copy * Cinp + ct * kTile + wave * 32 + lr) * Mp + (ptrdiff_t)dy * W;
   // image row of this lane's two chunk positions at K-step k0 (chunks never straddle rows: W % 8 == 0)
   int px0 = (k0 + c_even * 8) % W, py0 = ((k0 + c_even * 8) / W) % H;
   int px1 = (k0 + (c_even ^ 4) * 8) % W, py1 = ((k0 + (c_even ^ 4) * 8) / W) % H;
@@ -291,6 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail loads before the epilogue stores
 
+  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* dst = slab + (size_t)split * Cout * taps * Cin;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -300,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
       for (int r = 0; r < 16; ++r) {
         const int n = nt * kTile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int c = ct * kTile + wn * 64 + j * 32 + (lane & 31);
-        dst[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
+        if (n < Cout && c < Cin) dst[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
       }
 }
 
@@ -323,8 +278,8 @@ int padded_pixels(size_t m) {
   return (int)mp;
 }
 
-int pick_split(int cout, int cin, int mp, int taps = 9) {
-  const int tiles = (cout / kTile) * (cin / kTile) * taps;
+int pick_split(int coutp, int cinp, int mp, int taps) {
+  const int tiles = (coutp / kTile) * (cinp / kTile) * taps;
   int s = (3 * kCUs + tiles - 1) / tiles;          // aim at >= 3 workgroups per CU
   const int max_s = mp / (kBK * 8);                 // at least 8 K-steps per split
   if (s > max_s) s = max_s;
@@ -333,107 +288,131 @@ int pick_split(int cout, int cin, int mp, int taps = 9) {
   return s;
 }
 
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// How one convolution is laid out for the GEMM.
+struct WgradPlan {
+  int mode;        // 0: three dx copies + row offsets (3x3, stride 1, pad == dil) or plain 1x1 ; 1: one copy per tap
+  int taps, copies;
+  int wp;          // row pitch of the padded raster (mode 0, 3x3) / unused
+  int rows_h;      // H for the row mask (mode 0, 3x3) / huge
+  int mpix;        // valid extent of the pixel axis
+  int mp;          // its padded pitch
+  int coutp, cinp, split;
+  size_t gt_bytes, xt_bytes, slab_bytes, guard;
+};
+
+bool make_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad,
+               int dil, WgradPlan* p) {
+  if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ho <= 0 || wo <= 0) return false;
+  if (kh != kw || (kh != 1 && kh != 3) || stride < 1 || dil < 1 || pad < 0) return false;
+  if (cin % 8 || cout % 8) return false;
+  if (ho != (h + 2 * pad - dil * (kh - 1) - 1) / stride + 1 || wo != (w + 2 * pad - dil * (kw - 1) - 1) / stride + 1) return false;
+  p->taps = kh * kw;
+  p->coutp = round_up(cout, kTile);
+  p->cinp = round_up(cin, kTile);
+  if (kh == 3 && stride == 1 && pad == dil && dil <= kMaxDil) {
+    p->mode = 0; p->copies = 3; p->wp = round_up(w, 8); p->rows_h = h;
+    p->mpix = batch * h * p->wp;
+  } else if (kh == 1 && stride == 1 && pad == 0) {
+    p->mode = 0; p->copies = 1; p->wp = 64; p->rows_h = 1 << 30;
+    p->mpix = batch * h * w;
+  } else {
+    p->mode = 1; p->copies = p->taps; p->wp = 64; p->rows_h = 1 << 30;
+    p->mpix = batch * ho * wo;
+  }
+  p->mp = padded_pixels((size_t)p->mpix);
+  p->split = pick_split(p->coutp, p->cinp, p->mp, p->taps);
+  p->gt_bytes = align_up((size_t)p->coutp * p->mp * 2, 256);
+  p->xt_bytes = align_up((size_t)p->copies * p->cinp * p->mp * 2, 256);
+  p->slab_bytes = align_up((size_t)p->split * cout * p->taps * cin * 4, 256);
+  p->guard = align_up((size_t)dil * p->wp * 2 + 256, 256);
+  return true;
+}
+
 }  // namespace
 }  // namespace omnihd
 
 using namespace omnihd;
 
-extern "C" size_t omnihd_conv3x3_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout) {
-  if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 256;
-  const size_t M = (size_t)batch * h * w;
-  const size_t Mp = padded_pixels(M);
-  const int S = pick_split(cout, cin, (int)Mp);
-  // [pad row of W pixels] Gt [Cout][Mp] | guard | Xt [3][Cin][Mp] | guard | slabs
-  return 256 + align_up((size_t)cout * Mp * 2, 256) + align_up((size_t)3 * cin * Mp * 2, 256) +
-         align_up((size_t)S * cout * 9 * cin * 4, 256) + 4 * align_up((size_t)w * 2 + 256, 256);
+extern "C" size_t omnihd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout,
+                                                    int kh, int kw, int stride, int pad, int dil) {
+  WgradPlan p;
+  if (!make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, &p)) return 0;
+  return 256 + p.gt_bytes + p.xt_bytes + p.slab_bytes + 4 * p.guard;
 }
 
-extern "C" int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw,
-                                         int batch, int h, int w, int cin, int cout,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw, int batch, int h, int w,
+                                      int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad,
+                                      int dil, void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  OMNIHD_REQUIRE(batch > 0 && h > 0 && w > 0, "shape");
-  OMNIHD_REQUIRE(cin % kTile == 0 && cout % kTile == 0, "Cin and Cout must be multiples of 128");
-  OMNIHD_REQUIRE(w % 8 == 0, "W must be a multiple of 8");
+  WgradPlan p;
+  if (!make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, &p)) {
+    set_error("conv_wgrad: unsupported geometry (square 1x1/3x3 kernels, channels multiples of 8, consistent output size)");
+    return OMNIHD_ERR_ARG;
+  }
   OMNIHD_REQUIRE(x_nhwc && gout_nhwc && dw && workspace, "null pointer");
-  const size_t need = omnihd_conv3x3_wgrad_workspace_bytes(batch, h, w, cin, cout);
+  const size_t need = omnihd_conv_wgrad_workspace_bytes(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil);
   if (workspace_bytes < need) {
-    set_error("conv3x3_wgrad: workspace %zu < required %zu", workspace_bytes, need);
+    set_error("conv_wgrad: workspace %zu < required %zu", workspace_bytes, need);
     return OMNIHD_ERR_WORKSPACE;
   }
-  const int M = batch * h * w;
-  const int Mp = padded_pixels(M);
-  const int S = pick_split(cout, cin, Mp);
-  int k_per_split = ((Mp / kBK + S - 1) / S) * kBK;
-  const size_t guard = align_up((size_t)w * 2 + 256, 256);   // a dy = -1 read at k = 0 lands here, masked anyway
+  const int k_per_split = ((p.mp / kBK + p.split - 1) / p.split) * kBK;
   unsigned short* zero_page = static_cast<unsigned short*>(workspace);       // 256 zero bytes
   OMNIHD_HIP_TRY(hipMemsetAsync(zero_page, 0, 256, st));
-  char* p = static_cast<char*>(workspace) + 256 + guard;
-  unsigned short* Gt = reinterpret_cast<unsigned short*>(p);
-  p += align_up((size_t)cout * Mp * 2, 256) + guard;
-  unsigned short* Xt = reinterpret_cast<unsigned short*>(p);
-  p += align_up((size_t)3 * cin * Mp * 2, 256) + guard;
-  float* slab = reinterpret_cast<float*>(p);
+  char* q = static_cast<char*>(workspace) + 256 + p.guard;
+  unsigned short* Gt = reinterpret_cast<unsigned short*>(q);
+  q += p.gt_bytes + p.guard;
+  unsigned short* Xt = reinterpret_cast<unsigned short*>(q);
+  q += p.xt_bytes + p.guard;
+  float* slab = reinterpret_cast<float*>(q);
+  const unsigned short* xs = static_cast<const unsigned short*>(x_nhwc);
+  const unsigned short* gs = static_cast<const unsigned short*>(gout_nhwc);
 
-  const dim3 gG((Mp + 63) / 64, cout / 64), gX((Mp + 63) / 64, cin / 64);
-  hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, static_cast<const unsigned short*>(gout_nhwc), M,
-                     cout, w, Mp, 1, Gt);
-  hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, static_cast<const unsigned short*>(x_nhwc), M, cin,
-                     w, Mp, 3, Xt);
-  const int blocks = (cin / kTile) * (cout / kTile) * 9 * S;
-  static const int use_glds = [] { const char* e = getenv("OMNIHD_WGRAD_GLDS"); return e ? atoi(e) : 1; }();
-  if (use_glds)
-    hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, S > 1 ? slab : dw,
-                       cout, cin, M, Mp, h, w, S, k_per_split, 9);
-  else
-    hipLaunchKernelGGL(k_wgrad_mfma, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, S > 1 ? slab : dw, cout, cin, M,
-                       Mp, h, w, S, k_per_split);
-  if (S > 1) {
-    const size_t n = (size_t)cout * 9 * cin;
-    hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, S, n, dw);
+  const dim3 gG(p.mp / 64, p.coutp / 64), gX(p.mp / 64, p.cinp / 64);
+  if (p.mode == 0 && p.taps == 9) {
+    // G and X share the padded raster (b, y, x) with row pitch wp
+    hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, gs, batch * h * w, cout, p.coutp, w, p.wp, p.mp, 1, dil, Gt);
+    hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, xs, batch * h * w, cin, p.cinp, w, p.wp, p.mp, 3, dil, Xt);
+  } else if (p.mode == 0) {
+    // 1x1: the raster is the plain pixel index (one "row" of mp pixels, nothing to shift)
+    hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, gs, p.mpix, cout, p.coutp, p.mpix, p.mp, p.mp, 1, 1, Gt);
+    hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, xs, p.mpix, cin, p.cinp, p.mpix, p.mp, p.mp, 1, 1, Xt);
+  } else {
+    hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, gs, p.mpix, cout, p.coutp, p.mpix, p.mp, p.mp, 1, 1, Gt);
+    hipLaunchKernelGGL(k_taps_kmajor, dim3(p.mp / 64, p.cinp / 64, p.taps), dim3(kBlock), 0, st, xs, batch, h, w, cin,
+                       p.cinp, ho, wo, p.mp, kw, stride, pad, dil, Xt);
   }
-  return check_launch("conv3x3_wgrad_bf16");
+  const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * p.taps * p.split;
+  hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, p.split > 1 ? slab : dw,
+                     cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, p.split, k_per_split, p.taps, p.mode, dil);
+  if (p.split > 1) {
+    const size_t n = (size_t)cout * p.taps * cin;
+    hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, p.split, n, dw);
+  }
+  return check_launch("conv_wgrad_bf16");
 }
 
-// 1x1 convolution (taps = 1): dW[n][c] = sum_m G[m][n] * X[m][c]; x and gout are [m, c] / [m, cout] bf16 rows.
+// The two original entry points, kept as names for the common cases.
+extern "C" size_t omnihd_conv3x3_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout) {
+  const size_t n = omnihd_conv_wgrad_workspace_bytes(batch, h, w, cin, h, w, cout, 3, 3, 1, 1, 1);
+  return n ? n : 256;
+}
+
+extern "C" int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw, int batch, int h,
+                                         int w, int cin, int cout, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  return omnihd_conv_wgrad_bf16(x_nhwc, gout_nhwc, dw, batch, h, w, cin, h, w, cout, 3, 3, 1, 1, 1, workspace,
+                                workspace_bytes, stream);
+}
+
 extern "C" size_t omnihd_conv1x1_wgrad_workspace_bytes(int m, int cin, int cout) {
-  if (m <= 0 || cin <= 0 || cout <= 0) return 256;
-  const size_t Mp = padded_pixels((size_t)m);
-  const int S = pick_split(cout, cin, (int)Mp, 1);
-  return 256 + align_up((size_t)cout * Mp * 2, 256) + align_up((size_t)cin * Mp * 2, 256) +
-         align_up((size_t)S * cout * cin * 4, 256) + 4 * 1024;
+  const size_t n = omnihd_conv_wgrad_workspace_bytes(1, 1, m, cin, 1, m, cout, 1, 1, 1, 0, 1);
+  return n ? n : 256;
 }
 
 extern "C" int omnihd_conv1x1_wgrad_bf16(const void* x_rows, const void* gout_rows, float* dw, int m, int cin,
                                          int cout, void* workspace, size_t workspace_bytes, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  OMNIHD_REQUIRE(m > 0 && cin % kTile == 0 && cout % kTile == 0, "Cin and Cout must be multiples of 128");
-  OMNIHD_REQUIRE(x_rows && gout_rows && dw && workspace, "null pointer");
-  if (workspace_bytes < omnihd_conv1x1_wgrad_workspace_bytes(m, cin, cout)) {
-    set_error("conv1x1_wgrad: workspace too small");
-    return OMNIHD_ERR_WORKSPACE;
-  }
-  const int Mp = padded_pixels((size_t)m);
-  const int S = pick_split(cout, cin, Mp, 1);
-  const int k_per_split = ((Mp / kBK + S - 1) / S) * kBK;
-  unsigned short* zero_page = static_cast<unsigned short*>(workspace);
-  OMNIHD_HIP_TRY(hipMemsetAsync(zero_page, 0, 256, st));
-  char* p = static_cast<char*>(workspace) + 256 + 1024;
-  unsigned short* Gt = reinterpret_cast<unsigned short*>(p);
-  p += align_up((size_t)cout * Mp * 2, 256) + 1024;
-  unsigned short* Xt = reinterpret_cast<unsigned short*>(p);
-  p += align_up((size_t)cin * Mp * 2, 256) + 1024;
-  float* slab = reinterpret_cast<float*>(p);
-  const dim3 gG(Mp / 64, cout / 64), gX(Mp / 64, cin / 64);
-  // W = Mp: no image-row wrap, so the (single) dx = 0 shift never masks anything
-  hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, static_cast<const unsigned short*>(gout_rows), m, cout, Mp, Mp, 1, Gt);
-  hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, static_cast<const unsigned short*>(x_rows), m, cin, Mp, Mp, 1, Xt);
-  const int blocks = (cin / kTile) * (cout / kTile) * S;
-  hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, S > 1 ? slab : dw, cout, cin,
-                     m, Mp, 1 << 30, 64, S, k_per_split, 1);
-  if (S > 1) {
-    const size_t n = (size_t)cout * cin;
-    hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, S, n, dw);
-  }
-  return check_launch("conv1x1_wgrad_bf16");
+  return omnihd_conv_wgrad_bf16(x_rows, gout_rows, dw, 1, 1, m, cin, 1, m, cout, 1, 1, 1, 0, 1, workspace,
+                                workspace_bytes, stream);
 }

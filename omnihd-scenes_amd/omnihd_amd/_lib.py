@@ -37,6 +37,8 @@ PROTOTYPES = {
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     "omnihd_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "omnihd_conv3x3_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "omnihd_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 12),
+    "omnihd_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
     "omnihd_conv1x1_wgrad_workspace_bytes": (c_size_t, [c_int] * 3),
     "omnihd_conv1x1_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
     "omnihd_dcn3x3_sample_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

@@ -96,35 +96,48 @@ def bn_act(x, bn, relu=True, residual=None, inplace=True):
 
 class BevConv2d(nn.Conv2d):
     """nn.Conv2d (same parameters / state-dict keys) whose bf16 training path takes its weight gradient from
-    the hand-written MFMA kernels (omnihd_conv3x3_wgrad_bf16 / omnihd_conv1x1_wgrad_bf16); forward and
-    data gradient stay on MIOpen."""
+    the hand-written MFMA kernel (omnihd_conv_wgrad_bf16); forward and data gradient stay on MIOpen."""
 
-    def forward(self, x):
+    def _conv_forward(self, x, weight, bias):
         from .. import ops
-        if (self.training and self.weight.requires_grad and torch.is_autocast_enabled() and x.is_cuda
-                and self.dilation == (1, 1) and self.groups == 1):
+        if (self.training and weight.requires_grad and torch.is_autocast_enabled() and x.is_cuda and self.groups == 1
+                and self.padding_mode == "zeros" and not isinstance(self.padding, str)):
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            if ops.conv_wgrad_supported(xb, self.weight, self.stride, self.padding):
-                return ops.conv_hip_wgrad(xb, self.weight, self.bias, self.stride, self.padding)
-        return super().forward(x)
+            if ops.conv_wgrad_supported(xb, weight, self.stride, self.padding, self.dilation):
+                return ops.conv_hip_wgrad(xb, weight, bias, self.stride, self.padding, self.dilation)
+        return super()._conv_forward(x, weight, bias)
+
+
+class BevConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d with kernel == stride (SECONDFPN's up-sampling blocks): weight gradient as a 1x1
+    weight gradient on the MFMA kernel; everything else unchanged."""
+
+    def forward(self, x, output_size=None):
+        from .. import ops
+        if (self.training and self.weight.requires_grad and torch.is_autocast_enabled() and output_size is None):
+            xb = x.to(torch.bfloat16) if x.is_cuda else x
+            if ops.deconv_supported(xb, self.weight, self.kernel_size, self.stride, self.padding, self.output_padding,
+                                    self.groups, self.dilation, self.bias):
+                return ops.deconv_hip_wgrad(xb.contiguous(memory_format=torch.channels_last), self.weight,
+                                            self.kernel_size[0])
+        return super().forward(x, output_size)
 
 
 def use_bev_conv(module):
-    """Switch every eligible nn.Conv2d under ``module`` (3x3 s1 p1, or 1x1 p0 with stride 1/2; channel counts
-    multiples of 128) to BevConv2d in place; parameters and state-dict keys are kept.  Layers whose run-time
-    shapes do not fit (e.g. 3x3 with a feature-map width not divisible by 8) simply take the MIOpen path."""
+    """Switch every dense nn.Conv2d (square 1x1 / 3x3 kernel, groups 1, channel counts multiples of 8) and every
+    nn.ConvTranspose2d with kernel == stride under ``module`` to the classes above, in place; parameters and
+    state-dict keys are kept.  Shapes the kernel does not take at run time simply use the MIOpen path."""
     n = 0
     for m in module.modules():
-        if type(m) is not nn.Conv2d or m.groups != 1 or m.dilation != (1, 1):
-            continue
-        if m.in_channels % 128 or m.out_channels % 128:
-            continue
-        k3 = m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
-        k1 = m.kernel_size == (1, 1) and m.padding == (0, 0) and m.stride in ((1, 1), (2, 2))
-        if k3 or k1:
+        if type(m) is nn.Conv2d and m.groups == 1 and m.kernel_size in ((1, 1), (3, 3)) \
+                and m.in_channels % 8 == 0 and m.out_channels % 8 == 0:
             m.__class__ = BevConv2d
             n += 1
+        elif type(m) is nn.ConvTranspose2d and m.groups == 1 and m.kernel_size == m.stride and m.bias is None:
+            m.__class__ = BevConvTranspose2d
+            n += 1
     return n
+
 
 
 class BilinearResize(nn.Module):

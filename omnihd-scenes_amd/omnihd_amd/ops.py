@@ -384,24 +384,13 @@ def pillar_scatter(feats, coors, batch, ny, nx, channels_last=False):
 _WGRAD_WS = {}
 
 
-def conv3x3_wgrad(x, grad_out):
-    """x (B,Cin,H,W) bf16 channels-last, grad_out (B,Cout,H,W) bf16 channels-last ->
-    dW (Cout,Cin,3,3) fp32 in channels-last memory (3x3, stride 1, pad 1)."""
-    _want_cl(x, "x"); _want_cl(grad_out, "grad_out")
-    B, cin, H, W = x.shape
-    cout = grad_out.shape[1]
-    dev = x.device
-    dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        nbytes = lib().omnihd_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
-        key = (str(dev), torch.cuda.current_stream().cuda_stream)
-        ws = _WGRAD_WS.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = _workspace(nbytes, dev)
-            _WGRAD_WS[key] = ws
-        check(lib().omnihd_conv3x3_wgrad_bf16(_ptr(x), _ptr(grad_out), _ptr(dw), B, H, W, cin, cout, _ptr(ws),
-                                              ws.numel(), _stream()), "omnihd_conv3x3_wgrad_bf16")
-    return dw.permute(0, 3, 1, 2)
+def _wgrad_workspace(nbytes, dev):
+    key = (str(dev), torch.cuda.current_stream().cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _workspace(nbytes, dev)
+        _WGRAD_WS[key] = ws
+    return ws
 
 
 def _want_cl(t, name):
@@ -411,39 +400,53 @@ def _want_cl(t, name):
         raise ValueError(f"{name} must be channels-last contiguous")
 
 
-def conv1x1_wgrad(x, grad_out):
-    """x (B,Cin,H,W) bf16 channels-last (already sub-sampled for a strided conv), grad_out (B,Cout,H,W) bf16
-    channels-last -> dW (Cout,Cin,1,1) fp32."""
+def conv_wgrad(x, grad_out, kernel_size, stride=1, padding=0, dilation=1):
+    """Weight gradient of a dense Conv2d on the matrix cores: x (B,Cin,H,W) and grad_out (B,Cout,Ho,Wo) bf16
+    channels-last -> dW (Cout,Cin,k,k) fp32 in channels-last memory.  k in {1,3}, square stride/dilation."""
     _want_cl(x, "x"); _want_cl(grad_out, "grad_out")
     B, cin, H, W = x.shape
-    cout = grad_out.shape[1]
-    m = B * H * W
+    _, cout, Ho, Wo = grad_out.shape
+    k = int(kernel_size)
     dev = x.device
-    dw = torch.empty((cout, cin), dtype=torch.float32, device=dev)
+    dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
+    geo = (B, H, W, cin, Ho, Wo, cout, k, k, int(stride), int(padding), int(dilation))
     with torch.cuda.device(dev):
-        nbytes = lib().omnihd_conv1x1_wgrad_workspace_bytes(m, cin, cout)
-        key = (str(dev), torch.cuda.current_stream().cuda_stream)
-        ws = _WGRAD_WS.get(key)
-        if ws is None or ws.numel() < nbytes:
-            ws = _workspace(nbytes, dev)
-            _WGRAD_WS[key] = ws
-        check(lib().omnihd_conv1x1_wgrad_bf16(_ptr(x), _ptr(grad_out), _ptr(dw), m, cin, cout, _ptr(ws), ws.numel(),
-                                              _stream()), "omnihd_conv1x1_wgrad_bf16")
-    return dw.view(cout, cin, 1, 1)
+        nbytes = lib().omnihd_conv_wgrad_workspace_bytes(*geo)
+        if nbytes == 0:
+            raise ValueError(f"conv_wgrad: unsupported geometry {geo}")
+        ws = _wgrad_workspace(nbytes, dev)
+        check(lib().omnihd_conv_wgrad_bf16(_ptr(x), _ptr(grad_out), _ptr(dw), *geo, _ptr(ws), ws.numel(), _stream()),
+              "omnihd_conv_wgrad_bf16")
+    return dw.permute(0, 3, 1, 2)
 
 
-def conv_wgrad_supported(x, weight, stride, padding):
-    """3x3/s1/p1 (feature-map width % 8 == 0) or 1x1/p0 with stride 1 or 2; channels multiples of 128; bf16."""
+def conv3x3_wgrad(x, grad_out):
+    """3x3 / stride 1 / pad 1."""
+    return conv_wgrad(x, grad_out, 3, 1, 1, 1)
+
+
+def conv1x1_wgrad(x, grad_out):
+    """1x1 / stride 1 (a strided 1x1 conv may pass the sub-sampled input)."""
+    return conv_wgrad(x, grad_out, 1, 1, 0, 1)
+
+
+def _pair_same(v):
+    v = tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    return v[0] if len(v) == 2 and v[0] == v[1] else None
+
+
+def conv_wgrad_supported(x, weight, stride, padding, dilation=(1, 1)):
+    """bf16 device activations, square 1x1 / 3x3 kernel, equal stride / padding / dilation in both directions,
+    channel counts multiples of 8 (the kernel pads them to 128 internally)."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4):
         return False
-    if weight.shape[0] % 128 or weight.shape[1] % 128:
+    if weight.shape[0] % 8 or weight.shape[1] % 8 or weight.shape[1] != x.shape[1]:
         return False
     k = tuple(weight.shape[2:])
-    if k == (3, 3):
-        return stride == (1, 1) and padding == (1, 1) and x.shape[3] % 8 == 0
-    if k == (1, 1):
-        return padding == (0, 0) and stride in ((1, 1), (2, 2))
-    return False
+    s, p, d = _pair_same(stride), _pair_same(padding), _pair_same(dilation)
+    if k not in ((1, 1), (3, 3)) or s is None or p is None or d is None:
+        return False
+    return not (k == (3, 3) and s == 1 and p == d and d > 18) and s >= 1 and d >= 1
 
 
 def conv3x3_wgrad_supported(x, weight):
@@ -455,43 +458,84 @@ class _ConvHipWgrad(torch.autograd.Function):
     hand-written MFMA kernel (the slowest dense kernels of the training step under MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding):
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
         # ``weight`` / ``bias`` may be the fp32 master parameters: they are rounded to the activation dtype here
         # and their gradients are returned in THEIR dtype, so autograd adds no cast kernels of its own.
         wb = weight.detach().to(x.dtype)
         ctx.save_for_backward(x, wb)
         ctx.has_bias = bias is not None
-        ctx.conv = (list(stride), list(padding))
+        ctx.conv = (list(stride), list(padding), list(dilation))
         ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
-        return torch.nn.functional.conv2d(x, wb, None if bias is None else bias.detach().to(x.dtype), stride, padding)
+        return torch.nn.functional.conv2d(x, wb, None if bias is None else bias.detach().to(x.dtype), stride, padding,
+                                          dilation)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        stride, padding = ctx.conv
+        stride, padding, dilation = ctx.conv
         gx = gw = gb = None
         g = g.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, [1, 1], False, [0, 0], 1,
+            gx = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            if weight.shape[2] == 3:
-                gw = conv3x3_wgrad(x.contiguous(memory_format=torch.channels_last), g)
-            else:
-                xs = x if stride[0] == 1 else x[:, :, ::stride[0], ::stride[1]]
-                gw = conv1x1_wgrad(xs.contiguous(memory_format=torch.channels_last), g)
-            gw = gw.to(ctx.param_dtypes[0])
+            gw = conv_wgrad(x.contiguous(memory_format=torch.channels_last), g, weight.shape[2], stride[0], padding[0],
+                            dilation[0]).to(ctx.param_dtypes[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.param_dtypes[1])
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 def conv3x3(x, weight, bias=None):
-    return _ConvHipWgrad.apply(x, weight, bias, (1, 1), (1, 1))
+    return _ConvHipWgrad.apply(x, weight, bias, (1, 1), (1, 1), (1, 1))
 
 
-def conv_hip_wgrad(x, weight, bias, stride, padding):
-    return _ConvHipWgrad.apply(x, weight, bias, tuple(stride), tuple(padding))
+def conv_hip_wgrad(x, weight, bias, stride, padding, dilation=(1, 1)):
+    return _ConvHipWgrad.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation))
+
+
+class _DeconvHipWgrad(torch.autograd.Function):
+    """ConvTranspose2d with kernel == stride (non-overlapping up-sampling, SECONDFPN's ``deblocks``): forward
+    and data gradient on MIOpen; the weight gradient dW[cin][cout][ky][kx] = sum_m X[m][cin] * G[(s*y+ky,
+    s*x+kx)][cout] is a 1x1 weight gradient once G is viewed as rows of (ky, kx, cout) per INPUT pixel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, k):
+        wb = weight.detach().to(x.dtype)
+        ctx.save_for_backward(x, wb)
+        ctx.k, ctx.wdtype = k, weight.dtype
+        return torch.nn.functional.conv_transpose2d(x, wb, None, stride=k)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        k = ctx.k
+        gx = gw = None
+        g = g.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[0]:
+            gx = torch.nn.functional.conv2d(g, weight, None, stride=k)          # adjoint of the transposed conv
+        if ctx.needs_input_grad[1]:
+            B, cout, Ho, Wo = g.shape
+            H, W = Ho // k, Wo // k
+            # (B, Ho, Wo, cout) memory -> (B, H, W, ky, kx, cout): one row of k*k*cout values per input pixel
+            rows = g.permute(0, 2, 3, 1).reshape(B, H, k, W, k, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, k * k * cout)
+            rows = rows.permute(0, 3, 1, 2)                                     # NCHW-shaped view of NHWC memory
+            dw = conv_wgrad(x.contiguous(memory_format=torch.channels_last), rows.contiguous(memory_format=torch.channels_last),
+                            1, 1, 0, 1)                                         # (k*k*cout, cin, 1, 1)
+            cin = x.shape[1]
+            gw = dw.reshape(k, k, cout, cin).permute(3, 2, 0, 1).to(ctx.wdtype)
+        return gx, gw, None
+
+
+def deconv_supported(x, weight, kernel_size, stride, padding, output_padding, groups, dilation, bias):
+    k, s = _pair_same(kernel_size), _pair_same(stride)
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and k is not None and k == s and _pair_same(padding) == 0
+            and _pair_same(output_padding) == 0 and groups == 1 and _pair_same(dilation) == 1 and bias is None
+            and weight.shape[0] % 8 == 0 and (k * k * weight.shape[1]) % 8 == 0)
+
+
+def deconv_hip_wgrad(x, weight, k):
+    return _DeconvHipWgrad.apply(x, weight, int(k))
 
 
 # ---------------------------------------------------------------------------------------------

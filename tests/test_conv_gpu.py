@@ -169,3 +169,82 @@ def test_frozen_bn_blocks_fused_path_matches_torch_composition(cuda, monkeypatch
     assert fused_grad.keys() == plain_grad.keys() == exact_grad.keys() and len(fused_grad) > 10
     for k in fused_grad:
         assert rel(fused_grad[k], exact_grad[k]) <= 1.5 * rel(plain_grad[k], exact_grad[k]) + 5e-3, k
+
+
+# ---------------------------------------------------------------------------------------------
+# Generic convolution weight gradient (any 1x1 / 3x3 geometry of the detector) and transposed conv
+# ---------------------------------------------------------------------------------------------
+GEOMS = [  # B, H, W, cin, cout, k, stride, pad, dil
+    (6, 16, 44, 256, 256, 3, 1, 1, 1),       # ResNet layer3 / FPN level: width not a multiple of 8
+    (6, 8, 22, 512, 512, 3, 1, 1, 1),        # ResNet layer4
+    (1, 40, 60, 256, 256, 3, 1, 1, 1),       # SECOND stage 3
+    (1, 32, 48, 64, 64, 3, 1, 1, 1),         # SECOND stage 1: 64 channels (padded to 128 inside)
+    (2, 24, 40, 256, 256, 3, 1, 6, 6),       # ASPP dilation 6
+    (1, 40, 48, 128, 256, 3, 1, 18, 18),     # ASPP dilation 18 (> feature height/2)
+    (2, 32, 48, 128, 128, 3, 2, 1, 1),       # ResNet stage entry, stride 2
+    (1, 33, 47, 64, 128, 3, 2, 1, 1),        # odd input size, stride 2 (SECOND entry)
+    (1, 20, 24, 384, 72, 1, 1, 0, 1),        # head regression conv: Cout 72
+    (1, 20, 24, 384, 16, 1, 1, 0, 1),        # head direction conv
+    (2, 16, 24, 256, 512, 1, 2, 0, 1),       # ResNet downsample 1x1 stride 2
+    (1, 9, 10, 8, 8, 3, 1, 1, 1),            # smallest channel count
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,stride,pad,dil", GEOMS)
+def test_generic_wgrad_matches_fp32_reference(cuda, B, H, W, cin, cout, k, stride, pad, dil):
+    from omnihd_amd import ops
+    torch.manual_seed(H * W + cin + k)
+    x = torch.randn(B, cin, H, W, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w0 = torch.zeros(cout, cin, k, k, device=cuda, requires_grad=True)
+    y = F.conv2d(x.float(), w0, None, stride, pad, dil)
+    g = (torch.randn_like(y) * 0.1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    want = torch.autograd.grad(y, w0, g.float())[0]
+    assert ops.conv_wgrad_supported(x, w0, (stride, stride), (pad, pad), (dil, dil))
+    got = ops.conv_wgrad(x, g, k, stride, pad, dil)
+    assert got.shape == want.shape and got.dtype == torch.float32
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-3 * scale, float((got - want).abs().max()) / scale
+    assert torch.equal(got, ops.conv_wgrad(x, g, k, stride, pad, dil))          # deterministic
+
+
+def test_bevconv2d_module_gradients_match_plain_conv(cuda):
+    """BevConv2d inside autocast (dilated, strided, bias) vs nn.Conv2d: same forward, same three gradients."""
+    from omnihd_amd.mm.bricks import BevConv2d
+    torch.manual_seed(1)
+    for kw in (dict(kernel_size=3, stride=2, padding=1, bias=True), dict(kernel_size=3, padding=12, dilation=12, bias=False),
+               dict(kernel_size=1, bias=True)):
+        ref = torch.nn.Conv2d(64, 72, **kw).to(cuda).to(memory_format=torch.channels_last)
+        mod = BevConv2d(64, 72, **kw).to(cuda).to(memory_format=torch.channels_last)
+        mod.load_state_dict(ref.state_dict())
+        x1 = torch.randn(2, 64, 30, 44, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+        x2 = x1.detach().clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y1, y2 = ref(x1), mod(x2)
+        assert torch.equal(y1, y2)
+        gy = torch.randn_like(y1)
+        y1.backward(gy); y2.backward(gy)
+        torch.testing.assert_close(x2.grad, x1.grad, rtol=2e-2, atol=2e-2)
+        assert mod.weight.grad.dtype == torch.float32
+        err = float((mod.weight.grad - ref.weight.grad).abs().max()) / float(ref.weight.grad.abs().max())
+        assert err < 1e-2, (kw, err)                                           # MIOpen's own wrw is bf16-accumulate-limited
+        if kw.get("bias"):
+            torch.testing.assert_close(mod.bias.grad, ref.bias.grad, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("cin,cout,k,H,W", [(64, 128, 1, 40, 60), (128, 128, 2, 20, 30), (256, 128, 4, 10, 15)])
+def test_transposed_conv_weight_gradient(cuda, cin, cout, k, H, W):
+    from omnihd_amd import ops
+    torch.manual_seed(k)
+    x = torch.randn(1, cin, H, W, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (torch.randn(cin, cout, k, k, device=cuda) * 0.05).requires_grad_()
+    assert ops.deconv_supported(x, w, (k, k), (k, k), (0, 0), (0, 0), 1, (1, 1), None)
+    y = ops.deconv_hip_wgrad(x, w, k)
+    g = (torch.randn_like(y.float()) * 0.1).to(torch.bfloat16)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_()
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_()
+    yr = F.conv_transpose2d(xr, wr, None, stride=k)
+    yr.backward(g.float())
+    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=2e-2)
+    assert float((w.grad - wr.grad).abs().max()) <= 2e-3 * float(wr.grad.abs().max())
+    assert float((x.grad.float() - xr.grad).abs().max()) <= 2e-2 * float(xr.grad.abs().max())
