@@ -453,6 +453,53 @@ def conv3x3_wgrad_supported(x, weight):
     return conv_wgrad_supported(x, weight, (1, 1), (1, 1))
 
 
+# Which implementation computes the weight gradient of a given convolution geometry: the MFMA kernel chain of
+# this library ("hip") or MIOpen ("miopen").  The staged GEMM wins by 2-4x on the BEV-sized convolutions and on
+# small feature maps, MIOpen's direct implicit GEMM wins where the pixel axis is long and the channel counts are
+# small (scripts/wgrad_census.py), and which of MIOpen's solvers is picked depends on the box — so, like MIOpen's
+# own find step, the choice is MEASURED once per geometry (a handful of launches during warm-up) and cached.
+# OMNIHD_WGRAD_POLICY = tune (default) | hip | miopen
+_WGRAD_CHOICE = {}
+
+
+def _miopen_wgrad(x, g, weight, stride, padding, dilation):
+    return torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], 1,
+                                               [False, True, False])[1]
+
+
+def _tuned_wgrad(x, g, weight, stride, padding, dilation):
+    import os
+    policy = os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
+    k = weight.shape[2]
+    run_hip = lambda: conv_wgrad(x, g, k, stride[0], padding[0], dilation[0])
+    if policy == "hip":
+        return run_hip()
+    run_mi = lambda: _miopen_wgrad(x, g, weight, stride, padding, dilation)
+    if policy == "miopen":
+        return run_mi()
+    key = (tuple(x.shape), g.shape[1], k, stride[0], padding[0], dilation[0], x.device.index)
+    choice = _WGRAD_CHOICE.get(key)
+    if choice is None:
+        def clock(fn):
+            fn(); fn()
+            torch.cuda.synchronize(x.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(x.device)
+            return e0.elapsed_time(e1)
+        choice = "hip" if clock(run_hip) <= clock(run_mi) else "miopen"
+        _WGRAD_CHOICE[key] = choice
+    return run_hip() if choice == "hip" else run_mi()
+
+
+def wgrad_choices():
+    """{geometry: 'hip' | 'miopen'} decided so far (for logs and DESIGN.md tables)."""
+    return dict(_WGRAD_CHOICE)
+
+
 class _ConvHipWgrad(torch.autograd.Function):
     """Convolution whose forward and data gradient run on MIOpen and whose WEIGHT gradient runs on the
     hand-written MFMA kernel (the slowest dense kernels of the training step under MIOpen)."""
@@ -479,8 +526,8 @@ class _ConvHipWgrad(torch.autograd.Function):
             gx = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            gw = conv_wgrad(x.contiguous(memory_format=torch.channels_last), g, weight.shape[2], stride[0], padding[0],
-                            dilation[0]).to(ctx.param_dtypes[0])
+            gw = _tuned_wgrad(x.contiguous(memory_format=torch.channels_last), g, weight, stride, padding,
+                              dilation).to(ctx.param_dtypes[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(dim=(0, 2, 3), dtype=torch.float32).to(ctx.param_dtypes[1])
         return gx, gw, gb, None, None, None
