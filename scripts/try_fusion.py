@@ -19,3 +19,9 @@ for i in range(10):
     st.step()
 torch.cuda.synchronize(); dt = (time.time() - t0) / 10
 print(f"{res} {dtype}: {dt*1e3:.1f} ms/step  {1/dt:.2f} frames/s  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+try:
+    from omnihd_amd import ops
+    ch = ops.wgrad_choices()
+    print("wgrad choices: hip", sum(v == "hip" for v in ch.values()), "miopen", sum(v == "miopen" for v in ch.values()))
+except Exception as e:
+    print("no wgrad choices", e)
