@@ -314,6 +314,35 @@ int omnihd_affine_act_fwd(const void* x, const float* scale, const float* shift,
 int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gres,
                           long long n_rows, int c, int relu, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm (+ReLU) with the statistics exchange left to the caller ("naive" SyncBN:
+ * projects/mmdet3d_plugin/ops/norm.py:28-82 and mmdet3d's 1-D/2-D variants; plain BatchNorm on one rank)
+ * All activations are channels-last bf16 rows [rows, c]; c % 8 == 0, c <= 2048.
+ * ---------------------------------------------------------------------------------------- */
+
+size_t omnihd_bn_workspace_bytes(long long rows, int c);
+/* mode 0: sums[0:c] = mult * sum_rows a,  sums[c:2c] = mult * sum_rows a^2           (forward statistics)
+ * mode 1: g' = a * [mask > 0] (mask NULL: all pass); sums[0:c] = mult * sum g', sums[c:2c] = mult * sum g' * b
+ * Two-stage reduction in a fixed order (deterministic).                                              */
+int omnihd_bn_channel_sums(const void* a, const void* b, const void* mask, float* sums, long long rows, int c,
+                           int mode, float mult, void* workspace, size_t workspace_bytes, void* stream);
+/* stats = (mean, mean of squares) [2c], possibly summed over ranks: multiplied by rank_mult (1/R) here.
+ * Writes scale = gamma * invstd, shift = beta - mean * scale (feed omnihd_affine_act_fwd), mean, invstd,
+ * and updates running_mean / running_var (both NULL to skip) with `momentum`;
+ * running_var takes var * var_correction (n/(n-1) for torch BatchNorm, 1 for the reference's SyncBN).   */
+int omnihd_bn_fwd_consts(const float* stats, float rank_mult, const float* gamma, const float* beta, float eps,
+                         float momentum, float var_correction, int c, float* running_mean, float* running_var,
+                         float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* local_sums / global_sums: mode-1 sums of this rank / summed over ranks (the same array on one rank).
+ * dgamma, dbeta from the local sums; coef_a/b/c such that gx = g' * a[c] + x * b[c] + c[c];
+ * inv_count = 1 / (ranks * rows of THIS rank).                                                          */
+int omnihd_bn_bwd_consts(const float* local_sums, const float* global_sums, const float* gamma, const float* mean,
+                         const float* invstd, float inv_count, int c, float* dgamma, float* dbeta, float* coef_a,
+                         float* coef_b, float* coef_c, void* stream);
+/* gx = g' * a + x * b + c;  gres (may be NULL) = g', the gradient of a residual added before the ReLU.   */
+int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const void* x, const float* coef_a, const float* coef_b,
+                        const float* coef_c, void* gx, void* gres, long long rows, int c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

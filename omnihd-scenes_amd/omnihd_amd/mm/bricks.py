@@ -88,10 +88,38 @@ def bn_act(x, bn, relu=True, residual=None, inplace=True):
             and not bn.weight.requires_grad and not bn.bias.requires_grad and ops.affine_act_supported(x, residual)):
         scale, shift = frozen_bn_constants(bn)
         return ops.affine_act(x, scale, shift, residual, relu)
+    if (isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training and bn.affine and bn.momentum is not None
+            and bn.track_running_stats and ops.bn_train_supported(x)
+            and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype))):
+        group = None
+        if getattr(bn, "_omnihd_sync", False):
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                group = dist.group.WORLD
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return ops.bn_train_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, group,
+                                residual)
     out = bn(x)
     if residual is not None:
         out = out + residual
     return F.relu(out, inplace=inplace) if relu else out
+
+
+def run_fused(seq, x):
+    """Run an nn.Sequential, executing every (BatchNorm, ReLU) pair as one ``bn_act`` call."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = bn_act(x, m, relu=relu)
+            i += 2 if relu else 1
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 class BevConv2d(nn.Conv2d):
@@ -205,8 +233,11 @@ class ConvModule(nn.Module):
 
     def forward(self, x):
         x = self.conv(x)
+        relu = self.with_activation and isinstance(self.activate, nn.ReLU)
         if self.with_norm:
-            x = self.norm(x)
-        if self.with_activation:
+            x = bn_act(x, self.norm, relu=relu) if isinstance(self.norm, nn.modules.batchnorm._BatchNorm) else self.norm(x)
+            if self.with_activation and not (relu and isinstance(self.norm, nn.modules.batchnorm._BatchNorm)):
+                x = self.activate(x)
+        elif self.with_activation:
             x = self.activate(x)
         return x

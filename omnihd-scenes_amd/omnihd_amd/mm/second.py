@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .bricks import build_norm_layer
+from .bricks import build_norm_layer, run_fused
 from .registry import BACKBONES, MIDDLE_ENCODERS, NECKS
 
 
@@ -64,7 +64,7 @@ class SECOND(nn.Module):
     def forward(self, x):
         outs = []
         for b in self.blocks:
-            x = b(x)
+            x = run_fused(b, x)
             outs.append(x)
         return tuple(outs)
 
@@ -90,5 +90,5 @@ class SECONDFPN(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
-        ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
+        ups = [run_fused(d, x[i]) for i, d in enumerate(self.deblocks)]
         return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]

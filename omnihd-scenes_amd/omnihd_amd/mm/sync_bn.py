@@ -30,6 +30,7 @@ class AllReduceSum(Function):
 
 class _NaiveSyncBN(nn.modules.batchnorm._BatchNorm):
     _reduce_dims = None   # dims averaged locally
+    _omnihd_sync = True   # bricks.bn_act: statistics of this layer are averaged over the ranks
 
     def _check_input_dim(self, input):
         pass
@@ -38,6 +39,13 @@ class _NaiveSyncBN(nn.modules.batchnorm._BatchNorm):
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1 or not self.training:
             return super().forward(input)
         assert input.shape[0] > 0, "SyncBN does not support empty inputs"
+        from .. import ops
+        if ops.bn_train_supported(input) and self.momentum is not None and self.track_running_stats:
+            # fused kernels: one pass for the statistics, the exchange, one pass to normalise (csrc/batch_norm.hip)
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return ops.bn_train_act(input, self.weight, self.bias, self.running_mean, self.running_var, self.momentum,
+                                    self.eps, False, dist.group.WORLD)
         x = input.float()
         C = x.shape[1]
         dims = [d for d in range(x.dim()) if d != 1]

@@ -710,3 +710,90 @@ def affine_act(x, scale, shift, res=None, relu=True):
     _want(scale, torch.float32, "scale")
     _want(shift, torch.float32, "shift")
     return _AffineAct.apply(x, scale, shift, res, relu)
+
+
+# --------------------------------------------------------------------------------------------
+# Training-mode BatchNorm (+ReLU), statistics optionally averaged over ranks (naive SyncBN)
+# --------------------------------------------------------------------------------------------
+def _rows_view(t):
+    """(N,C,H,W) channels-last or (N,C) contiguous bf16 -> (rows, c)."""
+    if t.dim() == 4:
+        return t.shape[0] * t.shape[2] * t.shape[3], t.shape[1]
+    return t.shape[0], t.shape[1]
+
+
+class _BnTrainAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group, res):
+        import torch.distributed as dist
+        rows, c = _rows_view(x)
+        dev = x.device
+        ranks = dist.get_world_size(group) if group is not None else 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        stats = torch.empty(2 * c, **f32)
+        consts = torch.empty(4, c, **f32)                      # scale, shift, mean, invstd
+        y = torch.empty_like(x)
+        gamma, beta = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        with torch.cuda.device(dev):
+            ws = _wgrad_workspace(lib().omnihd_bn_workspace_bytes(rows, c), dev)
+            check(lib().omnihd_bn_channel_sums(_ptr(x), None, None, _ptr(stats), rows, c, 0, 1.0 / rows, _ptr(ws),
+                                               ws.numel(), _stream()), "omnihd_bn_channel_sums")
+            if ranks > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+            # torch's BatchNorm keeps the unbiased variance in running_var; the reference's SyncBN the biased one
+            corr = 1.0 if ranks > 1 else (rows / (rows - 1.0) if rows > 1 else 1.0)
+            check(lib().omnihd_bn_fwd_consts(_ptr(stats), 1.0 / ranks, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                             corr, c, _ptr(running_mean), _ptr(running_var), _ptr(consts[0]),
+                                             _ptr(consts[1]), _ptr(consts[2]), _ptr(consts[3]), _stream()),
+                  "omnihd_bn_fwd_consts")
+            check(lib().omnihd_affine_act_fwd(_ptr(x), _ptr(consts[0]), _ptr(consts[1]), _ptr(res), _ptr(y), rows, c,
+                                              1 if relu else 0, _stream()), "omnihd_affine_act_fwd")
+        ctx.save_for_backward(x, y if relu else None, gamma, consts)
+        ctx.relu, ctx.group, ctx.ranks, ctx.param_dtypes = relu, group, ranks, (weight.dtype, bias.dtype)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+        x, y, gamma, consts = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last) if gy.dim() == 4 else gy.contiguous()
+        rows, c = _rows_view(x)
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        local = torch.empty(2 * c, **f32)
+        out = torch.empty(5, c, **f32)                         # dgamma, dbeta, A, B, C
+        gx = torch.empty_like(x)
+        gres = None
+        if ctx.has_res and ctx.needs_input_grad[9]:
+            gres = torch.empty_like(x) if ctx.relu else gy          # without a ReLU the residual's gradient is gy itself
+        with torch.cuda.device(dev):
+            ws = _wgrad_workspace(lib().omnihd_bn_workspace_bytes(rows, c), dev)
+            check(lib().omnihd_bn_channel_sums(_ptr(gy), _ptr(x), _ptr(y), _ptr(local), rows, c, 1, 1.0, _ptr(ws),
+                                               ws.numel(), _stream()), "omnihd_bn_channel_sums")
+            glob = local
+            if ctx.ranks > 1:
+                glob = local.clone()
+                dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.group)
+            check(lib().omnihd_bn_bwd_consts(_ptr(local), _ptr(glob), _ptr(gamma), _ptr(consts[2]), _ptr(consts[3]),
+                                             1.0 / (ctx.ranks * rows), c, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                             _ptr(out[3]), _ptr(out[4]), _stream()), "omnihd_bn_bwd_consts")
+            check(lib().omnihd_bn_bwd_apply(_ptr(gy), _ptr(y), _ptr(x), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(gx),
+                                            _ptr(gres) if (gres is not None and ctx.relu) else None, rows, c, _stream()),
+                  "omnihd_bn_bwd_apply")
+        return (gx, out[0].to(ctx.param_dtypes[0]), out[1].to(ctx.param_dtypes[1]), None, None, None, None, None, None,
+                gres)
+
+
+def bn_train_supported(x):
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() in (2, 4) and x.shape[1] % 8 == 0 and x.shape[1] <= 2048):
+        return False
+    return x.numel() > 0
+
+
+def bn_train_act(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, group=None, residual=None):
+    """``act(BatchNorm_train(x) + residual)`` of a bf16 (N,C,H,W) [made channels-last] or (N,C) tensor; statistics are
+    the mean over ``group``'s ranks of the per-rank mean / mean of squares when a group with more than one rank is given."""
+    cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if x.dim() == 4 else (lambda t: t.contiguous())
+    return _BnTrainAct.apply(cl(x), weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), group,
+                             None if residual is None else cl(residual))

@@ -26,6 +26,7 @@ from torch import nn
 import omnihd_amd
 from omnihd_amd import ops as _ops
 from omnihd_amd.mm import build_conv_layer, build_norm_layer
+from omnihd_amd.mm.bricks import bn_act, run_fused
 from omnihd_amd.mm.resnet import BasicBlock
 from omnihd_amd.plan import planned_pool
 from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2  # noqa: F401  (API parity)
@@ -53,7 +54,7 @@ class _ASPPModule(nn.Module):
         nn.init.kaiming_normal_(self.atrous_conv.weight)
 
     def forward(self, x):
-        return self.relu(self.bn(self.atrous_conv(x)))
+        return bn_act(self.atrous_conv(x), self.bn, relu=True, inplace=False)
 
 
 class ASPP(nn.Module):
@@ -82,13 +83,13 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x)]
-        pooled = self.global_avg_pool(x)
+        pooled = run_fused(self.global_avg_pool, x)
         # bilinear (align_corners) up-sampling of a 1x1 map is a broadcast (reference :537-541)
         branches.append(pooled.expand(-1, -1, x.shape[2], x.shape[3]))
         # concatenate in NHWC: the result is channels-last whatever the layout of the broadcast branch
         # (torch.cat of mixed layouts falls back to an NCHW result that the next conv has to re-lay out)
         cat = torch.cat([b.permute(0, 2, 3, 1) for b in branches], dim=3).permute(0, 3, 1, 2)
-        x = self.relu(self.bn1(self.conv1(cat)))
+        x = bn_act(self.conv1(cat), self.bn1, relu=True, inplace=False)
         return self.dropout(x)
 
 
@@ -111,7 +112,7 @@ class DepthNet(nn.Module):
             nn.Conv2d(mid_channels, depth_channels, 1, stride=1, padding=0))
 
     def forward(self, x):
-        x = self.reduce_conv(x)
+        x = run_fused(self.reduce_conv, x)
         return torch.cat([self.depth_conv(x), self.context_conv(x)], dim=1)
 
 
@@ -269,7 +270,7 @@ class LiftSplatShoot_Depth(nn.Module):
             except (KeyError, TypeError):
                 key = None
         x, depth = self.get_voxels(x, rots, trans, post_rots, post_trans, extra_rots, extra_trans, plan_key=key)
-        return self.bevencode(self.s2c(x)), depth
+        return run_fused(self.bevencode, self.s2c(x)), depth
 
     # ---- depth supervision ------------------------------------------------------------------
     def get_klv_depth_loss(self, depth_labels, depth_preds):

@@ -1,0 +1,149 @@
+"""GPU parity of the fused training-mode BatchNorm (+ReLU, +residual) kernels (csrc/batch_norm.hip) against
+torch's BatchNorm on the same bf16 inputs, and of the rank-averaged ("naive" SyncBN, reference
+projects/mmdet3d_plugin/ops/norm.py:28-82) variant against the reference algorithm written with torch ops,
+two ranks sharing the one GPU over a gloo group."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+@pytest.mark.parametrize("shape,relu,with_res", [((6, 256, 16, 44), True, False), ((1, 64, 40, 60), True, True),
+                                                 ((2, 128, 9, 7), False, False), ((3, 8, 5, 3), False, True),
+                                                 ((4000, 64), True, False), ((1, 2048, 8, 22), True, False)])
+def test_bn_train_act_matches_torch_batch_norm(cuda, shape, relu, with_res):
+    from omnihd_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    c = shape[1]
+    mk = lambda: torch.randn(shape, generator=g).to(cuda).bfloat16()
+    cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if len(shape) == 4 else (lambda t: t)
+    x = cl(mk() * 1.5 + 0.3).requires_grad_()
+    res = cl(mk()).requires_grad_() if with_res else None
+    w = (torch.rand(c, generator=g) + 0.5).to(cuda).requires_grad_()
+    b = torch.randn(c, generator=g).to(cuda).requires_grad_()
+    rm, rv = torch.zeros(c, device=cuda), torch.ones(c, device=cuda)
+    gy = mk()
+    y = ops.bn_train_act(x, w, b, rm, rv, 0.1, 1e-3, relu, None, res)
+    y.backward(gy)
+    # reference: fp32 batch norm of the same bf16 values
+    xr = x.detach().float().requires_grad_()
+    rr = res.detach().float().requires_grad_() if with_res else None
+    wr, br = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    rm2, rv2 = torch.zeros(c, device=cuda), torch.ones(c, device=cuda)
+    yr = F.batch_norm(xr, rm2, rv2, wr, br, True, 0.1, 1e-3)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = yr.relu()
+    yr.backward(gy.float())
+    assert y.dtype == torch.bfloat16 and y.shape == x.shape
+    assert _rel(y, yr) < 4e-3                                   # one bf16 rounding of the output
+    torch.testing.assert_close(rm, rm2, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv, rv2, rtol=1e-4, atol=1e-5)   # unbiased variance, as torch keeps it
+    assert _rel(x.grad, xr.grad) < 8e-3
+    assert _rel(w.grad, wr.grad) < 2e-3 and _rel(b.grad, br.grad) < 2e-3
+    if with_res:
+        assert _rel(res.grad, rr.grad) < 8e-3
+    # deterministic
+    y2 = ops.bn_train_act(x.detach(), w.detach(), b.detach(), rm.clone(), rv.clone(), 0.1, 1e-3, relu, None,
+                          None if res is None else res.detach())
+    assert torch.equal(y2, y.detach())
+
+
+def test_modules_take_the_fused_path_and_match_plain_torch(cuda, monkeypatch):
+    """SECOND stage (conv-BN-ReLU chain) under autocast: fused BN path vs torch modules, same weights."""
+    from omnihd_amd import ops
+    from omnihd_amd.mm.second import SECOND
+    torch.manual_seed(0)
+    net = SECOND(in_channels=64, out_channels=(64, 128), layer_nums=(2, 2), layer_strides=(2, 2),
+                 norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01)).to(cuda).to(memory_format=torch.channels_last).train()
+    x = torch.randn(1, 64, 64, 96, device=cuda).contiguous(memory_format=torch.channels_last)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def run(autocast=True):
+        net.load_state_dict(state)
+        for p in net.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            outs = net(x)
+        sum(o.float().square().mean() for o in outs).backward()
+        return ([o.detach().float() for o in outs], {n: p.grad.detach().float().clone() for n, p in net.named_parameters()},
+                {k: v.clone() for k, v in net.state_dict().items() if "running" in k})
+    calls = []
+    real = ops.bn_train_act
+    monkeypatch.setattr(ops, "bn_train_act", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    f_out, f_grad, f_stats = run()
+    assert len(calls) == 6
+    monkeypatch.setattr(ops, "bn_train_supported", lambda *a, **k: False)
+    p_out, p_grad, p_stats = run()
+    e_out, e_grad, e_stats = run(autocast=False)
+    for f, p, e in zip(f_out, p_out, e_out):
+        assert _rel(f, e) <= 1.5 * _rel(p, e) + 2e-3, (_rel(f, e), _rel(p, e))
+    for k in f_grad:
+        assert _rel(f_grad[k], e_grad[k]) <= 1.5 * _rel(p_grad[k], e_grad[k]) + 1e-2, k
+    for k in f_stats:
+        assert _rel(f_stats[k], e_stats[k]) < 2e-2, k
+
+
+def _sync_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path[:0] = [root, os.path.join(root, "omnihd-scenes_amd")]
+        from omnihd_amd.mm.sync_bn import NaiveSyncBatchNorm2d
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(100 + rank)
+        n = 3 + rank                                             # different pixel counts per rank: mean of rank means
+        x = (torch.randn(n, 64, 12, 20, generator=g) * (1 + rank) + 0.5 * rank).to(dev).bfloat16()
+        x = x.contiguous(memory_format=torch.channels_last).requires_grad_()
+        gy = torch.randn(n, 64, 12, 20, generator=g).to(dev).bfloat16()
+        bn = NaiveSyncBatchNorm2d(64, eps=1e-3, momentum=0.01).to(dev).train()
+        torch.manual_seed(7)
+        bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+        y = bn(x)
+        y.backward(gy)
+        got = dict(y=y.detach().float().cpu(), gx=x.grad.float().cpu(), gw=bn.weight.grad.cpu(), gb=bn.bias.grad.cpu(),
+                   rm=bn.running_mean.cpu(), rv=bn.running_var.cpu())
+        # the reference algorithm in fp32 torch ops on the same values (sync_bn.py's unfused branch)
+        x2 = x.detach().float().requires_grad_()
+        bn2 = NaiveSyncBatchNorm2d(64, eps=1e-3, momentum=0.01).to(dev).train()
+        bn2.load_state_dict({k: v for k, v in bn.state_dict().items() if "running" not in k and "num" not in k}, strict=False)
+        bn2.running_mean.zero_(); bn2.running_var.fill_(1.0)
+        y2 = bn2(x2)                                             # fp32 input -> unfused reference path
+        y2.backward(gy.float())
+        want = dict(y=y2.detach().cpu(), gx=x2.grad.cpu(), gw=bn2.weight.grad.cpu(), gb=bn2.bias.grad.cpu(),
+                    rm=bn2.running_mean.cpu(), rv=bn2.running_var.cpu())
+        q.put((rank, {k: float((got[k] - want[k]).norm() / (want[k].norm() + 1e-12)) for k in got}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_averaged_statistics_two_ranks_on_one_gpu(cuda):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, errs = q.get(timeout=300)
+        res[rank] = errs
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, errs in res.items():
+        assert errs["y"] < 4e-3 and errs["gx"] < 1e-2, (rank, errs)
+        assert errs["gw"] < 3e-3 and errs["gb"] < 3e-3, (rank, errs)
+        assert errs["rm"] < 1e-3 and errs["rv"] < 1e-3, (rank, errs)
