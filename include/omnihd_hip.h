@@ -343,6 +343,15 @@ int omnihd_bn_bwd_consts(const float* local_sums, const float* global_sums, cons
 int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const void* x, const float* coef_a, const float* coef_b,
                         const float* coef_c, void* gx, void* gres, long long rows, int c, void* stream);
 
+/* One-call single-rank forms of the above (no statistics exchange): see csrc/batch_norm.hip.             */
+int omnihd_bn_train_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, float var_correction, int relu, void* y,
+                        float* stats2c, float* consts4c, long long rows, int c, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int omnihd_bn_train_bwd(const void* gy, const void* y_mask, const void* x, const float* gamma, const float* consts4c,
+                        void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,28 +43,41 @@ __global__ __launch_bounds__(256) void k_bn_partial(const u32x4* __restrict__ a,
   const long long begin = (long long)blockIdx.x * rows_per_block;
   const long long end = min(begin + rows_per_block, rows);
   if (r0 < rpi) {
-    for (long long r = begin + r0; r < end; r += rpi) {
-      const long long i = r * c8 + vcol;
-      const u32x4 av = __builtin_nontemporal_load(a + i);
-      const unsigned short* ae = reinterpret_cast<const unsigned short*>(&av);
-      if (MODE == 0) {
+    constexpr int U = 4;                          // independent row loads in flight per lane
+    for (long long rb = begin + r0; rb < end; rb += (long long)U * rpi) {
+      u32x4 av[U], bv[U], mv[U];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float v = bf2f(ae[k]);
-          s1[k] += v;
-          s2[k] = fmaf(v, v, s2[k]);
+      for (int u = 0; u < U; ++u) {
+        const long long r = rb + (long long)u * rpi;
+        const bool ok = r < end;
+        const long long i = (ok ? r : begin + r0) * c8 + vcol;
+        av[u] = __builtin_nontemporal_load(a + i);
+        if (MODE == 1) {
+          bv[u] = __builtin_nontemporal_load(b + i);
+          if (m) mv[u] = __builtin_nontemporal_load(m + i);
+          else mv[u] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};     // bf16 ones: mask passes
         }
-      } else {
-        const u32x4 bv = __builtin_nontemporal_load(b + i);
-        const unsigned short* be = reinterpret_cast<const unsigned short*>(&bv);
-        u32x4 mv = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};     // bf16 ones: mask passes
-        if (m) mv = __builtin_nontemporal_load(m + i);
-        const unsigned short* me = reinterpret_cast<const unsigned short*>(&mv);
+        if (!ok) av[u] = u32x4{0u, 0u, 0u, 0u};   // a zero row adds nothing to either sum
+      }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float g = bf2f(me[k]) > 0.f ? bf2f(ae[k]) : 0.f;
-          s1[k] += g;
-          s2[k] = fmaf(g, bf2f(be[k]), s2[k]);
+      for (int u = 0; u < U; ++u) {
+        const unsigned short* ae = reinterpret_cast<const unsigned short*>(&av[u]);
+        if (MODE == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float v = bf2f(ae[k]);
+            s1[k] += v;
+            s2[k] = fmaf(v, v, s2[k]);
+          }
+        } else {
+          const unsigned short* be = reinterpret_cast<const unsigned short*>(&bv[u]);
+          const unsigned short* me = reinterpret_cast<const unsigned short*>(&mv[u]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float g = bf2f(me[k]) > 0.f ? bf2f(ae[k]) : 0.f;
+            s1[k] += g;
+            s2[k] = fmaf(g, bf2f(be[k]), s2[k]);
+          }
         }
       }
     }
@@ -94,13 +107,23 @@ __global__ __launch_bounds__(256) void k_bn_partial(const u32x4* __restrict__ a,
   }
 }
 
-// sums[0][c], sums[1][c] = (sum over blocks of partial) * mult
+// sums[0][c], sums[1][c] = (sum over blocks of partial) * mult.  8 lanes share one output (strided over the
+// blocks, combined with a fixed shuffle tree), 32 outputs per workgroup: coalesced 128-byte reads.
 __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ partial, int n_blocks, int c, float mult,
                                                    float* __restrict__ sums) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * c; i += gridDim.x * 256) {
-    float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partial[(size_t)b * 2 * c + i];
-    sums[i] = s * mult;
+  const int out = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int part = threadIdx.x >> 5;             // 0..7
+  float s = 0.f;
+  if (out < 2 * c)
+    for (int b = part; b < n_blocks; b += 8) s += partial[(size_t)b * 2 * c + out];
+  __shared__ float red[8][32];
+  red[part][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && out < 2 * c) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[p][threadIdx.x];
+    sums[out] = t * mult;
   }
 }
 
@@ -182,8 +205,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const u32x4* __restrict__ 
 int plan_blocks(long long rows, int c8, long long* rows_per_block) {
   const int rpi = 256 / c8;
   long long iters = (rows + rpi - 1) / rpi;
-  long long blocks = (iters + 7) / 8;                       // >= 8 iterations per workgroup
-  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  long long blocks = (iters + 15) / 16;                     // >= 16 row-iterations per workgroup
+  if (blocks > 512) blocks = 512;                           // the second stage reads blocks x 2c floats
   if (blocks < 1) blocks = 1;
   long long per = (rows + blocks - 1) / blocks;
   per = (per + rpi - 1) / rpi * rpi;
@@ -221,7 +244,7 @@ extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* 
   else
     hipLaunchKernelGGL((k_bn_partial<1>), dim3(blocks), dim3(256), 0, st, (const u32x4*)a, (const u32x4*)b,
                        (const u32x4*)mask, partial, rows, c / 8, per);
-  hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 255) / 256), dim3(256), 0, st, partial, blocks, c, mult, sums);
+  hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 31) / 32), dim3(256), 0, st, partial, blocks, c, mult, sums);
   return check_launch("bn_channel_sums");
 }
 
@@ -256,4 +279,33 @@ extern "C" int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const voi
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n_vec, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)gy,
                      (const u32x4*)y_mask, (const u32x4*)x, coef_a, coef_b, coef_c, (u32x4*)gx, (u32x4*)gres, n_vec, c / 8);
   return check_launch("bn_bwd_apply");
+}
+
+/* Single-rank training step of BatchNorm in one call (no exchange between the statistics and their use):
+ * forward  = channel sums -> constants (+ running stats) -> y = act(x * scale + shift (+ res));
+ * consts [4, c] receives scale, shift, mean, invstd (kept for the backward).                            */
+extern "C" int omnihd_bn_train_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   float var_correction, int relu, void* y, float* stats2c, float* consts4c,
+                                   long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = omnihd_bn_channel_sums(x, nullptr, nullptr, stats2c, rows, c, 0, 1.0f / (float)rows, workspace, workspace_bytes,
+                                  stream);
+  if (rc) return rc;
+  rc = omnihd_bn_fwd_consts(stats2c, 1.0f, gamma, beta, eps, momentum, var_correction, c, running_mean, running_var,
+                            consts4c, consts4c + c, consts4c + 2 * c, consts4c + 3 * c, stream);
+  if (rc) return rc;
+  return omnihd_affine_act_fwd(x, consts4c, consts4c + c, res, y, rows, c, relu, stream);
+}
+
+/* backward = masked channel sums -> dgamma/dbeta + coefficients -> gx (and gres).  out5c [5, c] receives
+ * dgamma, dbeta and the three coefficient vectors; sums2c is scratch.                                     */
+extern "C" int omnihd_bn_train_bwd(const void* gy, const void* y_mask, const void* x, const float* gamma,
+                                   const float* consts4c, void* gx, void* gres, float* sums2c, float* out5c,
+                                   long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = omnihd_bn_channel_sums(gy, x, y_mask, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  rc = omnihd_bn_bwd_consts(sums2c, sums2c, gamma, consts4c + 2 * c, consts4c + 3 * c, 1.0f / (float)rows, c, out5c,
+                            out5c + c, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, stream);
+  if (rc) return rc;
+  return omnihd_bn_bwd_apply(gy, y_mask, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream);
 }

@@ -37,6 +37,22 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# The training step issues a few hundred of these calls; at ~45 ms per step the Python side must stay cheap:
+# no device context switch when the tensor's device is already current, size queries cached per geometry.
+import contextlib
+
+_NULL_CTX = contextlib.nullcontext()
+_SIZE_CACHE = {}
+
+
+def _on(dev):
+    return _NULL_CTX if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
+def _raw_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
 # ---------------------------------------------------------------------------------------------
 # bev_pool_v2
 # ---------------------------------------------------------------------------------------------
@@ -410,13 +426,16 @@ def conv_wgrad(x, grad_out, kernel_size, stride=1, padding=0, dilation=1):
     dev = x.device
     dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
     geo = (B, H, W, cin, Ho, Wo, cout, k, k, int(stride), int(padding), int(dilation))
-    with torch.cuda.device(dev):
-        nbytes = lib().omnihd_conv_wgrad_workspace_bytes(*geo)
+    L = lib()
+    with _on(dev):
+        nbytes = _SIZE_CACHE.get(geo)
+        if nbytes is None:
+            nbytes = _SIZE_CACHE[geo] = L.omnihd_conv_wgrad_workspace_bytes(*geo)
         if nbytes == 0:
             raise ValueError(f"conv_wgrad: unsupported geometry {geo}")
         ws = _wgrad_workspace(nbytes, dev)
-        check(lib().omnihd_conv_wgrad_bf16(_ptr(x), _ptr(grad_out), _ptr(dw), *geo, _ptr(ws), ws.numel(), _stream()),
-              "omnihd_conv_wgrad_bf16")
+        check(L.omnihd_conv_wgrad_bf16(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(), *geo, ws.data_ptr(), ws.numel(),
+                                       _raw_stream()), "omnihd_conv_wgrad_bf16")
     return dw.permute(0, 3, 1, 2)
 
 
@@ -676,10 +695,11 @@ class _AffineAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, shift, res, relu):
         n, c, h, w = x.shape
-        y = torch.empty_like(x, memory_format=torch.channels_last)
-        with torch.cuda.device(x.device):
-            check(lib().omnihd_affine_act_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y), n * h * w, c,
-                                              1 if relu else 0, _stream()), "omnihd_affine_act_fwd")
+        y = torch.empty_like(x)
+        with _on(x.device):
+            check(lib().omnihd_affine_act_fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                              None if res is None else res.data_ptr(), y.data_ptr(), n * h * w, c,
+                                              1 if relu else 0, _raw_stream()), "omnihd_affine_act_fwd")
         ctx.save_for_backward(y if relu else None, scale)
         ctx.relu, ctx.has_res = relu, res is not None
         return y
@@ -689,11 +709,12 @@ class _AffineAct(torch.autograd.Function):
         y, scale = ctx.saved_tensors
         gy = gy.contiguous(memory_format=torch.channels_last)
         n, c, h, w = gy.shape
-        gx = torch.empty_like(gy, memory_format=torch.channels_last)
-        gres = torch.empty_like(gy, memory_format=torch.channels_last) if ctx.has_res and ctx.needs_input_grad[3] else None
-        with torch.cuda.device(gy.device):
-            check(lib().omnihd_affine_act_bwd(_ptr(gy), _ptr(y), _ptr(scale), _ptr(gx), _ptr(gres), n * h * w, c,
-                                              1 if ctx.relu else 0, _stream()), "omnihd_affine_act_bwd")
+        gx = torch.empty_like(gy)
+        gres = torch.empty_like(gy) if ctx.has_res and ctx.needs_input_grad[3] else None
+        with _on(gy.device):
+            check(lib().omnihd_affine_act_bwd(gy.data_ptr(), None if y is None else y.data_ptr(), scale.data_ptr(),
+                                              gx.data_ptr(), None if gres is None else gres.data_ptr(), n * h * w, c,
+                                              1 if ctx.relu else 0, _raw_stream()), "omnihd_affine_act_bwd")
         return gx, None, None, gres, None
 
 
@@ -722,6 +743,11 @@ def _rows_view(t):
     return t.shape[0], t.shape[1]
 
 
+def _f32c(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
 class _BnTrainAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group, res):
@@ -729,25 +755,36 @@ class _BnTrainAct(torch.autograd.Function):
         rows, c = _rows_view(x)
         dev = x.device
         ranks = dist.get_world_size(group) if group is not None else 1
-        f32 = dict(dtype=torch.float32, device=dev)
-        stats = torch.empty(2 * c, **f32)
-        consts = torch.empty(4, c, **f32)                      # scale, shift, mean, invstd
+        buf = torch.empty(6, c, dtype=torch.float32, device=dev)           # [0:2] statistics, [2:6] scale, shift, mean, invstd
+        stats, consts = buf[:2].view(-1), buf[2:]
         y = torch.empty_like(x)
-        gamma, beta = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        with torch.cuda.device(dev):
-            ws = _wgrad_workspace(lib().omnihd_bn_workspace_bytes(rows, c), dev)
-            check(lib().omnihd_bn_channel_sums(_ptr(x), None, None, _ptr(stats), rows, c, 0, 1.0 / rows, _ptr(ws),
-                                               ws.numel(), _stream()), "omnihd_bn_channel_sums")
-            if ranks > 1:
+        gamma, beta = _f32c(weight), _f32c(bias)
+        L = lib()
+        st = _raw_stream()
+        rm = None if running_mean is None else running_mean.data_ptr()
+        rv = None if running_var is None else running_var.data_ptr()
+        resp = None if res is None else res.data_ptr()
+        with _on(dev):
+            nbytes = _SIZE_CACHE.get(("bn", rows, c))
+            if nbytes is None:
+                nbytes = _SIZE_CACHE[("bn", rows, c)] = L.omnihd_bn_workspace_bytes(rows, c)
+            ws = _wgrad_workspace(nbytes, dev)
+            if ranks == 1:
+                # torch's BatchNorm keeps the unbiased variance in running_var
+                corr = rows / (rows - 1.0) if rows > 1 else 1.0
+                check(L.omnihd_bn_train_fwd(x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr,
+                                            1 if relu else 0, y.data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c,
+                                            ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd")
+            else:
+                check(L.omnihd_bn_channel_sums(x.data_ptr(), None, None, stats.data_ptr(), rows, c, 0, 1.0 / rows, ws.data_ptr(),
+                                               ws.numel(), st), "omnihd_bn_channel_sums")
                 dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-            # torch's BatchNorm keeps the unbiased variance in running_var; the reference's SyncBN the biased one
-            corr = 1.0 if ranks > 1 else (rows / (rows - 1.0) if rows > 1 else 1.0)
-            check(lib().omnihd_bn_fwd_consts(_ptr(stats), 1.0 / ranks, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
-                                             corr, c, _ptr(running_mean), _ptr(running_var), _ptr(consts[0]),
-                                             _ptr(consts[1]), _ptr(consts[2]), _ptr(consts[3]), _stream()),
-                  "omnihd_bn_fwd_consts")
-            check(lib().omnihd_affine_act_fwd(_ptr(x), _ptr(consts[0]), _ptr(consts[1]), _ptr(res), _ptr(y), rows, c,
-                                              1 if relu else 0, _stream()), "omnihd_affine_act_fwd")
+                # the reference's SyncBN keeps the biased variance (ops/norm.py:74-75)
+                check(L.omnihd_bn_fwd_consts(stats.data_ptr(), 1.0 / ranks, gamma.data_ptr(), beta.data_ptr(), eps, momentum, 1.0,
+                                             c, rm, rv, consts[0].data_ptr(), consts[1].data_ptr(), consts[2].data_ptr(),
+                                             consts[3].data_ptr(), st), "omnihd_bn_fwd_consts")
+                check(L.omnihd_affine_act_fwd(x.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), resp, y.data_ptr(), rows, c,
+                                              1 if relu else 0, st), "omnihd_affine_act_fwd")
         ctx.save_for_backward(x, y if relu else None, gamma, consts)
         ctx.relu, ctx.group, ctx.ranks, ctx.param_dtypes = relu, group, ranks, (weight.dtype, bias.dtype)
         ctx.has_res = res is not None
@@ -760,27 +797,33 @@ class _BnTrainAct(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last) if gy.dim() == 4 else gy.contiguous()
         rows, c = _rows_view(x)
         dev = x.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        local = torch.empty(2 * c, **f32)
-        out = torch.empty(5, c, **f32)                         # dgamma, dbeta, A, B, C
+        buf = torch.empty(7, c, dtype=torch.float32, device=dev)           # [0:2] sums, [2:7] dgamma, dbeta, A, B, C
+        local, out = buf[:2].view(-1), buf[2:]
         gx = torch.empty_like(x)
         gres = None
         if ctx.has_res and ctx.needs_input_grad[9]:
             gres = torch.empty_like(x) if ctx.relu else gy          # without a ReLU the residual's gradient is gy itself
-        with torch.cuda.device(dev):
-            ws = _wgrad_workspace(lib().omnihd_bn_workspace_bytes(rows, c), dev)
-            check(lib().omnihd_bn_channel_sums(_ptr(gy), _ptr(x), _ptr(y), _ptr(local), rows, c, 1, 1.0, _ptr(ws),
-                                               ws.numel(), _stream()), "omnihd_bn_channel_sums")
-            glob = local
-            if ctx.ranks > 1:
+        gresp = gres.data_ptr() if (gres is not None and ctx.relu) else None
+        yp = None if y is None else y.data_ptr()
+        L = lib()
+        st = _raw_stream()
+        with _on(dev):
+            ws = _wgrad_workspace(_SIZE_CACHE[("bn", rows, c)], dev)
+            if ctx.ranks == 1:
+                check(L.omnihd_bn_train_bwd(gy.data_ptr(), yp, x.data_ptr(), gamma.data_ptr(), consts.data_ptr(), gx.data_ptr(),
+                                            gresp, local.data_ptr(), out.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st),
+                      "omnihd_bn_train_bwd")
+            else:
+                check(L.omnihd_bn_channel_sums(gy.data_ptr(), x.data_ptr(), yp, local.data_ptr(), rows, c, 1, 1.0, ws.data_ptr(),
+                                               ws.numel(), st), "omnihd_bn_channel_sums")
                 glob = local.clone()
                 dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.group)
-            check(lib().omnihd_bn_bwd_consts(_ptr(local), _ptr(glob), _ptr(gamma), _ptr(consts[2]), _ptr(consts[3]),
-                                             1.0 / (ctx.ranks * rows), c, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
-                                             _ptr(out[3]), _ptr(out[4]), _stream()), "omnihd_bn_bwd_consts")
-            check(lib().omnihd_bn_bwd_apply(_ptr(gy), _ptr(y), _ptr(x), _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(gx),
-                                            _ptr(gres) if (gres is not None and ctx.relu) else None, rows, c, _stream()),
-                  "omnihd_bn_bwd_apply")
+                check(L.omnihd_bn_bwd_consts(local.data_ptr(), glob.data_ptr(), gamma.data_ptr(), consts[2].data_ptr(),
+                                             consts[3].data_ptr(), 1.0 / (ctx.ranks * rows), c, out[0].data_ptr(),
+                                             out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(), st),
+                      "omnihd_bn_bwd_consts")
+                check(L.omnihd_bn_bwd_apply(gy.data_ptr(), yp, x.data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                                            out[4].data_ptr(), gx.data_ptr(), gresp, rows, c, st), "omnihd_bn_bwd_apply")
         return (gx, out[0].to(ctx.param_dtypes[0]), out[1].to(ctx.param_dtypes[1]), None, None, None, None, None, None,
                 gres)
 
