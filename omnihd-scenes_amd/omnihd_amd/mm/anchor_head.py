@@ -135,7 +135,7 @@ class BboxOverlapsNearest3D:
     def nearest_bev(b):
         rot = torch.abs(limit_period(b[:, 6], 0.5, math.pi))
         swap = (rot > math.pi / 4)[:, None]
-        dims = torch.where(swap, b[:, [4, 3]], b[:, [3, 4]])
+        dims = torch.where(swap, b[:, 3:5].flip(-1), b[:, 3:5])          # no index lists: they cost a host->device copy
         c = b[:, :2]
         return torch.cat([c - dims / 2, c + dims / 2], dim=-1)
 
@@ -170,9 +170,9 @@ class MaxIoUAssigner:
         overlaps = self.iou_calculator(gt_bboxes, bboxes)            # (num_gt, N)
         max_ov, argmax_ov = overlaps.max(dim=0)
         gt_max_ov, gt_argmax = overlaps.max(dim=1)
-        assigned[(max_ov >= 0) & (max_ov < self.neg_iou_thr)] = 0
-        pos = max_ov >= self.pos_iou_thr
-        assigned[pos] = argmax_ov[pos] + 1
+        # masks + torch.where instead of boolean-mask indexing: no host synchronisation anywhere in the assigner
+        assigned = torch.where((max_ov >= 0) & (max_ov < self.neg_iou_thr), torch.zeros_like(assigned), assigned)
+        assigned = torch.where(max_ov >= self.pos_iou_thr, argmax_ov + 1, assigned)
         if self.match_low_quality:
             # for gt i (in order; later gts overwrite earlier ones): every anchor reaching gt i's best IoU
             ok = gt_max_ov >= self.min_pos_iou
@@ -283,32 +283,28 @@ class Anchor3DHead(nn.Module):
 
     # ---- targets ----------------------------------------------------------------------------
     def _targets_single(self, anchors, gt_bboxes, gt_labels):
+        """Dense, mask-based target assignment: every quantity is computed for all anchors and selected with
+        ``torch.where`` — same values as gathering the positives, but no ``nonzero`` and hence no host sync."""
         n = anchors.shape[0]
         gt = _gt_tensor(gt_bboxes).to(anchors.device).float()
-        labels = anchors.new_full((n,), self.num_classes, dtype=torch.long)
-        label_weights = anchors.new_zeros(n)
-        bbox_targets = torch.zeros_like(anchors)
-        bbox_weights = torch.zeros_like(anchors)
-        dir_targets = anchors.new_zeros(n, dtype=torch.long)
-        dir_weights = anchors.new_zeros(n)
+        if gt.shape[0] == 0:
+            zeros = anchors.new_zeros(n)
+            return (anchors.new_full((n,), self.num_classes, dtype=torch.long), anchors.new_ones(n), torch.zeros_like(anchors),
+                    torch.zeros_like(anchors), zeros.long(), zeros, zeros.sum())
         assigned = self.bbox_assigner.assign(anchors, gt, None, gt_labels)
-        pos = assigned > 0
-        neg = assigned == 0
-        pos_inds = torch.nonzero(pos).flatten()
-        if pos_inds.numel() > 0:
-            gi = assigned[pos_inds] - 1
-            pos_anchors = anchors[pos_inds]
-            t = self.bbox_coder.encode(pos_anchors, gt[gi])
-            bbox_targets[pos_inds] = t
-            bbox_weights[pos_inds] = 1.0
-            rot_gt = t[..., 6] + pos_anchors[..., 6]
-            offset_rot = limit_period(rot_gt - self.dir_offset, 0, 2 * math.pi)
-            dir_targets[pos_inds] = torch.floor(offset_rot / math.pi).long().clamp(0, 1)
-            dir_weights[pos_inds] = 1.0
-            labels[pos_inds] = gt_labels.to(anchors.device).long()[gi]
-            label_weights[pos_inds] = 1.0
-        label_weights[neg] = 1.0
-        return labels, label_weights, bbox_targets, bbox_weights, dir_targets, dir_weights, pos_inds.numel()
+        pos, neg = assigned > 0, assigned == 0
+        gi = (assigned - 1).clamp(min=0)
+        t = self.bbox_coder.encode(anchors, gt[gi])
+        posc = pos.unsqueeze(-1)
+        bbox_targets = torch.where(posc, t, torch.zeros_like(t))
+        bbox_weights = posc.to(anchors.dtype).expand_as(anchors)
+        rot_gt = t[..., 6] + anchors[..., 6]
+        offset_rot = limit_period(rot_gt - self.dir_offset, 0, 2 * math.pi)
+        dir_targets = torch.where(pos, torch.floor(offset_rot / math.pi).long().clamp(0, 1), torch.zeros_like(assigned))
+        dir_weights = pos.to(anchors.dtype)
+        labels = torch.where(pos, gt_labels.to(anchors.device).long()[gi], torch.full_like(assigned, self.num_classes))
+        label_weights = (pos | neg).to(anchors.dtype)
+        return labels, label_weights, bbox_targets, bbox_weights, dir_targets, dir_weights, pos.sum()
 
     @staticmethod
     def add_sin_difference(b1, b2):
@@ -330,26 +326,23 @@ class Anchor3DHead(nn.Module):
         bbox_weights = torch.stack([t[3] for t in tg]).reshape(-1, self.box_code_size)
         dir_targets = torch.stack([t[4] for t in tg]).reshape(-1)
         dir_weights = torch.stack([t[5] for t in tg]).reshape(-1)
-        num_total_samples = sum(max(t[6], 1) for t in tg)
+        num_total_samples = torch.stack([t[6] for t in tg]).clamp(min=1).sum().to(cls_score.dtype)   # stays on the device
 
         cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
         loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
+        # Regression / direction losses over ALL anchors with zero weight off the positives (the vendored head
+        # gathers the positives first, det_anchor3d_head.py:236-262: same sums, but a gather needs a host sync).
         bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, self.box_code_size)
-        pos_inds = torch.nonzero((labels >= 0) & (labels < self.num_classes)).reshape(-1)
-        pos_pred, pos_t, pos_w = bbox_pred[pos_inds], bbox_targets[pos_inds], bbox_weights[pos_inds]
         dir_pred = dir_pred.permute(0, 2, 3, 1).reshape(-1, 2)
-        pos_dir_pred, pos_dir_t, pos_dir_w = dir_pred[pos_inds], dir_targets[pos_inds], dir_weights[pos_inds]
-        if pos_inds.numel() > 0:
-            cw = self.train_cfg.get("code_weight", None)
-            if cw:
-                pos_w = pos_w * pos_w.new_tensor(cw)
-            if self.diff_rad_by_sin:
-                pos_pred, pos_t = self.add_sin_difference(pos_pred, pos_t)
-            loss_bbox = self.loss_bbox(pos_pred, pos_t, pos_w, avg_factor=num_total_samples)
-            loss_dir = self.loss_dir(pos_dir_pred, pos_dir_t, pos_dir_w, avg_factor=num_total_samples)
-        else:
-            loss_bbox = pos_pred.sum()
-            loss_dir = pos_dir_pred.sum()
+        cw = self.train_cfg.get("code_weight", None)
+        if cw:
+            if getattr(self, "_code_weight", None) is None or self._code_weight.device != bbox_weights.device:
+                self._code_weight = torch.tensor(cw, dtype=bbox_weights.dtype, device=bbox_weights.device)
+            bbox_weights = bbox_weights * self._code_weight
+        if self.diff_rad_by_sin:
+            bbox_pred, bbox_targets = self.add_sin_difference(bbox_pred, bbox_targets)
+        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
+        loss_dir = self.loss_dir(dir_pred, dir_targets, dir_weights, avg_factor=num_total_samples)
         return dict(loss_cls=[loss_cls], loss_bbox=[loss_bbox], loss_dir=[loss_dir])
 
     # ---- test time --------------------------------------------------------------------------

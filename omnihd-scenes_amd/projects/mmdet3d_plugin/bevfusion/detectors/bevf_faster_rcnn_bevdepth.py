@@ -80,12 +80,22 @@ class BEVFUSION_depth(MVXFasterRCNN):
             x = self.pts_neck(x)
         return x
 
-    @staticmethod
-    def _cam_inverse(img_metas, device):
-        """rots (B,N,3,3), trans (B,N,3) = blocks of inverse(lidar2img) in fp32 (reference :116-130)."""
-        mats = torch.Tensor(np.stack([np.stack([np.asarray(m) for m in meta["lidar2img"]]) for meta in img_metas]))
-        inv = mats.inverse()
-        return inv[..., :3, :3].to(device), inv[..., :3, 3].to(device)
+    _inverse_cache = {}
+
+    @classmethod
+    def _cam_inverse(cls, img_metas, device):
+        """rots (B,N,3,3), trans (B,N,3) = blocks of inverse(lidar2img) in fp32 (reference :116-130), computed on
+        the host as the reference does and kept per calibration: a rig's matrices repeat frame after frame."""
+        arr = np.stack([np.stack([np.asarray(m) for m in meta["lidar2img"]]) for meta in img_metas])
+        key = (arr.tobytes(), str(device))
+        hit = cls._inverse_cache.get(key)
+        if hit is None:
+            inv = torch.Tensor(arr).inverse()
+            hit = (inv[..., :3, :3].to(device), inv[..., :3, 3].to(device))
+            if len(cls._inverse_cache) >= 64:
+                cls._inverse_cache.clear()
+            cls._inverse_cache[key] = hit
+        return hit
 
     def extract_feat(self, points, img, img_metas, gt_bboxes_3d=None):
         img_feats = self.extract_img_feat(img, img_metas)

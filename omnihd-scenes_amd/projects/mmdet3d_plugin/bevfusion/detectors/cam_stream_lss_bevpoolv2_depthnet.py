@@ -281,9 +281,12 @@ class LiftSplatShoot_Depth(nn.Module):
         values = depth_values.view(-1)
         rng = self.camera_depth_range
         fg = (values >= rng[0]) & (values <= (rng[1] - rng[2]))
-        target = target.view(-1, self.D)[fg]
-        pred = depth_preds.float().permute(0, 1, 3, 4, 2).contiguous().view(-1, self.D)[fg]
-        loss = F.kl_div(torch.log(pred + 1e-4), target, reduction="batchmean", log_target=False)
+        # "batchmean" over the foreground pixels, written with a mask instead of a boolean gather (a gather
+        # needs the pixel count on the host: one device synchronisation per step)
+        target = target.view(-1, self.D)
+        pred = depth_preds.float().permute(0, 1, 3, 4, 2).contiguous().view(-1, self.D)
+        kl = F.kl_div(torch.log(pred + 1e-4), target, reduction="none", log_target=False)
+        loss = (kl * fg.unsqueeze(-1)).sum() / fg.sum()
         return loss, depth_values.clone()
 
     def get_depth_loss(self, depth_labels, depth_preds, loss_depth_type):

@@ -31,7 +31,7 @@ def generate_guassian_depth_target(depth, stride, cam_depth_range, constant_std=
         std = torch.sqrt(var_sum / num)
         std[num == 1] = 1
     else:
-        std = torch.ones((B, H, W)).type_as(depth).float() * constant_std
+        std = torch.full((B, H, W), float(constant_std), dtype=torch.float32, device=depth.device)
     patches[~valid] = 1e10
     min_depth = patches.min(dim=-1)[0]
     min_depth[min_depth == 1e10] = 0
