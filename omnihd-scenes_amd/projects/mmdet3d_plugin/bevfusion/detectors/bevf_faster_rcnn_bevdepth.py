@@ -69,10 +69,10 @@ class BEVFUSION_depth(MVXFasterRCNN):
             for p in m.parameters():
                 p.requires_grad = False
 
-    def extract_pts_feat(self, pts, img_feats, img_metas):
+    def extract_pts_feat(self, pts, img_feats, img_metas, voxelized=None):
         if not self.with_pts_backbone:
             return None
-        voxels, num_points, coors = self.voxelize(pts)
+        voxels, num_points, coors = voxelized if voxelized is not None else self.voxelize(pts)
         voxel_features = self.pts_voxel_encoder(voxels, num_points, coors)
         x = self.pts_middle_encoder(voxel_features, coors, len(pts))
         x = self.pts_backbone(x)
@@ -98,8 +98,11 @@ class BEVFUSION_depth(MVXFasterRCNN):
         return hit
 
     def extract_feat(self, points, img, img_metas, gt_bboxes_3d=None):
+        # Voxelisation first: its voxel count comes back to the host (the one synchronisation of the forward
+        # pass) — at this point the device queue is short, later it would drain the whole image branch.
+        vox = self.voxelize(points) if self.with_pts_backbone and points is not None else None
         img_feats = self.extract_img_feat(img, img_metas)
-        pts_feats = self.extract_pts_feat(points, img_feats, img_metas)
+        pts_feats = self.extract_pts_feat(points, img_feats, img_metas, voxelized=vox)
         depth_dist = None
         if self.lift:
             BN, C, H, W = img_feats[0].shape
