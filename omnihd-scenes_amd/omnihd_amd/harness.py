@@ -201,16 +201,6 @@ class FusionTrainStep:
         model.train()
         self.raw_model = model
         self.model = model
-        # hipGraph capture of the static-shape image branch (forward AND backward replayed as one launch each):
-        # the step issues ~1800 kernels and is as much launch-bound on the host as it is GPU-bound.
-        self.graphed = []
-        want = os.environ.get("OMNIHD_GRAPH", "0")
-        if want not in ("", "0") and self.device.type == "cuda" and dtype == "bf16" and res != "tiny":
-            H, W, _ = RES[res]
-            with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=False):
-                sample = torch.randn(batch * 6, 3, H, W, device=self.device).contiguous(memory_format=torch.channels_last)
-                model.img_backbone = torch.cuda.make_graphed_callables(model.img_backbone, (sample,))
-            self.graphed.append("img_backbone")
         if ddp:
             self.model = nn.parallel.DistributedDataParallel(
                 model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
@@ -227,8 +217,7 @@ class FusionTrainStep:
         b = self.batches[self.i % len(self.batches)]
         self.i += 1
         self.opt.zero_grad(set_to_none=True)
-        with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.autocast,
-                            cache_enabled=not self.graphed):
+        with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.autocast):
             losses = self.model(return_loss=True, **b)
         total = sum(v if torch.is_tensor(v) else sum(v) for v in losses.values())
         total.backward()
