@@ -107,24 +107,18 @@ __global__ __launch_bounds__(256) void k_bn_partial(const u32x4* __restrict__ a,
   }
 }
 
-// sums[0][c], sums[1][c] = (sum over blocks of partial) * mult.  8 lanes share one output (strided over the
-// blocks, combined with a fixed shuffle tree), 32 outputs per workgroup: coalesced 128-byte reads.
+// sums[0][c], sums[1][c] = (sum over blocks of partial) * mult.  One wavefront per output: the 64 lanes stride
+// over the blocks (a handful of independent loads each) and combine with a fixed shuffle tree.
 __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ partial, int n_blocks, int c, float mult,
                                                    float* __restrict__ sums) {
-  const int out = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int part = threadIdx.x >> 5;             // 0..7
+  const int out = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (out >= 2 * c) return;
   float s = 0.f;
-  if (out < 2 * c)
-    for (int b = part; b < n_blocks; b += 8) s += partial[(size_t)b * 2 * c + out];
-  __shared__ float red[8][32];
-  red[part][threadIdx.x & 31] = s;
-  __syncthreads();
-  if (threadIdx.x < 32 && out < 2 * c) {
-    float t = 0.f;
+  for (int b = lane; b < n_blocks; b += 64) s += partial[(size_t)b * 2 * c + out];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) t += red[p][threadIdx.x];
-    sums[out] = t * mult;
-  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) sums[out] = s * mult;
 }
 
 // stats = (mean, meansqr) [2c] possibly summed over ranks -> * rank_mult; constants of the forward pass.
@@ -244,7 +238,7 @@ extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* 
   else
     hipLaunchKernelGGL((k_bn_partial<1>), dim3(blocks), dim3(256), 0, st, (const u32x4*)a, (const u32x4*)b,
                        (const u32x4*)mask, partial, rows, c / 8, per);
-  hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 31) / 32), dim3(256), 0, st, partial, blocks, c, mult, sums);
+  hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 3) / 4), dim3(256), 0, st, partial, blocks, c, mult, sums);
   return check_launch("bn_channel_sums");
 }
 
