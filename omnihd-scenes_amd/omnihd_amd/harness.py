@@ -102,6 +102,38 @@ def tiny_model_cfg(radar_dims=7):
     return cfg
 
 
+def occ_model_cfg(base):
+    """``base`` (a BEVFUSION_depth config dict) turned into the multi-task occupancy config of
+    projects/configs/bevfusion_NewScenes/bevfusion_occ.py:57-193: same trunk, detector BEVF_FasterRCNN_MTL, head
+    MultiTaskHeadv2 with the occupancy task enabled (12 classes x 16 height bins) and detection disabled."""
+    cfg = copy.deepcopy(base)
+    det_head = cfg.pop("pts_bbox_head")
+    det_head["type"] = "Anchor3DHeadV1"
+    det_head.update(in_channels=256, feat_channels=256)
+    r, g = cfg["pc_range"], cfg["grid"]
+    grid = dict(xbound=[r[0], r[3], g], ybound=[r[1], r[4], g], zbound=[-10.0, 10.0, 20.0], dbound=list(cfg["camera_depth_range"]))
+    cfg.update(type="BEVF_FasterRCNN_MTL", pts_bbox_head=dict(
+        type="MultiTaskHeadv2", in_channels=256, out_channels=256, grid_conf=grid, det_grid_conf=grid, occ_grid_conf=grid,
+        task_enbale={"3dod": False, "occ": True}, task_weights={"3dod": 1.0, "occ": 1.0}, bev_encode_block="Basic",
+        cfg_3dod=det_head, cfg_occ=dict(type="BEVOCCHead2Dv2", in_dim=256, out_dim=256, num_classes=12, use_predicter=True,
+                                        loss_occ=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0))))
+    return cfg
+
+
+def synthetic_occupancy(batch, nx, ny, nz, n_cls, device, seed):
+    """(B, Dx, Dy, Dz) class map: free space (0) with boxes of the other classes, a few unknown (255) voxels are NOT
+    generated — the reference's cross-entropy has no ignore index and would raise on them."""
+    rng = np.random.default_rng(seed + 77)
+    occ = np.zeros((batch, nx, ny, nz), dtype=np.int64)
+    for b in range(batch):
+        for _ in range(40):
+            c = int(rng.integers(1, n_cls))
+            x, y, z = int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(0, nz))
+            dx, dy, dz = (int(v) for v in rng.integers(1, 9, 3))
+            occ[b, x:x + dx, y:y + dy, z:z + min(dz, 4)] = c
+    return torch.from_numpy(occ).to(device)
+
+
 def synthetic_lidar2img(res):
     """Six pinhole cameras on a ring: float64 4x4 lidar2img per camera."""
     if res == "tiny":
@@ -188,11 +220,13 @@ class FusionTrainStep:
     dense convolutions (pooling, voxelisation and the losses stay fp32)."""
 
     def __init__(self, res="r1", batch=1, radar_dims=7, device="cuda:0", seed=0, dtype="bf16", ddp=False,
-                 channels_last=True, sets=2):
+                 channels_last=True, sets=2, task="det"):
         from .mm.config import build_detector
         self.device = torch.device(device)
         torch.manual_seed(0)                         # identical initial weights on every rank
         cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)
+        if task == "occ":
+            cfg = occ_model_cfg(cfg)
         model = build_detector(cfg).to(self.device)
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
@@ -210,6 +244,10 @@ class FusionTrainStep:
         self.params = params
         self.autocast = dtype == "bf16"
         self.batches = [synthetic_batch(res, batch, radar_dims, self.device, seed + 1000 * i) for i in range(sets)]
+        if task == "occ":
+            nx, ny = (int(round((cfg["pc_range"][3 + a] - cfg["pc_range"][a]) / cfg["grid"])) for a in (0, 1))
+            for i, b in enumerate(self.batches):
+                b["gt_occ"] = synthetic_occupancy(batch, nx, ny, 16, 12, self.device, seed + 1000 * i)
         self.i = 0
         self.last_losses = None
 

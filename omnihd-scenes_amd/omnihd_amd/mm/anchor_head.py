@@ -391,3 +391,8 @@ class Anchor3DHead(nn.Module):
             rot = limit_period(boxes[..., 6] - self.dir_offset, self.dir_limit_offset, np.pi)
             boxes[..., 6] = rot + self.dir_offset + np.pi * dirs.to(boxes.dtype)
         return box_type(boxes, box_dim=self.box_code_size), scores, labels
+
+
+# The reference vendors a copy of the upstream head under this name for its multi-task config
+# (projects/mmdet3d_plugin/bevfusion/dense_heads/det_anchor3d_head.py:18); same arguments, same arithmetic.
+HEADS.register_module(name="Anchor3DHeadV1", module=Anchor3DHead)

@@ -1,2 +1,3 @@
 from .detectors import *  # noqa: F401,F403
 from .necks import *  # noqa: F401,F403
+from .dense_heads import *  # noqa: F401,F403

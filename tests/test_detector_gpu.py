@@ -69,3 +69,36 @@ def test_full_size_detector_bf16_step_runs_and_is_finite(cuda):
     assert len(lss._plans) == 1
     assert np.isfinite([l0, l1]).all()
     assert set(st.last_losses) == {"loss_cls", "loss_bbox", "loss_dir", "img_depth_loss"}
+
+
+def test_occupancy_variant_tiny_parity_and_full_size_step(cuda):
+    """BEVF_FasterRCNN_MTL with the occupancy head — tiny model GPU (HIP ops) vs CPU (oracle ops)
+    in fp32, then one full-size bf16 step of the reference's occupancy configuration."""
+    import contextlib
+    from omnihd_amd.harness import FusionTrainStep
+    from oracle.torch_shim import oracle_ops
+
+    def run(device, use_oracle):
+        with (oracle_ops() if use_oracle else contextlib.nullcontext()):
+            st = FusionTrainStep(res="tiny", batch=2, radar_dims=7, device=device, seed=4, dtype="fp32", channels_last=False,
+                                 sets=1, task="occ")
+            m, b = st.raw_model, st.batches[0]
+            m.eval()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+            losses = m(return_loss=True, **b)
+            sum(v for v in losses.values()).backward()
+            g = m.pts_bbox_head.task_decoders["occ"].final_conv.conv.weight.grad.detach().cpu()
+            return {k: float(v) for k, v in losses.items()}, g
+    gl, gg = run("cuda:0", False)
+    cl, cg = run("cpu", True)
+    assert set(gl) == {"loss_ssc", "loss_occ", "occ_sum", "img_depth_loss"}
+    for k in cl:
+        assert abs(gl[k] - cl[k]) <= 1e-3 * max(abs(cl[k]), 1e-3), (k, gl[k], cl[k])
+    assert _close(gg, cg, 5e-3)
+    st = FusionTrainStep(res="r1", batch=1, radar_dims=7, device="cuda:0", dtype="bf16", task="occ")
+    l0 = float(st.step().detach())
+    l1 = float(st.step().detach())
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert set(st.last_losses) == {"loss_ssc", "loss_occ", "occ_sum", "img_depth_loss"}
