@@ -44,12 +44,18 @@ constexpr int kBK = 64;        // pixels per K-step
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxDil = 18;
 
-__global__ __launch_bounds__(kBlock) void k_to_kmajor(const unsigned short* __restrict__ in, int M,
-                                                      int C, int Cp, int W, int Wp, int Mp, int n_shifts,
-                                                      int dil, unsigned short* __restrict__ out) {
-  __shared__ unsigned short s[64][64 + 2 * kMaxDil + 2];   // [channel][pixel + halo]
+struct StageArgs {
+  const unsigned short* in;
+  unsigned short* out;
+  int C, Cp, n_shifts;
+};
+
+__device__ __forceinline__ void stage_kmajor(const unsigned short* __restrict__ in, int M, int C, int Cp, int W, int Wp,
+                                             int Mp, int n_shifts, int dil, unsigned short* __restrict__ out,
+                                             unsigned short (*s)[64 + 2 * kMaxDil + 2]) {
   const int m0 = blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
+  if (c0 >= Cp) return;
   const int tid = threadIdx.x;
   const int halo = (n_shifts == 1) ? 0 : dil;
   const int span = 64 + 2 * halo;
@@ -85,6 +91,14 @@ __global__ __launch_bounds__(kBlock) void k_to_kmajor(const unsigned short* __re
     *reinterpret_cast<uint4*>(out + ((size_t)sh * Cp + c0 + c) * Mp + m0 + q * 8) =
         *reinterpret_cast<const uint4*>(e);
   }
+}
+
+// One launch stages BOTH operands of a stride-1 convolution: blockIdx.z = 0 -> output gradient (one copy),
+// 1 -> input activations (n_shifts copies).  grid.y covers the wider of the two channel counts.
+__global__ __launch_bounds__(kBlock) void k_to_kmajor(StageArgs a0, StageArgs a1, int M, int W, int Wp, int Mp, int dil) {
+  __shared__ unsigned short s[64][64 + 2 * kMaxDil + 2];   // [channel][pixel + halo]
+  const StageArgs& a = blockIdx.z == 0 ? a0 : a1;
+  stage_kmajor(a.in, M, a.C, a.Cp, W, Wp, Mp, a.n_shifts, dil, a.out, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -290,6 +304,20 @@ int pick_split(int coutp, int cinp, int mp, int taps) {
 
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
+// 256 zero bytes per device, allocated once: the source of every masked LDS-DMA row (borders, K tail).
+const unsigned short* zero_page_for_current_device() {
+  static void* pages[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!pages[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;      // synchronous, once per device and process
+    pages[dev] = p;
+  }
+  return static_cast<const unsigned short*>(pages[dev]);
+}
+
 // How one convolution is laid out for the GEMM.
 struct WgradPlan {
   int mode;        // 0: three dx copies + row offsets (3x3, stride 1, pad == dil) or plain 1x1 ; 1: one copy per tap
@@ -358,8 +386,8 @@ extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc,
     return OMNIHD_ERR_WORKSPACE;
   }
   const int k_per_split = ((p.mp / kBK + p.split - 1) / p.split) * kBK;
-  unsigned short* zero_page = static_cast<unsigned short*>(workspace);       // 256 zero bytes
-  OMNIHD_HIP_TRY(hipMemsetAsync(zero_page, 0, 256, st));
+  const unsigned short* zero_page = zero_page_for_current_device();
+  OMNIHD_REQUIRE(zero_page != nullptr, "could not allocate the zero page");
   char* q = static_cast<char*>(workspace) + 256 + p.guard;
   unsigned short* Gt = reinterpret_cast<unsigned short*>(q);
   q += p.gt_bytes + p.guard;
@@ -369,17 +397,18 @@ extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc,
   const unsigned short* xs = static_cast<const unsigned short*>(x_nhwc);
   const unsigned short* gs = static_cast<const unsigned short*>(gout_nhwc);
 
-  const dim3 gG(p.mp / 64, p.coutp / 64), gX(p.mp / 64, p.cinp / 64);
+  const int cmax = p.coutp > p.cinp ? p.coutp : p.cinp;
+  const StageArgs aG{gs, Gt, cout, p.coutp, 1};
   if (p.mode == 0 && p.taps == 9) {
     // G and X share the padded raster (b, y, x) with row pitch wp
-    hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, gs, batch * h * w, cout, p.coutp, w, p.wp, p.mp, 1, dil, Gt);
-    hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, xs, batch * h * w, cin, p.cinp, w, p.wp, p.mp, 3, dil, Xt);
+    const StageArgs aX{xs, Xt, cin, p.cinp, 3};
+    hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, cmax / 64, 2), dim3(kBlock), 0, st, aG, aX, batch * h * w, w, p.wp, p.mp, dil);
   } else if (p.mode == 0) {
     // 1x1: the raster is the plain pixel index (one "row" of mp pixels, nothing to shift)
-    hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, gs, p.mpix, cout, p.coutp, p.mpix, p.mp, p.mp, 1, 1, Gt);
-    hipLaunchKernelGGL(k_to_kmajor, gX, dim3(kBlock), 0, st, xs, p.mpix, cin, p.cinp, p.mpix, p.mp, p.mp, 1, 1, Xt);
+    const StageArgs aX{xs, Xt, cin, p.cinp, 1};
+    hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, cmax / 64, 2), dim3(kBlock), 0, st, aG, aX, p.mpix, p.mpix, p.mp, p.mp, 1);
   } else {
-    hipLaunchKernelGGL(k_to_kmajor, gG, dim3(kBlock), 0, st, gs, p.mpix, cout, p.coutp, p.mpix, p.mp, p.mp, 1, 1, Gt);
+    hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, p.coutp / 64, 1), dim3(kBlock), 0, st, aG, aG, p.mpix, p.mpix, p.mp, p.mp, 1);
     hipLaunchKernelGGL(k_taps_kmajor, dim3(p.mp / 64, p.cinp / 64, p.taps), dim3(kBlock), 0, st, xs, batch, h, w, cin,
                        p.cinp, ho, wo, p.mp, kw, stride, pad, dil, Xt);
   }

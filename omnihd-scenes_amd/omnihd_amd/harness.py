@@ -261,5 +261,8 @@ class FusionTrainStep:
         total.backward()
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=35, norm_type=2)
         self.opt.step()
+        if self.device.type == "cuda":
+            from . import ops
+            ops.refresh_bf16_shadows()            # one fused fp32 -> bf16 copy of all convolution weights
         self.last_losses = losses
         return total

@@ -519,6 +519,42 @@ def wgrad_choices():
     return dict(_WGRAD_CHOICE)
 
 
+# bf16 images of the fp32 master weights.  Each convolution needs its weight rounded to bf16 once per step; done
+# layer by layer that is ~100 tiny cast kernels (and their Python) per step.  The images are kept here, keyed by
+# the parameter, and reused while the parameter's version counter is unchanged; a training loop may refresh all
+# of them with ONE multi-tensor copy right after the optimiser step (``refresh_bf16_shadows``).
+import weakref
+
+_BF16_SHADOW = {}
+
+
+def bf16_of(weight):
+    if weight.dtype == torch.bfloat16:
+        return weight.detach()
+    e = _BF16_SHADOW.get(id(weight))
+    if e is not None and e[0]() is weight and e[1] == weight._version and e[2].device == weight.device:
+        return e[2]
+    shadow = weight.detach().to(torch.bfloat16)
+    _BF16_SHADOW[id(weight)] = (weakref.ref(weight), weight._version, shadow)
+    return shadow
+
+
+def refresh_bf16_shadows():
+    """Bring every stale bf16 image up to date with one fused copy; returns how many were refreshed."""
+    src, dst, keys = [], [], []
+    for k, (ref, ver, shadow) in list(_BF16_SHADOW.items()):
+        w = ref()
+        if w is None:
+            del _BF16_SHADOW[k]
+        elif ver != w._version and w.device == shadow.device and w.shape == shadow.shape:
+            src.append(w.detach()); dst.append(shadow); keys.append((k, ref, w))
+    if src:
+        torch._foreach_copy_(dst, src)
+        for (k, ref, w), shadow in zip(keys, dst):
+            _BF16_SHADOW[k] = (ref, w._version, shadow)
+    return len(src)
+
+
 class _ConvHipWgrad(torch.autograd.Function):
     """Convolution whose forward and data gradient run on MIOpen and whose WEIGHT gradient runs on the
     hand-written MFMA kernel (the slowest dense kernels of the training step under MIOpen)."""
@@ -527,7 +563,7 @@ class _ConvHipWgrad(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, padding, dilation):
         # ``weight`` / ``bias`` may be the fp32 master parameters: they are rounded to the activation dtype here
         # and their gradients are returned in THEIR dtype, so autograd adds no cast kernels of its own.
-        wb = weight.detach().to(x.dtype)
+        wb = bf16_of(weight) if x.dtype == torch.bfloat16 else weight.detach().to(x.dtype)
         ctx.save_for_backward(x, wb)
         ctx.has_bias = bias is not None
         ctx.conv = (list(stride), list(padding), list(dilation))
@@ -567,7 +603,7 @@ class _DeconvHipWgrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, k):
-        wb = weight.detach().to(x.dtype)
+        wb = bf16_of(weight) if x.dtype == torch.bfloat16 else weight.detach().to(x.dtype)
         ctx.save_for_backward(x, wb)
         ctx.k, ctx.wdtype = k, weight.dtype
         return torch.nn.functional.conv_transpose2d(x, wb, None, stride=k)
