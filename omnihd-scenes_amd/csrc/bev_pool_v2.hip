@@ -198,6 +198,12 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+// Traffic attribution builds (scripts/pool_traffic_abl.sh): -DOMNIHD_POOL_ABL=1 replaces the depth gather by a
+// constant, =2 folds every feature gather onto 1024 L2-resident rows, =3 both.  Never defined in the product.
+#ifndef OMNIHD_POOL_ABL
+#define OMNIHD_POOL_ABL 0
+#endif
+
 template <int C4, int U>
 __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
     const float* __restrict__ depth, const float4* __restrict__ feat4,
@@ -321,9 +327,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   for (int k = 0; k < kPer; ++k) {
     const int i = tid + k * kBlock;
     if (i < npts) {
-      const float dv = depth[l_rd[k]];
+      const float dv = (OMNIHD_POOL_ABL & 1) ? 1.0f : depth[l_rd[k]];
       const int last = (l_row[k] != l_nxt[k]) ? (int)0x80000000 : 0;
-      s_rfd[i] = make_int2(l_rf[k] | last, __float_as_int(dv));
+      s_rfd[i] = make_int2(((OMNIHD_POOL_ABL & 2) ? (l_rf[k] & 1023) : l_rf[k]) | last, __float_as_int(dv));
       s_row[i] = l_row[k];
     }
   }

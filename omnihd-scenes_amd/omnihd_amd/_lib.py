@@ -4,7 +4,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libomnihd_hip.so")
+# OMNIHD_LIB_PATH: load another build of the same library (experiments such as scripts/pool_traffic_abl.sh)
+_LIB_PATH = os.environ.get("OMNIHD_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libomnihd_hip.so")
 
 # name -> (restype, argtypes); the authoritative declarations are in include/omnihd_hip.h
 PROTOTYPES = {
