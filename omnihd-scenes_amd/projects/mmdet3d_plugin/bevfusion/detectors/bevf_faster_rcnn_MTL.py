@@ -71,9 +71,8 @@ class BEVF_FasterRCNN_MTL(BEVFUSION_depth):
 
     @torch.no_grad()
     def simple_test(self, points, img_metas, img=None, gt_occ=None, rescale=False):
-        """-> {'bbox_results': [...], 'occ_pred': (B, Dx, Dy, Dz) class map}.  The reference goes on to score the
-        occupancy against ``gt_occ`` inside the model (:217-226, evaluation utilities of its occupancy toolkit);
-        here the class map is returned and scoring is left to the caller."""
+        """-> {'bbox_results': [...], 'occ_pred': (B, Dx, Dy, Dz) class map, 'occ_results': (B, n_cls, 3) counters
+        when ``gt_occ`` is given (reference :217-226)}."""
         fd = self.extract_feat(points, img=img, img_metas=img_metas)
         predictions = self.simple_test_pts(fd["pts_feats"], img_metas, rescale=rescale)
         if "bbox_results" in predictions:
@@ -82,6 +81,11 @@ class BEVF_FasterRCNN_MTL(BEVFUSION_depth):
             occ = predictions.pop("occ_pred")
             predictions["occ_pred"] = (occ.softmax(-1).argmax(-1) if self.use_semantic
                                        else torch.sigmoid(occ[..., 0]))
+            if gt_occ is not None and self.use_semantic:            # reference :217-222: score inside the model
+                from ...datasets.evaluation_metrics import aug_evaluation_semantic
+                gt = gt_occ[0] if isinstance(gt_occ, (list, tuple)) else gt_occ
+                predictions["occ_results"] = aug_evaluation_semantic(predictions["occ_pred"], gt, img_metas[0],
+                                                                     occ.shape[-1])
         return predictions
 
     def forward_test(self, points=None, img_metas=None, img=None, gt_occ=None, **kwargs):

@@ -129,6 +129,30 @@ class LoadRadarPointsMultiSweeps:
         return f"{self.__class__.__name__}(sweeps_num={self.sweeps_num})"
 
 
+class LoadOccupancy_Newscenes:
+    """Occupancy ground truth: ``results['occ_path']`` is an ``.npz`` whose ``occ_gt`` holds (N, 4) rows
+    (x, y, z voxel index, class); scattered into a dense ``occ_size`` grid, 0 = free (reference :66-104)."""
+
+    def __init__(self, use_semantic=True, class_names=None, occ_size=(240, 160, 16)):
+        self.use_semantic, self.class_names = use_semantic, class_names
+        self.num_classes = len(class_names or ()) + 1
+        self.occ_size = list(occ_size)
+
+    @staticmethod
+    def gt_to_voxel(gt, num_classes, occ_size):
+        voxel = np.zeros(occ_size)
+        voxel[gt[:, 0].astype(np.int64), gt[:, 1].astype(np.int64), gt[:, 2].astype(np.int64)] = gt[:, 3]
+        return voxel
+
+    def __call__(self, results):
+        occ = np.load(results["occ_path"])["occ_gt"].astype(np.float32)
+        results["gt_occ"] = self.gt_to_voxel(occ, self.num_classes, self.occ_size)
+        return results
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
 # ---- camera matrices that end up in img_metas['lidar2img'] ------------------------------------
 def half_scale_front_back(img_filenames, lidar2img, cam_intrinsic, factor=0.5):
     """Front and back cameras are stored at twice the resolution of the side cameras and are halved

@@ -67,3 +67,26 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def occupancy_scores():
+    """Second part: the reference's occupancy counters (datasets/evaluation_metrics.py:98-120), which import only
+    numpy and torch, on seeded class maps -> appended to occ_golden.npz."""
+    spec = importlib.util.spec_from_file_location("ref_eval", os.path.join(REF, "projects/mmdet3d_plugin/datasets/evaluation_metrics.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    path = os.path.join(HERE, "occ_golden.npz")
+    out = dict(np.load(path))
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randint(0, 12, (3, 20, 12, 8), generator=g)
+    gt = torch.randint(0, 12, (3, 20, 12, 8), generator=g)
+    gt[torch.rand(gt.shape, generator=g) < 0.6] = 0
+    pred[torch.rand(pred.shape, generator=g) < 0.5] = 0
+    out["score_pred"], out["score_gt"] = pred.numpy(), gt.numpy()
+    out["score_tables"] = ref.aug_evaluation_semantic(pred, gt, None, 12)
+    np.savez_compressed(path, **out)
+    print("scores", out["score_tables"].shape)
+
+
+if __name__ == "__main__":
+    occupancy_scores()

@@ -82,3 +82,27 @@ def test_tiny_occupancy_training_step_on_cpu_with_oracle_ops():
         m.eval()
         out = m(return_loss=False, points=[b["points"]], img_metas=[b["img_metas"]], img=[b["img"]])
     assert set(out) == {"occ_pred"} and out["occ_pred"].shape == (2, 16, 12, 16) and out["occ_pred"].dtype == torch.long
+
+
+def test_occupancy_counters_and_miou_match_reference(gold, tmp_path):
+    from projects.mmdet3d_plugin.datasets.evaluation_metrics import aug_evaluation_semantic, evaluation_semantic, occupancy_miou
+    from projects.mmdet3d_plugin.datasets.pipelines.loading import LoadOccupancy_Newscenes
+    pred, gt = torch.from_numpy(gold["score_pred"]), torch.from_numpy(gold["score_gt"])
+    tables = aug_evaluation_semantic(pred, gt, None, 12)
+    assert tables.dtype == np.float64 and np.array_equal(tables, gold["score_tables"])
+    names = [f"c{i}" for i in range(1, 12)]
+    res = occupancy_miou([t[None] for t in tables], names)
+    mean = gold["score_tables"].mean(0)
+    want = mean[:, 0] / (mean[:, 1] + mean[:, 2] - mean[:, 0])
+    assert res["IoU"] == want[0] and res["c5"] == want[5] and abs(res["mIoU"] - want[1:].mean()) < 1e-15
+    # sparse ground truth + unknown voxels, and the .npz loader
+    sparse = torch.tensor([[[0, 0, 0, 3], [1, 2, 3, 255], [4, 5, 6, 7]]])
+    dense_pred = torch.zeros(1, 20, 12, 8, dtype=torch.long)
+    dense_pred[0, 0, 0, 0] = 3; dense_pred[0, 1, 2, 3] = 9; dense_pred[0, 9, 9, 7] = 7
+    t = evaluation_semantic(dense_pred, sparse, dict(occ_size=[20, 12, 8]), 12)[0]
+    assert t[3].tolist() == [1, 1, 1] and t[7].tolist() == [0, 1, 1] and t[9].tolist() == [0, 0, 0]     # the 255 voxel is skipped
+    assert t[0].tolist() == [1, 2, 2]
+    path = tmp_path / "occ.npz"
+    np.savez(path, occ_gt=np.array([[0, 0, 0, 3], [4, 5, 6, 7]], dtype=np.int64))
+    vox = LoadOccupancy_Newscenes(class_names=names, occ_size=[20, 12, 8])({"occ_path": str(path)})["gt_occ"]
+    assert vox.shape == (20, 12, 8) and vox[0, 0, 0] == 3 and vox[4, 5, 6] == 7 and vox.sum() == 10
