@@ -477,7 +477,9 @@ def conv3x3_wgrad_supported(x, weight):
 # small feature maps, MIOpen's direct implicit GEMM wins where the pixel axis is long and the channel counts are
 # small (scripts/wgrad_census.py), and which of MIOpen's solvers is picked depends on the box — so, like MIOpen's
 # own find step, the choice is MEASURED once per geometry (a handful of launches during warm-up) and cached.
-# OMNIHD_WGRAD_POLICY = hip (default: in the full step the isolated timings did not carry over, 45.4 vs 46.3 ms) | tune | miopen
+# OMNIHD_WGRAD_POLICY = tune (default) | hip | miopen.  Measured in the full R1 step with MIOpen in find mode
+# (torch.backends.cudnn.benchmark = True): tune 35.8 ms (our chain on the 8 BEV-sized geometries, MIOpen on 37), hip 38.5 ms,
+# miopen 41.6 ms.  With MIOpen's immediate-mode kernels (benchmark off) our chain wins nearly everywhere: 45.4 vs 46.3 ms.
 _WGRAD_CHOICE = {}
 
 
@@ -488,7 +490,7 @@ def _miopen_wgrad(x, g, weight, stride, padding, dilation):
 
 def _tuned_wgrad(x, g, weight, stride, padding, dilation):
     import os
-    policy = os.environ.get("OMNIHD_WGRAD_POLICY", "hip")
+    policy = os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
     k = weight.shape[2]
     run_hip = lambda: conv_wgrad(x, g, k, stride[0], padding[0], dilation[0])
     if policy == "hip":
