@@ -130,6 +130,11 @@ class BevConv2d(nn.Conv2d):
         from .. import ops
         if (self.training and weight.requires_grad and torch.is_autocast_enabled() and x.is_cuda and self.groups == 1
                 and self.padding_mode == "zeros" and not isinstance(self.padding, str)):
+            # once a geometry has been measured in MIOpen's favour the layer is a plain convolution again
+            # (no Python in its backward); unmeasured geometries go through the function that measures
+            if ops.wgrad_choice_for(x.shape, weight.shape[0], weight.shape[2], self.stride[0], self.padding[0],
+                                    self.dilation[0], x.device.index) == "miopen":
+                return super()._conv_forward(x, weight, bias)
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             if ops.conv_wgrad_supported(xb, weight, self.stride, self.padding, self.dilation):
                 return ops.conv_hip_wgrad(xb, weight, bias, self.stride, self.padding, self.dilation)

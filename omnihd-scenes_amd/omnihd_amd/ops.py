@@ -516,6 +516,15 @@ def _tuned_wgrad(x, g, weight, stride, padding, dilation):
     return run_hip() if choice == "hip" else run_mi()
 
 
+def wgrad_choice_for(x_shape, cout, k, stride, padding, dilation, device_index):
+    """'hip' | 'miopen' | None (not measured yet) for a convolution geometry under the current policy."""
+    import os
+    policy = os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
+    if policy != "tune":
+        return policy
+    return _WGRAD_CHOICE.get((tuple(x_shape), cout, k, stride, padding, dilation, device_index))
+
+
 def wgrad_choices():
     """{geometry: 'hip' | 'miopen'} decided so far (for logs and DESIGN.md tables)."""
     return dict(_WGRAD_CHOICE)
