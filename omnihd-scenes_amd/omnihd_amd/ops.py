@@ -791,8 +791,8 @@ def _rows_view(t):
 
 
 def _f32c(t):
-    t = t.detach()
-    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+    # only the data pointer is read: a contiguous fp32 parameter is used as it is (no detach() object per call)
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
 
 
 class _BnTrainAct(torch.autograd.Function):
