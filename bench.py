@@ -314,7 +314,11 @@ def main():
     if a.workload == "fusion":
         from omnihd_amd.harness import FusionTrainStep
         wl = FusionTrainStep(res=a.res, batch=a.batch, radar_dims=radar_dims, device=f"cuda:{local}", seed=1234 + rank,
-                             dtype=a.dtype, ddp=world > 1)
+                             dtype=a.dtype, ddp=world > 1, miopen_find=True)
+        # set-up, not warm-up: MIOpen's find step and the per-geometry weight-gradient measurement run during the first
+        # two or three steps (each geometry once); they are finished before the W warm-up steps start
+        for _ in range(3):
+            wl.step()
     else:
         wl = BevOps(a.res, a.batch, dev, seed=1234 + rank)
 

@@ -220,12 +220,13 @@ class FusionTrainStep:
     dense convolutions (pooling, voxelisation and the losses stay fp32)."""
 
     def __init__(self, res="r1", batch=1, radar_dims=7, device="cuda:0", seed=0, dtype="bf16", ddp=False,
-                 channels_last=True, sets=2, task="det"):
+                 channels_last=True, sets=2, task="det", miopen_find=False):
         from .mm.config import build_detector
         self.device = torch.device(device)
-        if self.device.type == "cuda":
+        if self.device.type == "cuda" and miopen_find:
             # MIOpen "find" mode: every convolution geometry is timed once over the applicable solvers instead of
-            # taking the immediate-mode heuristic (41.0 -> 37.9 ms per step at R1)
+            # taking the immediate-mode heuristic (41.0 -> 37.9 ms per step at R1; costs ~1 min of warm-up, so it is
+            # opt-in: bench.py and the profiling scripts ask for it, the tests do not)
             torch.backends.cudnn.benchmark = True
         torch.manual_seed(0)                         # identical initial weights on every rank
         cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)

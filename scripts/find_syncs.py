@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "omnihd-scenes_amd")]
 import torch
 from omnihd_amd.harness import FusionTrainStep
 
-st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16")
+st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16", miopen_find=True)
 for _ in range(4):
     st.step()
 torch.cuda.synchronize()

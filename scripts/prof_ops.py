@@ -8,7 +8,7 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 from omnihd_amd.harness import FusionTrainStep
 
-st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16")
+st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16", miopen_find=True)
 for _ in range(6):
     st.step()
 torch.cuda.synchronize()

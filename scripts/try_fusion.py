@@ -9,7 +9,7 @@ from omnihd_amd.harness import FusionTrainStep
 res = sys.argv[1] if len(sys.argv) > 1 else "r1"
 dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 t0 = time.time()
-st = FusionTrainStep(res=res, batch=1, radar_dims=7 if res == "r1" else 8, dtype=dtype)
+st = FusionTrainStep(res=res, batch=1, radar_dims=7 if res == "r1" else 8, dtype=dtype, miopen_find=True)
 print("built", time.time() - t0)
 for i in range(3):
     t0 = time.time(); loss = st.step(); torch.cuda.synchronize()

@@ -18,7 +18,7 @@ def spy(x, g, k, stride=1, padding=0, dilation=1):
 
 
 ops.conv_wgrad = spy
-st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16")
+st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16", miopen_find=True)
 st.step(); st.step()
 seen.clear()
 st.step()
