@@ -59,15 +59,23 @@ class MVXFasterRCNN(nn.Module):
         return feats
 
     @torch.no_grad()
-    def voxelize(self, points):
-        """Per-sample hard voxelisation (HIP kernel), concatenated, batch index prepended to coors."""
+    def voxelize_begin(self, points):
+        """Enqueue the per-sample hard voxelisation (HIP kernels); nothing is read back yet."""
+        return [self.pts_voxel_layer.begin(res) for res in points]
+
+    @torch.no_grad()
+    def voxelize_end(self, pending):
+        """Voxel counts arrive (one event wait per sample), outputs are concatenated, batch index prepended."""
         voxels, coors, nums = [], [], []
-        for i, res in enumerate(points):
-            v, c, n = self.pts_voxel_layer(res)
+        for i, h in enumerate(pending):
+            v, c, n = h.get()
             voxels.append(v)
             nums.append(n)
             coors.append(F.pad(c, (1, 0), mode="constant", value=i))
         return torch.cat(voxels, dim=0), torch.cat(nums, dim=0), torch.cat(coors, dim=0)
+
+    def voxelize(self, points):
+        return self.voxelize_end(self.voxelize_begin(points))
 
     def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore=None):
         outs = self.pts_bbox_head(pts_feats)

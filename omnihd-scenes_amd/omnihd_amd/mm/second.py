@@ -27,6 +27,16 @@ class Voxelization(nn.Module):
         return ops.hard_voxelize(points.contiguous().float(), self.voxel_size, self.point_cloud_range,
                                  self.max_num_points, max_voxels)
 
+    def begin(self, points):
+        """Enqueue the voxelisation and return a handle whose ``get()`` yields ``forward``'s result (device tensors
+        only; CPU tensors — tests over the oracle — take the synchronous path)."""
+        if not points.is_cuda:
+            done = self.forward(points)
+            return type("Done", (), {"get": staticmethod(lambda: done)})()
+        max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
+        return ops.hard_voxelize_async(points.contiguous().float(), self.voxel_size, self.point_cloud_range,
+                                       self.max_num_points, max_voxels)
+
 
 @MIDDLE_ENCODERS.register_module()
 class PointPillarsScatter(nn.Module):

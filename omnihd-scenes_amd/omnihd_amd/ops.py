@@ -322,8 +322,21 @@ def backward_tables(ranks_bev, ranks_depth, ranks_feat, n_feat_rows=None):
 # ---------------------------------------------------------------------------------------------
 # radar: hard voxelisation + pillar scatter
 # ---------------------------------------------------------------------------------------------
-def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels):
-    """One sample: points (N,F) fp32 -> (voxels (M,max_points,F), coors (M,3)=(z,y,x) int32,
+class PendingVoxels:
+    """Voxelisation that has been enqueued; ``get()`` waits only for ITS event (the voxel count travelling to pinned
+    host memory), not for the device queue — so work enqueued in between (the image branch) is not drained."""
+
+    def __init__(self, voxels, coors, num_points, host_count, event):
+        self.voxels, self.coors, self.num_points, self.host_count, self.event = voxels, coors, num_points, host_count, event
+
+    def get(self):
+        self.event.synchronize()
+        m = int(self.host_count[0])
+        return self.voxels[:m], self.coors[:m], self.num_points[:m]
+
+
+def hard_voxelize_async(points, voxel_size, point_cloud_range, max_points, max_voxels):
+    """One sample: points (N,F) fp32 -> PendingVoxels of (voxels (M,max_points,F), coors (M,3)=(z,y,x) int32,
     num_points (M,) int32).  mmdet3d Voxelization semantics (see include/omnihd_hip.h)."""
     _want(points, torch.float32, "points")
     n, f = points.shape
@@ -332,21 +345,27 @@ def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels)
     coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
     num_points = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
     voxel_num = torch.zeros(1, dtype=torch.int32, device=dev)
-    h_num = ctypes.c_int(0)
     h_vs = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in voxel_size])
     h_rg = (ctypes.c_float * 6)(*[float(np.float32(v)) for v in point_cloud_range])
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws_bytes = lib().omnihd_voxelize_workspace_bytes(n)
         if ws_bytes == 0:
             check(-4, "omnihd_voxelize_workspace_bytes")
         ws = _workspace(ws_bytes, dev)
         check(lib().omnihd_voxelize_hard(_ptr(points), n, f, ctypes.cast(h_vs, ctypes.c_void_p),
                                          ctypes.cast(h_rg, ctypes.c_void_p), max_points, max_voxels,
-                                         _ptr(voxels), _ptr(coors), _ptr(num_points), _ptr(voxel_num),
-                                         ctypes.cast(ctypes.pointer(h_num), ctypes.c_void_p),
+                                         _ptr(voxels), _ptr(coors), _ptr(num_points), _ptr(voxel_num), None,
                                          _ptr(ws), ws.numel(), _stream()), "omnihd_voxelize_hard")
-    m = int(h_num.value)
-    return voxels[:m], coors[:m], num_points[:m]
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(voxel_num, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    return PendingVoxels(voxels, coors, num_points, host, ev)
+
+
+def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels):
+    """Synchronous form of ``hard_voxelize_async``."""
+    return hard_voxelize_async(points, voxel_size, point_cloud_range, max_points, max_voxels).get()
 
 
 class _PillarScatter(torch.autograd.Function):

@@ -98,11 +98,13 @@ class BEVFUSION_depth(MVXFasterRCNN):
         return hit
 
     def extract_feat(self, points, img, img_metas, gt_bboxes_3d=None):
-        # Voxelisation first: its voxel count comes back to the host (the one synchronisation of the forward
-        # pass) — at this point the device queue is short, later it would drain the whole image branch.
-        vox = self.voxelize(points) if self.with_pts_backbone and points is not None else None
+        # The voxelisation kernels are enqueued first and their voxel count is awaited (one event) only after the
+        # image branch has been enqueued: the host never drains the device queue inside a step, so it can run ahead
+        # of the GPU across step boundaries (7 ms of stall per step before).
+        vox = self.voxelize_begin(points) if self.with_pts_backbone and points is not None else None
         img_feats = self.extract_img_feat(img, img_metas)
-        pts_feats = self.extract_pts_feat(points, img_feats, img_metas, voxelized=vox)
+        pts_feats = self.extract_pts_feat(points, img_feats, img_metas,
+                                          voxelized=None if vox is None else self.voxelize_end(vox))
         depth_dist = None
         if self.lift:
             BN, C, H, W = img_feats[0].shape

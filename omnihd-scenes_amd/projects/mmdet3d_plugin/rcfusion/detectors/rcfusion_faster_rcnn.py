@@ -47,9 +47,10 @@ class RCFusion_FasterRCNN(BEVFUSION_depth):
     def extract_feat(self, points, img, img_metas, gt_bboxes_3d=None):
         if self.rc_fusion != "cross_attention":
             return super().extract_feat(points, img, img_metas, gt_bboxes_3d)
-        vox = self.voxelize(points) if self.with_pts_backbone and points is not None else None
+        vox = self.voxelize_begin(points) if self.with_pts_backbone and points is not None else None
         img_feats = self.extract_img_feat(img, img_metas)
-        pts_feats = self.extract_pts_feat(points, img_feats, img_metas, voxelized=vox)
+        pts_feats = self.extract_pts_feat(points, img_feats, img_metas,
+                                          voxelized=None if vox is None else self.voxelize_end(vox))
         depth_dist = None
         if self.lift:
             BN, C, H, W = img_feats[0].shape
