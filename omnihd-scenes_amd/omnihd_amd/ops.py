@@ -121,6 +121,22 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
               "omnihd_bev_pool_v2_fwd_csr")
 
 
+def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, depth_bins, feat_hw):
+    """Dense tiled forward reading one per-point table (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_lean)."""
+    _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
+    _want(ranks_depth, torch.int32, "ranks_depth"); _want(row_ptr, torch.int32, "row_ptr")
+    _want(tile_desc, torch.int32, "tile_desc")
+    c = feat.size(-1)
+    n_rows = row_ptr.numel() - 1
+    if out.numel() != n_rows * c:
+        raise ValueError(f"out has {out.numel()} elements, expected {n_rows}*{c}")
+    dev = _same_device(depth, feat, out, ranks_depth, row_ptr, tile_desc)
+    with _on(dev):
+        check(lib().omnihd_bev_pool_v2_fwd_lean(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(row_ptr), _ptr(tile_desc),
+                                                tile_desc.size(0), _ptr(out), c, n_rows, ranks_depth.numel(), int(depth_bins),
+                                                int(feat_hw), _stream()), "omnihd_bev_pool_v2_fwd_lean")
+
+
 def bev_pool_v2_backward_sched(out_grad, depth, feat, ranks_depth, ranks_row, pix_desc, depth_grad, feat_grad):
     """Scheduled backward (see include/omnihd_hip.h): ``pix_desc`` (8*k, 4) int32 lists every pixel once."""
     for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad),

@@ -42,6 +42,8 @@ class BevPoolPlan:
     bp_starts: torch.Tensor
     bp_lengths: torch.Tensor
     pix_desc: torch.Tensor = None   # int32 [8*k, 4] schedule of the scheduled backward (every pixel once)
+    depth_bins: int = 0             # D and fH*fW of the frustum the plan was built from (0: unknown, e.g. foreign
+    feat_hw: int = 0                # tables): with them the forward derives ranks_feat from ranks_depth in-kernel
 
     @property
     def n_intervals(self):
@@ -173,8 +175,10 @@ def build_plan(coor, dx, bx, nx, layout="byxz", origin_xy=None):
     if origin_xy is not None:
         origin_cell = ((float(origin_xy[0]) - (float(bx[0]) - float(dx[0]) / 2)) / float(dx[0]) - 0.5,
                        (float(origin_xy[1]) - (float(bx[1]) - float(dx[1]) / 2)) / float(dx[1]) - 0.5)
-    return _finish(layout, (B, Z, Y, X), rows, rd, rf, starts.contiguous(), lengths.contiguous(), B * N * H * W,
+    plan = _finish(layout, (B, Z, Y, X), rows, rd, rf, starts.contiguous(), lengths.contiguous(), B * N * H * W,
                    feat_hw=(H, W), origin_cell=origin_cell)
+    plan.depth_bins, plan.feat_hw = int(D), int(H * W)
+    return plan
 
 
 def plan_from_tables(ranks_bev, ranks_depth, ranks_feat, grid, n_feat_rows, layout="bzyx", feat_hw=None):
@@ -192,6 +196,12 @@ def plan_from_tables(ranks_bev, ranks_depth, ranks_feat, grid, n_feat_rows, layo
                    lengths.contiguous(), n_feat_rows, feat_hw=feat_hw)
 
 
+def _lean_forward():
+    """OMNIHD_POOL_LEAN=1: one-table forward kernel (k_pool_fwd_lean) instead of the three-table one."""
+    import os
+    return os.environ.get("OMNIHD_POOL_LEAN", "0") == "1"
+
+
 class _PlannedPool(torch.autograd.Function):
     """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order."""
 
@@ -200,8 +210,12 @@ class _PlannedPool(torch.autograd.Function):
         depth = depth.contiguous().float()
         feat = feat.contiguous().float()
         out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
-        ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
-                                    plan.ranks_row, plan.tile_desc)
+        if plan.depth_bins > 0 and plan.tile_desc is not None and plan.n_points > 0 and _lean_forward():
+            ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, out,
+                                         plan.depth_bins, plan.feat_hw)
+        else:
+            ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
+                                        plan.ranks_row, plan.tile_desc)
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan
         return out
