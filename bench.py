@@ -145,6 +145,7 @@ class BevOps:
         self.ops, self.omnihd = ops, omnihd_amd
         self.dev, self.batch = dev, batch
         self.tiled = True
+        self.lean = os.environ.get("OMNIHD_POOL_LEAN", "1") != "0"      # one-table forward kernel (default)
         self.sched_bwd = True
         self.scheduled = True
         H, W, _ = RES[res]
@@ -174,7 +175,10 @@ class BevOps:
 
     def pool_fwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
-        self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out, tb[9], tb[8] if self.tiled else None)
+        if self.tiled and self.lean:
+            self.ops.bev_pool_v2_forward_lean(depth, feat, tb[0], tb[2], tb[8], out, self.D, self.fH * self.fW)
+        else:
+            self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out, tb[9], tb[8] if self.tiled else None)
 
     def pool_bwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
@@ -391,7 +395,7 @@ def main():
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
                                        "overlapped with backward) + naiveSyncBN stat exchange" if a.workload == "fusion"
                                        else f"dp{world} (independent frames, no data-path collective)")},
-            "roofline": {"kernel": "k_pool_fwd_tiles<16,4> (bev_pool_v2 forward, dense, balanced tiles, azimuth XCD schedule)", "bound": "hbm",
+            "roofline": {"kernel": "k_pool_fwd_lean<16,4> (bev_pool_v2 forward, dense, balanced tiles, azimuth XCD schedule, one rank table)", "bound": "hbm",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_fwd * 1e6, 2),
                          "bwd_mean_launch_us": round(t_bwd * 1e6, 2)},

@@ -197,9 +197,10 @@ def plan_from_tables(ranks_bev, ranks_depth, ranks_feat, grid, n_feat_rows, layo
 
 
 def _lean_forward():
-    """OMNIHD_POOL_LEAN=1: one-table forward kernel (k_pool_fwd_lean) instead of the three-table one."""
+    """The one-table forward kernel (k_pool_fwd_lean) is the default when the plan knows its frustum geometry;
+    OMNIHD_POOL_LEAN=0 selects the three-table kernel (bit-identical results, 43.2 vs 51.2 us at R1 in one run)."""
     import os
-    return os.environ.get("OMNIHD_POOL_LEAN", "0") == "1"
+    return os.environ.get("OMNIHD_POOL_LEAN", "1") != "0"
 
 
 class _PlannedPool(torch.autograd.Function):

@@ -13,7 +13,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c: continue
         n = r["Kernel_Name"]
-        if "k_pool_fwd_tiles" in n: pool.append(float(r["Counter_Value"]))
+        if ("k_pool_fwd_tiles" in n or "k_pool_fwd_lean" in n): pool.append(float(r["Counter_Value"]))
         elif "MulFunctor" in n or "mul" in n.lower(): copy.append(float(r["Counter_Value"]))
     vals[c] = (sum(copy[-8:]) / max(len(copy[-8:]), 1), sum(pool) / max(len(pool), 1))
 copy_bytes = 128 * 1024 * 1024

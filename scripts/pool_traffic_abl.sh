@@ -14,7 +14,7 @@ f = glob.glob("$OUT/a$A/**/*counter_collection.csv", recursive=True)[0]
 pool, copy = [], []
 for r in csv.DictReader(open(f)):
     if r["Counter_Name"] != "FETCH_SIZE": continue
-    (pool if "k_pool_fwd_tiles" in r["Kernel_Name"] else copy if "MulFunctor" in r["Kernel_Name"] else []).append(float(r["Counter_Value"]))
+    (pool if ("k_pool_fwd_tiles" in r["Kernel_Name"] or "k_pool_fwd_lean" in r["Kernel_Name"]) else copy if "MulFunctor" in r["Kernel_Name"] else []).append(float(r["Counter_Value"]))
 cal = 128 * 1024 * 1024 / (sum(copy[-8:]) / len(copy[-8:]) * 1024)
 print("abl $A: fetch %.1f MB per launch (calibration x%.3f)" % (sum(pool) / len(pool) * 1024 * cal / 1e6, cal))
 PY
