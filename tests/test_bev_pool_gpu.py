@@ -10,7 +10,7 @@ import torch
 
 from oracle import cpu as OC
 from oracle import lss_oracle as O
-from tests.helpers import RefKernels, random_tables, t
+from tests.helpers import RefKernels, full_size_geometry, random_tables, t
 
 pytestmark = pytest.mark.gpu
 
@@ -285,3 +285,51 @@ def test_v1_pool_matches_oracle(cuda):
     want_xg = np.empty_like(xg_sorted)
     want_xg[order] = xg_sorted
     assert np.array_equal(x.grad.cpu().numpy(), want_xg)
+
+
+@pytest.mark.parametrize("tile_items,long_len", [(64, 64), (200, 256), (768, 512)])
+@pytest.mark.parametrize("c,B", [(64, 1), (8, 2)])
+def test_one_table_forward_is_bit_identical_to_three_table_forward(cuda, tile_items, long_len, c, B):
+    """k_pool_fwd_lean derives the pixel row from the depth index and the closing points from row_ptr: same bits as
+    k_pool_fwd_tiles on heavy-tailed rows (rows longer than a tile, empty runs, rows cut at piece boundaries)."""
+    from omnihd_amd import ops
+    from omnihd_amd.plan import tile_schedule
+    rng = np.random.default_rng(tile_items + c + B)
+    N, D, fH, fW = 2, 7, 5, 12
+    fhw, n_rows = fH * fW, 2500
+    rows = np.concatenate([np.full(4000, 3), np.full(1300, 4), np.full(2600, 1200), np.full(600, n_rows - 1),
+                           rng.choice(n_rows, 500, replace=False).repeat(rng.integers(1, 12, 500))])
+    rows = np.sort(rows).astype(np.int32)
+    rd = rng.integers(0, B * N * D * fhw, rows.size).astype(np.int32)
+    rf = ((rd // (D * fhw)) * fhw + rd % fhw).astype(np.int32)            # what the kernel must derive
+    depth = t(rng.random((B, N, D, fH, fW), dtype=np.float32), cuda)
+    feat = t(rng.standard_normal((B, N, fH, fW, c), dtype=np.float32), cuda)
+    row_ptr = ops.csr_from_sorted_keys(t(rows, cuda), n_rows)
+    tiles = ops.csr_tiles(row_ptr, tile_items, long_len)
+    for order in (None, tile_schedule(row_ptr, tiles, t(rf, cuda), (fH, fW))):
+        desc = ops.tile_descriptors(row_ptr, tiles, order)
+        a = torch.full((n_rows, c), float("nan"), device=cuda)
+        b = torch.full((n_rows, c), float("nan"), device=cuda)
+        ops.bev_pool_v2_forward_csr(depth, feat, t(rd, cuda), t(rf, cuda), row_ptr, a, t(rows, cuda), desc)
+        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b, D, fhw)
+        assert not torch.isnan(b).any()
+        assert torch.equal(a, b)
+    st, ln = O.run_length(rows)
+    want = OC.bev_pool_v2_fwd(depth.cpu().numpy(), feat.cpu().numpy(), rd, rf, rows, (1, 1, 1, n_rows, c), st, ln)
+    np.testing.assert_allclose(b.cpu().numpy(), want.reshape(n_rows, c), rtol=1e-5, atol=2e-4)
+
+
+def test_one_table_forward_full_size_plan(cuda):
+    """R1 frame geometry: the planned pool (one-table kernel by default) against the three-table kernel."""
+    from omnihd_amd import build_plan, ops
+    geom, dx, bx, nx = full_size_geometry("r1")
+    plan = build_plan(t(geom, cuda), dx, bx, nx, layout="byxz")
+    assert plan.depth_bins == 59 and plan.feat_hw == 64 * 176
+    g = torch.Generator(device="cpu").manual_seed(0)
+    depth = torch.rand(1, 6, 59, 64, 176, generator=g).softmax(2).to(cuda)
+    feat = torch.randn(1, 6, 64, 176, 64, generator=g).to(cuda)
+    a = torch.empty(plan.n_rows, 64, device=cuda)
+    b = torch.full((plan.n_rows, 64), float("nan"), device=cuda)
+    ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, a, plan.ranks_row, plan.tile_desc)
+    ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, b, plan.depth_bins, plan.feat_hw)
+    assert torch.equal(a, b)
