@@ -22,6 +22,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Traffic attribution builds (scripts/pool_traffic_abl.sh): -DOMNIHD_POOL_ABL=1 replaces the depth gather by a
+// constant, =2 folds every feature gather onto 1024 L2-resident rows, =3 both; +4 drops the stores of pooled rows, +8 the zero-fill stores (timing skeletons only).  Never defined in the product.
+#ifndef OMNIHD_POOL_ABL
+#define OMNIHD_POOL_ABL 0
+#endif
+
 namespace omnihd {
 namespace {
 
@@ -198,11 +204,6 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
-// Traffic attribution builds (scripts/pool_traffic_abl.sh): -DOMNIHD_POOL_ABL=1 replaces the depth gather by a
-// constant, =2 folds every feature gather onto 1024 L2-resident rows, =3 both.  Never defined in the product.
-#ifndef OMNIHD_POOL_ABL
-#define OMNIHD_POOL_ABL 0
-#endif
 
 template <int C4, int U>
 __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
       for (int k = 0; k < 64; k += GPW) {
         const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
         if (window == 0ull) continue;
-        if ((m >> (k + gw)) & 1ull)
+        if (((m >> (k + gw)) & 1ull) && !(OMNIHD_POOL_ABL & 8))
           store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
       }
     }
@@ -544,7 +545,10 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     const int i = tid + k * kBlock;
-    if (i < npts) s_rfd[i] = make_int2(pixel_row(l_rd[k]), __float_as_int(depth[l_rd[k]]));
+    if (i < npts) {
+      const int px = (OMNIHD_POOL_ABL & 2) ? (pixel_row(l_rd[k]) & 1023) : pixel_row(l_rd[k]);
+      s_rfd[i] = make_int2(px, __float_as_int((OMNIHD_POOL_ABL & 1) ? 1.0f : depth[l_rd[k]]));
+    }
   }
   if (tid < G) s_head_row[tid] = -1;
   __syncthreads();
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
             s_head[tid] = acc;
             if (sub == 0) s_head_row[grp] = row;
             head_pending = false;
-          } else {
+          } else if (!(OMNIHD_POOL_ABL & 4) || acc.x == 1.2345e30f) {
             store_row(out4 + (size_t)row * C4 + sub, acc, true);
           }
           acc = zero4;
