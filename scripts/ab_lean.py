@@ -9,6 +9,7 @@ from omnihd_amd import ops
 
 for res in (sys.argv[1:] or ["r1"]):
     wl = bench.BevOps(res, 1, torch.device("cuda:0"), 1234)
+    wl.lean = False                                   # wl.pool_fwd = the three-table kernel
     D, fhw = wl.D, wl.fH * wl.fW
 
     def lean(s):
