@@ -359,6 +359,23 @@ int omnihd_bn_train_bwd(const void* gy, const void* y_mask, const void* x, const
                         void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Radar input format: sweep merge + ego-motion compensation on the device
+ * ---------------------------------------------------------------------------------------- */
+
+/* ref: LoadRadarPointsMultiSweeps.__call__, projects/mmdet3d_plugin/datasets/pipelines/loading.py:229-309.
+ *   raw            [n, load_dim] f32: the returns of all used sweeps, concatenated in the reference's order
+ *                  (radar by radar, newest sweep first); columns x, y, z, v_r, power, motion_state, SNR, valid
+ *   sweep_offsets  [n_sweeps+1] i32: first row of each sweep in `raw`
+ *   sweep_consts   [n_sweeps, 17] f64 per sweep: ego velocity in the SENSOR frame (3), sensor2lidar rotation
+ *                  (9, row major), sensor2lidar translation (3), time lag dt (1), radar id (1)
+ *   out10          [n, 10] f32: x, y, z, vx_comp, vy_comp, power, snr, dt, Vr_comp, radar_id (LiDAR frame)
+ *   in_range       [n] u8 (may be NULL): strict range test against pc_range6 (device f32[6]), as RadarPoints.in_range_3d
+ * Positions are bit-identical to the host loader; velocity columns to float32 trigonometry accuracy.   */
+int omnihd_radar_merge(const float* raw, int n, int load_dim, const int* sweep_offsets, int n_sweeps,
+                       const double* sweep_consts, const float* pc_range6, float* out10, unsigned char* in_range,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "omnihd_bn_train_fwd": (c_int, [c_void_p] * 6 + [c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_int, c_void_p, c_size_t, c_void_p]),
     "omnihd_bn_train_bwd": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "omnihd_radar_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omnihd_iou_bev_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }
 

@@ -922,3 +922,27 @@ def bn_train_act(x, weight, bias, running_mean, running_var, momentum, eps, relu
     cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if x.dim() == 4 else (lambda t: t.contiguous())
     return _BnTrainAct.apply(cl(x), weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), group,
                              None if residual is None else cl(residual))
+
+
+# --------------------------------------------------------------------------------------------
+# Radar sweep merge on the device (LoadRadarPointsMultiSweeps arithmetic)
+# --------------------------------------------------------------------------------------------
+def radar_merge(raw, sweep_offsets, sweep_consts, pc_range=None):
+    """raw (N, load_dim) fp32, sweep_offsets (S+1,) int32, sweep_consts (S, 17) fp64 -> (points (N, 10) fp32,
+    in_range (N,) bool or None).  See include/omnihd_hip.h: omnihd_radar_merge."""
+    _want(raw, torch.float32, "raw"); _want(sweep_offsets, torch.int32, "sweep_offsets")
+    _want(sweep_consts, torch.float64, "sweep_consts")
+    dev = _same_device(raw, sweep_offsets, sweep_consts)
+    n, load_dim = raw.shape
+    n_sweeps = sweep_offsets.numel() - 1
+    if sweep_consts.shape != (n_sweeps, 17):
+        raise ValueError("sweep_consts must be (n_sweeps, 17)")
+    out = torch.empty((n, 10), dtype=torch.float32, device=dev)
+    mask = rng = None
+    if pc_range is not None:
+        mask = torch.empty((n,), dtype=torch.uint8, device=dev)
+        rng = torch.tensor([float(v) for v in pc_range], dtype=torch.float32, device=dev)
+    with _on(dev):
+        check(lib().omnihd_radar_merge(_ptr(raw), n, load_dim, _ptr(sweep_offsets), n_sweeps, _ptr(sweep_consts), _ptr(rng),
+                                       _ptr(out), _ptr(mask), _stream()), "omnihd_radar_merge")
+    return out, (None if mask is None else mask.bool())

@@ -73,6 +73,31 @@ def merge_radar_sweeps(radars, read_points, sweeps_num=3, load_dim=8):
     return np.concatenate(merged, axis=0)
 
 
+def merge_radar_sweeps_device(radars, read_points, device, sweeps_num=3, load_dim=8, pc_range=None):
+    """The same merge on the GPU (csrc/radar_merge.hip): the raw sweeps are concatenated and uploaded once, the
+    per-sweep constants (ego velocity turned into the sensor frame, rotation, translation, time lag, radar id) are
+    prepared on the host in float64 exactly as the reference does, one kernel does the per-return arithmetic.
+    -> (points (M, 10) fp32 on ``device``, in-range mask or None)."""
+    from omnihd_amd import ops
+    raws, consts, offsets = [], [], [0]
+    for key, sweeps in radars.items():
+        use = range(len(sweeps)) if len(sweeps) < sweeps_num else range(sweeps_num)
+        ts = int(sweeps[0]["timestamp"]) * 1e-6
+        for idx in use:
+            sweep = sweeps[idx]
+            pts = np.asarray(read_points(sweep["data_path"]), dtype=np.float32).reshape(-1, load_dim)
+            v_ego = np.array(sweep["ego_velocity"]).reshape(-1, 3)
+            v_sensor = (v_ego @ np.linalg.inv(quaternion_rotation_matrix(sweep["sensor2ego_rotation"])).T)[0]
+            consts.append(np.concatenate([v_sensor, np.asarray(sweep["sensor2lidar_rotation"], dtype=np.float64).ravel(),
+                                          np.asarray(sweep["sensor2lidar_translation"], dtype=np.float64),
+                                          [ts - int(sweep["timestamp"]) * 1e-6, float(RADAR_ID[key])]]))
+            raws.append(pts)
+            offsets.append(offsets[-1] + len(pts))
+    raw = torch.from_numpy(np.concatenate(raws, 0)).to(device)
+    return ops.radar_merge(raw, torch.tensor(offsets, dtype=torch.int32, device=device),
+                           torch.from_numpy(np.stack(consts)).to(device), pc_range)
+
+
 class RadarPoints:
     """Minimal point container (reference core/points/radar_points.py:5-28 over mmdet3d BasePoints):
     float32 tensor (N, points_dim), range test with strict inequalities, boolean indexing."""
@@ -106,8 +131,9 @@ class LoadRadarPointsMultiSweeps:
     ``file_client_args`` is accepted for config compatibility (only the disk backend exists here)."""
 
     def __init__(self, load_dim=8, use_dim=(0, 1, 2, 3, 4, 5, 6, 7), sweeps_num=3, file_client_args=None, max_num=300,
-                 pc_range=(-72, -56, -3.0, 72, 56, 5.0), test_mode=False):
+                 pc_range=(-72, -56, -3.0, 72, 56, 5.0), test_mode=False, device=None):
         self.load_dim, self.use_dim, self.sweeps_num = load_dim, list(use_dim), sweeps_num
+        self.device = device          # e.g. "cuda:0": merge on the GPU, the points never exist on the host
         self.max_num, self.pc_range, self.test_mode = max_num, list(pc_range), test_mode
         if file_client_args and file_client_args.get("backend", "disk") != "disk":
             raise NotImplementedError("only the disk backend is provided")
@@ -119,6 +145,12 @@ class LoadRadarPointsMultiSweeps:
         return np.fromfile(pts_filename, dtype=np.float32)
 
     def __call__(self, results):
+        if self.device is not None:
+            pts, mask = merge_radar_sweeps_device(results["radars"], self._load_points, self.device, self.sweeps_num,
+                                                  self.load_dim, self.pc_range)
+            pts = pts[mask][:, self.use_dim]
+            results["points"] = RadarPoints(pts, points_dim=pts.shape[-1], attribute_dims=None)
+            return results
         points = merge_radar_sweeps(results["radars"], self._load_points, self.sweeps_num, self.load_dim)
         points = points[:, self.use_dim]
         points = RadarPoints(points, points_dim=points.shape[-1], attribute_dims=None)
