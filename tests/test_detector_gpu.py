@@ -102,3 +102,27 @@ def test_occupancy_variant_tiny_parity_and_full_size_step(cuda):
     l1 = float(st.step().detach())
     assert np.isfinite(l0) and np.isfinite(l1)
     assert set(st.last_losses) == {"loss_ssc", "loss_occ", "occ_sum", "img_depth_loss"}
+
+
+def test_ddp_wrapped_step_on_one_gpu(cuda):
+    """DistributedDataParallel over RCCL with a single rank: the reducer's hooks, bucket views and our autograd functions
+    (weight-gradient chain, fused BatchNorm, pooling) in one bf16 training step; run in a child process so that the
+    process group does not leak into the other tests."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, math, torch, torch.distributed as dist\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'omnihd-scenes_amd')!r}]\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "from omnihd_amd.harness import FusionTrainStep\n"
+        "st = FusionTrainStep(res='r1', batch=1, radar_dims=7, device='cuda:0', dtype='bf16', ddp=True)\n"
+        "l = [float(st.step().detach()) for _ in range(3)]\n"
+        "torch.cuda.synchronize()\n"
+        "missing = [n for n, p in st.raw_model.named_parameters() if p.requires_grad and p.grad is None]\n"
+        "assert all(math.isfinite(v) for v in l) and not missing, (l, missing[:5])\n"
+        "dist.destroy_process_group()\n"
+        "print('DDP_OK', l)\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DDP_OK" in out.stdout, out.stderr[-2000:]
