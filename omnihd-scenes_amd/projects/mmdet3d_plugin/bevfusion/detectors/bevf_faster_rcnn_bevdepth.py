@@ -10,6 +10,8 @@ kernels; the pooled BEV tensor arrives channels-last and zero-copy; ``batch_size
 host (``len(img_metas)``) instead of the reference's device->host ``coors[-1, 0] + 1`` sync (:100);
 camera inverses are computed in one batched fp32 ``inverse`` on the host (:116-130 builds 12 tiny
 tensors per sample).  ``simple_test`` does not render debug figures (reference defect D7)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -80,6 +82,42 @@ class BEVFUSION_depth(MVXFasterRCNN):
             x = self.pts_neck(x)
         return x
 
+    def _radar_branch_async(self, points, img_metas, vox):
+        """Run the radar branch (pillar net, scatter, SECOND, FPN) on a second host thread and a second HIP stream
+        while this thread enqueues the camera branch: the step is as much bound by the host's enqueue rate as by the
+        GPU, and the radar kernels are too small to fill the chip on their own.  Returns a join function."""
+        import threading
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)
+        state = dict(grad=torch.is_grad_enabled(), amp=torch.is_autocast_enabled(),
+                     amp_dtype=torch.get_autocast_dtype("cuda"), device=torch.cuda.current_device())
+        box = {}
+
+        def work():
+            try:
+                torch.cuda.set_device(state["device"])
+                with torch.set_grad_enabled(state["grad"]), torch.cuda.stream(side), \
+                        torch.autocast("cuda", dtype=state["amp_dtype"], enabled=state["amp"]):
+                    box["out"] = self.extract_pts_feat(points, None, img_metas, voxelized=self.voxelize_end(vox))
+            except BaseException as e:      # re-raised on the calling thread
+                box["err"] = e
+
+        th = threading.Thread(target=work)
+        th.start()
+
+        def join():
+            th.join()
+            if "err" in box:
+                raise box["err"]
+            main.wait_stream(side)
+            for t in box["out"]:
+                t.record_stream(main)
+            return box["out"]
+        return join
+
     _inverse_cache = {}
 
     @classmethod
@@ -102,11 +140,30 @@ class BEVFUSION_depth(MVXFasterRCNN):
         # image branch has been enqueued: the host never drains the device queue inside a step, so it can run ahead
         # of the GPU across step boundaries (7 ms of stall per step before).
         vox = self.voxelize_begin(points) if self.with_pts_backbone and points is not None else None
+        radar = None
+        if vox is not None and img is not None and img.is_cuda and os.environ.get("OMNIHD_DUAL_STREAM", "0") == "1":
+            radar = self._radar_branch_async(points, img_metas, vox)     # second host thread + second stream
         img_feats = self.extract_img_feat(img, img_metas)
-        pts_feats = self.extract_pts_feat(points, img_feats, img_metas,
-                                          voxelized=None if vox is None else self.voxelize_end(vox))
+        if radar is None:
+            pts_feats = self.extract_pts_feat(points, img_feats, img_metas,
+                                              voxelized=None if vox is None else self.voxelize_end(vox))
         depth_dist = None
-        if self.lift:
+        if self.lift and radar is not None:
+            # camera stream first (this thread), then meet the radar branch
+            BN, C, H, W = img_feats[0].shape
+            view = img_feats[0].view(BN // self.num_views, self.num_views, C, H, W)
+            rots, trans = self._cam_inverse(img_metas, view.device)
+            img_bev_feat, depth_dist = self.lift_splat_shot_vis(view, rots, trans, lidar2img_rt=None, img_metas=img_metas)
+            pts_feats = radar()
+            if self.lc_fusion:
+                if img_bev_feat.shape[2:] != pts_feats[0].shape[2:]:
+                    img_bev_feat = F.interpolate(img_bev_feat, pts_feats[0].shape[2:], mode="bilinear", align_corners=True)
+                pts_feats = [self.reduc_conv(torch.cat([img_bev_feat, pts_feats[0]], dim=1))]
+                if self.se:
+                    pts_feats = [self.seblock(pts_feats[0])]
+        elif radar is not None:
+            pts_feats = radar()
+        elif self.lift:
             BN, C, H, W = img_feats[0].shape
             batch_size = BN // self.num_views
             view = img_feats[0].view(batch_size, self.num_views, C, H, W)
