@@ -147,3 +147,45 @@ def test_rank_averaged_statistics_two_ranks_on_one_gpu(cuda):
         assert errs["y"] < 4e-3 and errs["gx"] < 1e-2, (rank, errs)
         assert errs["gw"] < 3e-3 and errs["gb"] < 3e-3, (rank, errs)
         assert errs["rm"] < 1e-3 and errs["rv"] < 1e-3, (rank, errs)
+
+
+def _ddp_worker(rank, world, port, q, dual):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMNIHD_DUAL_STREAM="1" if dual else "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path[:0] = [root, os.path.join(root, "omnihd-scenes_amd")]
+        from omnihd_amd.harness import FusionTrainStep
+        st = FusionTrainStep(res="tiny", batch=1, radar_dims=7, device="cuda:0", seed=10 + rank, dtype="bf16", ddp=True, sets=1)
+        losses = [float(st.step().detach()) for _ in range(3)]
+        torch.cuda.synchronize()
+        digest = float(sum(p.detach().double().sum() for p in st.raw_model.parameters()))
+        q.put((rank, losses, digest))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_two_rank_ddp_step_with_synced_batch_norm_on_one_gpu(cuda, dual):
+    """Two ranks (gloo, both on this GPU) train the tiny detector under DDP with the fused rank-averaged BatchNorm —
+    single-stream and with the radar branch on a second host thread + stream: finite losses, identical weights on both
+    ranks after three steps (the gradient all-reduce and every statistics exchange happened in the same order)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000 + (7 if dual else 0)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, dual)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        rank, losses, digest = q.get(timeout=600)
+        res[rank] = (losses, digest)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, (losses, _) in res.items():
+        assert all(np.isfinite(losses)), (rank, losses)
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * max(abs(res[0][1]), 1.0), (res[0][1], res[1][1])
