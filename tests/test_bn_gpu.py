@@ -4,6 +4,8 @@ projects/mmdet3d_plugin/ops/norm.py:28-82) variant against the reference algorit
 two ranks sharing the one GPU over a gloo group."""
 import os
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
