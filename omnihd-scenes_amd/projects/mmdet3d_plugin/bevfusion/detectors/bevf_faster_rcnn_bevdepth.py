@@ -141,7 +141,9 @@ class BEVFUSION_depth(MVXFasterRCNN):
         # of the GPU across step boundaries (7 ms of stall per step before).
         vox = self.voxelize_begin(points) if self.with_pts_backbone and points is not None else None
         radar = None
-        if vox is not None and img is not None and img.is_cuda and os.environ.get("OMNIHD_DUAL_STREAM", "0") == "1":
+        # default on for training on the GPU (33.2 -> 31.7 ms per step at R1); OMNIHD_DUAL_STREAM=0 turns it off
+        if vox is not None and img is not None and img.is_cuda and self.training \
+                and os.environ.get("OMNIHD_DUAL_STREAM", "1") != "0":
             radar = self._radar_branch_async(points, img_metas, vox)     # second host thread + second stream
         img_feats = self.extract_img_feat(img, img_metas)
         if radar is None:
