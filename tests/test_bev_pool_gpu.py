@@ -227,14 +227,17 @@ def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
                                 ops.tile_descriptors(row_ptr, ops.csr_tiles(row_ptr, 128, 64)))
     assert out.abs().sum() == 0
     rows = torch.zeros(5000, dtype=torch.int32, device=cuda)             # one row holds everything
-    rd = torch.randint(0, 8, (5000,), dtype=torch.int32, device=cuda)
-    rf = torch.randint(0, 4, (5000,), dtype=torch.int32, device=cuda)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rd = torch.randint(0, 8, (5000,), dtype=torch.int32, generator=g).to(cuda)
+    rf = torch.randint(0, 4, (5000,), dtype=torch.int32, generator=g).to(cuda)
     row_ptr = ops.csr_from_sorted_keys(rows, 1)
     out = torch.empty(1, 64, device=cuda)
     ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out, rows,
                                 ops.tile_descriptors(row_ptr, ops.csr_tiles(row_ptr, 256, 256)))
-    want = (depth.view(-1)[rd.long()][:, None].double() * feat.view(4, 64)[rf.long()].double()).sum(0)
-    torch.testing.assert_close(out[0].double(), want, rtol=1e-5, atol=1e-4)
+    terms = depth.view(-1)[rd.long()][:, None].double() * feat.view(4, 64)[rf.long()].double()
+    want = terms.sum(0)
+    # 5000 fp32 products summed in the kernel's split order: error bound relative to the sum of magnitudes
+    assert float(((out[0].double() - want).abs() / terms.abs().sum(0)).max()) < 2e-6
 
 
 def test_against_reference_kernels_compiled_by_hipcc(cuda):
