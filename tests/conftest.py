@@ -28,3 +28,16 @@ def cuda():
     import omnihd_amd
     omnihd_amd.require_gpu()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _seed_everything():
+    """Every test starts from the same generator state (host and device): no run-to-run variation in inputs."""
+    import random
+
+    import numpy as np
+    import torch
+    random.seed(1234)
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    yield
