@@ -62,7 +62,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured here: copy 5.2 TB/s, fill 6.5 TB/s (scripts/write_bw.py)
 RES = {"r1": (256, 704, 410.0), "r2": (544, 960, 560.0)}
 PC_RANGE = [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
 
