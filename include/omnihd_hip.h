@@ -329,10 +329,13 @@ int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, voi
 
 size_t omnihd_bn_workspace_bytes(long long rows, int c);
 /* mode 0: sums[0:c] = mult * sum_rows a,  sums[c:2c] = mult * sum_rows a^2           (forward statistics)
- * mode 1: g' = a * [mask > 0] (mask NULL: all pass); sums[0:c] = mult * sum g', sums[c:2c] = mult * sum g' * b
+ * mode 1: g' = a * [mask > 0]; sums[0:c] = mult * sum g', sums[c:2c] = mult * sum g' * b.  With mask NULL the ReLU
+ *         mask is recomputed as [b * scale + shift > 0] from fwd_scale_shift [2c] (the forward's constants: no
+ *         saved output to read), or everything passes when that is NULL too.
  * Two-stage reduction in a fixed order (deterministic).                                              */
-int omnihd_bn_channel_sums(const void* a, const void* b, const void* mask, float* sums, long long rows, int c,
-                           int mode, float mult, void* workspace, size_t workspace_bytes, void* stream);
+int omnihd_bn_channel_sums(const void* a, const void* b, const void* mask, const float* fwd_scale_shift, float* sums,
+                           long long rows, int c, int mode, float mult, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* stats = (mean, mean of squares) [2c], possibly summed over ranks: multiplied by rank_mult (1/R) here.
  * Writes scale = gamma * invstd, shift = beta - mean * scale (feed omnihd_affine_act_fwd), mean, invstd,
  * and updates running_mean / running_var (both NULL to skip) with `momentum`;
@@ -347,17 +350,18 @@ int omnihd_bn_bwd_consts(const float* local_sums, const float* global_sums, cons
                          const float* invstd, float inv_count, int c, float* dgamma, float* dbeta, float* coef_a,
                          float* coef_b, float* coef_c, void* stream);
 /* gx = g' * a + x * b + c;  gres (may be NULL) = g', the gradient of a residual added before the ReLU.   */
-int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const void* x, const float* coef_a, const float* coef_b,
-                        const float* coef_c, void* gx, void* gres, long long rows, int c, void* stream);
+int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const float* fwd_scale_shift, const void* x,
+                        const float* coef_a, const float* coef_b, const float* coef_c, void* gx, void* gres,
+                        long long rows, int c, void* stream);
 
 /* One-call single-rank forms of the above (no statistics exchange): see csrc/batch_norm.hip.             */
 int omnihd_bn_train_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float momentum, float eps, float var_correction, int relu, void* y,
                         float* stats2c, float* consts4c, long long rows, int c, void* workspace,
                         size_t workspace_bytes, void* stream);
-int omnihd_bn_train_bwd(const void* gy, const void* y_mask, const void* x, const float* gamma, const float* consts4c,
-                        void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
-                        size_t workspace_bytes, void* stream);
+int omnihd_bn_train_bwd(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma,
+                        const float* consts4c, void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Radar input format: sweep merge + ego-motion compensation on the device

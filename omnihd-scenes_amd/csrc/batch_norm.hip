@@ -31,8 +31,9 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // partial[block][0][c] = s1, partial[block][1][c] = s2 over the block's rows.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bn_partial(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
-                                                    const u32x4* __restrict__ m, float* __restrict__ partial,
-                                                    long long rows, int c8, long long rows_per_block) {
+                                                    const u32x4* __restrict__ m, const float* __restrict__ fss,
+                                                    float* __restrict__ partial, long long rows, int c8,
+                                                    long long rows_per_block) {
   __shared__ float red[2][256][8];
   const int t = threadIdx.x;
   const int rpi = 256 / c8;                      // rows handled per iteration by the workgroup
@@ -74,9 +75,12 @@ __global__ __launch_bounds__(256) void k_bn_partial(const u32x4* __restrict__ a,
           const unsigned short* me = reinterpret_cast<const unsigned short*>(&mv[u]);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const float g = bf2f(me[k]) > 0.f ? bf2f(ae[k]) : 0.f;
+            const float xv = bf2f(be[k]);
+            // ReLU mask: from the saved output, or recomputed from x with the forward's own fmaf (no y to read)
+            const bool pass = (m || !fss) ? bf2f(me[k]) > 0.f : fmaf(xv, fss[vcol * 8 + k], fss[c8 * 8 + vcol * 8 + k]) > 0.f;
+            const float g = pass ? bf2f(ae[k]) : 0.f;
             s1[k] += g;
-            s2[k] = fmaf(g, bf2f(be[k]), s2[k]);
+            s2[k] = fmaf(g, xv, s2[k]);
           }
         }
       }
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_consts(const float* __restrict__
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const u32x4* __restrict__ gy, const u32x4* __restrict__ y,
                                                       const u32x4* __restrict__ x, const float* __restrict__ coefA,
                                                       const float* __restrict__ coefB, const float* __restrict__ coefC,
-                                                      u32x4* __restrict__ gx, u32x4* __restrict__ gres, int64_t n_vec,
-                                                      int c8) {
+                                                      const float* __restrict__ fss, u32x4* __restrict__ gx,
+                                                      u32x4* __restrict__ gres, int64_t n_vec, int c8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
     const u32x4 gv = __builtin_nontemporal_load(gy + i);
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const u32x4* __restrict__ 
     unsigned short* re = reinterpret_cast<unsigned short*>(&masked);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool pass = bf2f(me[k]) > 0.f;
+      const bool pass = (y || !fss) ? bf2f(me[k]) > 0.f : fmaf(bf2f(xe[k]), fss[c + k], fss[c8 * 8 + c + k]) > 0.f;
       re[k] = pass ? ge[k] : (unsigned short)0;
       const float g = pass ? bf2f(ge[k]) : 0.f;
       oe[k] = f2bf(fmaf(g, coefA[c + k], fmaf(bf2f(xe[k]), coefB[c + k], coefC[c + k])));
@@ -222,9 +226,9 @@ extern "C" size_t omnihd_bn_workspace_bytes(long long rows, int c) {
 
 /* mode 0: sums = (sum x, sum x^2) * mult over a [rows, c] bf16;  mode 1: (sum g', sum g' x) * mult with
  * g' = a * [mask > 0] (mask may be NULL), x = b.                                                       */
-extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* mask, float* sums, long long rows,
-                                      int c, int mode, float mult, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
+extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* mask, const float* fwd_scale_shift,
+                                      float* sums, long long rows, int c, int mode, float mult, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
   OMNIHD_REQUIRE(rows > 0 && c > 0 && c % 8 == 0 && c <= 2048, "rows > 0, C a multiple of 8, C <= 2048");
   OMNIHD_REQUIRE(a && sums && workspace && (mode == 0 || b), "null pointer");
   OMNIHD_REQUIRE(workspace_bytes >= omnihd_bn_workspace_bytes(rows, c), "workspace too small");
@@ -234,10 +238,10 @@ extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* 
   float* partial = static_cast<float*>(workspace);
   if (mode == 0)
     hipLaunchKernelGGL((k_bn_partial<0>), dim3(blocks), dim3(256), 0, st, (const u32x4*)a, (const u32x4*)nullptr,
-                       (const u32x4*)nullptr, partial, rows, c / 8, per);
+                       (const u32x4*)nullptr, (const float*)nullptr, partial, rows, c / 8, per);
   else
     hipLaunchKernelGGL((k_bn_partial<1>), dim3(blocks), dim3(256), 0, st, (const u32x4*)a, (const u32x4*)b,
-                       (const u32x4*)mask, partial, rows, c / 8, per);
+                       (const u32x4*)mask, fwd_scale_shift, partial, rows, c / 8, per);
   hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 3) / 4), dim3(256), 0, st, partial, blocks, c, mult, sums);
   return check_launch("bn_channel_sums");
 }
@@ -263,15 +267,16 @@ extern "C" int omnihd_bn_bwd_consts(const float* local_sums, const float* global
   return check_launch("bn_bwd_consts");
 }
 
-extern "C" int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const void* x, const float* coef_a,
-                                   const float* coef_b, const float* coef_c, void* gx, void* gres, long long rows,
-                                   int c, void* stream) {
+extern "C" int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const float* fwd_scale_shift, const void* x,
+                                   const float* coef_a, const float* coef_b, const float* coef_c, void* gx, void* gres,
+                                   long long rows, int c, void* stream) {
   OMNIHD_REQUIRE(rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
   if (rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && gx, "null pointer");
   const int64_t n_vec = (int64_t)rows * (c / 8);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n_vec, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)gy,
-                     (const u32x4*)y_mask, (const u32x4*)x, coef_a, coef_b, coef_c, (u32x4*)gx, (u32x4*)gres, n_vec, c / 8);
+                     (const u32x4*)y_mask, (const u32x4*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (u32x4*)gx, (u32x4*)gres, n_vec,
+                     c / 8);
   return check_launch("bn_bwd_apply");
 }
 
@@ -282,8 +287,8 @@ extern "C" int omnihd_bn_train_fwd(const void* x, const void* res, const float* 
                                    float* running_mean, float* running_var, float momentum, float eps,
                                    float var_correction, int relu, void* y, float* stats2c, float* consts4c,
                                    long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = omnihd_bn_channel_sums(x, nullptr, nullptr, stats2c, rows, c, 0, 1.0f / (float)rows, workspace, workspace_bytes,
-                                  stream);
+  int rc = omnihd_bn_channel_sums(x, nullptr, nullptr, nullptr, stats2c, rows, c, 0, 1.0f / (float)rows, workspace,
+                                  workspace_bytes, stream);
   if (rc) return rc;
   rc = omnihd_bn_fwd_consts(stats2c, 1.0f, gamma, beta, eps, momentum, var_correction, c, running_mean, running_var,
                             consts4c, consts4c + c, consts4c + 2 * c, consts4c + 3 * c, stream);
@@ -293,13 +298,14 @@ extern "C" int omnihd_bn_train_fwd(const void* x, const void* res, const float* 
 
 /* backward = masked channel sums -> dgamma/dbeta + coefficients -> gx (and gres).  out5c [5, c] receives
  * dgamma, dbeta and the three coefficient vectors; sums2c is scratch.                                     */
-extern "C" int omnihd_bn_train_bwd(const void* gy, const void* y_mask, const void* x, const float* gamma,
+extern "C" int omnihd_bn_train_bwd(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma,
                                    const float* consts4c, void* gx, void* gres, float* sums2c, float* out5c,
                                    long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = omnihd_bn_channel_sums(gy, x, y_mask, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream);
+  const float* fss = (relu_from_x && !y_mask) ? consts4c : nullptr;    // consts4c starts with scale, shift
+  int rc = omnihd_bn_channel_sums(gy, x, y_mask, fss, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream);
   if (rc) return rc;
   rc = omnihd_bn_bwd_consts(sums2c, sums2c, gamma, consts4c + 2 * c, consts4c + 3 * c, 1.0f / (float)rows, c, out5c,
                             out5c + c, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, stream);
   if (rc) return rc;
-  return omnihd_bn_bwd_apply(gy, y_mask, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream);
+  return omnihd_bn_bwd_apply(gy, y_mask, fss, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream);
 }

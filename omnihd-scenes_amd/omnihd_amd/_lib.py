@@ -52,13 +52,13 @@ PROTOTYPES = {
     "omnihd_affine_act_fwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "omnihd_affine_act_bwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
     "omnihd_bn_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "omnihd_bn_channel_sums": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "omnihd_bn_channel_sums": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "omnihd_bn_fwd_consts": (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_float, c_float, c_float, c_int] + [c_void_p] * 7),
     "omnihd_bn_bwd_consts": (c_int, [c_void_p] * 5 + [c_float, c_int] + [c_void_p] * 6),
-    "omnihd_bn_bwd_apply": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_void_p]),
+    "omnihd_bn_bwd_apply": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_void_p]),
     "omnihd_bn_train_fwd": (c_int, [c_void_p] * 6 + [c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_int, c_void_p, c_size_t, c_void_p]),
-    "omnihd_bn_train_bwd": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "omnihd_bn_train_bwd": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "omnihd_radar_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omnihd_iou_bev_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }

@@ -858,8 +858,8 @@ class _BnTrainAct(torch.autograd.Function):
                                             1 if relu else 0, y.data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c,
                                             ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd")
             else:
-                check(L.omnihd_bn_channel_sums(x.data_ptr(), None, None, stats.data_ptr(), rows, c, 0, 1.0 / rows, ws.data_ptr(),
-                                               ws.numel(), st), "omnihd_bn_channel_sums")
+                check(L.omnihd_bn_channel_sums(x.data_ptr(), None, None, None, stats.data_ptr(), rows, c, 0, 1.0 / rows,
+                                               ws.data_ptr(), ws.numel(), st), "omnihd_bn_channel_sums")
                 dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
                 # the reference's SyncBN keeps the biased variance (ops/norm.py:74-75)
                 check(L.omnihd_bn_fwd_consts(stats.data_ptr(), 1.0 / ranks, gamma.data_ptr(), beta.data_ptr(), eps, momentum, 1.0,
@@ -867,7 +867,9 @@ class _BnTrainAct(torch.autograd.Function):
                                              consts[3].data_ptr(), st), "omnihd_bn_fwd_consts")
                 check(L.omnihd_affine_act_fwd(x.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), resp, y.data_ptr(), rows, c,
                                               1 if relu else 0, st), "omnihd_affine_act_fwd")
-        ctx.save_for_backward(x, y if relu else None, gamma, consts)
+        # the ReLU mask of the backward is recomputed from x with the forward's constants; only a residual (which is
+        # not kept) makes the saved output necessary
+        ctx.save_for_backward(x, y if (relu and res is not None) else None, gamma, consts)
         ctx.relu, ctx.group, ctx.ranks, ctx.param_dtypes = relu, group, ranks, (weight.dtype, bias.dtype)
         ctx.has_res = res is not None
         return y
@@ -892,19 +894,20 @@ class _BnTrainAct(torch.autograd.Function):
         with _on(dev):
             ws = _wgrad_workspace(_SIZE_CACHE[("bn", rows, c)], dev)
             if ctx.ranks == 1:
-                check(L.omnihd_bn_train_bwd(gy.data_ptr(), yp, x.data_ptr(), gamma.data_ptr(), consts.data_ptr(), gx.data_ptr(),
-                                            gresp, local.data_ptr(), out.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st),
-                      "omnihd_bn_train_bwd")
+                check(L.omnihd_bn_train_bwd(gy.data_ptr(), yp, 1 if ctx.relu else 0, x.data_ptr(), gamma.data_ptr(),
+                                            consts.data_ptr(), gx.data_ptr(), gresp, local.data_ptr(), out.data_ptr(), rows, c,
+                                            ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_bwd")
             else:
-                check(L.omnihd_bn_channel_sums(gy.data_ptr(), x.data_ptr(), yp, local.data_ptr(), rows, c, 1, 1.0, ws.data_ptr(),
-                                               ws.numel(), st), "omnihd_bn_channel_sums")
+                fss = consts.data_ptr() if (ctx.relu and yp is None) else None
+                check(L.omnihd_bn_channel_sums(gy.data_ptr(), x.data_ptr(), yp, fss, local.data_ptr(), rows, c, 1, 1.0,
+                                               ws.data_ptr(), ws.numel(), st), "omnihd_bn_channel_sums")
                 glob = local.clone()
                 dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.group)
                 check(L.omnihd_bn_bwd_consts(local.data_ptr(), glob.data_ptr(), gamma.data_ptr(), consts[2].data_ptr(),
                                              consts[3].data_ptr(), 1.0 / (ctx.ranks * rows), c, out[0].data_ptr(),
                                              out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(), st),
                       "omnihd_bn_bwd_consts")
-                check(L.omnihd_bn_bwd_apply(gy.data_ptr(), yp, x.data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+                check(L.omnihd_bn_bwd_apply(gy.data_ptr(), yp, fss, x.data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
                                             out[4].data_ptr(), gx.data_ptr(), gresp, rows, c, st), "omnihd_bn_bwd_apply")
         return (gx, out[0].to(ctx.param_dtypes[0]), out[1].to(ctx.param_dtypes[1]), None, None, None, None, None, None,
                 gres)
