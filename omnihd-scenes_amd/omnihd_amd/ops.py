@@ -1,5 +1,6 @@
 """Tensor-level wrappers over the C ABI (argument checks + pointer/stream hand-over only)."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -869,7 +870,8 @@ class _BnTrainAct(torch.autograd.Function):
                                               1 if relu else 0, st), "omnihd_affine_act_fwd")
         # the ReLU mask of the backward is recomputed from x with the forward's constants; only a residual (which is
         # not kept) makes the saved output necessary
-        ctx.save_for_backward(x, y if (relu and res is not None) else None, gamma, consts)
+        keep_y = relu and (res is not None or os.environ.get("OMNIHD_BN_MASK_FROM_X", "1") == "0")
+        ctx.save_for_backward(x, y if keep_y else None, gamma, consts)
         ctx.relu, ctx.group, ctx.ranks, ctx.param_dtypes = relu, group, ranks, (weight.dtype, bias.dtype)
         ctx.has_res = res is not None
         return y
