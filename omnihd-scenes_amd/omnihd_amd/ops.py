@@ -868,9 +868,11 @@ class _BnTrainAct(torch.autograd.Function):
                                              consts[3].data_ptr(), st), "omnihd_bn_fwd_consts")
                 check(L.omnihd_affine_act_fwd(x.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), resp, y.data_ptr(), rows, c,
                                               1 if relu else 0, st), "omnihd_affine_act_fwd")
-        # the ReLU mask of the backward is recomputed from x with the forward's constants; only a residual (which is
-        # not kept) makes the saved output necessary
-        keep_y = relu and (res is not None or os.environ.get("OMNIHD_BN_MASK_FROM_X", "1") == "0")
+        # The ReLU mask of the backward comes from the saved output.  The kernels can also recompute it from x with the
+        # forward's constants (OMNIHD_BN_MASK_FROM_X=1: one tensor less to read), but that measured SLOWER in the full
+        # step (34.1-35.0 vs 32.5-33.3 ms, alternating blocks in one process): the per-element constant loads cost more
+        # than the streamed read they save.
+        keep_y = relu and (res is not None or os.environ.get("OMNIHD_BN_MASK_FROM_X", "0") != "1")
         ctx.save_for_backward(x, y if keep_y else None, gamma, consts)
         ctx.relu, ctx.group, ctx.ranks, ctx.param_dtypes = relu, group, ranks, (weight.dtype, bias.dtype)
         ctx.has_res = res is not None
