@@ -11,8 +11,7 @@ from typing import Callable
 import numpy as np
 
 from newscenes_devkit.eval.common.data_classes import EvalBoxes
-from newscenes_devkit.eval.common.utils import (angle_diff, center_distance, cummean, quaternion_yaw_wxyz, scale_iou,
-                                                 velocity_l2, yaw_diff)
+from newscenes_devkit.eval.common.utils import angle_diff, center_distance, cummean, quaternion_yaw_wxyz
 from newscenes_devkit.eval.detection.data_classes import DetectionMetricData
 
 

@@ -6,7 +6,6 @@ import json
 import os
 import time
 
-import numpy as np
 
 from newscenes_devkit.eval.common.loaders import filter_eval_boxes, load_prediction
 from newscenes_devkit.eval.detection.algo import accumulate, calc_ap, calc_tp

@@ -3,7 +3,6 @@
 ``img_backbone=dict(type='ResNet', depth=50, ...)`` (projects/configs/bevfusion_NewScenes/
 bevfusion.py:76-85) and ``BasicBlock`` inside DepthNet (cam_stream_lss_bevpoolv2_depthnet.py:583-585).
 Dense convolutions: executed by MIOpen through torch (channels-last bf16 when the harness enables it)."""
-import torch
 from torch import nn
 
 from .bricks import bn_act, build_norm_layer

@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI (argument checks + pointer/stream hand-over only)."""
 import ctypes
+import weakref
+import contextlib
 import os
 
 import numpy as np
@@ -40,7 +42,6 @@ def _workspace(nbytes, device):
 
 # The training step issues a few hundred of these calls; at ~45 ms per step the Python side must stay cheap:
 # no device context switch when the tensor's device is already current, size queries cached per geometry.
-import contextlib
 
 _NULL_CTX = contextlib.nullcontext()
 _SIZE_CACHE = {}
@@ -570,7 +571,6 @@ def wgrad_choices():
 # layer by layer that is ~100 tiny cast kernels (and their Python) per step.  The images are kept here, keyed by
 # the parameter, and reused while the parameter's version counter is unchanged; a training loop may refresh all
 # of them with ONE multi-tensor copy right after the optimiser step (``refresh_bf16_shadows``).
-import weakref
 
 _BF16_SHADOW = {}
 

@@ -5,7 +5,6 @@ feature is the BEVFUSION_depth path (same kernels); differences kept from the re
 lic+imc -> imc channels and the SE block has imc channels (:62-74), targets travel as one dict, the head is a
 ``MultiTaskHeadv2``."""
 import torch
-from torch import nn
 
 from omnihd_amd.mm import DETECTORS, ConvModule
 from omnihd_amd.mm.boxes import bbox3d2result

@@ -3,7 +3,6 @@ README.md:208), mirror of projects/mmdet3d_plugin/rcfusion/detectors/rcfusion_fa
 It shares the whole hot path with ``BEVFUSION_depth`` (same streams, same HIP operators); the
 differences are the radar pillar net (``RadarPillarFeatureNet``, chosen by the config) and the fusion:
 ``rc_fusion='cross_attention'`` -> ``Cross_Modal_Fusion``, ``'concat'`` -> reduc_conv (+ SE)."""
-import torch
 import torch.nn.functional as F
 
 from omnihd_amd.mm import DETECTORS, ConvModule

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every distinct convolution geometry that reaches the MFMA weight-gradient kernel in one training step,
 with its count, and the time of (a) our kernel chain and (b) MIOpen's weight gradient for the same shapes."""
-import collections, os, sys, time
+import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "omnihd-scenes_amd")]
 import torch
