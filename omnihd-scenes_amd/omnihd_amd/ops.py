@@ -1,8 +1,8 @@
 """Tensor-level wrappers over the C ABI (argument checks + pointer/stream hand-over only)."""
-import ctypes
-import weakref
 import contextlib
+import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
