@@ -526,7 +526,6 @@ def _miopen_wgrad(x, g, weight, stride, padding, dilation):
 
 
 def _tuned_wgrad(x, g, weight, stride, padding, dilation):
-    import os
     policy = os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
     k = weight.shape[2]
     run_hip = lambda: conv_wgrad(x, g, k, stride[0], padding[0], dilation[0])
@@ -555,7 +554,6 @@ def _tuned_wgrad(x, g, weight, stride, padding, dilation):
 
 def wgrad_choice_for(x_shape, cout, k, stride, padding, dilation, device_index):
     """'hip' | 'miopen' | None (not measured yet) for a convolution geometry under the current policy."""
-    import os
     policy = os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
     if policy != "tune":
         return policy
