@@ -47,9 +47,9 @@ class BEVFUSION_depth(MVXFasterRCNN):
         self.camera_depth_range = camera_depth_range
         self.lift, self.se = camera_stream, se
         if camera_stream:
-            self.lift_splat_shot_vis = LiftSplatShoot_Depth(lss=lss, grid=grid, inputC=imc, camC=64, pc_range=pc_range,
-                                                            camera_depth_range=camera_depth_range, final_dim=final_dim,
-                                                            downsample=downsample, norm_cfg=norm_cfg)
+            self.lift_splat_shot_vis = self._build_lift(lss=lss, grid=grid, inputC=imc, camC=64, pc_range=pc_range,
+                                                        camera_depth_range=camera_depth_range, final_dim=final_dim,
+                                                        downsample=downsample, norm_cfg=norm_cfg)
         if lc_fusion:
             if se:
                 self.seblock = SE_Block(lic)
@@ -60,6 +60,15 @@ class BEVFUSION_depth(MVXFasterRCNN):
         use_bev_conv(self)
         self.freeze_img = freeze_img
         self.freeze()
+
+    def _build_lift(self, norm_cfg, **kw):
+        """The camera stream of this detector (reference :54-56); BEVF_FasterRCNN swaps in the plain one."""
+        return LiftSplatShoot_Depth(norm_cfg=norm_cfg, **kw)
+
+    def _depth_loss(self, depth_dist, img_depth):
+        """Depth supervision term before weighting (reference :217-222)."""
+        return self.lift_splat_shot_vis.get_depth_loss(depth_labels=img_depth, depth_preds=depth_dist,
+                                                       loss_depth_type=self.img_depth_loss_method)[0]
 
     def freeze(self):
         if not self.freeze_img:
@@ -192,9 +201,7 @@ class BEVFUSION_depth(MVXFasterRCNN):
             losses.update(self.forward_pts_train(pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore))
         if img_feats:
             if img_depth is not None:
-                loss_depth, _ = self.lift_splat_shot_vis.get_depth_loss(depth_labels=img_depth, depth_preds=depth_dist,
-                                                                        loss_depth_type=self.img_depth_loss_method)
-                losses.update(img_depth_loss=self.img_depth_loss_weight * loss_depth)
+                losses.update(img_depth_loss=self.img_depth_loss_weight * self._depth_loss(depth_dist, img_depth))
             losses.update(self.forward_img_train(img_feats, img_metas=img_metas))
         return losses
 

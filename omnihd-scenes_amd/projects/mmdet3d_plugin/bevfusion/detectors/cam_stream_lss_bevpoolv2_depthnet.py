@@ -155,7 +155,7 @@ class LiftSplatShoot_Depth(nn.Module):
         self.camC, self.inputC, self.norm_cfg = camC, inputC, norm_cfg
         self.frustum = self.create_frustum()
         self.D = self.frustum.shape[0]
-        self.camencode = CamEncode(self.D, self.camC, self.inputC, self.norm_cfg)
+        self.camencode = self._build_camencode()
         self.constant_std = 0.5
         self.camera_depth_range = camera_depth_range
         self.use_quickcumsum = True
@@ -172,6 +172,9 @@ class LiftSplatShoot_Depth(nn.Module):
         self._plans = {}
         self._max_plans = 16
         self.pool_layout = "byxz"
+
+    def _build_camencode(self):
+        return CamEncode(self.D, self.camC, self.inputC, self.norm_cfg)
 
     # ---- geometry ---------------------------------------------------------------------------
     def create_frustum(self):

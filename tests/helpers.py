@@ -70,3 +70,28 @@ class RefKernels:
             ctypes.c_int(feat.size(-1)), ctypes.c_int(st.numel()), self._p(og), self._p(depth), self._p(feat),
             self._p(rd), self._p(rf), self._p(rb), self._p(st), self._p(ln), self._p(dg), self._p(fg))
         torch.cuda.synchronize()
+
+
+def seeded_state(module, seed):
+    """Fill every parameter and buffer of ``module`` from one numpy generator, in state-dict order, so
+    that a golden script and a test rebuild the same weights without storing them (BatchNorm running
+    variances and weights positive; integer buffers and ``frustum`` untouched)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for name, v in module.state_dict().items():
+            if not v.is_floating_point() or name.endswith("frustum"):
+                continue
+            shape = tuple(v.shape)
+            if name.endswith("running_var"):
+                a = rng.uniform(0.5, 2.0, shape)
+            elif name.endswith("running_mean"):
+                a = rng.normal(0.0, 0.2, shape)
+            elif v.dim() == 1 and name.endswith("weight"):            # norm scale
+                a = rng.uniform(0.5, 1.5, shape)
+            elif v.dim() == 1:                                        # biases
+                a = rng.normal(0.0, 0.1, shape)
+            else:                                                     # conv / linear weights: fan-in scaled
+                a = rng.normal(0.0, (2.0 / max(1, int(np.prod(shape[1:])))) ** 0.5, shape)
+            v.copy_(torch.from_numpy(a.astype(np.float32)))
+    return module
