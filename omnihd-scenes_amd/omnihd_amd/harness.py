@@ -120,6 +120,77 @@ def occ_model_cfg(base):
     return cfg
 
 
+def pillars_model_cfg(base, stream="radar"):
+    """``base`` (a BEVFUSION_depth config dict) cut down to the point-stream-only ``MVXFasterRCNN`` configs of the
+    reference: ``stream='radar'`` = projects/configs/bevfusion_NewScenes/radar_stream/pointpillars_4DRadar.py:23-118
+    (stage 1 of the fusion recipe; identical to PointPillars_NewScenes/pointpillars_4DRadar.py), ``'rcfusion'`` =
+    RCFusion_NewScenes/radar_stream/RadarPillarNet.py (RadarPillarFeatureNet), ``'lidar'`` =
+    PointPillars_NewScenes/pointpillars_LiDAR.py:21-118 (64 points per pillar, upstream HardVFE)."""
+    keep = ("pts_voxel_layer", "pts_voxel_encoder", "pts_middle_encoder", "pts_backbone", "pts_neck", "pts_bbox_head",
+            "train_cfg", "test_cfg")
+    cfg = {k: copy.deepcopy(base[k]) for k in keep}
+    cfg["type"] = "MVXFasterRCNN"
+    enc = cfg["pts_voxel_encoder"]
+    if stream == "rcfusion":
+        enc.update(type="RadarPillarFeatureNet", in_channels=7, with_cluster_center=True, with_voxel_center=True,
+                   with_velocity_snr_center=True)
+    elif stream == "lidar":
+        cfg["pts_voxel_layer"]["max_num_points"] = 64
+        cfg["pts_voxel_encoder"] = dict(type="HardVFE", in_channels=4, feat_channels=[64, 64], with_distance=False,
+                                        voxel_size=enc["voxel_size"], with_cluster_center=True, with_voxel_center=True,
+                                        point_cloud_range=enc["point_cloud_range"], norm_cfg=enc["norm_cfg"])
+    elif stream != "radar":
+        raise ValueError(stream)
+    return cfg
+
+
+def triple_model_cfg(base, queue_length=4):
+    """``base`` (a BEVFUSION_depth config dict) extended to BASELINE.json's last configuration: the LiDAR stream
+    of pointpillars_LiDAR.py next to the radar stream, and a queue of ``queue_length`` frames (a
+    composition, no reference config exists)."""
+    cfg = copy.deepcopy(base)
+    lidar = pillars_model_cfg(base, "lidar")
+    cfg.update(type="BEVFusionTripleTemporal", queue_length=queue_length,
+               lidar_stream={k: lidar[k] for k in ("pts_voxel_layer", "pts_voxel_encoder", "pts_middle_encoder",
+                                                   "pts_backbone", "pts_neck")})
+    return cfg
+
+
+def synthetic_queue(res, batch, radar_dims, device, seed, frames=4, lidar_points=None):
+    """Inputs of one step of the triple-modal temporal detector: ``frames`` time steps of images, radar and LiDAR
+    clouds per sample (queue-major), ego motion of ~1 m / 1 degree per frame, ground truth for the last frame."""
+    steps = [synthetic_batch(res, batch, radar_dims, device, seed + 17 * t) for t in range(frames)]
+    rng = np.random.default_rng(seed + 5)
+    r = TINY["pc_range"] if res == "tiny" else POINT_CLOUD_RANGE
+    n_lidar = lidar_points or (2000 if res == "tiny" else 120000)
+    lidar = []
+    for _ in range(batch):
+        seq = []
+        for _ in range(frames):
+            p = np.empty((n_lidar, 4), dtype=np.float32)
+            # two thirds of the returns within the inner third of the range, as a spinning LiDAR's density falls off
+            scale = np.where(rng.random(n_lidar) < 0.66, 0.33, 1.0)
+            p[:, 0] = rng.uniform(r[0], r[3], n_lidar) * scale
+            p[:, 1] = rng.uniform(r[1], r[4], n_lidar) * scale
+            p[:, 2] = rng.uniform(r[2], r[5], n_lidar)
+            p[:, 3] = rng.uniform(0, 1, n_lidar)
+            seq.append(torch.from_numpy(p).to(device))
+        lidar.append(seq)
+    metas = []
+    for b in range(batch):
+        seq = []
+        for t in range(frames):
+            back = frames - 1 - t
+            m = dict(steps[t]["img_metas"][b])
+            m["ego_delta"] = (-1.0 * back, 0.05 * back, math.radians(-1.0 * back))
+            seq.append(m)
+        metas.append(seq)
+    last = steps[-1]
+    return dict(points=[[steps[t]["points"][b] for t in range(frames)] for b in range(batch)], lidar_points=lidar,
+                img=torch.stack([s["img"] for s in steps], dim=1), img_metas=metas, img_depth=last["img_depth"],
+                gt_bboxes_3d=last["gt_bboxes_3d"], gt_labels_3d=last["gt_labels_3d"])
+
+
 def synthetic_occupancy(batch, nx, ny, nz, n_cls, device, seed):
     """(B, Dx, Dy, Dz) class map: free space (0) with boxes of the other classes, a few unknown (255) voxels are NOT
     generated — the reference's cross-entropy has no ignore index and would raise on them."""
@@ -220,7 +291,7 @@ class FusionTrainStep:
     dense convolutions (pooling, voxelisation and the losses stay fp32)."""
 
     def __init__(self, res="r1", batch=1, radar_dims=7, device="cuda:0", seed=0, dtype="bf16", ddp=False,
-                 channels_last=True, sets=2, task="det", miopen_find=False):
+                 channels_last=True, sets=2, task="det", miopen_find=False, frames=4):
         from .mm.config import build_detector
         self.device = torch.device(device)
         if self.device.type == "cuda" and miopen_find:
@@ -232,11 +303,14 @@ class FusionTrainStep:
         cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)
         if task == "occ":
             cfg = occ_model_cfg(cfg)
+        elif task == "triple":
+            cfg = triple_model_cfg(cfg, queue_length=frames)
         model = build_detector(cfg).to(self.device)
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
-            if hasattr(getattr(model, "pts_middle_encoder", None), "channels_last"):
-                model.pts_middle_encoder.channels_last = True      # radar canvas written NHWC by the scatter kernel
+            for mod in model.modules():                            # point canvases written NHWC by the scatter kernel
+                if hasattr(getattr(mod, "pts_middle_encoder", None), "channels_last"):
+                    mod.pts_middle_encoder.channels_last = True
         model.train()
         self.raw_model = model
         self.model = model
@@ -248,7 +322,11 @@ class FusionTrainStep:
         self.opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=self.device.type == "cuda")
         self.params = params
         self.autocast = dtype == "bf16"
-        self.batches = [synthetic_batch(res, batch, radar_dims, self.device, seed + 1000 * i) for i in range(sets)]
+        if task == "triple":
+            self.batches = [synthetic_queue(res, batch, radar_dims, self.device, seed + 1000 * i, frames=frames)
+                            for i in range(sets)]
+        else:
+            self.batches = [synthetic_batch(res, batch, radar_dims, self.device, seed + 1000 * i) for i in range(sets)]
         if task == "occ":
             nx, ny = (int(round((cfg["pc_range"][3 + a] - cfg["pc_range"][a]) / cfg["grid"])) for a in (0, 1))
             for i, b in enumerate(self.batches):

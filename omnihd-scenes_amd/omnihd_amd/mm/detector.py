@@ -3,17 +3,26 @@ reference's fusion detectors (bevfusion/detectors/bevf_faster_rcnn_bevdepth.py:3
 camera + radar BEV-fusion path uses is restated: sub-module construction from the config dict with
 the upstream attribute names (``pts_voxel_layer``, ``pts_voxel_encoder``, ``pts_middle_encoder``,
 ``pts_backbone``, ``pts_neck``, ``img_backbone``, ``img_neck``, ``pts_bbox_head``), ``voxelize``,
-``extract_img_feat`` and ``forward_pts_train``."""
+``extract_img_feat`` and ``forward_pts_train``.
+
+The class is also a detector in its own right, registered under its upstream name: the reference's
+radar-only and LiDAR-only PointPillars configs (projects/configs/bevfusion_NewScenes/radar_stream/
+pointpillars_4DRadar.py:23 — the stage-1 run whose checkpoint the fusion config loads with
+``load_from`` — RCFusion_NewScenes/radar_stream/RadarPillarNet.py and PointPillars_NewScenes/*.py)
+use ``type='MVXFasterRCNN'`` directly, i.e. upstream's ``extract_pts_feat`` / ``extract_feat`` /
+``forward_train`` / ``simple_test``.  That is the radar half of the hot path on its own: HIP hard
+voxelisation -> pillar feature net -> HIP pillar scatter -> SECOND -> SECONDFPN -> anchor head."""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .registry import BACKBONES, HEADS, MIDDLE_ENCODERS, NECKS, VOXEL_ENCODERS
+from .registry import BACKBONES, DETECTORS, HEADS, MIDDLE_ENCODERS, NECKS, VOXEL_ENCODERS
 from .boxes import bbox3d2result
 from .second import Voxelization
-from . import anchor_head, fpn, resnet, second  # noqa: F401  (register upstream type names)
+from . import anchor_head, fpn, hard_vfe, resnet, second  # noqa: F401  (register upstream type names)
 
 
+@DETECTORS.register_module()
 class MVXFasterRCNN(nn.Module):
     def __init__(self, pts_voxel_layer=None, pts_voxel_encoder=None, pts_middle_encoder=None, pts_fusion_layer=None,
                  img_backbone=None, pts_backbone=None, img_neck=None, pts_neck=None, pts_bbox_head=None,
@@ -52,7 +61,7 @@ class MVXFasterRCNN(nn.Module):
             return None
         if img.dim() == 5:
             B, N, C, H, W = img.shape
-            img = img.view(B * N, C, H, W)
+            img = img.reshape(B * N, C, H, W)
         feats = self.img_backbone(img)
         if self.with_img_neck:
             feats = self.img_neck(feats)
@@ -76,6 +85,45 @@ class MVXFasterRCNN(nn.Module):
 
     def voxelize(self, points):
         return self.voxelize_end(self.voxelize_begin(points))
+
+    # ---- upstream MVXTwoStageDetector bodies (subclasses of the reference override most of them) ----
+    def extract_pts_feat(self, pts, img_feats, img_metas):
+        if not self.with_pts_bbox:
+            return None
+        voxels, num_points, coors = self.voxelize(pts)
+        voxel_features = self.pts_voxel_encoder(voxels, num_points, coors, img_feats, img_metas)
+        # upstream reads the batch size back from the device (coors[-1, 0] + 1); the host already knows it
+        x = self.pts_middle_encoder(voxel_features, coors, len(pts))
+        x = self.pts_backbone(x)
+        if self.with_pts_neck:
+            x = self.pts_neck(x)
+        return x
+
+    def extract_feat(self, points, img, img_metas):
+        img_feats = self.extract_img_feat(img, img_metas)
+        return img_feats, self.extract_pts_feat(points, img_feats, img_metas)
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_labels=None,
+                      gt_bboxes=None, img=None, proposals=None, gt_bboxes_ignore=None):
+        img_feats, pts_feats = self.extract_feat(points, img=img, img_metas=img_metas)
+        losses = dict()
+        if pts_feats:
+            losses.update(self.forward_pts_train(pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore))
+        if img_feats:
+            losses.update(self.forward_img_train(img_feats, img_metas=img_metas))
+        return losses
+
+    @torch.no_grad()
+    def simple_test(self, points, img_metas, img=None, rescale=False):
+        _, pts_feats = self.extract_feat(points, img=img, img_metas=img_metas)
+        bbox_list = [dict() for _ in range(len(img_metas))]
+        if pts_feats and self.with_pts_bbox:
+            for result, pts_bbox in zip(bbox_list, self.simple_test_pts(pts_feats, img_metas, rescale=rescale)):
+                result["pts_bbox"] = pts_bbox
+        return bbox_list
+
+    def forward(self, return_loss=True, **kwargs):
+        return self.forward_train(**kwargs) if return_loss else self.forward_test(**kwargs)
 
     def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_ignore=None):
         outs = self.pts_bbox_head(pts_feats)
