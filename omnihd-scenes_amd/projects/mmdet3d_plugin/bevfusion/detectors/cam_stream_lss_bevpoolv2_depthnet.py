@@ -189,6 +189,23 @@ class LiftSplatShoot_Depth(nn.Module):
     def get_geometry(self, rots, trans, post_rots=None, post_trans=None, extra_rots=None, extra_trans=None):
         """Frustum points in the lidar frame, (B, N, D, fH, fW, 3) — reference :235-264."""
         B, N, _ = trans.shape
+        if post_rots is None and post_trans is None and extra_rots is None and extra_trans is None:
+            # The call every detector makes.  Written as three broadcast multiply-adds per axis,
+            # ((r0*u*d + r1*v*d) + r2*d) + t with every step rounded on its own (separate elementwise kernels, no
+            # contraction): bit for bit the reference's torch-CPU result (its 3x3 @ 3x1 matmul accumulates in this
+            # order) and oracle/lss_oracle.get_geometry.  The reference formulation is a batched matmul with one
+            # 3x3 product per frustum point — 24 million tiny GEMMs for a flat batch of six samples, which faults
+            # inside the BLAS library on the GPU.
+            fr = self.frustum
+            pz = fr[..., 2]
+            px, py = fr[..., 0] * pz, fr[..., 1] * pz
+            R, t = rots.view(B, N, 1, 1, 1, 3, 3), trans.view(B, N, 1, 1, 1, 3)
+            axes = []
+            for a in range(3):
+                acc = R[..., a, 0] * px + R[..., a, 1] * py
+                acc = acc + R[..., a, 2] * pz
+                axes.append(acc + t[..., a])
+            return torch.stack(axes, dim=-1)
         if post_rots is not None or post_trans is not None:
             points = self.frustum
             if post_trans is not None:
