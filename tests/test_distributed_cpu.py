@@ -60,7 +60,7 @@ def test_naive_sync_bn_two_ranks_mean_of_rank_means():
         assert dict(out) == {0: True, 1: True}
 
 
-def _ddp_worker(rank, world, port, out):
+def _ddp_worker(rank, world, port, out, task="det"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "omnihd-scenes_amd")]
@@ -69,7 +69,7 @@ def _ddp_worker(rank, world, port, out):
     _init(rank, world, port)
     with oracle_ops():
         st = FusionTrainStep(res="tiny", batch=1, radar_dims=7, device="cpu", seed=100 + rank, dtype="fp32", ddp=True,
-                             channels_last=False, sets=1)
+                             channels_last=False, sets=1, task=task, frames=2)
         losses = [float(st.step().detach()) for _ in range(2)]
     flat = torch.cat([p.detach().reshape(-1) for p in st.raw_model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
@@ -86,4 +86,17 @@ def test_tiny_detector_two_rank_ddp_step_keeps_replicas_identical():
         res = dict(out)
     assert res[0][1] and res[1][1]                       # parameters identical on both ranks after 2 steps
     assert res[0][0] != res[1][0]                        # ...although each rank saw different frames
+    assert all(np.isfinite(res[r][0]).all() for r in (0, 1))
+
+
+def test_triple_modal_temporal_two_rank_ddp_step_keeps_replicas_identical():
+    """The queue detector under DDP: history frames run without gradients and without SyncBN exchanges (eval mode), the
+    current frame's exchanges and the gradient all-reduce line up on both ranks."""
+    port = _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_ddp_worker, args=(2, port, out, "triple"), nprocs=2, join=True)
+        res = dict(out)
+    assert res[0][1] and res[1][1]
+    assert res[0][0] != res[1][0]
     assert all(np.isfinite(res[r][0]).all() for r in (0, 1))
