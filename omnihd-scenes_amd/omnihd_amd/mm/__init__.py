@@ -9,5 +9,5 @@ mmdet 2.14.0, mmdet3d v0.17.1); module/attribute names follow those releases so 
 checkpoints keep their state-dict keys.
 """
 from .registry import (BACKBONES, DETECTORS, HEADS, LOSSES, MIDDLE_ENCODERS, NECKS, NORM_LAYERS,  # noqa: F401
-                       VOXEL_ENCODERS, Registry, build_from_cfg)
+                       PIPELINES, VOXEL_ENCODERS, Registry, build_from_cfg)
 from .bricks import ConvModule, build_conv_layer, build_norm_layer, build_activation  # noqa: F401

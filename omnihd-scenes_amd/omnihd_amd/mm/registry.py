@@ -57,3 +57,4 @@ LOSSES = Registry("loss")
 VOXEL_ENCODERS = Registry("voxel_encoder")
 MIDDLE_ENCODERS = Registry("middle_encoder")
 NORM_LAYERS = Registry("norm layer")
+PIPELINES = Registry("pipeline")      # mmdet.datasets.builder.PIPELINES: data-pipeline steps by ``type=``

@@ -1,1 +1,4 @@
-from .loading import LoadRadarPointsMultiSweeps, RadarPoints, merge_radar_sweeps  # noqa: F401
+from .loading import (LoadGTDepth, LoadOccupancy_Newscenes, LoadRadarPointsMultiSweeps, RadarPoints,  # noqa: F401
+                      merge_radar_sweeps)
+from .transform_3d import (CustomCollect3D, NormalizeMultiviewImage, PadMultiViewImage,  # noqa: F401
+                           RandomScaleImageMultiViewImage)

@@ -17,6 +17,8 @@ stays out of scope; the 4x4 matrix bookkeeping that feeds ``img_metas['lidar2img
 import numpy as np
 import torch
 
+from omnihd_amd.mm.registry import PIPELINES
+
 RADAR_ID = {"radar_front": 0, "radar_left_front": 1, "radar_right_front": 2, "radar_back": 3, "radar_left_back": 4,
             "radar_right_back": 5}
 
@@ -126,6 +128,7 @@ class RadarPoints:
         return idx
 
 
+@PIPELINES.register_module()
 class LoadRadarPointsMultiSweeps:
     """Same constructor and ``__call__(results)`` contract as the reference class (:116-316);
     ``file_client_args`` is accepted for config compatibility (only the disk backend exists here)."""
@@ -161,6 +164,49 @@ class LoadRadarPointsMultiSweeps:
         return f"{self.__class__.__name__}(sweeps_num={self.sweeps_num})"
 
 
+@PIPELINES.register_module()
+class LoadGTDepth:
+    """Sparse depth ground truth of the depth-supervised configs (reference :17-63; bevfusion.py:186
+    ``dict(type='LoadGTDepth', scale=0.5)``).  Per camera image ``<...>/cameras/<cam>/<file>`` the file
+    ``<...>/depth_gt/<cam>/<file>.bin`` holds float32 rows ``[u, v, d]`` in the pixel grid of the STORED image; front
+    and back cameras are stored at twice the side cameras' resolution and are halved first (as their images are at load
+    time), then everything is scaled by ``scale``.  Coordinates are truncated through int16 exactly as the reference
+    does, points outside the ``depth_dim * scale`` map are dropped, later rows overwrite earlier rows of the same pixel
+    (numpy assignment order), and at ``scale == 0.5`` the map gets ``pad // 2`` zero rows on top AND bottom
+    (540 -> 544 rows: the reference pads the depth map symmetrically although the image is padded at the bottom only —
+    kept).  Output ``results['img_depth']``: float32 tensor (n_cams, H, W), what ``generate_guassian_depth_target``
+    consumes."""
+
+    def __init__(self, scale, pad=4, scale_factor_frontandback=0.5, depth_dim=(1080, 1920)):
+        self.scale_factor_frontandback, self.depth_dim, self.scale, self.pad = scale_factor_frontandback, depth_dim, scale, pad
+
+    def depth_map(self, cam_depth, cam_dir):
+        cam_depth = np.array(cam_depth, dtype=np.float32, copy=True).reshape(-1, 3)
+        if cam_dir in ("camera_front", "camera_back"):
+            cam_depth[:, :2] = cam_depth[:, :2] * self.scale_factor_frontandback
+        cam_depth[:, :2] = cam_depth[:, :2] * self.scale
+        uv = cam_depth[:, :2].astype(np.int16)
+        dim = (int(self.depth_dim[0] * self.scale), int(self.depth_dim[1] * self.scale))
+        out = np.zeros(dim)
+        ok = (uv[:, 1] < dim[0]) & (uv[:, 0] < dim[1]) & (uv[:, 1] >= 0) & (uv[:, 0] >= 0)
+        out[uv[ok, 1], uv[ok, 0]] = cam_depth[ok, 2]
+        if self.scale == 0.5:
+            out = np.pad(out, ((self.pad // 2, self.pad // 2), (0, 0)), "constant", constant_values=(0, 0))
+        return out
+
+    def __call__(self, results):
+        maps = []
+        for name in list(results["filename"]):
+            rows = np.fromfile(name.replace("cameras", "depth_gt") + ".bin", dtype=np.float32, count=-1)
+            maps.append(torch.Tensor(self.depth_map(rows, name.split("/")[-2])))
+        results["img_depth"] = torch.stack(maps)
+        return results
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+@PIPELINES.register_module()
 class LoadOccupancy_Newscenes:
     """Occupancy ground truth: ``results['occ_path']`` is an ``.npz`` whose ``occ_gt`` holds (N, 4) rows
     (x, y, z voxel index, class); scattered into a dense ``occ_size`` grid, 0 = free (reference :66-104)."""

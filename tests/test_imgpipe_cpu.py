@@ -1,0 +1,122 @@
+"""Image-side pipeline steps against vectors captured from the reference classes
+(tests/golden/make_golden_imgpipe.py -> imgpipe_golden.npz): the depth ground-truth format bit for bit,
+the normalise / scale / pad / collect bookkeeping (shapes, keys, float64 lidar2img, the sizes the reference
+asks mmcv for), and hand-computed cases for the restated mmcv/OpenCV pixel arithmetic (unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "imgpipe_golden.npz"))
+
+
+def _depth_tree(gold, tmp_path):
+    names = []
+    for ci, cam in enumerate(gold["depth_cams"].tolist()):
+        os.makedirs(tmp_path / "cameras" / cam, exist_ok=True)
+        os.makedirs(tmp_path / "depth_gt" / cam, exist_ok=True)
+        name = str(tmp_path / "cameras" / cam / f"{ci:04d}.jpg")
+        gold[f"depth_in_{ci}"].tofile(name.replace("cameras", "depth_gt") + ".bin")
+        names.append(name)
+    return names
+
+
+@pytest.mark.parametrize("tag,kw", [("half", dict(scale=0.5)), ("full", dict(scale=1.0)), ("half_pad8", dict(scale=0.5, pad=8))])
+def test_load_gt_depth_is_bit_identical_to_the_reference(gold, tmp_path, tag, kw):
+    from omnihd_amd.mm import PIPELINES
+    from projects.mmdet3d_plugin.datasets.pipelines import LoadGTDepth
+    assert PIPELINES.get("LoadGTDepth") is LoadGTDepth
+    names = _depth_tree(gold, tmp_path)
+    res = LoadGTDepth(**kw)(dict(filename=list(names)))
+    d = res["img_depth"]
+    assert isinstance(d, torch.Tensor) and d.dtype == torch.float32
+    assert np.array_equal(d.numpy(), gold[f"depth_{tag}"])
+    if tag == "half":          # the symmetric 2-row padding of the reference (540 -> 544)
+        assert d.shape == (6, 544, 960) and float(d[:, :2].abs().sum()) == 0 and float(d[:, -2:].abs().sum()) == 0
+
+
+def test_depth_map_feeds_the_gaussian_target(gold, tmp_path):
+    """LoadGTDepth -> generate_guassian_depth_target: the two halves of the depth supervision fit together."""
+    from projects.mmdet3d_plugin.datasets.pipelines import LoadGTDepth
+    from projects.mmdet3d_plugin.utils.gaussian import generate_guassian_depth_target
+    d = LoadGTDepth(scale=0.5)(dict(filename=_depth_tree(gold, tmp_path)))["img_depth"][None]       # (1, 6, 544, 960)
+    target, min_depth = generate_guassian_depth_target(d, 4, [1, 60, 1], constant_std=0.5)
+    assert target.shape == (6, 136, 240, 59) and min_depth.shape == (6, 136, 240)            # B*N flattened
+    assert int((min_depth > 0).sum()) > 10000
+    assert torch.isfinite(target).all() and float(target.sum(-1).max()) <= 1.0 + 1e-4
+
+
+def test_normalise_scale_pad_collect_bookkeeping_matches_the_reference(gold):
+    from omnihd_amd.mm import PIPELINES
+    from projects.mmdet3d_plugin.datasets.pipelines import (CustomCollect3D, NormalizeMultiviewImage, PadMultiViewImage,
+                                                             RandomScaleImageMultiViewImage)
+    book = json.loads(str(gold["book_json"]))
+    for n in ("CustomCollect3D", "NormalizeMultiviewImage", "PadMultiViewImage", "RandomScaleImageMultiViewImage",
+              "LoadRadarPointsMultiSweeps", "LoadOccupancy_Newscenes"):
+        assert n in PIPELINES, n
+    rng = np.random.default_rng(1)
+    l2i = [m.copy() for m in gold["pipe_lidar2img_in"]]
+    results = dict(img=[rng.uniform(0, 255, (1080, 1920, 3)).astype(np.float32) for _ in range(6)], lidar2img=l2i,
+                   filename=["f"] * 6, pts_filename="x.bin", sample_idx="tok", box_type_3d="LiDAR", points="PTS",
+                   gt_bboxes_3d="BOX", scene_token="scene", can_bus=np.arange(18.0))
+    results = NormalizeMultiviewImage(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)(results)
+    assert results["img"][0].dtype == np.float32
+    results = RandomScaleImageMultiViewImage(scales=[0.5])(results)
+    assert [list(s) for s in results["img_shape"]] == book["after_scale"]["img_shape"]
+    assert [list(s) for s in results["ori_shape"]] == book["after_scale"]["ori_shape"]
+    # the sizes the reference asked mmcv.imresize for (w, h)
+    asked = [c[2] for c in book["calls"] if c[0] == "imresize"]
+    assert [[im.shape[1], im.shape[0]] for im in results["img"]] == asked
+    results = PadMultiViewImage(size_divisor=32)(results)
+    for k in ("img_shape", "ori_shape", "pad_shape"):
+        assert [list(s) for s in results[k]] == book[k], k
+    assert results["pad_fixed_size"] == book["pad_fixed_size"] and results["pad_size_divisor"] == book["pad_size_divisor"]
+    assert np.array_equal(np.stack(results["lidar2img"]), gold["pipe_lidar2img_out"])              # float64, bit for bit
+    cfg = results["img_norm_cfg"]
+    assert cfg["mean"].tolist() == book["norm_cfg"]["mean"] and cfg["std"].tolist() == book["norm_cfg"]["std"]
+    assert str(cfg["mean"].dtype) == book["norm_cfg"]["mean_dtype"] and cfg["to_rgb"] == book["norm_cfg"]["to_rgb"]
+    assert float(np.abs(results["img"][0][540:]).sum()) == 0.0                                     # 4 padded rows, zeros
+    data = CustomCollect3D(keys=["gt_bboxes_3d", "gt_labels_3d", "img", "points", "img_depth"])(results)
+    assert sorted(data.keys()) == book["collect_keys"]
+    assert sorted(k for k, v in data.items() if v is None) == book["collect_none"]
+    assert sorted(data["img_metas"].data.keys()) == book["meta_keys"] and data["img_metas"].cpu_only == book["meta_cpu_only"]
+    assert list(CustomCollect3D(keys=[]).meta_keys) == book["default_meta_keys"]
+    # odd sizes, no matrix update, fixed-size padding
+    r2 = dict(img=[rng.uniform(0, 1, (541, 961, 3)).astype(np.float32)], lidar2img=[np.eye(4)])
+    r2 = RandomScaleImageMultiViewImage(scales=[0.3], scale_lidar2img=False)(r2)
+    r2 = PadMultiViewImage(size=(200, 320), pad_val=7)(r2)
+    odd = book["odd"]
+    assert [list(s) for s in r2["img_shape"]] == odd["img_shape"] and [list(s) for s in r2["ori_shape"]] == odd["ori_shape"]
+    assert np.array_equal(r2["lidar2img"][0], np.eye(4)) == odd["lidar2img_unchanged"]
+    assert list(r2["pad_fixed_size"]) == odd["pad_fixed_size"] and r2["pad_size_divisor"] == odd["pad_size_divisor"]
+    assert float(r2["img"][0][-1, -1, 0]) == 7.0
+    with pytest.raises(AssertionError):
+        RandomScaleImageMultiViewImage(scales=[0.5, 0.8])
+    with pytest.raises(AssertionError):
+        PadMultiViewImage()
+
+
+def test_pixel_arithmetic_known_answers():
+    from projects.mmdet3d_plugin.datasets.pipelines.transform_3d import imnormalize, impad, imresize_bilinear
+    img = np.array([[[10, 20, 30], [40, 50, 60]], [[70, 80, 90], [100, 110, 120]]], dtype=np.uint8)     # BGR
+    out = imnormalize(img, np.array([1, 2, 3], np.float32), np.array([2, 4, 8], np.float32), to_rgb=True)
+    assert out.dtype == np.float32
+    assert np.array_equal(out[0, 0], np.array([(30 - 1) / 2, (20 - 2) / 4, (10 - 3) / 8], np.float32))  # R, G, B
+    assert np.array_equal(imnormalize(img, [0, 0, 0], [1, 1, 1], to_rgb=False)[1, 1], np.array([100, 110, 120], np.float32))
+    assert img[0, 0, 0] == 10                                                                           # input untouched
+    # scale 0.5 = mean of each 2x2 block, horizontal pass first, each pass rounded once
+    x = np.random.default_rng(0).uniform(-3, 3, (6, 8, 3)).astype(np.float32)
+    half = imresize_bilinear(x, (4, 3))
+    h = x[:, 0::2] * np.float32(0.5) + x[:, 1::2] * np.float32(0.5)
+    want = h[0::2] * np.float32(0.5) + h[1::2] * np.float32(0.5)
+    assert half.shape == (3, 4, 3) and np.array_equal(half, want)
+    assert np.array_equal(imresize_bilinear(x, (8, 6)), x)                                              # identity
+    up = imresize_bilinear(np.array([[[0.0], [4.0]]], dtype=np.float32), (4, 1))[0, :, 0]               # 2 -> 4 pixels
+    assert np.allclose(up, [0.0, 1.0, 3.0, 4.0])                                                        # clamped borders
+    p = impad(np.ones((2, 3, 1), np.float32), (4, 4), pad_val=0)
+    assert p.shape == (4, 4, 1) and p.sum() == 6 and p[2:].sum() == 0
