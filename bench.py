@@ -400,8 +400,8 @@ def main():
                          "traffic": traffic, "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_fwd * 1e6, 2),
                          "bwd_mean_launch_us": round(t_bwd * 1e6, 2)},
         }
-        if not a.no_cpu_baseline:
-            if a.workload == "fusion":
+        if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would sit in the
+            if a.workload == "fusion":                # closing barrier for minutes while the host cores are busy
                 line["cpu_baseline"] = run_cpu_baseline_child(a.res, radar_dims)
             else:
                 line["cpu_baseline"] = cpu_baseline(a.res)
