@@ -119,13 +119,20 @@ def lss_constants(res):
 
 
 def geometry(frustum, rots, trans):
-    """get_geometry (:235-264) with the same torch ops, on the device."""
+    """get_geometry (:235-264) on the device, as the product computes it (LiftSplatShoot_Depth.get_geometry): three
+    broadcast multiply-adds per axis in the reference's accumulation order — bit for bit the reference's torch-CPU
+    result, without its one-3x3-GEMM-per-frustum-point batched matmul."""
     B, N, _ = trans.shape
-    pts = frustum.to(rots.device).repeat(B, N, 1, 1, 1, 1).unsqueeze(-1)
-    pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
-    pts = rots.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
-    pts += trans.view(B, N, 1, 1, 1, 3)
-    return pts
+    fr = frustum.to(rots.device)
+    pz = fr[..., 2]
+    px, py = fr[..., 0] * pz, fr[..., 1] * pz
+    R, t = rots.view(B, N, 1, 1, 1, 3, 3), trans.view(B, N, 1, 1, 1, 3)
+    axes = []
+    for a in range(3):
+        acc = R[..., a, 0] * px + R[..., a, 1] * py
+        acc = acc + R[..., a, 2] * pz
+        axes.append(acc + t[..., a])
+    return torch.stack(axes, dim=-1)
 
 
 def radar_points(rng, n):
