@@ -82,7 +82,6 @@ def test_tiny_queue_step_over_the_oracle_and_queue_semantics():
         with torch.no_grad():
             one = m.extract_feat([b["points"][1][0]], b["img"][1:2, 0], [dict(b["img_metas"][1][0])],
                                  lidar_points=[b["lidar_points"][1][0]])["pts_feats"][0]
-        from tests.test_triple_cpu import _warp
         want = _warp(one, b["img_metas"][1][0]["ego_delta"], m._pc_range)
         assert torch.allclose(hist[1, :384], want[0], atol=1e-4)
         m.train()
