@@ -1,0 +1,106 @@
+"""The image-side pipeline steps and the depth ground-truth scatter as DEVICE work (no reference
+counterpart: the reference does both per frame on the host, in dataloader workers —
+pipelines/transform_3d.py:64-98,295-337,9-60 and pipelines/loading.py:17-63).
+
+On an MI355X node eight ranks share one host; normalising and resizing 6 x 1080p float images and
+densifying six 544 x 960 depth maps per frame on the CPU costs more host time than the whole GPU
+step.  Here the loader uploads what is on disk — the uint8 images (37 MB per frame) and the sparse
+``[u, v, d]`` rows (a few hundred KB) — and the tensors the detector consumes are produced on the
+device by plain torch elementwise / gather / scatter kernels (plumbing, no hand-written kernel: the
+work is a single pass over ~150 MB).
+
+Both functions repeat the host mirrors' arithmetic operation by operation (separately rounded fp32
+products, the same tap tables, the same int16 truncation, "the later row wins" resolved by an
+order-independent max over row numbers), so their results are bit-identical to
+``transform_3d.py`` / ``LoadGTDepth`` — asserted on CPU tensors in tests/test_imgpipe_cpu.py; the
+code is device-agnostic torch, its first run on the GPU is still to be done (round 2).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .transform_3d import _axis_taps
+
+__all__ = ["DeviceImagePipeline", "device_depth_maps"]
+
+
+class DeviceImagePipeline:
+    """NormalizeMultiviewImage -> RandomScaleImageMultiViewImage(scales=[s]) -> PadMultiViewImage(size_divisor=d)
+    for one frame: ``views`` = (N, H, W, 3) uint8 or float tensor/array in the stored channel order, result
+    (N, 3, H', W') float32 on ``device`` plus the updated ``lidar2img`` list (host float64, as the reference)."""
+
+    def __init__(self, mean, std, to_rgb=True, scale=0.5, size_divisor=32, pad_val=0, device="cuda:0"):
+        self.device = torch.device(device)
+        self.mean = torch.tensor(np.asarray(mean, dtype=np.float32), device=self.device)
+        self.inv = torch.tensor((1.0 / np.float64(np.asarray(std, dtype=np.float32))).astype(np.float32), device=self.device)
+        self.to_rgb, self.scale, self.size_divisor, self.pad_val = to_rgb, scale, size_divisor, pad_val
+        self._taps = {}
+
+    def _tap(self, n_in, n_out):
+        key = (n_in, n_out)
+        if key not in self._taps:
+            lo, hi, w = _axis_taps(n_in, n_out)
+            self._taps[key] = (torch.from_numpy(lo).to(self.device), torch.from_numpy(hi).to(self.device),
+                               torch.from_numpy(w).to(self.device))
+        return self._taps[key]
+
+    @torch.no_grad()
+    def __call__(self, views, lidar2img=None):
+        x = torch.as_tensor(views).to(self.device)
+        assert x.dim() == 4 and x.shape[-1] == 3, "views must be (N, H, W, 3)"
+        x = x.to(torch.float32)
+        if self.to_rgb:
+            x = x.flip(-1)
+        x = (x - self.mean) * self.inv
+        H, W = x.shape[1:3]
+        h2, w2 = int(H * self.scale), int(W * self.scale)
+        if (h2, w2) != (H, W):
+            lo, hi, w = self._tap(W, w2)
+            w = w.view(1, 1, -1, 1)
+            x = x[:, :, lo] * (1.0 - w) + x[:, :, hi] * w                 # horizontal pass first, as cv2
+            lo, hi, w = self._tap(H, h2)
+            w = w.view(1, -1, 1, 1)
+            x = x[:, lo] * (1.0 - w) + x[:, hi] * w
+        d = self.size_divisor
+        hp, wp = -(-h2 // d) * d, -(-w2 // d) * d
+        x = x.permute(0, 3, 1, 2)                                          # channels first (DefaultFormatBundle3D)
+        if (hp, wp) != (h2, w2):
+            x = F.pad(x, (0, wp - w2, 0, hp - h2), value=float(self.pad_val))
+        out = x.contiguous()
+        if lidar2img is None:
+            return out
+        s = np.eye(4)
+        s[0, 0] *= self.scale
+        s[1, 1] *= self.scale
+        return out, [s @ m for m in lidar2img]
+
+
+@torch.no_grad()
+def device_depth_maps(rows_per_cam, cam_dirs, scale, pad=4, scale_factor_frontandback=0.5, depth_dim=(1080, 1920),
+                      device="cuda:0"):
+    """``LoadGTDepth`` for one frame on the device: ``rows_per_cam`` = one (n_i, 3) float32 array of ``[u, v, d]`` per
+    camera (coordinates within the int16 range, as on disk), ``cam_dirs`` the camera directory names.  One scatter
+    for all cameras; where several rows hit a pixel the one with the highest row number wins, like numpy's
+    assignment order in the reference.  -> (n_cams, H, W) float32."""
+    device = torch.device(device)
+    H, W = int(depth_dim[0] * scale), int(depth_dim[1] * scale)
+    n_cams = len(rows_per_cam)
+    sizes = [int(np.asarray(r).reshape(-1, 3).shape[0]) for r in rows_per_cam]
+    rows = torch.from_numpy(np.concatenate([np.asarray(r, dtype=np.float32).reshape(-1, 3) for r in rows_per_cam])).to(device)
+    cam = torch.repeat_interleave(torch.arange(n_cams, device=device), torch.tensor(sizes, device=device))
+    big = torch.tensor([c in ("camera_front", "camera_back") for c in cam_dirs], device=device)[cam]
+    uv = rows[:, :2]
+    uv = torch.where(big[:, None], uv * scale_factor_frontandback, uv)
+    uv = (uv * scale).to(torch.int16).long()
+    ok = (uv[:, 1] < H) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 0] >= 0)
+    lin = (cam * (H * W) + uv[:, 1] * W + uv[:, 0])[ok]
+    order = torch.arange(rows.shape[0], device=device)[ok]
+    winner = torch.full((n_cams * H * W,), -1, dtype=torch.long, device=device)
+    winner.scatter_reduce_(0, lin, order, reduce="amax", include_self=True)
+    hit = winner >= 0
+    out = torch.zeros(n_cams * H * W, dtype=torch.float32, device=device)
+    out[hit] = rows[winner[hit], 2]
+    out = out.view(n_cams, H, W)
+    if scale == 0.5:
+        out = F.pad(out, (0, 0, pad // 2, pad // 2))
+    return out

@@ -177,8 +177,9 @@ class LoadGTDepth:
     kept).  Output ``results['img_depth']``: float32 tensor (n_cams, H, W), what ``generate_guassian_depth_target``
     consumes."""
 
-    def __init__(self, scale, pad=4, scale_factor_frontandback=0.5, depth_dim=(1080, 1920)):
+    def __init__(self, scale, pad=4, scale_factor_frontandback=0.5, depth_dim=(1080, 1920), device=None):
         self.scale_factor_frontandback, self.depth_dim, self.scale, self.pad = scale_factor_frontandback, depth_dim, scale, pad
+        self.device = device          # e.g. "cuda:0": upload the sparse rows, build the maps on the GPU (device_prep.py)
 
     def depth_map(self, cam_depth, cam_dir):
         cam_depth = np.array(cam_depth, dtype=np.float32, copy=True).reshape(-1, 3)
@@ -195,6 +196,13 @@ class LoadGTDepth:
         return out
 
     def __call__(self, results):
+        if self.device is not None:
+            from .device_prep import device_depth_maps
+            names = list(results["filename"])
+            rows = [np.fromfile(n.replace("cameras", "depth_gt") + ".bin", dtype=np.float32, count=-1) for n in names]
+            results["img_depth"] = device_depth_maps(rows, [n.split("/")[-2] for n in names], self.scale, self.pad,
+                                                     self.scale_factor_frontandback, self.depth_dim, self.device)
+            return results
         maps = []
         for name in list(results["filename"]):
             rows = np.fromfile(name.replace("cameras", "depth_gt") + ".bin", dtype=np.float32, count=-1)

@@ -120,3 +120,31 @@ def test_pixel_arithmetic_known_answers():
     assert np.allclose(up, [0.0, 1.0, 3.0, 4.0])                                                        # clamped borders
     p = impad(np.ones((2, 3, 1), np.float32), (4, 4), pad_val=0)
     assert p.shape == (4, 4, 1) and p.sum() == 6 and p[2:].sum() == 0
+
+
+@pytest.mark.parametrize("tag,kw", [("half", dict(scale=0.5)), ("full", dict(scale=1.0)), ("half_pad8", dict(scale=0.5, pad=8))])
+def test_device_depth_scatter_is_bit_identical_to_the_reference(gold, tmp_path, tag, kw):
+    """The scatter written for the GPU (device-agnostic torch), run here on CPU tensors."""
+    from projects.mmdet3d_plugin.datasets.pipelines import LoadGTDepth
+    res = LoadGTDepth(device="cpu", **kw)(dict(filename=_depth_tree(gold, tmp_path)))
+    assert res["img_depth"].dtype == torch.float32 and np.array_equal(res["img_depth"].numpy(), gold[f"depth_{tag}"])
+
+
+def test_device_image_pipeline_is_bit_identical_to_the_host_steps():
+    from projects.mmdet3d_plugin.datasets.pipelines import (NormalizeMultiviewImage, PadMultiViewImage,
+                                                             RandomScaleImageMultiViewImage)
+    from projects.mmdet3d_plugin.datasets.pipelines.device_prep import DeviceImagePipeline
+    rng = np.random.default_rng(3)
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    for (H, W), scale in [((270, 480), 0.5), ((135, 241), 0.5), ((96, 160), 1.0), ((120, 200), 0.3)]:
+        views = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+        l2i = [rng.normal(size=(4, 4)) for _ in range(3)]
+        r = dict(img=[v for v in views], lidar2img=[m.copy() for m in l2i])
+        r = NormalizeMultiviewImage(mean=mean, std=std, to_rgb=True)(r)
+        r = RandomScaleImageMultiViewImage(scales=[scale])(r)
+        r = PadMultiViewImage(size_divisor=32)(r)
+        want = np.stack([im.transpose(2, 0, 1) for im in r["img"]])
+        got, got_l2i = DeviceImagePipeline(mean, std, True, scale, 32, device="cpu")(views, l2i)
+        assert got.dtype == torch.float32 and got.shape == want.shape and got.is_contiguous()
+        assert np.array_equal(got.numpy(), want), (H, W, scale)
+        assert all(np.array_equal(a, b) for a, b in zip(got_l2i, r["lidar2img"]))
