@@ -186,43 +186,39 @@ class LiftSplatShoot_Depth(nn.Module):
         ys = torch.linspace(0, H - 1, self.fH, dtype=torch.float).view(1, self.fH, 1).expand(D, self.fH, self.fW)
         return nn.Parameter(torch.stack((xs, ys, ds), -1), requires_grad=False)
 
+    @staticmethod
+    def _rotate(R, p):
+        """R (B,N,1,1,1,3,3) applied to points p (..., 3): ((r0*p0 + r1*p1) + r2*p2) per axis, every step its own fp32
+        elementwise kernel (no contraction, no autocast down-cast) — the accumulation order of the reference's 3x3 @ 3x1
+        matmul on the CPU, bit for bit."""
+        axes = []
+        for a in range(3):
+            acc = R[..., a, 0] * p[..., 0] + R[..., a, 1] * p[..., 1]
+            axes.append(acc + R[..., a, 2] * p[..., 2])
+        return torch.stack(axes, dim=-1)
+
     def get_geometry(self, rots, trans, post_rots=None, post_trans=None, extra_rots=None, extra_trans=None):
-        """Frustum points in the lidar frame, (B, N, D, fH, fW, 3) — reference :235-264."""
+        """Frustum points in the lidar frame, (B, N, D, fH, fW, 3) — reference :235-264.
+
+        The reference writes every rotation as a batched matmul with one 3x3 product per frustum point.  That is 24
+        million tiny GEMMs for a flat batch of six samples (the launch faults inside the BLAS library on the GPU), and
+        under bf16 autocast torch runs it in bf16, which moves points across voxel borders.  Here rotations are three
+        broadcast multiply-adds per axis (``_rotate``): exact against the reference's torch-CPU result and
+        oracle/lss_oracle.get_geometry."""
         B, N, _ = trans.shape
-        if post_rots is None and post_trans is None and extra_rots is None and extra_trans is None:
-            # The call every detector makes.  Written as three broadcast multiply-adds per axis,
-            # ((r0*u*d + r1*v*d) + r2*d) + t with every step rounded on its own (separate elementwise kernels, no
-            # contraction): bit for bit the reference's torch-CPU result (its 3x3 @ 3x1 matmul accumulates in this
-            # order) and oracle/lss_oracle.get_geometry.  The reference formulation is a batched matmul with one
-            # 3x3 product per frustum point — 24 million tiny GEMMs for a flat batch of six samples, which faults
-            # inside the BLAS library on the GPU.
-            fr = self.frustum
-            pz = fr[..., 2]
-            px, py = fr[..., 0] * pz, fr[..., 1] * pz
-            R, t = rots.view(B, N, 1, 1, 1, 3, 3), trans.view(B, N, 1, 1, 1, 3)
-            axes = []
-            for a in range(3):
-                acc = R[..., a, 0] * px + R[..., a, 1] * py
-                acc = acc + R[..., a, 2] * pz
-                axes.append(acc + t[..., a])
-            return torch.stack(axes, dim=-1)
-        if post_rots is not None or post_trans is not None:
-            points = self.frustum
-            if post_trans is not None:
-                points = points - post_trans.view(B, N, 1, 1, 1, 3)
-            if post_rots is not None:
-                points = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(points.unsqueeze(-1))
-            else:
-                points = points.unsqueeze(-1)
-        else:
-            points = self.frustum.repeat(B, N, 1, 1, 1, 1).unsqueeze(-1)
-        points = torch.cat((points[..., :2, :] * points[..., 2:3, :], points[..., 2:3, :]), 5)
-        points = rots.view(B, N, 1, 1, 1, 3, 3).matmul(points).squeeze(-1)
-        points = points + trans.view(B, N, 1, 1, 1, 3)
+        shape = (B, N, 1, 1, 1)
+        points = self.frustum                                              # (D, fH, fW, 3): (u, v, d)
+        if post_trans is not None:
+            points = points - post_trans.view(*shape, 3)
+        if post_rots is not None:
+            points = self._rotate(torch.inverse(post_rots).view(*shape, 3, 3), points)
+        depth = points[..., 2]
+        points = torch.stack((points[..., 0] * depth, points[..., 1] * depth, depth), dim=-1)
+        points = self._rotate(rots.view(*shape, 3, 3), points) + trans.view(*shape, 3)
         if extra_rots is not None:
-            points = extra_rots.view(B, N, 1, 1, 1, 3, 3).matmul(points.unsqueeze(-1)).squeeze(-1)
+            points = self._rotate(extra_rots.view(*shape, 3, 3), points)
         if extra_trans is not None:
-            points = points + extra_trans.view(B, N, 1, 1, 1, 3)
+            points = points + extra_trans.view(*shape, 3)
         return points
 
     def get_cam_feats(self, x):

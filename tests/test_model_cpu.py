@@ -93,6 +93,33 @@ def test_lss_geometry_and_frustum_match_reference(golden):
     assert [k for k, _ in lss.bevencode.named_parameters()][:2] == ["0.weight", "1.weight"]
 
 
+def test_lss_geometry_is_fp32_under_autocast_and_general_path_equals_the_reference_formula(golden):
+    """bf16 autocast must not touch the geometry (a matmul formulation is down-cast by torch and moves points across
+    voxel borders); post-/extra- transforms give what the reference's batched-matmul text gives."""
+    from projects.mmdet3d_plugin.bevfusion.detectors.cam_stream_lss_bevpoolv2_depthnet import LiftSplatShoot_Depth
+    lss = LiftSplatShoot_Depth(final_dim=(32, 48), camera_depth_range=[1.0, 9.0, 1.0], pc_range=golden["g2_pc_range"].tolist(),
+                               downsample=4, grid=1.0, inputC=16, camC=8, norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01))
+    rots, trans = torch.from_numpy(golden["g2_rots"]), torch.from_numpy(golden["g2_trans"])
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        geom = lss.get_geometry(rots, trans)
+    assert geom.dtype == torch.float32 and np.array_equal(geom.numpy(), golden["g2_geom"])
+    B, N = rots.shape[:2]
+    torch.manual_seed(0)
+    post_rots = torch.linalg.qr(torch.randn(B, N, 3, 3))[0] + 0.1 * torch.randn(B, N, 3, 3)
+    extra_rots = torch.linalg.qr(torch.randn(B, N, 3, 3))[0]
+    post_trans, extra_trans = torch.randn(B, N, 3), torch.randn(B, N, 3)
+    # the reference's text (cam_stream_lss_bevpoolv2_depthnet.py:244-263) with all four optional transforms
+    p = lss.frustum.data - post_trans.view(B, N, 1, 1, 1, 3)
+    p = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(p.unsqueeze(-1))
+    p = torch.cat((p[:, :, :, :, :, :2] * p[:, :, :, :, :, 2:3], p[:, :, :, :, :, 2:3]), 5)
+    p = rots.view(B, N, 1, 1, 1, 3, 3).matmul(p).squeeze(-1) + trans.view(B, N, 1, 1, 1, 3)
+    p = extra_rots.view(B, N, 1, 1, 1, 3, 3).matmul(p.unsqueeze(-1)).squeeze(-1) + extra_trans.view(B, N, 1, 1, 1, 3)
+    got = lss.get_geometry(rots, trans, post_rots, post_trans, extra_rots, extra_trans)
+    assert got.shape == p.shape and float((got - p).abs().max()) <= 1e-5 * float(p.abs().max())
+    only_extra = lss.get_geometry(rots, trans, extra_trans=extra_trans)
+    assert torch.equal(only_extra, lss.get_geometry(rots, trans) + extra_trans.view(B, N, 1, 1, 1, 3))
+
+
 def test_dcn_zero_offsets_is_a_grouped_conv_and_offsets_shift_samples():
     from omnihd_amd.mm.dcn import DeformConv2dPack
     torch.manual_seed(0)
