@@ -136,3 +136,19 @@ def test_bevf_faster_rcnn_builds_from_the_fusion_config_and_trains_a_tiny_step()
         assert m.lift_splat_shot_vis.camencode.depthnet.weight.grad.abs().sum() > 0
         with pytest.raises(TypeError):
             build_detector(dict(cfg, norm_cfg=dict(type="BN")))
+
+
+def test_freeze_img_freezes_the_image_branch_and_the_camera_stream():
+    """Reference :77-87: with freeze_img the image backbone, neck and the whole lift module stop training."""
+    from omnihd_amd.harness import tiny_model_cfg
+    from omnihd_amd.mm.config import build_detector
+    for typ in ("BEVF_FasterRCNN", "BEVFUSION_depth"):
+        cfg = dict(tiny_model_cfg(7), type=typ, freeze_img=True)
+        if typ == "BEVF_FasterRCNN":
+            cfg.pop("norm_cfg", None)
+        m = build_detector(cfg)
+        frozen = {n.split(".")[0] for n, p in m.named_parameters() if not p.requires_grad}
+        trainable = {n.split(".")[0] for n, p in m.named_parameters() if p.requires_grad}
+        assert {"img_backbone", "img_neck", "lift_splat_shot_vis"} <= frozen
+        assert not ({"img_backbone", "img_neck", "lift_splat_shot_vis"} & trainable)
+        assert {"pts_voxel_encoder", "pts_backbone", "pts_neck", "reduc_conv", "pts_bbox_head"} <= trainable
