@@ -152,3 +152,47 @@ def test_freeze_img_freezes_the_image_branch_and_the_camera_stream():
         assert {"img_backbone", "img_neck", "lift_splat_shot_vis"} <= frozen
         assert not ({"img_backbone", "img_neck", "lift_splat_shot_vis"} & trainable)
         assert {"pts_voxel_encoder", "pts_backbone", "pts_neck", "reduc_conv", "pts_bbox_head"} <= trainable
+
+
+def test_camera_only_stage1_config_trains_and_tests_a_tiny_step():
+    """projects/configs/bevfusion_NewScenes/cam_stream/LSS.py:30-123 (BASELINE configs[1]'s reference artefact): the fusion
+    detector without a point stream and without the fusion conv — SyncBN everywhere, head on the 256-channel camera BEV."""
+    import math
+    from omnihd_amd import harness
+    from omnihd_amd.mm.config import build_detector, load_config
+    from oracle.torch_shim import oracle_ops
+    ref = "/root/reference/projects/configs/bevfusion_NewScenes/cam_stream/LSS.py"
+    if os.path.exists(ref):
+        full = build_detector(load_config(ref)["model"])
+        keys = set(full.state_dict())
+        assert not any(k.startswith(("pts_voxel", "pts_middle", "pts_backbone", "pts_neck", "reduc_conv", "seblock")) for k in keys)
+        assert full.pts_bbox_head.conv_cls.in_channels == 256 and sum(p.numel() for p in full.parameters()) == 58911173
+        assert type(full.img_backbone.bn1).__name__ in ("SyncBatchNorm", "NaiveSyncBatchNorm2d", "BatchNorm2d")
+    cfg = harness.tiny_model_cfg(7)
+    for k in ("pts_voxel_layer", "pts_voxel_encoder", "pts_middle_encoder", "pts_backbone", "pts_neck", "se"):
+        cfg.pop(k, None)
+    cfg.update(lc_fusion=False, norm_cfg=dict(type="SyncBN", requires_grad=True))
+    cfg["img_backbone"].update(norm_cfg=dict(type="SyncBN", requires_grad=True), norm_eval=False)
+    cfg["pts_bbox_head"].update(in_channels=256, feat_channels=256)
+    torch.set_num_threads(4)
+    torch.manual_seed(0)
+    with oracle_ops():
+        m = build_detector(cfg)
+        b = harness.synthetic_batch("tiny", 2, 7, "cpu", 0)
+        m.train()
+        opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=2e-3)
+        hist = []
+        for _ in range(4):
+            losses = m(return_loss=True, points=None, img_metas=b["img_metas"], gt_bboxes_3d=b["gt_bboxes_3d"],
+                       gt_labels_3d=b["gt_labels_3d"], img=b["img"], img_depth=b["img_depth"])
+            total = sum(v[0] if isinstance(v, list) else v for v in losses.values())
+            opt.zero_grad()
+            total.backward()
+            opt.step()
+            hist.append(float(total.detach()))
+        assert set(losses) == {"loss_cls", "loss_bbox", "loss_dir", "img_depth_loss"}
+        assert all(math.isfinite(h) for h in hist) and hist[-1] < hist[0]
+        m.eval()
+        torch.nn.init.constant_(m.pts_bbox_head.conv_cls.bias, 0.0)
+        out = m(return_loss=False, points=[None], img_metas=[b["img_metas"]], img=[b["img"]])
+    assert len(out) == 2 and all(len(r["pts_bbox"]["boxes_3d"]) > 0 for r in out)
