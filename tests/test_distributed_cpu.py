@@ -100,3 +100,41 @@ def test_triple_modal_temporal_two_rank_ddp_step_keeps_replicas_identical():
     assert res[0][1] and res[1][1]
     assert res[0][0] != res[1][0]
     assert all(np.isfinite(res[r][0]).all() for r in (0, 1))
+
+
+def _sampler_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "omnihd-scenes_amd")]
+    from projects.mmdet3d_plugin.datasets.samplers import DistributedGroupSampler, DistributedSampler
+    _init(rank, world, port)
+
+    class Data:
+        flag = np.zeros(41, dtype=np.uint8)
+
+        def __len__(self):
+            return 41
+    s = DistributedGroupSampler(Data(), samples_per_gpu=1, seed=0)          # rank / world size from the process group
+    s.set_epoch(2)
+    mine = torch.tensor(list(s))
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    t = torch.tensor(list(DistributedSampler(Data(), shuffle=False)))
+    tg = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(tg, t)
+    out[rank] = (s.rank, s.num_replicas, [g.tolist() for g in gathered], [g.tolist() for g in tg])
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_the_frames_through_the_reference_samplers():
+    port = _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_sampler_worker, args=(2, port, out), nprocs=2, join=True)
+        res = dict(out)
+    assert (res[0][0], res[0][1]) == (0, 2) and (res[1][0], res[1][1]) == (1, 2)
+    assert res[0][2] == res[1][2]                                              # both ranks see the same global picture
+    a, b = res[0][2]
+    assert len(a) == len(b) == 21 and set(a) | set(b) == set(range(41)) and len(set(a) & set(b)) == 1   # one padded repeat
+    ta, tb = res[0][3]
+    assert ta == list(range(21)) and tb == list(range(21, 41)) + [0]           # contiguous blocks at test time
