@@ -127,6 +127,40 @@ class RadarPoints:
         self.tensor = self.tensor[idx]
         return idx
 
+    # ---- augmentation hooks: columns 3:5 are the compensated velocity (vx, vy) and move with the geometry
+    # (reference core/points/radar_points.py:30-98; none of them is used by the NewScenes fusion pipelines) ----
+    def flip(self, bev_direction="horizontal"):
+        pos, vel = {"horizontal": (1, 4), "vertical": (0, 3)}[bev_direction]      # mirror y & vy, or x & vx
+        self.tensor[:, pos] = -self.tensor[:, pos]
+        self.tensor[:, vel] = -self.tensor[:, vel]
+
+    def scale(self, scale_factor):
+        self.tensor[:, :3] *= scale_factor
+        self.tensor[:, 3:5] *= scale_factor
+
+    def rotate(self, rotation, axis=None):
+        """Angle (about ``axis``, default z) or 3x3 matrix; returns the transposed matrix that was right-multiplied."""
+        if not isinstance(rotation, torch.Tensor):
+            rotation = self.tensor.new_tensor(rotation)
+        assert rotation.shape == torch.Size([3, 3]) or rotation.numel() == 1, f"invalid rotation shape {rotation.shape}"
+        axis = self.rotation_axis if axis is None else axis
+        if rotation.numel() == 1:
+            s, c = torch.sin(rotation), torch.cos(rotation)
+            rows = {1: [[c, 0, -s], [0, 1, 0], [s, 0, c]], 2: [[c, -s, 0], [s, c, 0], [0, 0, 1]],
+                    -1: [[c, -s, 0], [s, c, 0], [0, 0, 1]], 0: [[0, c, -s], [0, s, c], [1, 0, 0]]}
+            if axis not in rows:
+                raise ValueError("axis should in range")
+            rot_mat_T = rotation.new_tensor(rows[axis]).T
+        else:
+            rot_mat_T = rotation
+        self.tensor[:, :3] = self.tensor[:, :3] @ rot_mat_T
+        self.tensor[:, 3:5] = self.tensor[:, 3:5] @ rot_mat_T[:2, :2]
+        return rot_mat_T
+
+    def in_range_bev(self, point_range):
+        t = self.tensor
+        return (t[:, 0] > point_range[0]) & (t[:, 1] > point_range[1]) & (t[:, 0] < point_range[2]) & (t[:, 1] < point_range[3])
+
 
 @PIPELINES.register_module()
 class LoadRadarPointsMultiSweeps:

@@ -149,3 +149,35 @@ def test_dataset_evaluate_end_to_end_with_perfect_and_shifted_detections():
     assert set(sub) == {"meta", "results"} and set(sub["results"]) == {f"s{i}" for i in range(6)}
     rec = sub["results"]["s5"][0]
     assert set(rec) == {"sample_token", "translation", "size", "rotation", "velocity", "detection_name", "detection_score"}
+
+
+def test_radar_points_augmentation_hooks_match_the_reference():
+    """flip / scale / rotate / in_range_bev: positions AND the compensated velocity columns move together
+    (tests/golden/make_golden_points.py ran the reference class)."""
+    import os
+    from projects.mmdet3d_plugin.core.points.radar_points import RadarPoints
+    from projects.mmdet3d_plugin.datasets.pipelines import RadarPoints as SamePoints
+    assert RadarPoints is SamePoints
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "points_golden.npz"))
+    new = lambda: RadarPoints(g["pts"].copy(), points_dim=8)          # noqa: E731
+    for d in ("horizontal", "vertical"):
+        p = new(); p.flip(d)
+        assert np.array_equal(p.tensor.numpy(), g[f"flip_{d}"]), d
+    p = new(); p.scale(1.25)
+    assert np.array_equal(p.tensor.numpy(), g["scale"])
+    for tag, (rot, axis) in {"z": (0.3, None), "y": (-0.7, 1), "x": (1.1, 0), "m1": (0.5, -1)}.items():
+        p = new()
+        T = p.rotate(rot, axis)
+        assert np.array_equal(np.asarray(T), g[f"rot_{tag}_T"]) and np.array_equal(p.tensor.numpy(), g[f"rot_{tag}"]), tag
+    p = new()
+    T = p.rotate(torch.from_numpy(g["rot_mat_in"]))
+    assert np.array_equal(np.asarray(T), g["rot_mat_T"]) and np.array_equal(p.tensor.numpy(), g["rot_mat"])
+    assert np.array_equal(new().in_range_bev(g["bev_range"].tolist()).numpy(), g["in_bev"])
+    with pytest.raises(ValueError):
+        new().rotate(0.1, axis=5)
+
+
+def test_reference_module_paths_of_head_and_points_exist():
+    from omnihd_amd.mm import HEADS
+    from projects.mmdet3d_plugin.bevfusion.dense_heads.det_anchor3d_head import Anchor3DHeadV1
+    assert HEADS.get("Anchor3DHeadV1") is Anchor3DHeadV1
