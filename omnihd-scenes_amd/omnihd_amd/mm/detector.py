@@ -91,13 +91,21 @@ class MVXFasterRCNN(nn.Module):
         if not self.with_pts_bbox:
             return None
         voxels, num_points, coors = self.voxelize(pts)
-        voxel_features = self.pts_voxel_encoder(voxels, num_points, coors, img_feats, img_metas)
+        voxel_features = self.pts_voxel_encoder(voxels, num_points, coors, img_feats, img_metas, **self._encoder_hints(pts))
         # upstream reads the batch size back from the device (coors[-1, 0] + 1); the host already knows it
         x = self.pts_middle_encoder(voxel_features, coors, len(pts))
         x = self.pts_backbone(x)
         if self.with_pts_neck:
             x = self.pts_neck(x)
         return x
+
+    def _encoder_hints(self, pts):
+        """Host-known facts a voxel encoder can use without asking the device: HardVFE's packed evaluation sizes its
+        point buffer by the number of input points (an upper bound of the occupied slots)."""
+        from .hard_vfe import HardVFE
+        if isinstance(getattr(self, "pts_voxel_encoder", None), HardVFE):
+            return dict(max_real_points=sum(int(p.shape[0]) for p in pts))
+        return {}
 
     def extract_feat(self, points, img, img_metas):
         img_feats = self.extract_img_feat(img, img_metas)

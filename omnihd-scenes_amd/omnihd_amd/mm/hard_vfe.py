@@ -13,7 +13,22 @@ scale) and take part in the max, exactly as upstream.
 
 State-dict names are upstream's (``vfe_layers.{i}.linear.weight``, ``vfe_layers.{i}.norm.*``).
 Not built: ``fusion_layer`` (point-image fusion of MVX-Net) and ``with_distance`` — no NewScenes
-config sets them."""
+config sets them.
+
+PACKED EVALUATION (``packed=True`` / ``OMNIHD_VFE_PACKED=1``; off by default until its first GPU run).
+The dense formulation above pushes every one of the M x T slots through every layer: at the LiDAR
+stream's sizes (30 000-40 000 pillars x 64 slots per sample, ~3 points per pillar on average) that
+is 15 M rows x 64..128 channels per flat batch of six samples — several multi-GB passes, ~95 % of them
+over empty slots.  But an empty slot's value is the same for every empty slot of a voxel (layer 1: the
+constant relu(bn(0)); deeper layers: a function of the voxel's aggregate only), so the same numbers
+follow from the REAL points plus ONE representative row per voxel that stands for its (T - n) empty
+slots: the representative takes part in the max when T - n > 0 and enters the BatchNorm statistics with
+weight T - n.  Work and traffic then scale with the number of points, not slots (20-60x less here),
+with identical outputs, running statistics and gradients (tests/test_pillars_cpu.py).  Real points are
+packed without any host synchronisation into a buffer of the stream's input size (a cumulative sum
+over the slot mask gives every real slot its place)."""
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -54,8 +69,9 @@ class HardVFE(nn.Module):
     def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
                  with_voxel_center=False, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
                  norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), mode="max", fusion_layer=None,
-                 return_point_feats=False):
+                 return_point_feats=False, packed=None):
         super().__init__()
+        self.packed = packed          # None: follow OMNIHD_VFE_PACKED at call time (default 0)
         assert len(feat_channels) > 0
         if with_distance or fusion_layer is not None or return_point_feats:
             raise NotImplementedError("HardVFE: with_distance / fusion_layer / return_point_feats are used by no "
@@ -78,7 +94,10 @@ class HardVFE(nn.Module):
         self.num_vfe = len(layers)
         self.fusion_layer = None
 
-    def forward(self, features, num_points, coors, img_feats=None, img_metas=None):
+    def forward(self, features, num_points, coors, img_feats=None, img_metas=None, max_real_points=None):
+        packed = self.packed if self.packed is not None else os.environ.get("OMNIHD_VFE_PACKED", "0") == "1"
+        if packed:
+            return self._forward_packed(features, num_points, coors, max_real_points)
         parts = [features]
         if self._with_cluster_center:
             mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_points.type_as(features).view(-1, 1, 1)
@@ -94,3 +113,78 @@ class HardVFE(nn.Module):
         for vfe in self.vfe_layers:
             x = vfe(x)
         return x
+
+    # ---- packed evaluation: real points + one representative row per voxel ---------------------------------------
+    @staticmethod
+    def _weighted_norm(norm, rows, w_rows, reps, w_reps, n_total):
+        """BatchNorm of the M*T dense rows expressed on (rows with 0/1 weights) + (representatives with weights T-n):
+        the statistics, the running-statistics update and the exchange between ranks are the layer's own."""
+        from torch import distributed as dist
+        if not norm.training:
+            scale = norm.weight * torch.rsqrt(norm.running_var + norm.eps)
+            shift = norm.bias - norm.running_mean * scale
+            return rows * scale + shift, reps * scale + shift
+        s1 = (rows * w_rows).sum(0) + (reps * w_reps).sum(0)
+        s2 = (rows * rows * w_rows).sum(0) + (reps * reps * w_reps).sum(0)
+        mean, meansqr = s1 / n_total, s2 / n_total
+        synced = getattr(norm, "_omnihd_sync", False) and dist.is_available() and dist.is_initialized() \
+            and dist.get_world_size() > 1
+        if synced:          # naiveSyncBN: mean of the per-rank means (mm/sync_bn.py)
+            from .sync_bn import AllReduceSum
+            vec = AllReduceSum.apply(torch.cat([mean, meansqr])) * (1.0 / dist.get_world_size())
+            mean, meansqr = torch.split(vec, mean.numel())
+        var = meansqr - mean * mean
+        with torch.no_grad():
+            if norm.track_running_stats and norm.momentum is not None:
+                unbias = 1.0 if synced else n_total / max(n_total - 1, 1)          # torch's BatchNorm keeps the unbiased one
+                norm.running_mean += norm.momentum * (mean - norm.running_mean)
+                norm.running_var += norm.momentum * (var * unbias - norm.running_var)
+                if norm.num_batches_tracked is not None and not synced:      # as the layer's own two branches do
+                    norm.num_batches_tracked += 1
+        scale = norm.weight * torch.rsqrt(var + norm.eps)
+        shift = norm.bias - mean * scale
+        return rows * scale + shift, reps * scale + shift
+
+    def _forward_packed(self, features, num_points, coors, max_real_points=None):
+        M, T, C = features.shape
+        dev = features.device
+        n = num_points.to(torch.long).clamp(max=T)
+        cap = int(max_real_points) if max_real_points is not None else M * T       # upper bound of real slots, host-known
+        cap = min(cap, M * T)
+        slots = torch.arange(T, device=dev).view(1, T)
+        mask = (slots < n.view(M, 1)).reshape(-1)                                   # (M*T,) real slots
+        # place of every real slot in the packed buffer; slots beyond ``cap`` cannot exist when cap >= #points in
+        place = torch.cumsum(mask, 0) - 1
+        src = torch.full((cap + 1,), M * T, dtype=torch.long, device=dev)           # M*T = a zero dummy row
+        src.scatter_(0, torch.where(mask, place.clamp(max=cap), torch.full_like(place, cap)), torch.arange(M * T, device=dev))
+        src = src[:cap]
+        live = (src < M * T)
+        w_rows = live.to(features.dtype).unsqueeze(1)
+        vox = torch.where(live, src // T, torch.full_like(src, M))                  # dummy rows belong to voxel M
+        flat = torch.cat([features.reshape(M * T, C), features.new_zeros(1, C)], 0)
+        pts = flat[src]                                                             # (cap, C) real points, zeros elsewhere
+        parts = [pts]
+        if self._with_cluster_center:      # the dense expression: sum over ALL slots / count (empty slots are zero rows)
+            mean = features[:, :, :3].sum(dim=1) / num_points.type_as(features).view(-1, 1)
+            parts.append(pts[:, :3] - torch.cat([mean, mean.new_zeros(1, 3)], 0)[vox])
+        if self._with_voxel_center:
+            c = coors.type_as(features)
+            centre = torch.stack((c[:, 3] * self.vx + self.x_offset, c[:, 2] * self.vy + self.y_offset,
+                                  c[:, 1] * self.vz + self.z_offset), dim=-1)
+            parts.append(pts[:, :3] - torch.cat([centre, centre.new_zeros(1, 3)], 0)[vox])
+        rows = torch.cat(parts, dim=-1) * w_rows                                    # masked decorated points
+        reps = rows.new_zeros(M, rows.shape[1])                                     # an empty slot's input is a zero row
+        w_reps = (T - n).to(rows.dtype).unsqueeze(1)                                # how many empty slots it stands for
+        has_empty = (n < T).unsqueeze(1)
+        n_total = float(M * T)
+        for i, vfe in enumerate(self.vfe_layers):
+            yr, yp = self._weighted_norm(vfe.norm, vfe.linear(rows), w_rows, vfe.linear(reps), w_reps, n_total)
+            pr, pp = F.relu(yr), F.relu(yp)
+            agg = pr.new_full((M + 1, pr.shape[1]), float("-inf"))
+            agg = agg.scatter_reduce(0, vox.unsqueeze(1).expand(-1, pr.shape[1]), pr, reduce="amax", include_self=True)[:M]
+            agg = torch.where(has_empty, torch.maximum(agg, pp), agg)
+            if not vfe.cat_max:
+                return agg
+            rows = torch.cat([pr, torch.cat([agg, agg.new_zeros(1, agg.shape[1])], 0)[vox]], dim=1) * w_rows
+            reps = torch.cat([pp, agg], dim=1)
+        return rows

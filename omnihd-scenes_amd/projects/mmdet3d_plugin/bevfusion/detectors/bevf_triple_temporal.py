@@ -79,10 +79,11 @@ class BEVFusionTripleTemporal(BEVFUSION_depth):
         self.freeze()
 
     # ---- one time step, flat batch ------------------------------------------------------------------------
-    def _lidar_feat(self, pending, n_samples):
+    def _lidar_feat(self, pending, lidar_points):
         s = self.lidar_stream
         voxels, num_points, coors = s.voxelize_end(pending)
-        x = s.pts_middle_encoder(s.pts_voxel_encoder(voxels, num_points, coors), coors, n_samples)
+        feats = s.pts_voxel_encoder(voxels, num_points, coors, **s._encoder_hints(lidar_points))
+        x = s.pts_middle_encoder(feats, coors, len(lidar_points))
         return s.pts_neck(s.pts_backbone(x))
 
     def extract_feat(self, points, img, img_metas, lidar_points=None, gt_bboxes_3d=None):
@@ -97,7 +98,7 @@ class BEVFusionTripleTemporal(BEVFUSION_depth):
         rots, trans = self._cam_inverse(img_metas, view.device)
         cam_bev, depth_dist = self.lift_splat_shot_vis(view, rots, trans, lidar2img_rt=None, img_metas=img_metas)
         radar_bev = self.extract_pts_feat(points, img_feats, img_metas, voxelized=self.voxelize_end(radar_vox))[0]
-        lidar_bev = self._lidar_feat(lidar_vox, len(lidar_points))[0]
+        lidar_bev = self._lidar_feat(lidar_vox, lidar_points)[0]
         if cam_bev.shape[2:] != radar_bev.shape[2:]:
             cam_bev = F.interpolate(cam_bev, radar_bev.shape[2:], mode="bilinear", align_corners=True)
         fused = self.reduc_conv(torch.cat([cam_bev, radar_bev, lidar_bev], dim=1))

@@ -138,3 +138,45 @@ def test_two_ranks_shard_the_frames_through_the_reference_samplers():
     assert len(a) == len(b) == 21 and set(a) | set(b) == set(range(41)) and len(set(a) & set(b)) == 1   # one padded repeat
     ta, tb = res[0][3]
     assert ta == list(range(21)) and tb == list(range(21, 41)) + [0]           # contiguous blocks at test time
+
+
+def _vfe_worker(rank, world, port, out):
+    import copy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "omnihd-scenes_amd")]
+    from omnihd_amd.mm.hard_vfe import HardVFE
+    _init(rank, world, port)
+    torch.manual_seed(0)                                    # same weights on both ranks, different voxels
+    dense = HardVFE(in_channels=4, feat_channels=[32, 32], with_cluster_center=True, with_voxel_center=True,
+                    voxel_size=[0.5, 0.5, 2.0], point_cloud_range=[-8.0, -6.0, -1.0, 8.0, 6.0, 1.0],
+                    norm_cfg=dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), packed=False).double().train()
+    packed = copy.deepcopy(dense)
+    packed.packed = True
+    g = torch.Generator().manual_seed(10 + rank)
+    M, T = 60 + 20 * rank, 12                                # ranks hold different numbers of voxels
+    n = torch.randint(1, 5, (M,), generator=g, dtype=torch.int32)
+    vox = torch.zeros(M, T, 4, dtype=torch.float64)
+    for k in range(M):
+        vox[k, :n[k]] = torch.randn(int(n[k]), 4, generator=g, dtype=torch.float64) * 3
+    coors = torch.stack([torch.zeros(M), torch.zeros(M), torch.randint(0, 24, (M,), generator=g),
+                         torch.randint(0, 32, (M,), generator=g)], 1).int()
+    a, b = dense(vox, n, coors), packed(vox, n, coors, max_real_points=int(n.sum()))
+    a.sum().backward(); b.sum().backward()
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max())      # noqa: E731
+    out[rank] = (rel(b, a), max(rel(q.grad, p.grad) for p, q in zip(dense.parameters(), packed.parameters())),
+                 max(float((x.double() - y.double()).abs().max()) for x, y in zip(dense.buffers(), packed.buffers())),
+                 float(dense.vfe_layers[0].norm.running_mean.abs().sum()))
+    dist.destroy_process_group()
+
+
+def test_packed_hard_vfe_exchanges_statistics_like_the_dense_one_on_two_ranks():
+    """naiveSyncBN inside HardVFE at world size 2: mean of the per-rank means, taken over ALL slots of each rank."""
+    port = _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_vfe_worker, args=(2, port, out), nprocs=2, join=True)
+        res = dict(out)
+    for r in (0, 1):
+        assert res[r][0] < 1e-6 and res[r][1] < 1e-5 and res[r][2] < 1e-6, res[r]      # the layer's exchange branch computes in float32
+    assert abs(res[0][3] - res[1][3]) < 1e-6                 # both ranks hold the same running statistics

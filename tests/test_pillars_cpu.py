@@ -149,3 +149,86 @@ def test_stream_only_detector_trains_and_tests_a_tiny_step_over_the_oracle(strea
     assert len(out) == 2 and all("pts_bbox" in r for r in out)
     assert all(len(r["pts_bbox"]["boxes_3d"]) == r["pts_bbox"]["scores_3d"].numel() for r in out)
     assert np.isfinite(hist).all()
+
+
+@pytest.mark.parametrize("norm", ["BN1d", "naiveSyncBN1d"])
+@pytest.mark.parametrize("chans", [[64, 64], [32], [16, 24, 40]])
+def test_hard_vfe_packed_evaluation_equals_the_dense_one(norm, chans):
+    """Real points + one representative row per voxel (standing for its empty slots in the max and, weighted, in the
+    BatchNorm statistics) == all M x T slots: outputs, parameter gradients and running statistics, eval and train."""
+    import copy
+    from omnihd_amd.mm.hard_vfe import HardVFE
+    torch.manual_seed(len(chans) * 7 + len(norm))
+    M, T = 150, 16
+    dense = HardVFE(in_channels=4, feat_channels=chans, with_cluster_center=True, with_voxel_center=True,
+                    voxel_size=[0.5, 0.5, 2.0], point_cloud_range=[-8.0, -6.0, -1.0, 8.0, 6.0, 1.0],
+                    norm_cfg=dict(type=norm, eps=1e-3, momentum=0.01), packed=False)
+    for m in dense.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(); m.running_var.uniform_(0.5, 2); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.5)
+    packed = copy.deepcopy(dense)
+    packed.packed = True
+    n = torch.randint(1, T + 1, (M,), dtype=torch.int32)
+    n[:5] = T                                                   # full voxels: no empty slot takes part
+    n[5:10] = 1
+    vox = torch.zeros(M, T, 4)
+    for k in range(M):
+        vox[k, :n[k]] = torch.randn(int(n[k]), 4) * 3
+    coors = torch.stack([torch.zeros(M), torch.zeros(M), torch.randint(0, 24, (M,)), torch.randint(0, 32, (M,))], 1).int()
+    for mode in ("eval", "train"):
+        getattr(dense, mode)(); getattr(packed, mode)()
+        a = dense(vox, n, coors)
+        b = packed(vox, n, coors, max_real_points=int(n.sum()) + 11)          # any upper bound of the real slots
+        assert a.shape == b.shape == (M, chans[-1]) and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), mode
+        w = torch.randn_like(a)
+        dense.zero_grad(); packed.zero_grad()
+        (a * w).sum().backward(); (b * w).sum().backward()
+        for (name, p), q in zip(dense.named_parameters(), packed.parameters()):
+            assert float((p.grad - q.grad).abs().max()) <= 2e-5 * float(p.grad.abs().max() + 1e-9), (mode, name)
+        for (name, x), y in zip(dense.named_buffers(), packed.buffers()):
+            assert torch.allclose(x.float(), y.float(), atol=2e-6), (mode, name)
+    # without the hint the buffer is sized by the slots (still exact), and the switch can come from the environment
+    assert torch.allclose(packed(vox, n, coors), dense(vox, n, coors), atol=1e-4)
+
+
+def test_packed_encoder_on_voxeliser_output_matches_a_float64_yardstick(monkeypatch):
+    """On real voxeliser output (64 slots, 1-5 points per pillar: 95 % empty slots) the two evaluations are the same
+    function (1e-13 in float64); in float32 the packed one is the ACCURATE one — the dense BatchNorm backward cancels
+    over 38 000 mostly-zero rows and is off by ~1 % — so both are held against the float64 dense result."""
+    import copy
+    from omnihd_amd import harness
+    from omnihd_amd.mm.config import build_detector
+    from oracle.torch_shim import oracle_ops
+    torch.set_num_threads(4)
+    with oracle_ops():
+        torch.manual_seed(0)
+        m = build_detector(harness.pillars_model_cfg(harness.tiny_model_cfg(7), "lidar")).train()
+        b = harness.synthetic_batch("tiny", 2, 7, "cpu", 0)
+        pts = [p[:, :4].contiguous() for p in b["points"]]
+        vox, num, coors = m.voxelize(pts)
+        hints = m._encoder_hints(pts)
+        assert hints == dict(max_real_points=sum(p.shape[0] for p in pts)) and int(num.sum()) <= hints["max_real_points"]
+        # whole-detector step with the switch on: same loss as with it off
+        totals = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("OMNIHD_VFE_PACKED", flag)
+            torch.manual_seed(0)
+            d = build_detector(harness.pillars_model_cfg(harness.tiny_model_cfg(7), "lidar")).train()
+            losses = d(return_loss=True, points=pts, img_metas=b["img_metas"], gt_bboxes_3d=b["gt_bboxes_3d"],
+                       gt_labels_3d=b["gt_labels_3d"])
+            totals[flag] = float(sum(v[0] if isinstance(v, list) else v for v in losses.values()).detach())
+        assert abs(totals["0"] - totals["1"]) <= 1e-5 * abs(totals["0"])
+    w = torch.randn(vox.shape[0], 64, generator=torch.Generator().manual_seed(1))
+
+    def run(dtype, packed):
+        e = copy.deepcopy(m.pts_voxel_encoder).to(dtype)
+        e.packed = packed
+        out = e(vox.to(dtype), num, coors, **hints)
+        (out * w.to(dtype)).sum().backward()
+        return out.detach().double(), e.vfe_layers[0].linear.weight.grad.double(), e.vfe_layers[1].norm.running_var.double()
+
+    rel = lambda a, ref: float((a - ref).abs().max() / ref.abs().max())       # noqa: E731
+    d64, p64, d32, p32 = run(torch.float64, False), run(torch.float64, True), run(torch.float32, False), run(torch.float32, True)
+    assert all(rel(a, r) < 1e-11 for a, r in zip(p64, d64))                     # the same function
+    assert rel(p32[0], d64[0]) < 1e-5 and rel(p32[1], d64[1]) < 1e-4 and rel(p32[2], d64[2]) < 1e-5
+    assert rel(d32[0], d64[0]) < 1e-4 and rel(d32[1], d64[1]) < 5e-2           # the dense float32 gradient is the loose one
