@@ -23,7 +23,8 @@ that every ingredient is the already-pinned one and that the HIP path agrees wit
 
 Inputs (queue-major, as BEVFormer's): ``img (B, T, N, 3, H, W)``; ``points`` / ``lidar_points`` = list
 over B of lists over T of (n, C) tensors; ``img_metas`` = list over B of lists over T of dicts
-(``lidar2img``, optional ``ego_delta``); ground truth and ``img_depth (B, N, H, W)`` belong to the last
+(``lidar2img``, optional ``ego_delta`` and ``history_valid`` — ``datasets/temporal_queue.py`` derives both from the
+reference's ``can_bus`` / ``scene_token`` metas); ground truth and ``img_depth (B, N, H, W)`` belong to the last
 frame.  No CPU path: the HIP operators raise on CPU tensors.
 """
 import math
@@ -135,6 +136,9 @@ class BEVFusionTripleTemporal(BEVFUSION_depth):
                         grid = F.affine_grid(theta, list(bev.shape), align_corners=False)
                         bev = F.grid_sample(bev.float(), grid, mode="bilinear", padding_mode="zeros",
                                             align_corners=False).to(bev.dtype)
+                if not all(m.get("history_valid", True) for m in metas):      # frames of another scene contribute nothing
+                    keep = torch.tensor([bool(m.get("history_valid", True)) for m in metas], device=bev.device)
+                    bev = bev * keep.view(-1, 1, 1, 1).to(bev.dtype)
         finally:
             self.train(was_training)
         return bev.reshape(B, (T - 1) * bev.shape[1], *bev.shape[2:])
