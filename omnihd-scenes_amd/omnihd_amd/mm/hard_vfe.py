@@ -120,6 +120,8 @@ class HardVFE(nn.Module):
         """BatchNorm of the M*T dense rows expressed on (rows with 0/1 weights) + (representatives with weights T-n):
         the statistics, the running-statistics update and the exchange between ranks are the layer's own."""
         from torch import distributed as dist
+        if rows.dtype in (torch.bfloat16, torch.float16):      # statistics and normalisation in fp32 whatever autocast
+            rows, reps = rows.float(), reps.float()            # made of the Linear
         if not norm.training:
             scale = norm.weight * torch.rsqrt(norm.running_var + norm.eps)
             shift = norm.bias - norm.running_mean * scale
