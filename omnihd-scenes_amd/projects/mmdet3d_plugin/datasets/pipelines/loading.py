@@ -10,9 +10,10 @@ On-disk format: one little-endian float32 ``.bin`` per radar sweep, rows of ``lo
 
 The arithmetic follows the reference line by line (numpy, float32 inputs promoted exactly where the
 reference promotes them) so that results are bit-identical; ``merge_radar_sweeps`` is the array-level
-core, the class only adds file reading.  Image decoding / undistortion (OpenCV) is dataset IO and
-stays out of scope; the 4x4 matrix bookkeeping that feeds ``img_metas['lidar2img']`` is restated in
-``half_scale_front_back`` / ``scale_lidar2img``.
+core, the class only adds file reading.  The image loader of the same file (``LoadMultiViewImageFromFiles_newsc``)
+decodes with PIL and restates OpenCV's undistortion (pixel parity unpinned, bookkeeping pinned); the 4x4 matrix
+bookkeeping that feeds ``img_metas['lidar2img']`` is also available on its own in ``half_scale_front_back`` /
+``scale_lidar2img``.
 """
 import numpy as np
 import torch
@@ -271,6 +272,110 @@ class LoadOccupancy_Newscenes:
 
     def __repr__(self):
         return self.__class__.__name__
+
+
+# ---- camera images ------------------------------------------------------------------------------
+def undistort_map(K, dist, height, width):
+    """Source coordinates (map_x, map_y), float64 (H, W), of ``cv2.undistort(img, K, dist, None, K)``: every output
+    pixel is un-projected with K, pushed through the Brown-Conrady model (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1 s2 s3 s4]]]) and
+    projected with K again (OpenCV ``initUndistortRectifyMap`` with R = I and the same camera matrix)."""
+    d = np.zeros(12, dtype=np.float64)
+    dist = np.asarray(dist, dtype=np.float64).reshape(-1)
+    if dist.size not in (4, 5, 8, 12):
+        raise ValueError(f"distortion vector of {dist.size} coefficients (4, 5, 8 or 12 supported; no tilt terms)")
+    d[:dist.size] = dist
+    k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4 = d
+    K = np.asarray(K, dtype=np.float64)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+    x, y = (u - cx) / fx, (v - cy) / fy
+    r2 = x * x + y * y
+    radial = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2)
+    xd = x * radial + 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + s1 * r2 + s2 * r2 * r2
+    yd = y * radial + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + s3 * r2 + s4 * r2 * r2
+    return fx * xd + cx, fy * yd + cy
+
+
+def undistort(img, K, dist):
+    """``cv2.undistort(img, K, dist, None, K)`` restated: bilinear sampling at ``undistort_map``, zeros outside the image
+    (cv2's remap defaults: INTER_LINEAR, BORDER_CONSTANT 0).  cv2 interpolates 8-bit images in 1/32-pixel fixed point;
+    this restatement interpolates in float64 and rounds once — PIXEL PARITY WITH OpenCV IS UNPINNED (it is absent from
+    the image), the geometry of the map is the published model."""
+    h, w = img.shape[:2]
+    mx, my = undistort_map(K, dist, h, w)
+    x0, y0 = np.floor(mx).astype(np.int64), np.floor(my).astype(np.int64)
+    ax, ay = mx - x0, my - y0
+    src = np.asarray(img, dtype=np.float64).reshape(h, w, -1)
+    out = np.zeros_like(src)
+    for dy, wy in ((0, 1 - ay), (1, ay)):
+        for dx, wx in ((0, 1 - ax), (1, ax)):
+            xs, ys = x0 + dx, y0 + dy
+            ok = (xs >= 0) & (xs < w) & (ys >= 0) & (ys < h)
+            tap = src[np.clip(ys, 0, h - 1), np.clip(xs, 0, w - 1)] * ok[..., None]
+            out += tap * (wy * wx)[..., None]
+    out = out.reshape(img.shape)
+    if np.issubdtype(np.asarray(img).dtype, np.integer):
+        info = np.iinfo(np.asarray(img).dtype)
+        return np.clip(np.rint(out), info.min, info.max).astype(np.asarray(img).dtype)
+    return out.astype(np.asarray(img).dtype)
+
+
+def _read_image_bgr(path):
+    """Decoded image in OpenCV's channel order (what ``mmcv.imread(path, 'unchanged')`` returns for colour JPEG/PNG)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im)
+    return a[..., ::-1].copy() if a.ndim == 3 and a.shape[2] >= 3 else a
+
+
+@PIPELINES.register_module()
+class LoadMultiViewImageFromFiles_newsc:
+    """Six camera images of a frame (reference :318-405): decode, undistort with the camera's own intrinsics, halve
+    the front and back views (stored at twice the side views' resolution) together with their ``lidar2img`` /
+    ``cam_intrinsic``, and fill the shape keys the later steps expect.  ``results['img_shape']`` etc. are the shape
+    of the (H, W, 3, n_views) stack, as in the reference.  ``read`` lets a caller supply its own decoder."""
+
+    def __init__(self, to_float32=False, color_type="unchanged", read=None):
+        self.to_float32, self.color_type = to_float32, color_type
+        self.read = read or _read_image_bgr
+
+    def __call__(self, results):
+        from .transform_3d import imresize_bilinear
+        filename = results["img_filename"]
+        views, lidar2img, cam_intrinsic = [], [], []
+        half = 0.5
+        for i, name in enumerate(filename):
+            k = results["cam_intrinsic"][i]
+            view = undistort(self.read(name), k[:3, :3], results["cam_distortion"][i])
+            if name.split("/")[-2] in ("camera_front", "camera_back"):
+                small = imresize_bilinear(view, (int(view.shape[1] * half), int(view.shape[0] * half)))
+                if np.issubdtype(view.dtype, np.integer):
+                    small = np.clip(np.rint(small), 0, np.iinfo(view.dtype).max).astype(view.dtype)
+                view = small
+                s = np.eye(4)
+                s[0, 0] *= half
+                s[1, 1] *= half
+                lidar2img.append(s @ results["lidar2img"][i])
+                cam_intrinsic.append(s @ k)
+            else:
+                lidar2img.append(results["lidar2img"][i])
+                cam_intrinsic.append(k)
+            views.append(view)
+        img = np.stack(views, axis=-1)
+        results["lidar2img"], results["cam_intrinsic"] = lidar2img, cam_intrinsic
+        if self.to_float32:
+            img = img.astype(np.float32)
+        results["filename"] = filename
+        results["img"] = [img[..., i] for i in range(img.shape[-1])]
+        results["img_shape"] = results["ori_shape"] = results["pad_shape"] = img.shape
+        results["scale_factor"] = 1.0
+        channels = 1 if img.ndim < 3 else img.shape[2]
+        results["img_norm_cfg"] = dict(mean=np.zeros(channels, dtype=np.float32), std=np.ones(channels, dtype=np.float32),
+                                       to_rgb=False)
+        return results
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(to_float32={self.to_float32}, color_type='{self.color_type}')"
 
 
 # ---- camera matrices that end up in img_metas['lidar2img'] ------------------------------------

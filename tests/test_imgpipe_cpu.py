@@ -148,3 +148,79 @@ def test_device_image_pipeline_is_bit_identical_to_the_host_steps():
         assert got.dtype == torch.float32 and got.shape == want.shape and got.is_contiguous()
         assert np.array_equal(got.numpy(), want), (H, W, scale)
         assert all(np.array_equal(a, b) for a, b in zip(got_l2i, r["lidar2img"]))
+
+
+def test_image_loader_bookkeeping_matches_the_reference(tmp_path):
+    """Which views are halved, the float64 matrix updates, the K / distortion handed to the undistortion, shapes and
+    keys: pinned by tests/golden/make_golden_imgload.py (reference class over recording stand-ins for mmcv / cv2)."""
+    from projects.mmdet3d_plugin.datasets.pipelines import LoadMultiViewImageFromFiles_newsc
+    from projects.mmdet3d_plugin.datasets.pipelines import loading as L
+    with open(os.path.join(os.path.dirname(__file__), "golden", "imgload_golden.json")) as f:
+        g = json.load(f)
+    sizes = dict(zip(g["names"], g["sizes"]))
+    seen = []
+    real_undistort = L.undistort
+
+    def spy(img, K, dist):
+        seen.append([list(img.shape), np.asarray(K).tolist(), np.asarray(dist).tolist()])
+        return img                                               # identity, like the stand-in of the golden run
+    L.undistort = spy
+    try:
+        for run in g["runs"]:
+            seen.clear()
+            reads = []
+
+            def read(name):
+                reads.append(name)
+                return np.full(tuple(sizes[name]) + (3,), len(reads), dtype=np.uint8)
+            res = LoadMultiViewImageFromFiles_newsc(to_float32=run["to_float32"], read=read)(
+                dict(img_filename=list(g["names"]), cam_intrinsic=[np.array(k) for k in g["K"]],
+                     cam_distortion=[np.array(d) for d in g["dist"]], lidar2img=[np.array(m) for m in g["lidar2img"]]))
+            assert sorted(res.keys()) == run["keys"] and str(res["img"][0].dtype) == run["dtype"]
+            assert len(res["img"]) == run["n_img"] and list(res["img"][0].shape) == run["img0_shape"]
+            for k in ("img_shape", "ori_shape", "pad_shape"):
+                assert list(res[k]) == run[k], k
+            assert res["scale_factor"] == run["scale_factor"] and (res["filename"] == g["names"]) == run["filename_same"]
+            n = res["img_norm_cfg"]
+            assert n["mean"].tolist() == run["norm"]["mean"] and n["std"].tolist() == run["norm"]["std"]
+            assert n["to_rgb"] == run["norm"]["to_rgb"] and str(n["mean"].dtype) == run["norm"]["dtype"]
+            assert np.array_equal(np.array(res["lidar2img"]), np.array(run["lidar2img"]))            # float64, bit for bit
+            assert np.array_equal(np.array(res["cam_intrinsic"]), np.array(run["cam_intrinsic"]))
+            want_und = [[c[1], c[2], c[3]] for c in run["calls"] if c[0] == "undistort"]
+            assert seen == want_und                                 # same image shapes, K[:3,:3] and distortion vectors
+            assert all(c[4] is True and c[5] == c[2] for c in run["calls"] if c[0] == "undistort")   # R=None, newK=K
+            halved = [c[2] for c in run["calls"] if c[0] == "imresize"]
+            ours = [[im.shape[1], im.shape[0]] for im, name in zip(res["img"], g["names"])
+                    if name.split("/")[-2] in ("camera_front", "camera_back")]
+            assert ours == halved
+    finally:
+        L.undistort = real_undistort
+
+
+def test_undistort_known_answers_and_decoder(tmp_path):
+    from projects.mmdet3d_plugin.datasets.pipelines.loading import _read_image_bgr, undistort, undistort_map
+    K = np.array([[200.0, 0, 96.0], [0, 210.0, 54.0], [0, 0, 1]])
+    img = np.random.default_rng(0).integers(0, 256, (108, 192, 3), dtype=np.uint8)
+    assert np.array_equal(undistort(img, K, np.zeros(5)), img)                    # no distortion: identity
+    mx, my = undistort_map(K, [0.1, 0, 0, 0, 0], 108, 192)                         # pure k1
+    u, v = 150, 20
+    x, y = (u - 96.0) / 200.0, (v - 54.0) / 210.0
+    r2 = x * x + y * y
+    assert abs(mx[v, u] - (200.0 * x * (1 + 0.1 * r2) + 96.0)) < 1e-9 and abs(my[v, u] - (210.0 * y * (1 + 0.1 * r2) + 54.0)) < 1e-9
+    assert mx[54, 96] == 96.0 and my[54, 96] == 54.0                               # the principal point stays
+    mx, my = undistort_map(K, [0, 0, 0.01, -0.02], 108, 192)                       # tangential only, 4 coefficients
+    assert abs(mx[v, u] - (200.0 * (x + 2 * 0.01 * x * y - 0.02 * (r2 + 2 * x * x)) + 96.0)) < 1e-9
+    out = undistort(np.full((108, 192, 3), 200, np.uint8), K, [0.5, 0, 0, 0, 0])   # barrel: corners sample outside -> 0
+    assert out[54, 96, 0] == 200 and out[0, 0, 0] == 0
+    ramp = np.tile(np.arange(192, dtype=np.float32)[None, :, None], (108, 1, 1))   # linear image: bilinear is exact
+    got = undistort(ramp, K, [0.05, 0, 0, 0, 0])
+    mx, my = undistort_map(K, [0.05, 0, 0, 0, 0], 108, 192)
+    inside = (mx >= 0) & (mx <= 191) & (my >= 0) & (my <= 107)
+    assert np.allclose(got[..., 0][inside], mx[inside], atol=1e-3)
+    with pytest.raises(ValueError):
+        undistort_map(K, np.zeros(14), 4, 4)
+    from PIL import Image                                                           # decoder: OpenCV channel order
+    rgb = np.zeros((4, 5, 3), np.uint8); rgb[..., 0] = 250; rgb[..., 2] = 10
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    bgr = _read_image_bgr(str(tmp_path / "a.png"))
+    assert bgr.shape == (4, 5, 3) and bgr[0, 0].tolist() == [10, 0, 250]
