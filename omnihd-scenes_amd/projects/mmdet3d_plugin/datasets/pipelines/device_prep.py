@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .transform_3d import _axis_taps
 
-__all__ = ["DeviceImagePipeline", "device_depth_maps"]
+__all__ = ["DeviceImageLoader", "DeviceImagePipeline", "device_depth_maps"]
 
 
 class DeviceImagePipeline:
@@ -73,6 +73,79 @@ class DeviceImagePipeline:
         s[0, 0] *= self.scale
         s[1, 1] *= self.scale
         return out, [s @ m for m in lidar2img]
+
+
+class DeviceImageLoader:
+    """``LoadMultiViewImageFromFiles_newsc`` after the decode, on the device: undistortion of every view with a
+    per-camera tap table (source positions and weights of ``loading.undistort_map``, built once per calibration on the
+    host in float64 and kept on the device), halving of the front / back views, and the matrix bookkeeping.  The
+    arithmetic repeats the host mirror's (float64 taps and accumulation, one rounding to the image's integer type; the
+    halving in float32 with the host's tap tables), so the views are bit-identical to the host loader's
+    (tests/test_imgpipe_cpu.py, on CPU tensors).  Input: decoded views as uint8 arrays/tensors (H_i, W_i, 3)."""
+
+    def __init__(self, device="cuda:0", half_scale=0.5):
+        self.device, self.half = torch.device(device), half_scale
+        self._maps, self._taps = {}, {}
+
+    def _map(self, K, dist, h, w):
+        from .loading import undistort_map
+        key = (np.asarray(K, dtype=np.float64).tobytes(), np.asarray(dist, dtype=np.float64).tobytes(), h, w)
+        hit = self._maps.get(key)
+        if hit is None:
+            mx, my = undistort_map(K, dist, h, w)
+            x0, y0 = np.floor(mx).astype(np.int64), np.floor(my).astype(np.int64)
+            hit = tuple(torch.from_numpy(a).to(self.device) for a in (x0, y0, mx - x0, my - y0))
+            if len(self._maps) >= 32:
+                self._maps.clear()
+            self._maps[key] = hit
+        return hit
+
+    def _undistort(self, img, K, dist):
+        h, w = img.shape[:2]
+        x0, y0, ax, ay = self._map(K, dist, h, w)
+        src = img.to(torch.float64).reshape(h, w, -1)
+        out = torch.zeros_like(src)
+        for dy, wy in ((0, 1 - ay), (1, ay)):
+            for dx, wx in ((0, 1 - ax), (1, ax)):
+                xs, ys = x0 + dx, y0 + dy
+                ok = (xs >= 0) & (xs < w) & (ys >= 0) & (ys < h)
+                tap = src[ys.clamp(0, h - 1), xs.clamp(0, w - 1)] * ok.unsqueeze(-1)
+                out += tap * (wy * wx).unsqueeze(-1)
+        return torch.clamp(torch.round(out), 0, 255).to(torch.uint8).reshape(img.shape)
+
+    def _halve(self, img):
+        h, w = img.shape[:2]
+        h2, w2 = int(h * self.half), int(w * self.half)
+        key = (h, w)
+        if key not in self._taps:
+            self._taps[key] = tuple(tuple(torch.from_numpy(a).to(self.device) for a in _axis_taps(n, m))
+                                    for n, m in ((w, w2), (h, h2)))
+        (lo, hi, wt), (lo2, hi2, wt2) = self._taps[key]
+        x = img.to(torch.float32)
+        x = x[:, lo] * (1.0 - wt.view(1, -1, 1)) + x[:, hi] * wt.view(1, -1, 1)
+        x = x[lo2] * (1.0 - wt2.view(-1, 1, 1)) + x[hi2] * wt2.view(-1, 1, 1)
+        return torch.clamp(torch.round(x), 0, 255).to(torch.uint8)
+
+    @torch.no_grad()
+    def __call__(self, decoded_views, filenames, cam_intrinsic, cam_distortion, lidar2img):
+        """-> (views (N, H, W, 3) uint8 on the device, lidar2img list, cam_intrinsic list) — the reference's outputs
+        before ``to_float32``; feed the views to ``DeviceImagePipeline``."""
+        views, l2i, ks = [], [], []
+        for i, name in enumerate(filenames):
+            k = np.asarray(cam_intrinsic[i])
+            v = self._undistort(torch.as_tensor(decoded_views[i]).to(self.device), k[:3, :3], cam_distortion[i])
+            if name.split("/")[-2] in ("camera_front", "camera_back"):
+                v = self._halve(v)
+                s = np.eye(4)
+                s[0, 0] *= self.half
+                s[1, 1] *= self.half
+                l2i.append(s @ lidar2img[i])
+                ks.append(s @ k)
+            else:
+                l2i.append(lidar2img[i])
+                ks.append(k)
+            views.append(v)
+        return torch.stack(views), l2i, ks
 
 
 @torch.no_grad()

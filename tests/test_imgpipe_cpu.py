@@ -224,3 +224,39 @@ def test_undistort_known_answers_and_decoder(tmp_path):
     Image.fromarray(rgb).save(tmp_path / "a.png")
     bgr = _read_image_bgr(str(tmp_path / "a.png"))
     assert bgr.shape == (4, 5, 3) and bgr[0, 0].tolist() == [10, 0, 250]
+
+
+def test_device_image_loader_plus_pipeline_equal_the_host_chain():
+    """decoded uint8 views -> undistort -> halve front/back -> normalise -> scale 0.5 -> pad: device classes (run on CPU
+    tensors) against the host mirrors, bit for bit, including the matrices."""
+    from projects.mmdet3d_plugin.datasets.pipelines import (LoadMultiViewImageFromFiles_newsc, NormalizeMultiviewImage,
+                                                             PadMultiViewImage, RandomScaleImageMultiViewImage)
+    from projects.mmdet3d_plugin.datasets.pipelines.device_prep import DeviceImageLoader, DeviceImagePipeline
+    rng = np.random.default_rng(9)
+    cams = ["camera_front", "camera_left_front", "camera_right_front", "camera_back", "camera_left_back", "camera_right_back"]
+    names = [f"/d/cameras/{c}/0.jpg" for c in cams]
+    big = lambda n: n.split("/")[-2] in ("camera_front", "camera_back")          # noqa: E731  (stored at twice the resolution)
+    decoded = {n: rng.integers(0, 256, (216, 384, 3) if big(n) else (108, 192, 3), dtype=np.uint8) for n in names}
+    K = []
+    for n in names:
+        h, w = decoded[n].shape[:2]
+        k = np.eye(4); k[0, 0], k[1, 1], k[0, 2], k[1, 2] = 0.9 * w, 0.95 * w, w / 2 + 1.5, h / 2 - 2.0
+        K.append(k)
+    dist = [np.array([-0.12, 0.03, 1e-3, -2e-3, 0.01]) * (1 + 0.1 * i) for i in range(6)]
+    l2i = [rng.normal(size=(4, 4)) for _ in range(6)]
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    r = LoadMultiViewImageFromFiles_newsc(to_float32=True, read=lambda n: decoded[n])(
+        dict(img_filename=list(names), cam_intrinsic=[k.copy() for k in K], cam_distortion=dist, lidar2img=[m.copy() for m in l2i]))
+    host_views = np.stack(r["img"])
+    r = NormalizeMultiviewImage(mean=mean, std=std, to_rgb=True)(r)
+    r = RandomScaleImageMultiViewImage(scales=[0.5])(r)
+    r = PadMultiViewImage(size_divisor=32)(r)
+    want = np.stack([im.transpose(2, 0, 1) for im in r["img"]])
+    views, d_l2i, d_k = DeviceImageLoader(device="cpu")([decoded[n] for n in names], names, K, dist, l2i)
+    assert views.dtype == torch.uint8 and np.array_equal(views.numpy().astype(np.float32), host_views)
+    assert all(np.array_equal(a, b) for a, b in zip(d_k, r["cam_intrinsic"]))
+    got, got_l2i = DeviceImagePipeline(mean, std, True, 0.5, 32, device="cpu")(views, d_l2i)
+    assert got.shape == want.shape == (6, 3, 64, 96) and np.array_equal(got.numpy(), want)
+    assert all(np.array_equal(a, b) for a, b in zip(got_l2i, r["lidar2img"]))
+    plain = np.stack([decoded[n][::2, ::2] if big(n) else decoded[n] for n in names]).astype(np.float32)
+    assert float(np.abs(host_views - plain).mean()) > 0.5                           # the undistortion did move pixels
