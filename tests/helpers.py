@@ -72,16 +72,21 @@ class RefKernels:
         torch.cuda.synchronize()
 
 
-def seeded_state(module, seed):
+def seeded_state(module, seed, by_name=False):
     """Fill every parameter and buffer of ``module`` from one numpy generator, in state-dict order, so
     that a golden script and a test rebuild the same weights without storing them (BatchNorm running
-    variances and weights positive; integer buffers and ``frustum`` untouched)."""
+    variances and weights positive; integer buffers and ``frustum`` untouched).  ``by_name``: one generator per
+    tensor, seeded by the tensor's NAME, so that the values do not depend on the order of the state dict."""
+    import zlib
+
     import torch
     rng = np.random.default_rng(seed)
     with torch.no_grad():
         for name, v in module.state_dict().items():
             if not v.is_floating_point() or name.endswith("frustum"):
                 continue
+            if by_name:
+                rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
             shape = tuple(v.shape)
             if name.endswith("running_var"):
                 a = rng.uniform(0.5, 2.0, shape)
