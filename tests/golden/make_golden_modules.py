@@ -119,6 +119,18 @@ def main():
         out["se_x"], out["se_y"] = x.numpy(), se(x).numpy()
     save_state(out, "se", se)
 
+    # ---- KL depth loss of the DepthNet stream (cam_stream_lss_bevpoolv2_depthnet.py:428-456) on a shell ``self`` ----
+    import types
+    shell = types.SimpleNamespace(downsample=4, camera_depth_range=[1.0, 9.0, 1.0], constant_std=0.5, D=8)
+    shell.get_klv_depth_loss = types.MethodType(lss.LiftSplatShoot_Depth.get_klv_depth_loss, shell)
+    dm = torch.zeros(2, 3, 32, 48)
+    hit = torch.from_numpy(rng.random((2, 3, 32, 48))) < 0.1
+    dm[hit] = torch.from_numpy(rng.uniform(0.2, 12.0, int(hit.sum())).astype(np.float32))     # some beyond the range
+    pred = torch.from_numpy(rng.normal(size=(2, 3, 8, 8, 12)).astype(np.float32)).softmax(2)
+    loss, mind = lss.LiftSplatShoot_Depth.get_depth_loss(shell, dm, pred, "kld")
+    out["kld_depth_map"], out["kld_pred"], out["kld_loss"], out["kld_min_depth"] = dm.numpy(), pred.numpy(), loss.numpy(), mind.numpy()
+    print("kld depth loss", float(loss))
+
     path = os.path.join(HERE, "modules_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB;", len(out), "arrays")

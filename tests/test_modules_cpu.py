@@ -69,3 +69,19 @@ def test_se_block_matches_the_reference(gold):
     assert sorted(m.state_dict().keys()) == gold["se_keys"].tolist()
     with torch.no_grad():
         assert _close(m(torch.from_numpy(gold["se_x"])), gold["se_y"], 1e-6)
+
+
+def test_kl_depth_loss_matches_the_reference_method(gold):
+    """``get_depth_loss(..., 'kld')`` of the DepthNet stream: masked mean instead of the reference's boolean gather (no
+    host synchronisation), same value and the same returned min-depth map; gradient finite."""
+    from projects.mmdet3d_plugin.bevfusion.detectors.cam_stream_lss_bevpoolv2_depthnet import LiftSplatShoot_Depth
+    lss = LiftSplatShoot_Depth(final_dim=(32, 48), camera_depth_range=[1.0, 9.0, 1.0], pc_range=[-8.0, -6.0, -1.0, 8.0, 6.0, 1.0],
+                               downsample=4, grid=1.0, inputC=16, camC=8, norm_cfg=NORM)
+    pred = torch.from_numpy(gold["kld_pred"]).requires_grad_()
+    loss, mind = lss.get_depth_loss(torch.from_numpy(gold["kld_depth_map"]), pred, "kld")
+    assert abs(float(loss) - float(gold["kld_loss"])) <= 1e-5 * abs(float(gold["kld_loss"]))
+    assert np.array_equal(mind.numpy(), gold["kld_min_depth"])
+    loss.backward()
+    assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().sum()) > 0
+    with pytest.raises(NotImplementedError):
+        lss.get_depth_loss(torch.from_numpy(gold["kld_depth_map"]), pred, "bce")
