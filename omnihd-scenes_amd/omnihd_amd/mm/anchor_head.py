@@ -327,7 +327,17 @@ class Anchor3DHead(nn.Module):
         dir_targets = torch.stack([t[4] for t in tg]).reshape(-1)
         dir_weights = torch.stack([t[5] for t in tg]).reshape(-1)
         num_total_samples = torch.stack([t[6] for t in tg]).clamp(min=1).sum().to(cls_score.dtype)   # stays on the device
+        return self.loss_from_targets(cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,
+                                      dir_targets, dir_weights, num_total_samples)
 
+    def loss_from_targets(self, cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,
+                          dir_targets, dir_weights, num_total_samples):
+        """``loss_single`` of the vendored head (det_anchor3d_head.py:192-277) for one level: (B, A*K, H, W) maps and
+        flattened targets in, the three losses out."""
+        labels, label_weights = labels.reshape(-1), label_weights.reshape(-1)
+        bbox_targets = bbox_targets.reshape(-1, self.box_code_size)
+        bbox_weights = bbox_weights.reshape(-1, self.box_code_size)
+        dir_targets, dir_weights = dir_targets.reshape(-1), dir_weights.reshape(-1)
         cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
         loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
         # Regression / direction losses over ALL anchors with zero weight off the positives (the vendored head

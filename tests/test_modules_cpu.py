@@ -85,3 +85,58 @@ def test_kl_depth_loss_matches_the_reference_method(gold):
     assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().sum()) > 0
     with pytest.raises(NotImplementedError):
         lss.get_depth_loss(torch.from_numpy(gold["kld_depth_map"]), pred, "bce")
+
+
+@pytest.mark.parametrize("tag,cw,sin", [("cw_sin", [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2], True), ("plain", None, False)])
+def test_head_loss_from_targets_matches_the_vendored_head(tag, cw, sin):
+    """``Anchor3DHeadV1.loss_single`` (the copy of the anchor head the reference vendors) on synthetic maps and targets
+    (tests/golden/make_golden_head.py) against ``Anchor3DHead.loss_from_targets`` with the restated upstream losses:
+    the gather-free formulation (all anchors, zero weight off the positives) gives the same three numbers."""
+    from omnihd_amd.mm.anchor_head import Anchor3DHead, CrossEntropyLoss, FocalLoss, SmoothL1Loss
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "head_golden.npz"))
+    head = Anchor3DHead.__new__(Anchor3DHead)                      # the loss tail reads these attributes only
+    torch.nn.Module.__init__(head)
+    head.num_classes, head.box_code_size, head.diff_rad_by_sin = 3, 9, sin
+    head.train_cfg = dict(code_weight=cw)
+    head.loss_cls = FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0)
+    head.loss_bbox = SmoothL1Loss(beta=1.0 / 9.0, loss_weight=1.0)
+    head.loss_dir = CrossEntropyLoss(use_sigmoid=False, loss_weight=0.2)
+    t = lambda k: torch.from_numpy(g[k])      # noqa: E731
+    out = head.loss_from_targets(t("cls"), t("box"), t("dirs"), t("labels"), t("label_w"), t("box_t"), t("box_w"),
+                                 t("dir_t"), t("dir_w"), torch.tensor(float(g["num_total"])))
+    got = np.array([float(out["loss_cls"][0]), float(out["loss_bbox"][0]), float(out["loss_dir"][0])])
+    assert np.allclose(got, g[f"{tag}_losses"], rtol=2e-6, atol=0), (got, g[f"{tag}_losses"])
+    s1, s2 = Anchor3DHead.add_sin_difference(t("sin_b1"), t("sin_b2"))
+    assert np.array_equal(s1.numpy(), g["sin_o1"]) and np.array_equal(s2.numpy(), g["sin_o2"])
+
+
+def test_head_test_time_branch_matches_the_vendored_head():
+    """``Anchor3DHeadV1.get_bboxes_single``: what goes INTO the multi-class NMS (decoded boxes, corner form, padded score
+    matrix, direction bins, thresholds) and the yaw fix-up applied to what comes OUT, with the NMS itself replaced by the
+    same recording stand-in on both sides (two levels: ``nms_pre`` cuts the first only)."""
+    from omnihd_amd.mm import boxes as B
+    from omnihd_amd.mm.anchor_head import Anchor3DHead, DeltaXYZWLHRBBoxCoder
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "head_golden.npz"))
+    head = Anchor3DHead.__new__(Anchor3DHead)
+    torch.nn.Module.__init__(head)
+    head.num_classes, head.box_code_size, head.use_sigmoid_cls = 3, 9, True
+    head.bbox_coder, head.dir_offset, head.dir_limit_offset = DeltaXYZWLHRBBoxCoder(code_size=9), 0.7854, 0
+    head.test_cfg = dict(nms_pre=40, score_thr=0.05, max_num=20, use_rotate_nms=True, nms_thr=0.2)
+    seen = {}
+
+    def nms_recorder(bboxes, for_nms, scores, score_thr, max_num, cfg, dir_scores):
+        seen.update(bboxes=bboxes.clone(), for_nms=for_nms.clone(), scores=scores.clone(), thr_max=[score_thr, max_num],
+                    dir_scores=dir_scores.clone())
+        keep = torch.arange(0, bboxes.shape[0], 3)[:max_num]
+        best, lab = scores[keep, :-1].max(dim=1)
+        return bboxes[keep], best, lab, dir_scores[keep]
+    t = lambda k: torch.from_numpy(g[k])      # noqa: E731
+    with mock.patch.object(B, "box3d_multiclass_nms", nms_recorder):
+        boxes, scores, labels = head.get_bboxes_single([t("tt_cls0"), t("tt_cls1")], [t("tt_box0"), t("tt_box1")],
+                                                       [t("tt_dir0"), t("tt_dir1")], [t("tt_anc0"), t("tt_anc1")], dict())
+    assert torch.allclose(seen["bboxes"], t("tt_nms_in_bboxes"), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(seen["for_nms"], t("tt_nms_in_for_nms"), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(seen["scores"], t("tt_nms_in_scores"), rtol=1e-6, atol=1e-7) and seen["scores"].shape[1] == 4
+    assert torch.equal(seen["dir_scores"], t("tt_nms_in_dir_scores")) and seen["thr_max"] == g["tt_nms_in_thr_max"].tolist()
+    assert torch.allclose(boxes.tensor, t("tt_boxes"), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(scores, t("tt_scores"), rtol=1e-6, atol=1e-7) and torch.equal(labels, t("tt_labels"))
