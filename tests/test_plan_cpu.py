@@ -1,0 +1,95 @@
+"""Host-side planning of the pooling kernels (``omnihd_amd/plan.py``: tile and pixel schedules) on CPU tensors: only the
+ORDER of work is chosen there, so the properties to hold are "every unit exactly once", consistency with the tables, and
+the balance the XCD mapping relies on."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lss_oracle as O
+
+
+def _tables(seed=0):
+    rng = np.random.default_rng(seed)
+    fr = O.create_frustum((32, 48), 4, [1.0, 9.0, 1.0])
+    l2i = O.synthetic_rig(32, 48, 30.0, yaws_deg=(0, 90, 180, 270), radius=0.5, height=0.3)
+    inv = [np.linalg.inv(m).astype(np.float32) for m in l2i]
+    rots = np.stack([m[:3, :3] for m in inv])[None]
+    trans = np.stack([m[:3, 3] for m in inv])[None]
+    dx, bx, nx = O.gen_dx_bx([-8.0, 8.0, 1.0], [-6.0, 6.0, 1.0], [-1.0, 1.0, 1.0])
+    rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(O.get_geometry(fr, rots, trans), dx, bx, nx)
+    return rb, rd, rf, st, ln, tuple(int(v) for v in nx), rng
+
+
+def _csr(rb, n_rows):
+    counts = np.bincount(rb, minlength=n_rows)
+    return np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+
+
+@pytest.mark.parametrize("use_grid", [True, False])
+@pytest.mark.parametrize("tile_rows", [7, 40])
+def test_tile_schedule_is_a_balanced_permutation(use_grid, tile_rows):
+    from omnihd_amd.plan import tile_schedule
+    rb, rd, rf, st, ln, (X, Y, Z), _ = _tables()
+    n_rows = Z * Y * X                                    # B = 1; rows in (z, y, x) order = ranks_bev
+    row_ptr = torch.from_numpy(_csr(rb, n_rows))
+    tile_row = torch.arange(0, n_rows + tile_rows, tile_rows).clamp(max=n_rows).int()
+    tile_row = torch.unique_consecutive(tile_row)
+    n_tiles = tile_row.numel() - 1
+    kw = dict(grid=(1, Z, Y, X), layout="bzyx") if use_grid else dict(feat_hw=(8, 12))
+    flat = tile_schedule(row_ptr, tile_row, torch.from_numpy(rf), n_xcd=8, **kw)
+    per = (n_tiles + 7) // 8
+    assert flat.dtype == torch.int32 and flat.numel() == 8 * per
+    used = flat[flat >= 0].numpy()
+    assert sorted(used.tolist()) == list(range(n_tiles))                     # every tile exactly once
+    # work (points + rows) per XCD: balanced up to the largest tile
+    lo, hi = row_ptr[tile_row[:-1].long()].numpy(), row_ptr[tile_row[1:].long()].numpy()
+    work = (hi - lo) + (tile_row[1:] - tile_row[:-1]).numpy()
+    per_xcd = [int(work[flat[k * per:(k + 1) * per][flat[k * per:(k + 1) * per] >= 0].numpy()].sum()) for k in range(8)]
+    assert max(per_xcd) - min(per_xcd) <= 2 * int(work.max()) + int(work.sum()) // 8 // 4, per_xcd
+    if use_grid:                                                              # azimuth order: a run is an angular wedge
+        mid = ((tile_row[:-1] + tile_row[1:]) // 2).long().clamp(max=n_rows - 1).numpy()
+        yy, xx = (mid // X) % Y, mid % X
+        ang = np.arctan2(yy - (Y - 1) / 2.0, xx - (X - 1) / 2.0)
+        first = flat[:per][flat[:per] >= 0].numpy()
+        assert np.all(np.diff(ang[first]) >= -1e-12)
+
+
+def test_tile_schedule_spills_when_one_run_holds_too_many_tiles():
+    """Many empty tiles sort together: a run longer than its slot count spills into free slots, nothing is lost."""
+    from omnihd_amd.plan import tile_schedule
+    n_rows, tile_rows = 640, 4
+    counts = np.zeros(n_rows, dtype=np.int64)
+    counts[:16] = 500                                       # all the points in the first four tiles
+    row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+    tile_row = torch.arange(0, n_rows + 1, tile_rows).int()
+    rf = torch.zeros(int(counts.sum()), dtype=torch.int32)
+    flat = tile_schedule(row_ptr, tile_row, rf, feat_hw=None, n_xcd=8)
+    n_tiles = tile_row.numel() - 1
+    assert sorted(flat[flat >= 0].tolist()) == list(range(n_tiles)) and int((flat < 0).sum()) == flat.numel() - n_tiles
+
+
+def test_pixel_schedule_lists_every_pixel_once_with_its_points():
+    from omnihd_amd.plan import pixel_schedule
+    rb, rd, rf, st, ln, _, _ = _tables()
+    bp = O.backward_tables(rb, rd, rf)                     # (ranks_bev, ranks_depth, ranks_feat, starts, lengths) sorted by pixel
+    n_pix = 4 * 8 * 12
+    desc = pixel_schedule(torch.from_numpy(bp[2]), torch.from_numpy(bp[3]), torch.from_numpy(bp[4]), n_pix, feat_hw=(8, 12))
+    per = (n_pix + 7) // 8
+    assert desc.shape == (8 * per, 4) and desc.dtype == torch.int32
+    rows = desc[desc[:, 0] >= 0]
+    assert sorted(rows[:, 0].tolist()) == list(range(n_pix))                 # pixels without points are listed too
+    starts, lengths = bp[3], bp[4]
+    for pix, s, n, z in rows.tolist():
+        assert z == 0
+        if n:
+            assert np.all(bp[2][s:s + n] == pix)                              # its run of the pixel-sorted tables
+        else:
+            assert s == 0
+    assert int(rows[:, 2].sum()) == len(rb)
+    # 4x4 patches: the first 16 descriptors of a run cover one 4x4 block of one image
+    first = rows[:16, 0].numpy()
+    h, w = (first // 12) % 8, first % 12
+    assert len({int(v) for v in first // 96}) == 1 and h.max() - h.min() <= 3 and w.max() - w.min() <= 3
+    empty = pixel_schedule(torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32),
+                           10, feat_hw=None)
+    assert sorted(empty[empty[:, 0] >= 0][:, 0].tolist()) == list(range(10)) and int(empty[:, 2].sum()) == 0
