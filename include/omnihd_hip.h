@@ -97,10 +97,12 @@ int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
 
 /* The same dense forward reading ONE per-point table: the pixel row is derived from the depth index
  * (rf = (rd / (d_bins*fhw)) * fhw + rd % fhw, i.e. depth (B,N,D,fH,fW) and feat (B,N,fH,fW,C) of the same frames)
- * and the closing point of every output row comes from row_ptr.  tile_desc: 8*k slots as above (required).    */
+ * and the closing point of every output row comes from row_ptr.  tile_desc: 8*k slots as above (required).
+ * n_feat_rows = B*N*fH*fW, the number of rows of `feat` (the kernel gathers them with range-checked buffer loads:
+ * n_feat_rows*c*4 must stay below 2 GiB; 0 = unknown selects the first-generation kernel with 64-bit addressing). */
 int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int* ranks_depth, const int* row_ptr,
                                 const int* tile_desc, int n_tiles, float* out, int c, int n_rows, int n_points,
-                                int d_bins, int fhw, void* stream);
+                                int d_bins, int fhw, int n_feat_rows, void* stream);
 
 /* Schedule descriptors for the call above from a tile table (omnihd_csr_tiles) and an optional
  * tile order (8*ceil(n_tiles/8) ints, -1 = idle slot, NULL = tiles in index order).          */

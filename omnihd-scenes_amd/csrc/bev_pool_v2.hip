@@ -23,9 +23,25 @@
 #include <stdlib.h>
 
 // Traffic attribution builds (scripts/pool_traffic_abl.sh): -DOMNIHD_POOL_ABL=1 replaces the depth gather by a
-// constant, =2 folds every feature gather onto 1024 L2-resident rows, =3 both; +4 drops the stores of pooled rows, +8 the zero-fill stores (timing skeletons only).  Never defined in the product.
+// constant, =2 folds every feature gather onto 1024 L2-resident rows, =3 both; +4 drops the stores of pooled rows, +8 the zero-fill stores, +16 the feature gathers altogether (timing skeletons only).  Never defined in the product.
 #ifndef OMNIHD_POOL_ABL
 #define OMNIHD_POOL_ABL 0
+#endif
+
+// Phase-timeline builds (scripts/lab/pool_trace.py): -DOMNIHD_POOL_TRACE makes thread 0 of every workgroup of the lean
+// forward write wall_clock64() at its phase boundaries into a device buffer set by omnihd_lab_set_trace().  Never defined
+// in the product.
+#ifdef OMNIHD_POOL_TRACE
+__device__ unsigned long long* g_omnihd_trace = nullptr;
+#define OMNIHD_STAMP(k)                                                                         \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && g_omnihd_trace) g_omnihd_trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
+  } while (0)
+extern "C" int omnihd_lab_set_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_omnihd_trace), &p, sizeof(p));
+}
+#else
+#define OMNIHD_STAMP(k) do {} while (0)
 #endif
 
 namespace omnihd {
@@ -426,9 +442,11 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
   float4* s_tail = reinterpret_cast<float4*>(s_mem);
 
   if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+  OMNIHD_STAMP(0);
   const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
   const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
   if (nrows <= 0) return;
+  OMNIHD_STAMP(1);
 
   const int tid = threadIdx.x;
   const int sub = tid % C4;
@@ -487,6 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
     l_close[0] = npts - 1;                         // the single row of the tile closes at its last point
     l_crow[0] = Ra;
   }
+  OMNIHD_STAMP(2);
   if (npts == 0) return;
 
   float4 acc = zero4;
@@ -552,6 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
   }
   if (tid < G) s_head_row[tid] = -1;
   __syncthreads();
+  OMNIHD_STAMP(3);
   // ---- closing flags + row ids from the CSR boundaries (each closing record has exactly one owner) ----
 #pragma unroll
   for (int j = 0; j < kRowsPerLane; ++j)
@@ -560,6 +580,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
       s_row[l_close[j]] = l_crow[j];
     }
   __syncthreads();
+  OMNIHD_STAMP(4);
 
   // ---- phase P: equal pieces of the point list, one per group ----------------------------------
   const int w = (npts + G - 1) / G;
@@ -576,7 +597,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
       const int2 rc = s_rfd[min(i + u, i1 - 1)];
       d[u] = __int_as_float(rc.y);
       fl[u] = rc.x;
-      v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
+      if (OMNIHD_POOL_ABL & 16) { const float t = (float)(rc.x & 0xffff); v[u] = make_float4(t, t, t, t); }
+      else v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -599,7 +621,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
   }
   // piece ends inside a row (or is empty: then it is "inside" whatever row surrounds it, with a zero partial)
   const bool open_end = (i1 <= i0) || (s_rfd[i1 - 1].x >= 0);
-  __syncthreads();   // every group is done with the records: their LDS is reused for the tails
+  OMNIHD_STAMP(5);
+  __syncthreads();
+  OMNIHD_STAMP(6);   // every group is done with the records: their LDS is reused for the tails
   s_tail[tid] = acc;
   if (sub == 0) s_tail_flags[grp] = (open_end ? 1 : 0) | (closed_any ? 0 : 2);
   __syncthreads();
@@ -620,6 +644,274 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
     tsum = add4(tsum, s_head[tid]);
     store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
   }
+  OMNIHD_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pool_fwd_lean2: the same tiles, plan and one-table phase L as k_pool_fwd_lean, with the point loop rewritten for
+// ISSUE cost.  Phase timelines of k_pool_fwd_lean (scripts/lab/pool_trace.py, wall_clock64 stamps per workgroup) showed the
+// point loop taking 10.6 of a workgroup's 20.2 us — and still 6.0 us with every feature gather AND every store compiled
+// out: the loop was bound by instruction issue (about 40 wave-instructions per step of 4 points, most of them exec-mask
+// bookkeeping for bounds checks and the three-way "first close of a continued row / later close / no close" branch), not
+// by memory.  Changes:
+//   * every group runs the SAME number of full steps: the record list is padded to G * Wp entries whose pixel offset lies
+//     outside the feature buffer — a raw buffer load returns zeros there (hardware range check), so a pad point adds
+//     0 * 0 and no bounds test exists in the loop; the trip count is a scalar;
+//   * gathers are `buffer_load_dwordx4 ... offen` with a 32-bit offset (pixel << 8 | lane*16: ONE v_lshl_or_b32, the
+//     closing flag in bit 31 shifts out) instead of 64-bit address arithmetic;
+//   * the closing flag and the output row travel together in ONE LDS word (s_row[i] = row | 1<<31, zero otherwise), read
+//     four at a time with one ds_read_b128; two ds_read_b128 fetch four {pixel, depth} records;
+//   * the head partial of a row continued from an earlier piece stays in registers (no LDS head slots);
+//   * the closing words are written by the lanes that look at row_ptr in the zero-fill phase BEFORE the depth gather
+//     returns (the LDS row words are zeroed behind an early barrier), so the second barrier of the old kernel and its
+//     phase are gone.
+// Results: same tiles, same per-piece fma order, pieces of Wp = roundup(ceil(n/G), U) points (the old kernel: ceil(n/G)),
+// so rows cut by a piece boundary may differ from k_pool_fwd_lean in the last bit; run-to-run identical, no atomics.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+template <int C4, int U>
+__global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
+    const float* __restrict__ depth, const float* __restrict__ feat, unsigned feat_bytes,
+    const int* __restrict__ ranks_depth, const int* __restrict__ row_ptr, const int4* __restrict__ tile_desc,
+    float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw, float inv_dfhw) {
+  static_assert(U == 4, "the record reads below are written for 4 points per step");
+  constexpr int G = kBlock / C4;
+  constexpr int GPW = 64 / C4;
+  constexpr int SH = (C4 == 1 ? 4 : C4 == 2 ? 5 : C4 == 4 ? 6 : C4 == 8 ? 7 : C4 == 16 ? 8 : C4 == 32 ? 9 : 10);  // log2(row bytes)
+  constexpr int kPad = G * U;
+  constexpr int kRec = kCap + kPad;
+  constexpr int kRowsPerLane = 3;
+  constexpr int kMemInts = (kRec * 3 > kBlock * 4) ? kRec * 3 : kBlock * 4;
+  __shared__ __attribute__((aligned(16))) int s_mem[kMemInts];   // [0, 2*kRec) records {pixel, depth}; [2*kRec, 3*kRec) row words
+  __shared__ int s_tail_flags[G];
+  __shared__ float4 s_head[kBlock];                               // head partials (rare path), outside the aliased area
+  __shared__ int s_head_row[G];
+  int2* s_rec = reinterpret_cast<int2*>(s_mem);
+  int* s_row = s_mem + 2 * kRec;
+  float4* s_tail = reinterpret_cast<float4*>(s_mem);              // after the point loop
+
+  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+  OMNIHD_STAMP(0);
+  const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
+  const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
+  if (nrows <= 0) return;
+  OMNIHD_STAMP(1);
+
+  const int tid = threadIdx.x;
+  const int sub = tid % C4;
+  const int grp = tid / C4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* out4 = reinterpret_cast<float4*>(out);
+  const float4* feat4 = reinterpret_cast<const float4*>(feat);
+  const bool long_row = (nrows == 1 && npts > kCap);
+  const bool staged = (npts > 0 && npts <= kCap && nrows <= kRowsPerLane * kBlock);
+
+  auto pixel_row = [&](int rd) {
+    const int n = div_const(rd, dfhw, inv_dfhw);
+    const int q = div_const(rd, fhw, inv_fhw);
+    return n * fhw + (rd - q * fhw);
+  };
+
+  // ---- phase L (issue): the one rank table -> registers -----------------------------------------
+  constexpr int kPer = (kCap + kBlock - 1) / kBlock;
+  int l_rd[kPer];
+  if (staged) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = tid + k * kBlock;
+      if (i < npts) l_rd[k] = ranks_depth[Pa + i];
+    }
+    // row words of this tile start at zero (a closing record overwrites its word below)
+    for (int i = tid; i < kRec; i += kBlock) s_row[i] = 0;
+    __syncthreads();
+  }
+
+  // ---- phase Z: zero-fill the empty rows; the lane that sees a non-empty row marks its closing record --------
+  if (!(nrows == 1 && npts > 0)) {
+    const int lane = tid & 63;
+    const int gw = lane / C4;
+    for (int base = 0; base < nrows; base += kBlock) {
+      const int i = base + tid;
+      bool empty = false;
+      if (i < nrows) {
+        const int s0 = row_ptr[Ra + i], e0 = row_ptr[Ra + i + 1];
+        empty = e0 == s0;
+        if (!empty && staged) s_row[e0 - 1 - Pa] = i | (int)0x80000000;   // row offset inside the tile
+      }
+      const unsigned long long m = __ballot(empty);
+      if (m == 0ull) continue;
+      const int wave_row0 = Ra + base + (tid & ~63);
+      for (int k = 0; k < 64; k += GPW) {
+        const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
+        if (window == 0ull) continue;
+        if (((m >> (k + gw)) & 1ull) && !(OMNIHD_POOL_ABL & 8))
+          store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
+      }
+    }
+  } else if (tid == 0 && staged) {
+    s_row[npts - 1] = (int)0x80000000;             // the single row of the tile (offset 0) closes at its last point
+  }
+  OMNIHD_STAMP(2);
+  if (npts == 0) return;
+
+  float4 acc = zero4;
+
+  // ---- a single long row: windows of kCap points, every group accumulates, one combine --------
+  if (long_row) {
+    for (int base = 0; base < npts; base += kCap) {
+      const int n = min(kCap, npts - base);
+      for (int i = tid; i < n; i += kBlock) {
+        const int rd = ranks_depth[Pa + base + i];
+        s_rec[i] = make_int2(pixel_row(rd), __float_as_int(depth[rd]));
+      }
+      __syncthreads();
+      const int cw = (n + G - 1) / G;
+      const int j0 = min(grp * cw, n), j1 = min(j0 + cw, n);
+      for (int j = j0; j < j1; j += U) {
+        float4 v[U];
+        float d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int2 rc = s_rec[min(j + u, j1 - 1)];
+          d[u] = (j + u < j1) ? __int_as_float(rc.y) : 0.f;
+          v[u] = feat4[(size_t)rc.x * C4 + sub];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fma4(d[u], v[u], acc);
+      }
+      __syncthreads();
+    }
+    s_tail[tid] = acc;
+    __syncthreads();
+    if (grp == 0) {
+      float4 tsum = s_tail[sub];
+      for (int g = 1; g < G; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
+      store_row(out4 + (size_t)Ra * C4 + sub, tsum, true);
+    }
+    return;
+  }
+
+  // ---- a tile that does not fit the LDS window (only for foreign tile tables): row by row -----
+  if (!staged) {
+    for (int r = Ra + grp; r < Ra + nrows; r += G) {
+      const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
+      if (len <= 0) continue;
+      float4 a4 = zero4;
+      for (int q = s0; q < s0 + len; ++q) {
+        const int rd = ranks_depth[q];
+        a4 = fma4(depth[rd], feat4[(size_t)pixel_row(rd) * C4 + sub], a4);
+      }
+      store_row(out4 + (size_t)r * C4 + sub, a4, true);
+    }
+    return;
+  }
+
+  // ---- phase L (finish): pixel row, depth gather, records -> LDS; pad records gather zeros ---------
+  const int w = (npts + G - 1) / G;
+  const int Wp = (w + U - 1) / U * U;              // points per group, the same for every group
+  const int n_rec = G * Wp;                        // <= npts + G*U - 1 < kRec
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = tid + k * kBlock;
+    if (i < npts) {
+      const int px = (OMNIHD_POOL_ABL & 2) ? (pixel_row(l_rd[k]) & 1023) : pixel_row(l_rd[k]);
+      s_rec[i] = make_int2(px, __float_as_int((OMNIHD_POOL_ABL & 1) ? 1.0f : depth[l_rd[k]]));
+    }
+  }
+  for (int i = npts + tid; i < n_rec; i += kBlock) s_rec[i] = make_int2(0x7fffffff, 0);   // offset beyond the buffer
+  __syncthreads();
+  OMNIHD_STAMP(3);
+  OMNIHD_STAMP(4);
+
+  // ---- phase P: Wp points per group, U per step, no bounds tests -------------------------------
+  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
+  // output window of this tile: rows [Ra, Ra + nrows); the row words hold offsets relative to Ra
+  const __amdgpu_buffer_rsrc_t out_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)Ra * (C4 * 4)), 0, nrows << SH, 0x00020000);
+  const unsigned lane_off = (unsigned)sub << 4;
+  const int i0 = grp * Wp;
+  // `pending`: my first point continues a row that an earlier piece started, so the first row I close holds only a
+  // HEAD partial.  It is stored like any other row (and kept in LDS); the fix-up below stores the full sum over it
+  // (same lanes, same address, later in program order).  `pend` is the wave's mask of still-pending lanes: the head
+  // branch is skipped by a scalar test once every group of the wave has closed a row.
+  const bool was_pending = (i0 > 0 && i0 < npts && s_row[i0 - 1] >= 0);
+  unsigned long long pend = __builtin_amdgcn_ballot_w64(was_pending);
+  const int lane = tid & 63;
+  const int4* rec4 = reinterpret_cast<const int4*>(s_rec + i0);      // 2 records per int4 (i0 is a multiple of U)
+  const int4* row4 = reinterpret_cast<const int4*>(s_row + i0);
+  const int steps = Wp / U;
+
+  // (A variant that issued the gathers of step b+1 before the stores of step b — so that the in-order vmcnt wait for a
+  // step's last gather would not cover that step's own stores — needed 72-78 VGPRs and measured the same: 41.7-43.0 us
+  // against 42.3-42.6 us in alternating runs; the simple loop is kept.)
+  for (int b = 0; b < steps; ++b) {
+    const int4 ra = rec4[2 * b], rb = rec4[2 * b + 1];
+    const int4 rw = row4[b];
+    const int px[U] = {ra.x, ra.z, rb.x, rb.z};
+    const float d[U] = {__int_as_float(ra.y), __int_as_float(ra.w), __int_as_float(rb.y), __int_as_float(rb.w)};
+    const int cl[U] = {rw.x, rw.y, rw.z, rw.w};
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (OMNIHD_POOL_ABL & 16) {
+        const float t = (float)(px[u] & 0xffff);
+        v[u] = make_float4(t, t, t, t);
+      } else {
+        const u32x4v raw = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, ((unsigned)px[u] << SH) | lane_off, 0, 0);
+        v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = fma4(d[u], v[u], acc);
+      const bool closing = cl[u] < 0;                    // this point closes its output row
+      const unsigned long long cm = __builtin_amdgcn_ballot_w64(closing);
+      if (closing) {
+        if (!(OMNIHD_POOL_ABL & 4) || acc.x == 1.2345e30f) {
+          const u32x4v o = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
+          __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)cl[u] << SH) | lane_off, 0, 2 /* nt */);
+        }
+        if ((pend & cm) != 0ull) {                       // wave-uniform: a closing group still owes its head partial
+          if ((pend >> lane) & 1ull) {
+            s_head[tid] = acc;
+            if (sub == 0) s_head_row[grp] = cl[u];
+          }
+        }
+        acc = zero4;
+      }
+      pend &= ~cm;
+    }
+  }
+  const bool pending = ((pend >> lane) & 1ull) != 0ull;   // started inside a row and never closed it
+  // piece ends inside a row (or is empty: then it lies "inside" whatever row surrounds it, with a zero partial)
+  const int i1 = min(i0 + Wp, npts);
+  const bool open_end = (i1 <= i0) || (s_row[i1 - 1] >= 0);
+  OMNIHD_STAMP(5);
+  __syncthreads();   // every group is done with the records: their LDS is reused for the tails
+  OMNIHD_STAMP(6);
+  s_tail[tid] = acc;
+  // bit0: the piece ends inside a row; bit1: the piece lies entirely inside one row that started before it
+  if (sub == 0) s_tail_flags[grp] = (open_end ? 1 : 0) | ((pending || i1 <= i0) ? 2 : 0);
+  __syncthreads();
+
+  if (was_pending && !pending) {
+    // the row I closed first started in earlier pieces: add their open tails, walking back through pieces that lie
+    // entirely inside the row and stopping after the first one that started a row of its own
+    int g0 = grp;
+    while (g0 > 0) {
+      const int f = s_tail_flags[g0 - 1];
+      if (!(f & 1)) break;
+      --g0;
+      if (!(f & 2)) break;
+    }
+    float4 tsum = zero4;                             // point order
+    for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
+    tsum = add4(tsum, s_head[tid]);
+    const u32x4v o = {__float_as_uint(tsum.x), __float_as_uint(tsum.y), __float_as_uint(tsum.z), __float_as_uint(tsum.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)s_head_row[grp] << SH) | lane_off, 0, 2);
+  }
+  OMNIHD_STAMP(7);
 }
 
 // schedule slot -> {first row, #rows, first point, #points}; idle slots get #rows = 0
@@ -914,8 +1206,9 @@ extern "C" int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const i
 
 extern "C" int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int* ranks_depth,
                                            const int* row_ptr, const int* tile_desc, int n_tiles, float* out, int c,
-                                           int n_rows, int n_points, int d_bins, int fhw, void* stream) {
-  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles > 0 && n_points >= 0 && d_bins > 0 && fhw > 0, "sizes");
+                                           int n_rows, int n_points, int d_bins, int fhw, int n_feat_rows,
+                                           void* stream) {
+  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles > 0 && n_points >= 0 && d_bins > 0 && fhw > 0 && n_feat_rows >= 0, "sizes");
   if (n_rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(depth && feat && row_ptr && out && tile_desc && (n_points == 0 || ranks_depth), "null pointer");
   OMNIHD_REQUIRE(vec_ok(c, feat, out) && (reinterpret_cast<uintptr_t>(tile_desc) & 15u) == 0 && n_tiles % 8 == 0,
@@ -928,6 +1221,33 @@ extern "C" int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat
   const int4* td = reinterpret_cast<const int4*>(tile_desc);
   float4* o4 = reinterpret_cast<float4*>(out);
   const int dfhw = d_bins * fhw;
+  // k_pool_fwd_lean2 (issue-lean point loop) is the default; OMNIHD_POOL_LEAN2=0 selects the first lean kernel.  It needs
+  // 32-bit byte offsets into the feature table (buffer loads): the caller's feature table ends at the last pixel a rank
+  // names, and the wrapper passes its size in rows through n_feat_rows (0: unknown -> first lean kernel).
+  static const bool lean2 = [] { const char* e = getenv("OMNIHD_POOL_LEAN2"); return !(e && e[0] == '0'); }();
+  const long long feat_bytes = (long long)n_feat_rows * c * 4;
+  if (lean2 && n_feat_rows > 0 && feat_bytes < (1ll << 31)) {
+#define OMNIHD_LEAN2_CASE(C4)                                                                                     \
+  case C4:                                                                                                        \
+    hipLaunchKernelGGL((k_pool_fwd_lean2<C4, 4>), grid, dim3(kBlock), 0, st, depth, feat, (unsigned)feat_bytes,   \
+                       ranks_depth, row_ptr, td, out, tiles_per_xcd, fhw, dfhw, 1.0f / (float)fhw,               \
+                       1.0f / (float)dfhw);                                                                       \
+    break;
+    switch (c / 4) {
+      OMNIHD_LEAN2_CASE(1)
+      OMNIHD_LEAN2_CASE(2)
+      OMNIHD_LEAN2_CASE(4)
+      OMNIHD_LEAN2_CASE(8)
+      OMNIHD_LEAN2_CASE(16)
+      OMNIHD_LEAN2_CASE(32)
+      OMNIHD_LEAN2_CASE(64)
+      default:
+        set_error("bev_pool_v2_fwd_lean: C/4 must be a power of two <= 64");
+        return OMNIHD_ERR_ARG;
+    }
+#undef OMNIHD_LEAN2_CASE
+    return check_launch("bev_pool_v2_fwd_lean(2)");
+  }
 #define OMNIHD_LEAN_CASE(C4)                                                                                     \
   case C4:                                                                                                       \
     hipLaunchKernelGGL((k_pool_fwd_lean<C4, 4>), grid, dim3(kBlock), 0, st, depth, f4, ranks_depth, row_ptr, td, \

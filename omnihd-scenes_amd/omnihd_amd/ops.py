@@ -123,8 +123,9 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
               "omnihd_bev_pool_v2_fwd_csr")
 
 
-def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, depth_bins, feat_hw):
-    """Dense tiled forward reading one per-point table (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_lean)."""
+def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, depth_bins, feat_hw, gen=2):
+    """Dense tiled forward reading one per-point table (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_lean).
+    ``gen=1`` asks for the first-generation kernel (64-bit addressing; bit-identical to the three-table kernel)."""
     _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
     _want(ranks_depth, torch.int32, "ranks_depth"); _want(row_ptr, torch.int32, "row_ptr")
     _want(tile_desc, torch.int32, "tile_desc")
@@ -136,7 +137,7 @@ def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, 
     with _on(dev):
         check(lib().omnihd_bev_pool_v2_fwd_lean(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(row_ptr), _ptr(tile_desc),
                                                 tile_desc.size(0), _ptr(out), c, n_rows, ranks_depth.numel(), int(depth_bins),
-                                                int(feat_hw), _stream()), "omnihd_bev_pool_v2_fwd_lean")
+                                                int(feat_hw), feat.numel() // c if gen != 1 else 0, _stream()), "omnihd_bev_pool_v2_fwd_lean")
 
 
 def bev_pool_v2_backward_sched(out_grad, depth, feat, ranks_depth, ranks_row, pix_desc, depth_grad, feat_grad):

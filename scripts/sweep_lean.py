@@ -19,7 +19,7 @@ def run(s):
     ops.bev_pool_v2_forward_lean(depth, feat, tb[0], tb[2], cur[s], out, D, fhw)
 
 
-for items, long_len in ((384, 384), (512, 512), (640, 512), (768, 512), (768, 256), (896, 384), (1024, 256), (640, 640)):
+for items, long_len in ((192, 192), (256, 256), (320, 256), (384, 256), (384, 384), (448, 384), (512, 384), (512, 512), (640, 512), (768, 512), (896, 384)):
     tiles = ops.csr_tiles(wl.plan.row_ptr, items, long_len)
     order = P.tile_schedule(wl.plan.row_ptr, tiles, wl.plan.ranks_feat, (wl.fH, wl.fW), grid=wl.plan.grid, layout="byxz")
     desc = ops.tile_descriptors(wl.plan.row_ptr, tiles, order)

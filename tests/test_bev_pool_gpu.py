@@ -313,13 +313,25 @@ def test_one_table_forward_is_bit_identical_to_three_table_forward(cuda, tile_it
         desc = ops.tile_descriptors(row_ptr, tiles, order)
         a = torch.full((n_rows, c), float("nan"), device=cuda)
         b = torch.full((n_rows, c), float("nan"), device=cuda)
+        b2 = torch.full((n_rows, c), float("nan"), device=cuda)
         ops.bev_pool_v2_forward_csr(depth, feat, t(rd, cuda), t(rf, cuda), row_ptr, a, t(rows, cuda), desc)
-        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b, D, fhw)
-        assert not torch.isnan(b).any()
+        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b, D, fhw, gen=1)
+        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b2, D, fhw)
+        assert not torch.isnan(b).any() and not torch.isnan(b2).any()
         assert torch.equal(a, b)
+        # the second-generation kernel (the default) cuts a tile's points into pieces of a different length: rows cut by a
+        # piece boundary associate their partial sums differently (last bit), every other row is bit-identical
+        assert float((a - b2).abs().max()) <= 2e-6 * float(a.abs().max())
+        b3 = torch.full((n_rows, c), float("nan"), device=cuda)
+        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b3, D, fhw)
+        assert torch.equal(b2, b3)                                                        # run-to-run identical
     st, ln = O.run_length(rows)
     want = OC.bev_pool_v2_fwd(depth.cpu().numpy(), feat.cpu().numpy(), rd, rf, rows, (1, 1, 1, n_rows, c), st, ln)
     np.testing.assert_allclose(b.cpu().numpy(), want.reshape(n_rows, c), rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(b2.cpu().numpy(), want.reshape(n_rows, c), rtol=1e-5, atol=2e-4)
+    # rows of one point have no summation order at all: both kernels must reproduce the oracle's single product exactly
+    one = np.bincount(rows, minlength=n_rows) == 1
+    assert np.array_equal(b2.cpu().numpy()[one], want.reshape(n_rows, c)[one])
 
 
 def test_one_table_forward_full_size_plan(cuda):
@@ -334,5 +346,37 @@ def test_one_table_forward_full_size_plan(cuda):
     a = torch.empty(plan.n_rows, 64, device=cuda)
     b = torch.full((plan.n_rows, 64), float("nan"), device=cuda)
     ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, a, plan.ranks_row, plan.tile_desc)
-    ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, b, plan.depth_bins, plan.feat_hw)
+    ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, b, plan.depth_bins, plan.feat_hw,
+                                 gen=1)
     assert torch.equal(a, b)
+    b2 = torch.full((plan.n_rows, 64), float("nan"), device=cuda)
+    ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, b2, plan.depth_bins, plan.feat_hw)
+    assert not torch.isnan(b2).any() and float((a - b2).abs().max()) <= 2e-6 * float(a.abs().max())
+    assert torch.equal((a == 0).all(1), (b2 == 0).all(1))                 # the same rows are empty
+
+
+def test_default_dense_forward_full_size_against_the_oracle(cuda, golden):
+    """The headline kernel (k_pool_fwd_lean2, what ``planned_pool`` launches) at the BASELINE frame size R1 against the
+    CPU restatement of the reference kernel on the reference-format tables of the same geometry: every output row,
+    1e-5 relative (summation order of rows cut inside a tile differs; north_star allows 1e-3), empty rows exactly zero,
+    and rows with a single point bit-exact."""
+    from omnihd_amd import build_plan
+    from omnihd_amd.plan import planned_pool
+    geom, dx, bx, nx = full_size_geometry("r1")
+    plan = build_plan(t(geom, cuda), dx, bx, nx, layout="bzyx")              # the reference's (B,Z,Y,X,C) row order
+    rng = np.random.default_rng(5)
+    depth = rng.random((1, 6, 59, 64, 176), dtype=np.float32)
+    depth /= depth.sum(2, keepdims=True)
+    feat = rng.standard_normal((1, 6, 64, 176, 64), dtype=np.float32)
+    got = planned_pool(t(depth, cuda), t(feat, cuda), plan)                   # logical (B,C,Z,Y,X)
+    rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(geom, dx, bx, nx)
+    assert len(rb) == int(golden["full_r1_checksums"][0]) == 2025022        # the point count the reference produced (SURVEY 8d)
+    want = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, (1, 16, 160, 240, 64), st, ln, threads=True)   # (B,Z,Y,X,C)
+    got = got.permute(0, 2, 3, 4, 1).contiguous().cpu().numpy()
+    assert got.shape == want.shape
+    scale = float(np.abs(want).max())
+    assert float(np.abs(got - want).max()) <= 1e-5 * scale
+    assert np.array_equal((got == 0).all(-1), (want == 0).all(-1))
+    single = np.zeros(16 * 160 * 240, dtype=bool)
+    single[rb[st[ln == 1]]] = True
+    assert np.array_equal(got.reshape(-1, 64)[single], want.reshape(-1, 64)[single])

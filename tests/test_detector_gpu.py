@@ -40,7 +40,6 @@ def _close(a, b, tol=1e-3):
 
 
 def test_tiny_detector_hip_ops_match_oracle_ops(cuda):
-    torch.backends.cudnn.allow_tf32 = False
     gpu = _run("cuda:0", use_oracle=False)
     cpu = _run("cpu", use_oracle=True)
     assert _close(gpu["depth"], cpu["depth"]), "depth distribution"

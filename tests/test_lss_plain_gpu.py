@@ -22,6 +22,40 @@ def lss_golden():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "lss_golden.npz"))
 
 
+def _stage_report(g):
+    """Layer-by-layer GPU (HIP path) vs CPU (oracle) comparison, printed when the input gradient misses the golden:
+    names the stage where the deviation enters (scripts/bisect_lss_grad.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bisect_lss_grad", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "scripts", "bisect_lss_grad.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cpu, gpu = mod.run("cpu", g, True), mod.run("cuda:0", g, False)
+    lines = ["flags: allow_tf32=%s conv.fp32_precision=%s benchmark=%s" % (
+        torch.backends.cudnn.allow_tf32, torch.backends.cudnn.conv.fp32_precision, torch.backends.cudnn.benchmark)]
+    lines += ["%-12s fwd %.3e grad %.3e" % (k, mod.rel(gpu[k][0], cpu[k][0]), mod.rel(gpu[k][1], cpu[k][1])) for k in cpu]
+    # the BatchNorm+ReLU backward of every encoder stage in isolation: same inputs (from the CPU run) on both devices
+    import torch.nn.functional as F
+    for conv, bn in (("conv0", "bn1"), ("conv3", "bn4"), ("conv6", "bn7"), ("conv9", "bn10")):
+        xin, gy = cpu[conv][0], cpu[bn][1]
+        c = xin.shape[1]
+
+        def one(dev, fmt, enabled=True):
+            with torch.backends.cudnn.flags(enabled=enabled):
+                xx = xin.to(dev).contiguous(memory_format=fmt).clone().detach().requires_grad_(True)
+                w = torch.ones(c, device=dev, requires_grad=True)
+                b = torch.zeros(c, device=dev, requires_grad=True)
+                y = F.relu(F.batch_norm(xx, None, None, w, b, True, 0.1, 1e-5))
+                y.backward(gy.to(dev).contiguous(memory_format=fmt))
+                return xx.grad.cpu()
+        ref = one("cpu", torch.contiguous_format)
+        lines.append("%s backward alone: NHWC %.2e %.2e  NCHW %.2e  NHWC(no miopen) %.2e  shape %s" % (
+            bn, mod.rel(one("cuda:0", torch.channels_last), ref), mod.rel(one("cuda:0", torch.channels_last), ref),
+            mod.rel(one("cuda:0", torch.contiguous_format), ref), mod.rel(one("cuda:0", torch.channels_last, False), ref),
+            tuple(xin.shape)))
+    return "\n".join(lines)
+
+
 def test_reference_forward_and_backward_through_the_hip_path(cuda, lss_golden):
     from projects.mmdet3d_plugin.bevfusion.detectors import LiftSplatShoot
     g = lss_golden
@@ -40,7 +74,7 @@ def test_reference_forward_and_backward_through_the_hip_path(cuda, lss_golden):
     bev_t, _ = net(xg, rots, trans)
     (bev_t * t(g["l1_w"], cuda)).sum().backward()
     assert _close(bev_t.detach().cpu(), g["l1_bev_train"], 1e-3)
-    assert _close(xg.grad.cpu(), g["l1_x_grad"], 1e-3)
+    assert _close(xg.grad.cpu(), g["l1_x_grad"], 1e-3), _stage_report(g)
     assert _close(net.camencode.depthnet.weight.grad.cpu(), g["l1_depthnet_w_grad"], 1e-3)
 
 
