@@ -109,6 +109,19 @@ int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int
 int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const int* tile_order,
                      int n_tiles, int* tile_desc, void* stream);
 
+/* Patch backward used by our own LSS module for C = 64 (same arithmetic as omnihd_bev_pool_v2_bwd; replaces the
+ * re-sort + one-thread-per-pixel kernel of ops/bev_pool_v2/bev_pool.py:43-83 / src/bev_pool_cuda.cu:67-121).
+ * depth (n_img, d_bins, fhw) and feat (n_img*fhw, 64) of the same frames; out_grad (n_rows, 64).  The backward tables
+ * ranks_depth / ranks_row are sorted by pixel (omnihd_sort_ranks by ranks_feat); pix_ptr (n_img*fhw + 1 ints) is the CSR
+ * of that order: points [pix_ptr[f], pix_ptr[f+1]) belong to pixel f.  patch_order (n_slots = 8*k ints): entry
+ * [x*k + i] = the i-th patch handled on XCD x, patch p = 16 consecutive pixels [16*(p % ppi), ...) of image p / ppi with
+ * ppi = ceil(fhw/16); -1 = idle slot; every patch exactly once.  BOTH outputs are written densely (depth_grad zero where
+ * no frustum point lies, feat_grad zero for pixels without points): the caller does not clear them.                    */
+int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* depth, const float* feat,
+                                 const int* ranks_depth, const int* ranks_row, const int* pix_ptr,
+                                 const int* patch_order, int n_slots, int n_img, int d_bins, int fhw,
+                                 long long n_rows, float* depth_grad, float* feat_grad, int c, void* stream);
+
 /* Scheduled backward used by our own LSS module (same arithmetic as omnihd_bev_pool_v2_bwd).
  * pix_desc: 8 * groups_per_xcd descriptors of 4 ints {pixel row f, first point, #points, 0},
  * 16-byte aligned; entry [x*groups_per_xcd + i] is the i-th pixel handled on XCD x; f = -1 marks
@@ -322,11 +335,20 @@ int omnihd_affine_act_fwd(const void* x, const float* scale, const float* shift,
  * gx = gres * scale[c].  y is the forward output (only read when relu != 0); gres may be NULL.       */
 int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gres,
                           long long n_rows, int c, int relu, void* stream);
+/* The same two passes on fp32 rows (the reference-precision step: the reference trains in fp32).       */
+int omnihd_affine_act_fwd_f32(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                              long long n_rows, int c, int relu, void* stream);
+int omnihd_affine_act_bwd_f32(const float* gy, const float* y, const float* scale, float* gx, float* gres,
+                              long long n_rows, int c, int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm (+ReLU) with the statistics exchange left to the caller ("naive" SyncBN:
  * projects/mmdet3d_plugin/ops/norm.py:28-82 and mmdet3d's 1-D/2-D variants; plain BatchNorm on one rank)
- * All activations are channels-last bf16 rows [rows, c]; c % 8 == 0, c <= 2048.
+ * All activations are channels-last rows [rows, c], bf16 — or fp32 in the *_f32 forms, whose argument meaning is the
+ * same; c % 8 == 0, c <= 2048.  Why fp32 rows do not go to torch: torch's native channels-last BatchNorm kernels combine
+ * their per-block partial sums inside ONE launch behind a semaphore without an acquire on the reading side, and on this
+ * 8-XCD part (per-XCD L2s, not coherent inside a launch) that returned wrong input gradients in some processes
+ * (tests/test_lss_plain_gpu.py, round 1's red suite).  Here every reduction crosses a kernel boundary.
  * ---------------------------------------------------------------------------------------- */
 
 size_t omnihd_bn_workspace_bytes(long long rows, int c);
@@ -356,6 +378,13 @@ int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const float* fwd_sca
                         const float* coef_a, const float* coef_b, const float* coef_c, void* gx, void* gres,
                         long long rows, int c, void* stream);
 
+int omnihd_bn_channel_sums_f32(const float* a, const float* b, const float* mask, const float* fwd_scale_shift,
+                               float* sums, long long rows, int c, int mode, float mult, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int omnihd_bn_bwd_apply_f32(const float* gy, const float* y_mask, const float* fwd_scale_shift, const float* x,
+                            const float* coef_a, const float* coef_b, const float* coef_c, float* gx, float* gres,
+                            long long rows, int c, void* stream);
+
 /* One-call single-rank forms of the above (no statistics exchange): see csrc/batch_norm.hip.             */
 int omnihd_bn_train_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float momentum, float eps, float var_correction, int relu, void* y,
@@ -364,6 +393,13 @@ int omnihd_bn_train_fwd(const void* x, const void* res, const float* gamma, cons
 int omnihd_bn_train_bwd(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma,
                         const float* consts4c, void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c,
                         void* workspace, size_t workspace_bytes, void* stream);
+int omnihd_bn_train_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, float var_correction, int relu, float* y,
+                            float* stats2c, float* consts4c, long long rows, int c, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int omnihd_bn_train_bwd_f32(const float* gy, const float* y_mask, int relu_from_x, const float* x, const float* gamma,
+                            const float* consts4c, float* gx, float* gres, float* sums2c, float* out5c, long long rows,
+                            int c, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Radar input format: sweep merge + ego-motion compensation on the device

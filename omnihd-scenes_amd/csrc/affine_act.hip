@@ -9,75 +9,88 @@
 // whole epilogue of a convolution is ONE pass each way, channels-last in and out:
 //     forward : y = act(x * scale + shift [+ res])
 //     backward: gres = gy * [y > 0],  gx = gres * scale          (scale/shift are constants: no gradient)
-// HBM-bound streaming: 16 B per lane (8 channels), fp32 arithmetic, one rounding to bf16.
+// HBM-bound streaming: 8 channels per lane (16 B of bf16 or 32 B of fp32), fp32 arithmetic, one rounding to bf16.
+// The element type is a template parameter (bn_vec.h): bf16 rows under autocast, fp32 rows for the reference-precision
+// step — the *_f32 entry points.
 #include "common.h"
+#include "bn_vec.h"
 
 namespace omnihd {
 namespace {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {              // round to nearest even, NaN kept quiet
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void k_affine_fwd(const u32x4* __restrict__ x, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, const u32x4* __restrict__ res,
-                                                    u32x4* __restrict__ y, int64_t n_vec, int c8) {
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void k_affine_fwd(const T* __restrict__ x, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const T* __restrict__ res,
+                                                    T* __restrict__ y, int64_t n_vec, int c8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
-    const u32x4 xv = __builtin_nontemporal_load(x + i);
-    u32x4 rv = {0u, 0u, 0u, 0u};
-    if (RES) rv = __builtin_nontemporal_load(res + i);
+    float xv[8], rv[8], out[8];
+    load8(x, i, xv);
+    if (RES) load8(res, i, rv);
     const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(shift + c), b1 = *reinterpret_cast<const float4*>(shift + c + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    const unsigned short* xe = reinterpret_cast<const unsigned short*>(&xv);
-    const unsigned short* re = reinterpret_cast<const unsigned short*>(&rv);
-    u32x4 out;
-    unsigned short* oe = reinterpret_cast<unsigned short*>(&out);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float v = fmaf(bf2f(xe[k]), sc[k], sh[k]);
-      if (RES) v += bf2f(re[k]);
+      float v = fmaf(xv[k], sc[k], sh[k]);
+      if (RES) v += rv[k];
       if (RELU) v = fmaxf(v, 0.f);
-      oe[k] = f2bf(v);
+      out[k] = v;
     }
-    y[i] = out;
+    store8(y, i, out);
   }
 }
 
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void k_affine_bwd(const u32x4* __restrict__ gy, const u32x4* __restrict__ y,
-                                                    const float* __restrict__ scale, u32x4* __restrict__ gx,
-                                                    u32x4* __restrict__ gres, int64_t n_vec, int c8) {
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void k_affine_bwd(const T* __restrict__ gy, const T* __restrict__ y,
+                                                    const float* __restrict__ scale, T* __restrict__ gx,
+                                                    T* __restrict__ gres, int64_t n_vec, int c8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
-    const u32x4 gv = __builtin_nontemporal_load(gy + i);
-    u32x4 yv = {0u, 0u, 0u, 0u};
-    if (RELU) yv = __builtin_nontemporal_load(y + i);
+    float gv[8], yv[8], o1[8], o2[8];
+    load8(gy, i, gv);
+    if (RELU) load8(y, i, yv);
     const float4 s0 = *reinterpret_cast<const float4*>(scale + c), s1 = *reinterpret_cast<const float4*>(scale + c + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const unsigned short* ge = reinterpret_cast<const unsigned short*>(&gv);
-    const unsigned short* ye = reinterpret_cast<const unsigned short*>(&yv);
-    u32x4 o1, o2;
-    unsigned short* e1 = reinterpret_cast<unsigned short*>(&o1);
-    unsigned short* e2 = reinterpret_cast<unsigned short*>(&o2);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool pass = !RELU || bf2f(ye[k]) > 0.f;
-      const unsigned short g = pass ? ge[k] : (unsigned short)0;
-      e2[k] = g;
-      e1[k] = f2bf(bf2f(g) * sc[k]);
+      const bool pass = !RELU || yv[k] > 0.f;
+      const float g = pass ? gv[k] : 0.f;
+      o2[k] = g;
+      o1[k] = g * sc[k];
     }
-    gx[i] = o1;
-    if (RES) gres[i] = o2;
+    store8(gx, i, o1);
+    if (RES) store8(gres, i, o2);
   }
+}
+
+template <typename T>
+int affine_fwd_t(const void* x, const float* scale, const float* shift, const void* res, void* y, long long n_rows, int c,
+                 int relu, void* stream) {
+  const int64_t n_vec = (int64_t)n_rows * (c / 8);
+  const dim3 grid(grid_for(n_vec, 256 * 2)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const T *xv = (const T*)x, *rv = (const T*)res;
+  if (relu && res) hipLaunchKernelGGL((k_affine_fwd<T, true, true>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
+  else if (relu) hipLaunchKernelGGL((k_affine_fwd<T, true, false>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
+  else if (res) hipLaunchKernelGGL((k_affine_fwd<T, false, true>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
+  else hipLaunchKernelGGL((k_affine_fwd<T, false, false>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
+  return check_launch("affine_act_fwd");
+}
+
+template <typename T>
+int affine_bwd_t(const void* gy, const void* y, const float* scale, void* gx, void* gres, long long n_rows, int c, int relu,
+                 void* stream) {
+  const int64_t n_vec = (int64_t)n_rows * (c / 8);
+  const dim3 grid(grid_for(n_vec, 256 * 2)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const T *gv = (const T*)gy, *yv = (const T*)y;
+  if (relu && gres) hipLaunchKernelGGL((k_affine_bwd<T, true, true>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
+  else if (relu) hipLaunchKernelGGL((k_affine_bwd<T, true, false>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
+  else if (gres) hipLaunchKernelGGL((k_affine_bwd<T, false, true>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
+  else hipLaunchKernelGGL((k_affine_bwd<T, false, false>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
+  return check_launch("affine_act_bwd");
 }
 
 }  // namespace
@@ -90,15 +103,15 @@ extern "C" int omnihd_affine_act_fwd(const void* x, const float* scale, const fl
   OMNIHD_REQUIRE(n_rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
   if (n_rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(x && scale && shift && y, "null pointer");
-  const int64_t n_vec = (int64_t)n_rows * (c / 8);
-  const dim3 grid(grid_for(n_vec, 256 * 2)), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  const u32x4 *xv = (const u32x4*)x, *rv = (const u32x4*)res;
-  if (relu && res) hipLaunchKernelGGL((k_affine_fwd<true, true>), grid, block, 0, st, xv, scale, shift, rv, (u32x4*)y, n_vec, c / 8);
-  else if (relu) hipLaunchKernelGGL((k_affine_fwd<true, false>), grid, block, 0, st, xv, scale, shift, rv, (u32x4*)y, n_vec, c / 8);
-  else if (res) hipLaunchKernelGGL((k_affine_fwd<false, true>), grid, block, 0, st, xv, scale, shift, rv, (u32x4*)y, n_vec, c / 8);
-  else hipLaunchKernelGGL((k_affine_fwd<false, false>), grid, block, 0, st, xv, scale, shift, rv, (u32x4*)y, n_vec, c / 8);
-  return check_launch("affine_act_fwd");
+  return affine_fwd_t<bf16_t>(x, scale, shift, res, y, n_rows, c, relu, stream);
+}
+
+extern "C" int omnihd_affine_act_fwd_f32(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                                         long long n_rows, int c, int relu, void* stream) {
+  OMNIHD_REQUIRE(n_rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
+  if (n_rows == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(x && scale && shift && y, "null pointer");
+  return affine_fwd_t<float>(x, scale, shift, res, y, n_rows, c, relu, stream);
 }
 
 extern "C" int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gres,
@@ -106,13 +119,13 @@ extern "C" int omnihd_affine_act_bwd(const void* gy, const void* y, const float*
   OMNIHD_REQUIRE(n_rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
   if (n_rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(gy && scale && gx && (!relu || y), "null pointer");
-  const int64_t n_vec = (int64_t)n_rows * (c / 8);
-  const dim3 grid(grid_for(n_vec, 256 * 2)), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  const u32x4 *gv = (const u32x4*)gy, *yv = (const u32x4*)y;
-  if (relu && gres) hipLaunchKernelGGL((k_affine_bwd<true, true>), grid, block, 0, st, gv, yv, scale, (u32x4*)gx, (u32x4*)gres, n_vec, c / 8);
-  else if (relu) hipLaunchKernelGGL((k_affine_bwd<true, false>), grid, block, 0, st, gv, yv, scale, (u32x4*)gx, (u32x4*)gres, n_vec, c / 8);
-  else if (gres) hipLaunchKernelGGL((k_affine_bwd<false, true>), grid, block, 0, st, gv, yv, scale, (u32x4*)gx, (u32x4*)gres, n_vec, c / 8);
-  else hipLaunchKernelGGL((k_affine_bwd<false, false>), grid, block, 0, st, gv, yv, scale, (u32x4*)gx, (u32x4*)gres, n_vec, c / 8);
-  return check_launch("affine_act_bwd");
+  return affine_bwd_t<bf16_t>(gy, y, scale, gx, gres, n_rows, c, relu, stream);
+}
+
+extern "C" int omnihd_affine_act_bwd_f32(const float* gy, const float* y, const float* scale, float* gx, float* gres,
+                                         long long n_rows, int c, int relu, void* stream) {
+  OMNIHD_REQUIRE(n_rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
+  if (n_rows == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(gy && scale && gx && (!relu || y), "null pointer");
+  return affine_bwd_t<float>(gy, y, scale, gx, gres, n_rows, c, relu, stream);
 }

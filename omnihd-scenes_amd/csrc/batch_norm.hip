@@ -13,25 +13,17 @@
 //             -> k_bn_bwd_apply  gx = g' * A[c] + x * B[c] + C[c]   (one pass)
 // HBM-bound streaming; reductions are two-stage with a fixed order (deterministic, no atomics).
 #include "common.h"
+#include "bn_vec.h"
 
 namespace omnihd {
 namespace {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
 // MODE 0: s1 = sum x,  s2 = sum x*x                       (a = x)
 // MODE 1: s1 = sum g', s2 = sum g'*x,  g' = gy * [y > 0]  (a = gy, b = x, m = y or nullptr)
-// partial[block][0][c] = s1, partial[block][1][c] = s2 over the block's rows.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bn_partial(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
-                                                    const u32x4* __restrict__ m, const float* __restrict__ fss,
+// partial[block][0][c] = s1, partial[block][1][c] = s2 over the block's rows.  T: bf16 or fp32 rows.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_bn_partial(const T* __restrict__ a, const T* __restrict__ b,
+                                                    const T* __restrict__ m, const float* __restrict__ fss,
                                                     float* __restrict__ partial, long long rows, int c8,
                                                     long long rows_per_block) {
   __shared__ float red[2][256][8];
@@ -44,41 +36,44 @@ __global__ __launch_bounds__(256) void k_bn_partial(const u32x4* __restrict__ a,
   const long long begin = (long long)blockIdx.x * rows_per_block;
   const long long end = min(begin + rows_per_block, rows);
   if (r0 < rpi) {
-    constexpr int U = 4;                          // independent row loads in flight per lane
+    constexpr int U = (sizeof(T) == 2) ? 4 : 2;   // independent row loads in flight per lane (16 B resp. 32 B each)
     for (long long rb = begin + r0; rb < end; rb += (long long)U * rpi) {
-      u32x4 av[U], bv[U], mv[U];
+      float av[U][8], bv[U][8], mv[U][8];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long long r = rb + (long long)u * rpi;
         const bool ok = r < end;
         const long long i = (ok ? r : begin + r0) * c8 + vcol;
-        av[u] = __builtin_nontemporal_load(a + i);
+        load8(a, i, av[u]);
         if (MODE == 1) {
-          bv[u] = __builtin_nontemporal_load(b + i);
-          if (m) mv[u] = __builtin_nontemporal_load(m + i);
-          else mv[u] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};     // bf16 ones: mask passes
+          load8(b, i, bv[u]);
+          if (m) load8(m, i, mv[u]);
+          else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mv[u][k] = 1.f;                                   // mask passes
+          }
         }
-        if (!ok) av[u] = u32x4{0u, 0u, 0u, 0u};   // a zero row adds nothing to either sum
+        if (!ok) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) av[u][k] = 0.f;                                     // a zero row adds nothing to either sum
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const unsigned short* ae = reinterpret_cast<const unsigned short*>(&av[u]);
         if (MODE == 0) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const float v = bf2f(ae[k]);
+            const float v = av[u][k];
             s1[k] += v;
             s2[k] = fmaf(v, v, s2[k]);
           }
         } else {
-          const unsigned short* be = reinterpret_cast<const unsigned short*>(&bv[u]);
-          const unsigned short* me = reinterpret_cast<const unsigned short*>(&mv[u]);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const float xv = bf2f(be[k]);
+            const float xv = bv[u][k];
             // ReLU mask: from the saved output, or recomputed from x with the forward's own fmaf (no y to read)
-            const bool pass = (m || !fss) ? bf2f(me[k]) > 0.f : fmaf(xv, fss[vcol * 8 + k], fss[c8 * 8 + vcol * 8 + k]) > 0.f;
-            const float g = pass ? bf2f(ae[k]) : 0.f;
+            const bool pass = (m || !fss) ? mv[u][k] > 0.f : fmaf(xv, fss[vcol * 8 + k], fss[c8 * 8 + vcol * 8 + k]) > 0.f;
+            const float g = pass ? av[u][k] : 0.f;
             s1[k] += g;
             s2[k] = fmaf(g, xv, s2[k]);
           }
@@ -135,7 +130,7 @@ __global__ __launch_bounds__(256) void k_bn_fwd_consts(const float* __restrict__
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= c) return;
   const float mean = stats[i] * rank_mult, msq = stats[c + i] * rank_mult;
-  const float var = msq - mean * mean;
+  const float var = fmaxf(msq - mean * mean, 0.f);          // E[x^2] - E[x]^2 can cancel below zero for |mean| >> std
   const float invstd = rsqrtf(var + eps);
   const float sc = gamma[i] * invstd;
   scale[i] = sc;
@@ -171,32 +166,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_consts(const float* __restrict__
   coefC[i] = dmu * inv_count;
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const u32x4* __restrict__ gy, const u32x4* __restrict__ y,
-                                                      const u32x4* __restrict__ x, const float* __restrict__ coefA,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ gy, const T* __restrict__ y,
+                                                      const T* __restrict__ x, const float* __restrict__ coefA,
                                                       const float* __restrict__ coefB, const float* __restrict__ coefC,
-                                                      const float* __restrict__ fss, u32x4* __restrict__ gx,
-                                                      u32x4* __restrict__ gres, int64_t n_vec, int c8) {
+                                                      const float* __restrict__ fss, T* __restrict__ gx,
+                                                      T* __restrict__ gres, int64_t n_vec, int c8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
-    const u32x4 gv = __builtin_nontemporal_load(gy + i);
-    const u32x4 xv = __builtin_nontemporal_load(x + i);
-    u32x4 mv = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    if (y) mv = __builtin_nontemporal_load(y + i);
-    const unsigned short* ge = reinterpret_cast<const unsigned short*>(&gv);
-    const unsigned short* xe = reinterpret_cast<const unsigned short*>(&xv);
-    const unsigned short* me = reinterpret_cast<const unsigned short*>(&mv);
-    u32x4 out, masked;
-    unsigned short* oe = reinterpret_cast<unsigned short*>(&out);
-    unsigned short* re = reinterpret_cast<unsigned short*>(&masked);
+    float gv[8], xv[8], mv[8], out[8], masked[8];
+    load8(gy, i, gv);
+    load8(x, i, xv);
+    if (y) load8(y, i, mv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool pass = (y || !fss) ? bf2f(me[k]) > 0.f : fmaf(bf2f(xe[k]), fss[c + k], fss[c8 * 8 + c + k]) > 0.f;
-      re[k] = pass ? ge[k] : (unsigned short)0;
-      const float g = pass ? bf2f(ge[k]) : 0.f;
-      oe[k] = f2bf(fmaf(g, coefA[c + k], fmaf(bf2f(xe[k]), coefB[c + k], coefC[c + k])));
+      const bool pass = y ? mv[k] > 0.f : (!fss || fmaf(xv[k], fss[c + k], fss[c8 * 8 + c + k]) > 0.f);
+      const float g = pass ? gv[k] : 0.f;
+      masked[k] = g;
+      out[k] = fmaf(g, coefA[c + k], fmaf(xv[k], coefB[c + k], coefC[c + k]));
     }
-    gx[i] = out;
-    if (gres) gres[i] = masked;                    // gradient of a residual added before the ReLU
+    store8(gx, i, out);
+    if (gres) store8(gres, i, masked);             // gradient of a residual added before the ReLU
   }
 }
 
@@ -224,11 +214,10 @@ extern "C" size_t omnihd_bn_workspace_bytes(long long rows, int c) {
   return align_up((size_t)blocks * 2 * c * sizeof(float), 256);
 }
 
-/* mode 0: sums = (sum x, sum x^2) * mult over a [rows, c] bf16;  mode 1: (sum g', sum g' x) * mult with
- * g' = a * [mask > 0] (mask may be NULL), x = b.                                                       */
-extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* mask, const float* fwd_scale_shift,
-                                      float* sums, long long rows, int c, int mode, float mult, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+namespace {
+template <typename T>
+int channel_sums_t(const void* a, const void* b, const void* mask, const float* fwd_scale_shift, float* sums, long long rows,
+                   int c, int mode, float mult, void* workspace, size_t workspace_bytes, void* stream) {
   OMNIHD_REQUIRE(rows > 0 && c > 0 && c % 8 == 0 && c <= 2048, "rows > 0, C a multiple of 8, C <= 2048");
   OMNIHD_REQUIRE(a && sums && workspace && (mode == 0 || b), "null pointer");
   OMNIHD_REQUIRE(workspace_bytes >= omnihd_bn_workspace_bytes(rows, c), "workspace too small");
@@ -237,13 +226,40 @@ extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* 
   const int blocks = plan_blocks(rows, c / 8, &per);
   float* partial = static_cast<float*>(workspace);
   if (mode == 0)
-    hipLaunchKernelGGL((k_bn_partial<0>), dim3(blocks), dim3(256), 0, st, (const u32x4*)a, (const u32x4*)nullptr,
-                       (const u32x4*)nullptr, (const float*)nullptr, partial, rows, c / 8, per);
+    hipLaunchKernelGGL((k_bn_partial<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)a, (const T*)nullptr, (const T*)nullptr,
+                       (const float*)nullptr, partial, rows, c / 8, per);
   else
-    hipLaunchKernelGGL((k_bn_partial<1>), dim3(blocks), dim3(256), 0, st, (const u32x4*)a, (const u32x4*)b,
-                       (const u32x4*)mask, fwd_scale_shift, partial, rows, c / 8, per);
+    hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)a, (const T*)b, (const T*)mask,
+                       fwd_scale_shift, partial, rows, c / 8, per);
   hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 3) / 4), dim3(256), 0, st, partial, blocks, c, mult, sums);
   return check_launch("bn_channel_sums");
+}
+
+template <typename T>
+int bwd_apply_t(const void* gy, const void* y_mask, const float* fwd_scale_shift, const void* x, const float* coef_a,
+                const float* coef_b, const float* coef_c, void* gx, void* gres, long long rows, int c, void* stream) {
+  OMNIHD_REQUIRE(rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
+  if (rows == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && gx, "null pointer");
+  const int64_t n_vec = (int64_t)rows * (c / 8);
+  hipLaunchKernelGGL((k_bn_bwd_apply<T>), dim3(grid_for(n_vec, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const T*)gy,
+                     (const T*)y_mask, (const T*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (T*)gx, (T*)gres, n_vec, c / 8);
+  return check_launch("bn_bwd_apply");
+}
+}  // namespace
+
+/* mode 0: sums = (sum x, sum x^2) * mult over a [rows, c] bf16;  mode 1: (sum g', sum g' x) * mult with
+ * g' = a * [mask > 0] (mask may be NULL), x = b.  The _f32 forms take fp32 rows.                          */
+extern "C" int omnihd_bn_channel_sums(const void* a, const void* b, const void* mask, const float* fwd_scale_shift,
+                                      float* sums, long long rows, int c, int mode, float mult, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  return channel_sums_t<bf16_t>(a, b, mask, fwd_scale_shift, sums, rows, c, mode, mult, workspace, workspace_bytes, stream);
+}
+
+extern "C" int omnihd_bn_channel_sums_f32(const float* a, const float* b, const float* mask, const float* fwd_scale_shift,
+                                          float* sums, long long rows, int c, int mode, float mult, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  return channel_sums_t<float>(a, b, mask, fwd_scale_shift, sums, rows, c, mode, mult, workspace, workspace_bytes, stream);
 }
 
 extern "C" int omnihd_bn_fwd_consts(const float* stats, float rank_mult, const float* gamma, const float* beta, float eps,
@@ -270,15 +286,43 @@ extern "C" int omnihd_bn_bwd_consts(const float* local_sums, const float* global
 extern "C" int omnihd_bn_bwd_apply(const void* gy, const void* y_mask, const float* fwd_scale_shift, const void* x,
                                    const float* coef_a, const float* coef_b, const float* coef_c, void* gx, void* gres,
                                    long long rows, int c, void* stream) {
-  OMNIHD_REQUIRE(rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
-  if (rows == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && gx, "null pointer");
-  const int64_t n_vec = (int64_t)rows * (c / 8);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n_vec, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)gy,
-                     (const u32x4*)y_mask, (const u32x4*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (u32x4*)gx, (u32x4*)gres, n_vec,
-                     c / 8);
-  return check_launch("bn_bwd_apply");
+  return bwd_apply_t<bf16_t>(gy, y_mask, fwd_scale_shift, x, coef_a, coef_b, coef_c, gx, gres, rows, c, stream);
 }
+
+extern "C" int omnihd_bn_bwd_apply_f32(const float* gy, const float* y_mask, const float* fwd_scale_shift, const float* x,
+                                       const float* coef_a, const float* coef_b, const float* coef_c, float* gx, float* gres,
+                                       long long rows, int c, void* stream) {
+  return bwd_apply_t<float>(gy, y_mask, fwd_scale_shift, x, coef_a, coef_b, coef_c, gx, gres, rows, c, stream);
+}
+
+namespace {
+template <typename T>
+int train_fwd_t(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
+                float* running_var, float momentum, float eps, float var_correction, int relu, void* y, float* stats2c,
+                float* consts4c, long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = channel_sums_t<T>(x, nullptr, nullptr, nullptr, stats2c, rows, c, 0, 1.0f / (float)rows, workspace,
+                             workspace_bytes, stream);
+  if (rc) return rc;
+  rc = omnihd_bn_fwd_consts(stats2c, 1.0f, gamma, beta, eps, momentum, var_correction, c, running_mean, running_var,
+                            consts4c, consts4c + c, consts4c + 2 * c, consts4c + 3 * c, stream);
+  if (rc) return rc;
+  if (sizeof(T) == 2) return omnihd_affine_act_fwd(x, consts4c, consts4c + c, res, y, rows, c, relu, stream);
+  return omnihd_affine_act_fwd_f32((const float*)x, consts4c, consts4c + c, (const float*)res, (float*)y, rows, c, relu, stream);
+}
+
+template <typename T>
+int train_bwd_t(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma, const float* consts4c,
+                void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
+                size_t workspace_bytes, void* stream) {
+  const float* fss = (relu_from_x && !y_mask) ? consts4c : nullptr;    // consts4c starts with scale, shift
+  int rc = channel_sums_t<T>(gy, x, y_mask, fss, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  rc = omnihd_bn_bwd_consts(sums2c, sums2c, gamma, consts4c + 2 * c, consts4c + 3 * c, 1.0f / (float)rows, c, out5c,
+                            out5c + c, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, stream);
+  if (rc) return rc;
+  return bwd_apply_t<T>(gy, y_mask, fss, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream);
+}
+}  // namespace
 
 /* Single-rank training step of BatchNorm in one call (no exchange between the statistics and their use):
  * forward  = channel sums -> constants (+ running stats) -> y = act(x * scale + shift (+ res));
@@ -287,13 +331,16 @@ extern "C" int omnihd_bn_train_fwd(const void* x, const void* res, const float* 
                                    float* running_mean, float* running_var, float momentum, float eps,
                                    float var_correction, int relu, void* y, float* stats2c, float* consts4c,
                                    long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = omnihd_bn_channel_sums(x, nullptr, nullptr, nullptr, stats2c, rows, c, 0, 1.0f / (float)rows, workspace,
-                                  workspace_bytes, stream);
-  if (rc) return rc;
-  rc = omnihd_bn_fwd_consts(stats2c, 1.0f, gamma, beta, eps, momentum, var_correction, c, running_mean, running_var,
-                            consts4c, consts4c + c, consts4c + 2 * c, consts4c + 3 * c, stream);
-  if (rc) return rc;
-  return omnihd_affine_act_fwd(x, consts4c, consts4c + c, res, y, rows, c, relu, stream);
+  return train_fwd_t<bf16_t>(x, res, gamma, beta, running_mean, running_var, momentum, eps, var_correction, relu, y, stats2c,
+                             consts4c, rows, c, workspace, workspace_bytes, stream);
+}
+
+extern "C" int omnihd_bn_train_fwd_f32(const float* x, const float* res, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps,
+                                       float var_correction, int relu, float* y, float* stats2c, float* consts4c,
+                                       long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
+  return train_fwd_t<float>(x, res, gamma, beta, running_mean, running_var, momentum, eps, var_correction, relu, y, stats2c,
+                            consts4c, rows, c, workspace, workspace_bytes, stream);
 }
 
 /* backward = masked channel sums -> dgamma/dbeta + coefficients -> gx (and gres).  out5c [5, c] receives
@@ -301,11 +348,14 @@ extern "C" int omnihd_bn_train_fwd(const void* x, const void* res, const float* 
 extern "C" int omnihd_bn_train_bwd(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma,
                                    const float* consts4c, void* gx, void* gres, float* sums2c, float* out5c,
                                    long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
-  const float* fss = (relu_from_x && !y_mask) ? consts4c : nullptr;    // consts4c starts with scale, shift
-  int rc = omnihd_bn_channel_sums(gy, x, y_mask, fss, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream);
-  if (rc) return rc;
-  rc = omnihd_bn_bwd_consts(sums2c, sums2c, gamma, consts4c + 2 * c, consts4c + 3 * c, 1.0f / (float)rows, c, out5c,
-                            out5c + c, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, stream);
-  if (rc) return rc;
-  return omnihd_bn_bwd_apply(gy, y_mask, fss, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream);
+  return train_bwd_t<bf16_t>(gy, y_mask, relu_from_x, x, gamma, consts4c, gx, gres, sums2c, out5c, rows, c, workspace,
+                             workspace_bytes, stream);
+}
+
+extern "C" int omnihd_bn_train_bwd_f32(const float* gy, const float* y_mask, int relu_from_x, const float* x,
+                                       const float* gamma, const float* consts4c, float* gx, float* gres, float* sums2c,
+                                       float* out5c, long long rows, int c, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  return train_bwd_t<float>(gy, y_mask, relu_from_x, x, gamma, consts4c, gx, gres, sums2c, out5c, rows, c, workspace,
+                            workspace_bytes, stream);
 }

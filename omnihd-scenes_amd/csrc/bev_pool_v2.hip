@@ -1095,6 +1095,145 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_sched(
   feat_grad4[(size_t)f * C4 + sub] = fg;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Patch backward (C = 64): one workgroup per PATCH of 16 consecutive image-feature pixels (a run along the image row), one
+// group of 16 lanes per pixel.
+//   * depth_grad is written DENSELY: the D x 16 block of depth gradients of the patch is assembled in LDS (zero where a
+//     frustum point falls outside the grid) and stored as D segments of 64 contiguous bytes.  The scheduled kernel scattered
+//     2 million 4-byte stores, 45 KB apart along a ray, into a buffer that a separate 16 MB memset had cleared;
+//   * the depth values of the patch are read the same way (D coalesced 64-byte segments into LDS) instead of one
+//     4-byte gather per point;
+//   * the tables of a pixel are read 16 points at a time, one per lane, and handed to the row's lanes by DPP row
+//     broadcasts (v_mov_dpp row_newbcast, no LDS round trip); the channel sum of a point's depth gradient is four
+//     v_add_f32_dpp row_ror adds;
+//   * out_grad rows are gathered with range-checked buffer loads (32-bit offsets, a lane past the end of its pixel's point
+//     list asks for a row beyond the buffer and gets zeros: no bounds branches in the point loop).
+// feat_grad: fg += depth * g in table order (the reference's fma chain, bit-exact); depth_grad: channel sums in a fixed
+// lane order (run-to-run identical; differs from the reference's serial channel loop by fp32 rounding).
+// ---------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ int dpp_row_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);       // row_newbcast:J (16-lane rows)
+}
+template <int J>
+__device__ __forceinline__ float dpp_row_bcast_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float dpp_ror_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+
+constexpr int kPatch = 16;     // pixels per patch = groups per workgroup at C = 64
+
+typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+
+// one point of the current 16-point chunk: g = its out_grad row (already gathered), d = its depth value
+template <int JJ>
+__device__ __forceinline__ void patch_point(const u32x4t a, float d, const float4 x, float4& fg, float& mydot, int sub) {
+  const float4 g = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+  fg = fma4(d, g, fg);
+  float p = fmaf(g.w, x.w, fmaf(g.z, x.z, fmaf(g.y, x.y, g.x * x.x)));
+  p = dpp_ror_add<8>(p); p = dpp_ror_add<4>(p); p = dpp_ror_add<2>(p); p = dpp_ror_add<1>(p);   // channel sum over the 16 lanes
+  mydot = (sub == JJ) ? p : mydot;
+}
+
+// points J0 .. J0+7 of the current chunk: eight gathers in flight per lane group
+template <int J0>
+__device__ __forceinline__ void patch_batch8(const __amdgpu_buffer_rsrc_t og_rsrc, unsigned lane_off, int rr, float dval,
+                                             const float4 x, float4& fg, float& mydot, int sub) {
+#define OMNIHD_G(K) const u32x4t a##K = __builtin_amdgcn_raw_buffer_load_b128(og_rsrc, ((unsigned)dpp_row_bcast_i<J0 + K>(rr) << 8) | lane_off, 0, 0);
+  OMNIHD_G(0) OMNIHD_G(1) OMNIHD_G(2) OMNIHD_G(3) OMNIHD_G(4) OMNIHD_G(5) OMNIHD_G(6) OMNIHD_G(7)
+#undef OMNIHD_G
+  patch_point<J0 + 0>(a0, dpp_row_bcast_f<J0 + 0>(dval), x, fg, mydot, sub);
+  patch_point<J0 + 1>(a1, dpp_row_bcast_f<J0 + 1>(dval), x, fg, mydot, sub);
+  patch_point<J0 + 2>(a2, dpp_row_bcast_f<J0 + 2>(dval), x, fg, mydot, sub);
+  patch_point<J0 + 3>(a3, dpp_row_bcast_f<J0 + 3>(dval), x, fg, mydot, sub);
+  patch_point<J0 + 4>(a4, dpp_row_bcast_f<J0 + 4>(dval), x, fg, mydot, sub);
+  patch_point<J0 + 5>(a5, dpp_row_bcast_f<J0 + 5>(dval), x, fg, mydot, sub);
+  patch_point<J0 + 6>(a6, dpp_row_bcast_f<J0 + 6>(dval), x, fg, mydot, sub);
+  patch_point<J0 + 7>(a7, dpp_row_bcast_f<J0 + 7>(dval), x, fg, mydot, sub);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
+    const float* __restrict__ og, unsigned og_bytes, const float* __restrict__ depth, const float4* __restrict__ feat4,
+    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_row, const int* __restrict__ pix_ptr,
+    const int* __restrict__ patch_order, int patches_per_xcd, int patches_per_img, int fhw, int d_bins, float inv_fhw,
+    float* __restrict__ depth_grad, float4* __restrict__ feat_grad4) {
+  constexpr int C4 = 16;
+  extern __shared__ float s_dyn[];                 // [0, D*16) depth values of the patch, [D*16, 2*D*16) depth gradients
+  const int slot = (int)(blockIdx.x >> 3);
+  if (slot >= patches_per_xcd) return;
+  const int patch = patch_order[(size_t)(blockIdx.x & 7) * patches_per_xcd + slot];
+  if (patch < 0) return;
+  const int tid = threadIdx.x;
+  const int sub = tid % C4;
+  const int grp = tid / C4;
+  const int img = patch / patches_per_img;
+  const int hw0 = (patch - img * patches_per_img) * kPatch;
+  const int npx = min(kPatch, fhw - hw0);
+  float* s_dv = s_dyn;
+  float* s_dg = s_dyn + d_bins * kPatch;
+  const size_t img_base = (size_t)img * d_bins * fhw + hw0;     // index of (img, d = 0, pixel hw0) in depth / depth_grad
+
+  // ---- depth values of the patch -> LDS (D segments of 64 contiguous bytes), gradients start at zero ----------
+  const int n_cell = d_bins * kPatch;
+  for (int i = tid; i < n_cell; i += kBlock) {
+    const int d = i / kPatch, px = i % kPatch;
+    s_dv[i] = (px < npx) ? depth[img_base + (size_t)d * fhw + px] : 0.f;
+    s_dg[i] = 0.f;
+  }
+  const bool valid = grp < npx;
+  const int f = img * fhw + hw0 + grp;                          // my pixel (feature row)
+  int s = 0, len = 0;
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) {
+    s = pix_ptr[f];
+    len = pix_ptr[f + 1] - s;
+    x = feat4[(size_t)f * C4 + sub];
+  }
+  // the longest point list among the four pixels of this wavefront bounds the (wave-uniform) trip count
+  int ml = len;
+  ml = max(ml, __shfl_xor(ml, 16));
+  ml = max(ml, __shfl_xor(ml, 32));
+  const int wave_len = __builtin_amdgcn_readfirstlane(ml);
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t og_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)og_bytes, 0x00020000);
+  const unsigned lane_off = (unsigned)sub << 4;
+  const int rd_base = (img * d_bins) * fhw + hw0 + grp;         // ranks_depth of (my pixel, d = 0)
+  float4 fg = make_float4(0.f, 0.f, 0.f, 0.f);
+  // tables of the first chunk; each chunk's tables are requested one chunk ahead
+  int rr_n = 0x00ffffff, rd_n = rd_base;                        // row beyond the buffer: the gather returns zeros
+  if (sub < len) {
+    rr_n = ranks_row[s + sub];
+    rd_n = ranks_depth[s + sub];
+  }
+  for (int cb = 0; cb < wave_len; cb += kPatch) {
+    const int mine = cb + sub;
+    const bool inb = mine < len;
+    const int rr = rr_n;
+    const int dk = div_const(rd_n - rd_base, fhw, inv_fhw);
+    rr_n = 0x00ffffff;
+    rd_n = rd_base;
+    if (mine + kPatch < len) {
+      rr_n = ranks_row[s + mine + kPatch];
+      rd_n = ranks_depth[s + mine + kPatch];
+    }
+    const float dval = inb ? s_dv[dk * kPatch + grp] : 0.f;
+    float mydot = 0.f;
+    patch_batch8<0>(og_rsrc, lane_off, rr, dval, x, fg, mydot, sub);
+    if (cb + 8 < wave_len) patch_batch8<8>(og_rsrc, lane_off, rr, dval, x, fg, mydot, sub);
+    if (inb) s_dg[dk * kPatch + grp] = mydot;
+  }
+  if (valid) feat_grad4[(size_t)f * C4 + sub] = fg;
+  __syncthreads();
+  for (int i = tid; i < n_cell; i += kBlock) {
+    const int d = i / kPatch, px = i % kPatch;
+    if (px < npx) depth_grad[img_base + (size_t)d * fhw + px] = s_dg[i];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_pool_bwd_generic(
     const float* __restrict__ og, const float* __restrict__ depth, const float* __restrict__ feat,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
@@ -1400,4 +1539,26 @@ extern "C" int omnihd_bev_pool_v2_bwd_sched(const float* out_grad, const float* 
   }
 #undef OMNIHD_BWDS_CASE
   return check_launch("bev_pool_v2_bwd_sched");
+}
+
+extern "C" int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* depth, const float* feat,
+                                            const int* ranks_depth, const int* ranks_row, const int* pix_ptr,
+                                            const int* patch_order, int n_slots, int n_img, int d_bins, int fhw,
+                                            long long n_rows, float* depth_grad, float* feat_grad, int c, void* stream) {
+  OMNIHD_REQUIRE(c == 64, "the patch backward is written for C = 64 (use omnihd_bev_pool_v2_bwd_sched otherwise)");
+  OMNIHD_REQUIRE(n_slots >= 0 && n_slots % 8 == 0 && n_img > 0 && d_bins > 0 && fhw > 0 && n_rows > 0, "sizes");
+  if (n_slots == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(out_grad && depth && feat && pix_ptr && patch_order && depth_grad && feat_grad, "null pointer");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(out_grad) | reinterpret_cast<uintptr_t>(feat) |
+                   reinterpret_cast<uintptr_t>(feat_grad)) & 15u) == 0, "16-byte alignment");
+  OMNIHD_REQUIRE(n_rows * 256 < (1ll << 32) && n_rows < 0x00ffffff, "out_grad must stay below 4 GiB (32-bit gather offsets)");
+  OMNIHD_REQUIRE((long long)d_bins * fhw * n_img < (1ll << 31), "depth tensor too large for int32 ranks");
+  const size_t lds = (size_t)2 * d_bins * kPatch * sizeof(float);
+  OMNIHD_REQUIRE(lds <= 64 * 1024, "too many depth bins for the LDS patch buffers");
+  hipStream_t st = (hipStream_t)stream;
+  const int patches_per_img = (fhw + kPatch - 1) / kPatch;
+  hipLaunchKernelGGL(k_pool_bwd_patch, dim3(n_slots), dim3(kBlock), lds, st, out_grad, (unsigned)(n_rows * 256), depth,
+                     reinterpret_cast<const float4*>(feat), ranks_depth, ranks_row, pix_ptr, patch_order, n_slots / 8,
+                     patches_per_img, fhw, d_bins, 1.0f / (float)fhw, depth_grad, reinterpret_cast<float4*>(feat_grad));
+  return check_launch("bev_pool_v2_bwd_patch");
 }

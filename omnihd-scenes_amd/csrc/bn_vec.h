@@ -1,0 +1,44 @@
+// Eight consecutive channels of one channels-last row as fp32 values, for bf16 rows (16 B per lane) and fp32 rows
+// (two 16-B accesses per lane).  Streaming accesses: non-temporal loads, plain stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace omnihd {
+
+typedef unsigned short bf16_t;                       // storage type of a bf16 element
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {              // round to nearest even, NaN kept quiet
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// vector i = elements [8*i, 8*i + 8) of the array
+__device__ __forceinline__ void load8(const bf16_t* __restrict__ p, int64_t i, float (&v)[8]) {
+  const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + i);
+  const unsigned short* e = reinterpret_cast<const unsigned short*>(&raw);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = bf2f(e[k]);
+}
+__device__ __forceinline__ void load8(const float* __restrict__ p, int64_t i, float (&v)[8]) {
+  const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + 2 * i);
+  const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + 2 * i + 1);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(bf16_t* __restrict__ p, int64_t i, const float (&v)[8]) {
+  u32x4 raw;
+  unsigned short* e = reinterpret_cast<unsigned short*>(&raw);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = f2bf(v[k]);
+  reinterpret_cast<u32x4*>(p)[i] = raw;
+}
+__device__ __forceinline__ void store8(float* __restrict__ p, int64_t i, const float (&v)[8]) {
+  reinterpret_cast<f32x4*>(p)[2 * i] = f32x4{v[0], v[1], v[2], v[3]};
+  reinterpret_cast<f32x4*>(p)[2 * i + 1] = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+}  // namespace omnihd

@@ -17,6 +17,7 @@ PROTOTYPES = {
     "omnihd_bev_pool_v2_fwd_csr": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_fwd_lean": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_bwd_sched": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "omnihd_bev_pool_v2_bwd_patch": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "omnihd_tile_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "omnihd_csr_tiles_workspace_bytes": (c_size_t, [c_int]),
     "omnihd_csr_tiles": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -59,6 +60,13 @@ PROTOTYPES = {
     "omnihd_bn_train_fwd": (c_int, [c_void_p] * 6 + [c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_int, c_void_p, c_size_t, c_void_p]),
     "omnihd_bn_train_bwd": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "omnihd_affine_act_fwd_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
+    "omnihd_affine_act_bwd_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
+    "omnihd_bn_channel_sums_f32": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "omnihd_bn_bwd_apply_f32": (c_int, [c_void_p] * 9 + [c_int64, c_int, c_void_p]),
+    "omnihd_bn_train_fwd_f32": (c_int, [c_void_p] * 6 + [c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                        c_int, c_void_p, c_size_t, c_void_p]),
+    "omnihd_bn_train_bwd_f32": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "omnihd_radar_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omnihd_iou_bev_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }

@@ -80,9 +80,12 @@ def frozen_bn_constants(bn):
 
 
 def bn_act(x, bn, relu=True, residual=None, inplace=True):
-    """``relu(bn(x) + residual)``.  A frozen BatchNorm (eval mode, affine parameters without gradient) on a
-    bf16 device tensor is an affine map with constant coefficients: that case runs as ONE fused
-    channels-last pass each way (csrc/affine_act.hip); everything else is the plain torch composition."""
+    """``relu(bn(x) + residual)``.  A frozen BatchNorm (eval mode, affine parameters without gradient) on a bf16 or fp32
+    device tensor is an affine map with constant coefficients: ONE fused channels-last pass each way
+    (csrc/affine_act.hip).  A training-mode BatchNorm on a device tensor runs on csrc/batch_norm.hip in either precision
+    (statistics exchanged between ranks for naiveSyncBN and torch SyncBatchNorm layers).  Everything else — CPU tensors,
+    channel counts that are not multiples of 8, eval-mode layers with trainable affine parameters — is the plain torch
+    composition."""
     from .. import ops
     if (isinstance(bn, nn.modules.batchnorm._BatchNorm) and not bn.training and bn.track_running_stats and bn.affine
             and not bn.weight.requires_grad and not bn.bias.requires_grad and ops.affine_act_supported(x, residual)):
@@ -91,15 +94,28 @@ def bn_act(x, bn, relu=True, residual=None, inplace=True):
     if (isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training and bn.affine and bn.momentum is not None
             and bn.track_running_stats and ops.bn_train_supported(x)
             and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype))):
-        group = None
-        if getattr(bn, "_omnihd_sync", False):
+        group, unbiased_sync = None, False
+        torch_sync = isinstance(bn, nn.SyncBatchNorm)
+        if getattr(bn, "_omnihd_sync", False) or torch_sync:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                group = dist.group.WORLD
+            if dist.is_available() and dist.is_initialized():
+                g = (bn.process_group if torch_sync and bn.process_group is not None else dist.group.WORLD)
+                if dist.get_world_size(g) > 1:
+                    group = g
+        if torch_sync and group is not None:
+            # torch's SyncBatchNorm weights every rank by its row count; the fused exchange averages per-rank moments, which
+            # is the same thing only when all ranks hold the same number of rows: image-shaped (4-D) activations.  Anything
+            # else (per-rank pillar counts) keeps torch's own implementation.
+            if x.dim() != 4:
+                out = bn(x)
+                if residual is not None:
+                    out = out + residual
+                return F.relu(out, inplace=inplace) if relu else out
+            unbiased_sync = True
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         return ops.bn_train_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, group,
-                                residual)
+                                residual, unbiased_sync)
     out = bn(x)
     if residual is not None:
         out = out + residual

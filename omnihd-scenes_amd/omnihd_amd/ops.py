@@ -157,6 +157,28 @@ def bev_pool_v2_backward_sched(out_grad, depth, feat, ranks_depth, ranks_row, pi
               "omnihd_bev_pool_v2_bwd_sched")
 
 
+def bev_pool_v2_backward_patch(out_grad, depth, feat, ranks_depth, ranks_row, pix_ptr, patch_order, depth_grad, feat_grad):
+    """Patch backward for C = 64 (see include/omnihd_hip.h): writes BOTH gradients densely (no zero-fill by the caller).
+    depth (B,N,D,H,W), feat (B,N,H,W,64), out_grad (n_rows, 64); tables sorted by pixel + their CSR ``pix_ptr``."""
+    for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad),
+                 ("feat_grad", feat_grad)):
+        _want(t, torch.float32, n)
+    for n, t in (("ranks_depth", ranks_depth), ("ranks_row", ranks_row), ("pix_ptr", pix_ptr), ("patch_order", patch_order)):
+        _want(t, torch.int32, n)
+    if depth.dim() != 5 or feat.dim() != 5 or feat.size(-1) != 64:
+        raise ValueError("depth must be (B,N,D,H,W) and feat (B,N,H,W,64)")
+    B, N, D, H, W = depth.shape
+    n_img, fhw = B * N, H * W
+    if pix_ptr.numel() != n_img * fhw + 1 or patch_order.numel() % 8:
+        raise ValueError("pix_ptr must have B*N*H*W + 1 entries and patch_order 8*k")
+    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, ranks_depth, ranks_row, pix_ptr, patch_order)
+    with _on(dev):
+        check(lib().omnihd_bev_pool_v2_bwd_patch(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_row),
+                                                 _ptr(pix_ptr), _ptr(patch_order), patch_order.numel(), n_img, D, fhw,
+                                                 out_grad.numel() // 64, _ptr(depth_grad), _ptr(feat_grad), 64, _stream()),
+              "omnihd_bev_pool_v2_bwd_patch")
+
+
 def tile_descriptors(row_ptr, tile_row, tile_order=None):
     """(8*ceil(n_tiles/8), 4) int32 launch schedule {first row, #rows, first point, #points}."""
     _want(row_ptr, torch.int32, "row_ptr"); _want(tile_row, torch.int32, "tile_row")
@@ -779,34 +801,35 @@ class _AffineAct(torch.autograd.Function):
         n, c, h, w = x.shape
         y = torch.empty_like(x)
         with _on(x.device):
-            check(lib().omnihd_affine_act_fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                              None if res is None else res.data_ptr(), y.data_ptr(), n * h * w, c,
-                                              1 if relu else 0, _raw_stream()), "omnihd_affine_act_fwd")
+            fwd = lib().omnihd_affine_act_fwd_f32 if x.dtype == torch.float32 else lib().omnihd_affine_act_fwd
+            check(fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(),
+                      n * h * w, c, 1 if relu else 0, _raw_stream()), "omnihd_affine_act_fwd")
         ctx.save_for_backward(y if relu else None, scale)
-        ctx.relu, ctx.has_res = relu, res is not None
+        ctx.relu, ctx.has_res, ctx.dtype = relu, res is not None, x.dtype
         return y
 
     @staticmethod
     def backward(ctx, gy):
         y, scale = ctx.saved_tensors
-        gy = gy.contiguous(memory_format=torch.channels_last)
+        gy = gy.to(ctx.dtype).contiguous(memory_format=torch.channels_last)
         n, c, h, w = gy.shape
         gx = torch.empty_like(gy)
         gres = torch.empty_like(gy) if ctx.has_res and ctx.needs_input_grad[3] else None
         with _on(gy.device):
-            check(lib().omnihd_affine_act_bwd(gy.data_ptr(), None if y is None else y.data_ptr(), scale.data_ptr(),
-                                              gx.data_ptr(), None if gres is None else gres.data_ptr(), n * h * w, c,
-                                              1 if ctx.relu else 0, _raw_stream()), "omnihd_affine_act_bwd")
+            bwd = lib().omnihd_affine_act_bwd_f32 if gy.dtype == torch.float32 else lib().omnihd_affine_act_bwd
+            check(bwd(gy.data_ptr(), None if y is None else y.data_ptr(), scale.data_ptr(), gx.data_ptr(),
+                      None if gres is None else gres.data_ptr(), n * h * w, c, 1 if ctx.relu else 0, _raw_stream()),
+                  "omnihd_affine_act_bwd")
         return gx, None, None, gres, None
 
 
 def affine_act_supported(x, res=None):
-    ok = x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0
+    ok = x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % 8 == 0
     return ok and (res is None or (res.shape == x.shape and res.dtype == x.dtype and res.is_cuda))
 
 
 def affine_act(x, scale, shift, res=None, relu=True):
-    """x, res (N,C,H,W) bf16 (made channels-last if they are not), scale/shift (C,) fp32 constants."""
+    """x, res (N,C,H,W) bf16 or fp32 (made channels-last if they are not), scale/shift (C,) fp32 constants."""
     x = x.contiguous(memory_format=torch.channels_last)
     if res is not None:
         res = res.contiguous(memory_format=torch.channels_last)
@@ -832,11 +855,12 @@ def _f32c(t):
 
 class _BnTrainAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group, res):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group, res, unbiased_sync=False):
         import torch.distributed as dist
         rows, c = _rows_view(x)
         dev = x.device
         ranks = dist.get_world_size(group) if group is not None else 1
+        sfx = "_f32" if x.dtype == torch.float32 else ""
         buf = torch.empty(6, c, dtype=torch.float32, device=dev)           # [0:2] statistics, [2:6] scale, shift, mean, invstd
         stats, consts = buf[:2].view(-1), buf[2:]
         y = torch.empty_like(x)
@@ -854,19 +878,22 @@ class _BnTrainAct(torch.autograd.Function):
             if ranks == 1:
                 # torch's BatchNorm keeps the unbiased variance in running_var
                 corr = rows / (rows - 1.0) if rows > 1 else 1.0
-                check(L.omnihd_bn_train_fwd(x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr,
-                                            1 if relu else 0, y.data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c,
-                                            ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd")
+                check(getattr(L, "omnihd_bn_train_fwd" + sfx)(
+                    x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr, 1 if relu else 0,
+                    y.data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd")
             else:
-                check(L.omnihd_bn_channel_sums(x.data_ptr(), None, None, None, stats.data_ptr(), rows, c, 0, 1.0 / rows,
-                                               ws.data_ptr(), ws.numel(), st), "omnihd_bn_channel_sums")
+                check(getattr(L, "omnihd_bn_channel_sums" + sfx)(x.data_ptr(), None, None, None, stats.data_ptr(), rows, c, 0,
+                                                                 1.0 / rows, ws.data_ptr(), ws.numel(), st), "omnihd_bn_channel_sums")
                 dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-                # the reference's SyncBN keeps the biased variance (ops/norm.py:74-75)
-                check(L.omnihd_bn_fwd_consts(stats.data_ptr(), 1.0 / ranks, gamma.data_ptr(), beta.data_ptr(), eps, momentum, 1.0,
+                # the reference's SyncBN keeps the biased variance (ops/norm.py:74-75); torch's SyncBatchNorm the unbiased
+                # one over the rows of all ranks
+                total = float(ranks * rows)
+                corr = total / (total - 1.0) if (unbiased_sync and total > 1) else 1.0
+                check(L.omnihd_bn_fwd_consts(stats.data_ptr(), 1.0 / ranks, gamma.data_ptr(), beta.data_ptr(), eps, momentum, corr,
                                              c, rm, rv, consts[0].data_ptr(), consts[1].data_ptr(), consts[2].data_ptr(),
                                              consts[3].data_ptr(), st), "omnihd_bn_fwd_consts")
-                check(L.omnihd_affine_act_fwd(x.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), resp, y.data_ptr(), rows, c,
-                                              1 if relu else 0, st), "omnihd_affine_act_fwd")
+                check(getattr(L, "omnihd_affine_act_fwd" + sfx)(x.data_ptr(), consts[0].data_ptr(), consts[1].data_ptr(), resp,
+                                                                y.data_ptr(), rows, c, 1 if relu else 0, st), "omnihd_affine_act_fwd")
         # The ReLU mask of the backward comes from the saved output.  The kernels can also recompute it from x with the
         # forward's constants (OMNIHD_BN_MASK_FROM_X=1: one tensor less to read), but that measured SLOWER in the full
         # step (34.1-35.0 vs 32.5-33.3 ms, alternating blocks in one process): the per-element constant loads cost more
@@ -881,7 +908,9 @@ class _BnTrainAct(torch.autograd.Function):
     def backward(ctx, gy):
         import torch.distributed as dist
         x, y, gamma, consts = ctx.saved_tensors
+        gy = gy.to(x.dtype)
         gy = gy.contiguous(memory_format=torch.channels_last) if gy.dim() == 4 else gy.contiguous()
+        sfx = "_f32" if x.dtype == torch.float32 else ""
         rows, c = _rows_view(x)
         dev = x.device
         buf = torch.empty(7, c, dtype=torch.float32, device=dev)           # [0:2] sums, [2:7] dgamma, dbeta, A, B, C
@@ -897,37 +926,41 @@ class _BnTrainAct(torch.autograd.Function):
         with _on(dev):
             ws = _wgrad_workspace(_SIZE_CACHE[("bn", rows, c)], dev)
             if ctx.ranks == 1:
-                check(L.omnihd_bn_train_bwd(gy.data_ptr(), yp, 1 if ctx.relu else 0, x.data_ptr(), gamma.data_ptr(),
-                                            consts.data_ptr(), gx.data_ptr(), gresp, local.data_ptr(), out.data_ptr(), rows, c,
-                                            ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_bwd")
+                check(getattr(L, "omnihd_bn_train_bwd" + sfx)(
+                    gy.data_ptr(), yp, 1 if ctx.relu else 0, x.data_ptr(), gamma.data_ptr(), consts.data_ptr(), gx.data_ptr(),
+                    gresp, local.data_ptr(), out.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_bwd")
             else:
                 fss = consts.data_ptr() if (ctx.relu and yp is None) else None
-                check(L.omnihd_bn_channel_sums(gy.data_ptr(), x.data_ptr(), yp, fss, local.data_ptr(), rows, c, 1, 1.0,
-                                               ws.data_ptr(), ws.numel(), st), "omnihd_bn_channel_sums")
+                check(getattr(L, "omnihd_bn_channel_sums" + sfx)(gy.data_ptr(), x.data_ptr(), yp, fss, local.data_ptr(), rows, c,
+                                                                 1, 1.0, ws.data_ptr(), ws.numel(), st), "omnihd_bn_channel_sums")
                 glob = local.clone()
                 dist.all_reduce(glob, op=dist.ReduceOp.SUM, group=ctx.group)
                 check(L.omnihd_bn_bwd_consts(local.data_ptr(), glob.data_ptr(), gamma.data_ptr(), consts[2].data_ptr(),
                                              consts[3].data_ptr(), 1.0 / (ctx.ranks * rows), c, out[0].data_ptr(),
                                              out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(), st),
                       "omnihd_bn_bwd_consts")
-                check(L.omnihd_bn_bwd_apply(gy.data_ptr(), yp, fss, x.data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
-                                            out[4].data_ptr(), gx.data_ptr(), gresp, rows, c, st), "omnihd_bn_bwd_apply")
+                check(getattr(L, "omnihd_bn_bwd_apply" + sfx)(gy.data_ptr(), yp, fss, x.data_ptr(), out[2].data_ptr(),
+                                                              out[3].data_ptr(), out[4].data_ptr(), gx.data_ptr(), gresp, rows, c,
+                                                              st), "omnihd_bn_bwd_apply")
         return (gx, out[0].to(ctx.param_dtypes[0]), out[1].to(ctx.param_dtypes[1]), None, None, None, None, None, None,
-                gres)
+                gres, None)
 
 
 def bn_train_supported(x):
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() in (2, 4) and x.shape[1] % 8 == 0 and x.shape[1] <= 2048):
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() in (2, 4) and x.shape[1] % 8 == 0
+            and x.shape[1] <= 2048):
         return False
     return x.numel() > 0
 
 
-def bn_train_act(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, group=None, residual=None):
-    """``act(BatchNorm_train(x) + residual)`` of a bf16 (N,C,H,W) [made channels-last] or (N,C) tensor; statistics are
-    the mean over ``group``'s ranks of the per-rank mean / mean of squares when a group with more than one rank is given."""
+def bn_train_act(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, group=None, residual=None,
+                 unbiased_sync=False):
+    """``act(BatchNorm_train(x) + residual)`` of a bf16 or fp32 (N,C,H,W) [made channels-last] or (N,C) tensor; statistics
+    are the mean over ``group``'s ranks of the per-rank mean / mean of squares when a group with more than one rank is
+    given (``unbiased_sync``: running_var takes the unbiased variance over all ranks' rows, as torch's SyncBatchNorm)."""
     cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if x.dim() == 4 else (lambda t: t.contiguous())
     return _BnTrainAct.apply(cl(x), weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), group,
-                             None if residual is None else cl(residual))
+                             None if residual is None else cl(residual), bool(unbiased_sync))
 
 
 # --------------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ class BevPoolPlan:
     bp_starts: torch.Tensor
     bp_lengths: torch.Tensor
     pix_desc: torch.Tensor = None   # int32 [8*k, 4] schedule of the scheduled backward (every pixel once)
+    pix_ptr: torch.Tensor = None    # int32 [n_feat_rows+1] CSR of the backward tables over image-feature pixels
+    patch_order: torch.Tensor = None  # int32 [8*k] schedule of the patch backward (16-pixel patches, -1 idle)
     depth_bins: int = 0             # D and fH*fW of the frustum the plan was built from (0: unknown, e.g. foreign
     feat_hw: int = 0                # tables): with them the forward derives ranks_feat from ranks_depth in-kernel
 
@@ -145,6 +147,33 @@ def pixel_schedule(bp_ranks_feat, bp_starts, bp_lengths, n_feat_rows, feat_hw=No
     return desc.contiguous()
 
 
+PATCH = 16   # pixels per patch of the patch backward (one 64-byte segment of depth / depth_grad per depth bin)
+
+
+def patch_schedule(n_img, feat_hw, n_xcd=8):
+    """Launch schedule of the patch backward: patch p = pixels [16*(p % ppi), 16*(p % ppi) + 16) of image p // ppi,
+    ppi = ceil(fH*fW / 16).  The patches are walked image by image in blocks of 4 image rows (vertically adjacent pixels
+    see the same BEV cells at neighbouring heights, so the out_grad rows one patch fetched are still in L2 for the next)
+    and cut into ``n_xcd`` contiguous runs, one per XCD.  int32 [n_xcd * per], -1 = idle slot.  Host-side planning, once
+    per calibration; only the ORDER is a performance choice, every patch appears exactly once."""
+    fH, fW = feat_hw
+    fhw = fH * fW
+    ppi = (fhw + PATCH - 1) // PATCH
+    p = torch.arange(n_img * ppi)
+    img, k = p // ppi, p % ppi
+    h, w = (k * PATCH) // fW, (k * PATCH) % fW
+    key = ((img * ((fH + 3) // 4) + h // 4) * ((fW + PATCH - 1) // PATCH + 1) + w // PATCH) * 4 + h % 4
+    order = p[torch.argsort(key, stable=True)]
+    n = order.numel()
+    per = (n + n_xcd - 1) // n_xcd
+    flat = torch.full((n_xcd * per,), -1, dtype=torch.int32)
+    bounds = [(n * k) // n_xcd for k in range(n_xcd + 1)]
+    for k in range(n_xcd):
+        run = order[bounds[k]:bounds[k + 1]]
+        flat[k * per:k * per + run.numel()] = run.int()
+    return flat.contiguous()
+
+
 def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=None, origin_cell=None):
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X
@@ -154,8 +183,12 @@ def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=No
     tile_desc = ops.tile_descriptors(row_ptr, tile_row, tile_order)
     bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
     pix_desc = pixel_schedule(bp[2], bp[3], bp[4], n_feat_rows, feat_hw)
-    return BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, tile_row, tile_order,
+    plan = BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, tile_row, tile_order,
                        tile_desc, starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4], pix_desc)
+    if feat_hw is not None and n_feat_rows % (feat_hw[0] * feat_hw[1]) == 0:
+        plan.pix_ptr = ops.csr_from_sorted_keys(bp[2], n_feat_rows)
+        plan.patch_order = patch_schedule(n_feat_rows // (feat_hw[0] * feat_hw[1]), feat_hw).to(rows.device)
+    return plan
 
 
 def build_plan(coor, dx, bx, nx, layout="byxz", origin_xy=None):
@@ -203,6 +236,12 @@ def _lean_forward():
     return os.environ.get("OMNIHD_POOL_LEAN", "1") != "0"
 
 
+def _patch_backward():
+    """The patch backward (k_pool_bwd_patch, C = 64) is the default; OMNIHD_POOL_BWD_PATCH=0 selects the scheduled kernel."""
+    import os
+    return os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"
+
+
 class _PlannedPool(torch.autograd.Function):
     """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order."""
 
@@ -226,8 +265,14 @@ class _PlannedPool(torch.autograd.Function):
         depth, feat = ctx.saved_tensors
         plan = ctx.plan
         out_grad = out_grad.contiguous().float()
-        depth_grad = torch.zeros_like(depth)
         c = feat.size(-1)
+        if (c == 64 and plan.patch_order is not None and plan.depth_bins > 0 and depth.dim() == 5
+                and plan.n_rows * 256 < 2 ** 32 and _patch_backward()):
+            depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)   # both written densely
+            ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat, plan.bp_ranks_depth,
+                                           plan.bp_ranks_row, plan.pix_ptr, plan.patch_order, depth_grad, feat_grad)
+            return depth_grad, feat_grad, None
+        depth_grad = torch.zeros_like(depth)
         if plan.pix_desc is not None and c in (4, 8, 16, 32, 64):
             feat_grad = torch.empty_like(feat)          # written densely by the scheduled kernel
             ops.bev_pool_v2_backward_sched(out_grad.view(plan.n_rows, c), depth, feat, plan.bp_ranks_depth,

@@ -91,6 +91,27 @@ class BEVFUSION_depth(MVXFasterRCNN):
             x = self.pts_neck(x)
         return x
 
+    def _side_thread_is_safe(self):
+        """The radar branch may run on a second host thread only if that thread is the ONLY one that issues collectives
+        during the forward pass: two threads enqueueing on one communicator can do so in a different order on different
+        ranks (mismatched collectives: a hang or mixed-up statistics).  The radar branch's synchronised norm layers are
+        fine on their own; any synchronised norm layer OUTSIDE it (image backbone / neck / lift stream / fusion conv built
+        with norm_cfg SyncBN or naiveSyncBN) turns the side thread off when more than one rank runs."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return True
+        cached = getattr(self, "_side_thread_ok", None)
+        if cached is None:
+            radar = set()
+            for name in ("pts_voxel_encoder", "pts_middle_encoder", "pts_backbone", "pts_neck"):
+                mod = getattr(self, name, None)
+                if mod is not None:
+                    radar.update(id(m) for m in mod.modules())
+            cached = not any((getattr(m, "_omnihd_sync", False) or isinstance(m, nn.SyncBatchNorm)) and id(m) not in radar
+                             for m in self.modules())
+            self._side_thread_ok = cached
+        return cached
+
     def _radar_branch_async(self, points, img_metas, vox):
         """Run the radar branch (pillar net, scatter, SECOND, FPN) on a second host thread and a second HIP stream
         while this thread enqueues the camera branch: the step is as much bound by the host's enqueue rate as by the
@@ -152,7 +173,7 @@ class BEVFUSION_depth(MVXFasterRCNN):
         radar = None
         # default on for training on the GPU (33.2 -> 31.7 ms per step at R1); OMNIHD_DUAL_STREAM=0 turns it off
         if vox is not None and img is not None and img.is_cuda and self.training \
-                and os.environ.get("OMNIHD_DUAL_STREAM", "1") != "0":
+                and os.environ.get("OMNIHD_DUAL_STREAM", "1") != "0" and self._side_thread_is_safe():
             radar = self._radar_branch_async(points, img_metas, vox)     # second host thread + second stream
         img_feats = self.extract_img_feat(img, img_metas)
         if radar is None:

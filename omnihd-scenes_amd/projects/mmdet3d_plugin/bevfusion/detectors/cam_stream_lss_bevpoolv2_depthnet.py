@@ -235,8 +235,12 @@ class LiftSplatShoot_Depth(nn.Module):
 
     def _plan_for(self, rots, trans, extra, key=None):
         if key is None:
-            key = hashlib.sha1(torch.cat([rots.reshape(-1), trans.reshape(-1)]).detach().cpu().numpy().tobytes()
-                               ).hexdigest()
+            # the geometry is a function of EVERY transform handed in (image / BEV augmentation arrives through the
+            # post_* and extra_* arguments): all of them go into the key, with their presence pattern
+            parts = [rots.reshape(-1).float(), trans.reshape(-1).float()]
+            present = "".join("1" if e is not None else "0" for e in extra)
+            parts += [e.reshape(-1).float() for e in extra if e is not None]
+            key = present + hashlib.sha1(torch.cat(parts).detach().cpu().numpy().tobytes()).hexdigest()
         key = (key, tuple(rots.shape), str(rots.device), self.pool_layout)
         plan = self._plans.get(key)
         if plan is None:

@@ -59,6 +59,64 @@ def test_bn_train_act_matches_torch_batch_norm(cuda, shape, relu, with_res):
     assert torch.equal(y2, y.detach())
 
 
+@pytest.mark.parametrize("shape,relu,with_res", [((2, 512, 12, 16), True, False), ((1, 64, 40, 60), True, True),
+                                                 ((3, 8, 5, 3), False, True), ((4000, 64), True, False),
+                                                 ((1, 2048, 8, 22), False, False)])
+def test_fp32_bn_train_act_matches_float64_batch_norm(cuda, shape, relu, with_res):
+    """The fp32 forms of the same kernels (the reference-precision step) against float64 BatchNorm on the CPU: torch's
+    own channels-last BatchNorm kernels on the device are NOT used as the checker (they are the kernels that returned
+    wrong input gradients in round 1's red suite, see include/omnihd_hip.h)."""
+    from omnihd_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(sum(shape) + 1)
+    c = shape[1]
+    mk = lambda: torch.randn(shape, generator=g)
+    cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if len(shape) == 4 else (lambda t: t)
+    x0, r0, gy0 = mk() * 1.5 + 0.3, mk(), mk()
+    w0, b0 = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    x = cl(x0.to(cuda)).requires_grad_()
+    res = cl(r0.to(cuda)).requires_grad_() if with_res else None
+    w, b = w0.to(cuda).requires_grad_(), b0.to(cuda).requires_grad_()
+    rm, rv = torch.zeros(c, device=cuda), torch.ones(c, device=cuda)
+    y = ops.bn_train_act(x, w, b, rm, rv, 0.1, 1e-3, relu, None, res)
+    y.backward(gy0.to(cuda))
+    xr, wr, br = x0.double().requires_grad_(), w0.double().requires_grad_(), b0.double().requires_grad_()
+    rr = r0.double().requires_grad_() if with_res else None
+    rm2, rv2 = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    yr = F.batch_norm(xr, rm2, rv2, wr, br, True, 0.1, 1e-3)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = yr.relu()
+    yr.backward(gy0.double())
+    rel = lambda a, b_: float((a.detach().cpu().double() - b_).norm() / (b_.norm() + 1e-30))
+    assert y.dtype == torch.float32 and y.shape == x.shape
+    assert rel(y, yr) < 2e-6 and rel(rm, rm2) < 1e-5 and rel(rv, rv2) < 1e-5
+    assert rel(x.grad, xr.grad) < 2e-5 and rel(w.grad, wr.grad) < 1e-5 and rel(b.grad, br.grad) < 1e-5
+    assert float((x.grad.cpu().double() - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max())
+    if with_res:
+        assert rel(res.grad, rr.grad) < 1e-6
+    y2 = ops.bn_train_act(x.detach(), w.detach(), b.detach(), rm.clone(), rv.clone(), 0.1, 1e-3, relu, None,
+                          None if res is None else res.detach())
+    assert torch.equal(y2, y.detach())
+
+
+def test_fp32_frozen_affine_act_matches_torch_composition(cuda):
+    from omnihd_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x0, r0, gy0 = (torch.randn(2, 64, 9, 11, generator=g) for _ in range(3))
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    x, r = x0.to(cuda).requires_grad_(), r0.to(cuda).requires_grad_()
+    y = ops.affine_act(x, sc.to(cuda), sh.to(cuda), r, True)
+    y.backward(gy0.to(cuda))
+    xr, rr = x0.double().requires_grad_(), r0.double().requires_grad_()
+    yr = (xr * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + rr).relu()
+    yr.backward(gy0.double())
+    assert y.dtype == torch.float32
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(x.grad.cpu().double(), xr.grad, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(r.grad.cpu().double(), rr.grad, rtol=1e-6, atol=1e-6)
+
+
 def test_modules_take_the_fused_path_and_match_plain_torch(cuda, monkeypatch):
     """SECOND stage (conv-BN-ReLU chain) under autocast: fused BN path vs torch modules, same weights."""
     from omnihd_amd import ops
@@ -121,11 +179,25 @@ def _sync_worker(rank, world, port, q):
         bn2 = NaiveSyncBatchNorm2d(64, eps=1e-3, momentum=0.01).to(dev).train()
         bn2.load_state_dict({k: v for k, v in bn.state_dict().items() if "running" not in k and "num" not in k}, strict=False)
         bn2.running_mean.zero_(); bn2.running_var.fill_(1.0)
-        y2 = bn2(x2)                                             # fp32 input -> unfused reference path
+        from omnihd_amd import ops
+        fused_ok = ops.bn_train_supported
+        ops.bn_train_supported = lambda *_a, **_k: False         # the unfused branch of sync_bn.py = the reference algorithm
+        y2 = bn2(x2)
         y2.backward(gy.float())
+        ops.bn_train_supported = fused_ok
         want = dict(y=y2.detach().cpu(), gx=x2.grad.cpu(), gw=bn2.weight.grad.cpu(), gb=bn2.bias.grad.cpu(),
                     rm=bn2.running_mean.cpu(), rv=bn2.running_var.cpu())
-        q.put((rank, {k: float((got[k] - want[k]).norm() / (want[k].norm() + 1e-12)) for k in got}))
+        errs = {k: float((got[k] - want[k]).norm() / (want[k].norm() + 1e-12)) for k in got}
+        # the fp32 form of the fused kernels on the same fp32 values: rounding-level agreement with the reference algorithm
+        x3 = x.detach().float().requires_grad_()
+        bn3 = NaiveSyncBatchNorm2d(64, eps=1e-3, momentum=0.01).to(dev).train()
+        bn3.load_state_dict({k: v for k, v in bn.state_dict().items() if "running" not in k and "num" not in k}, strict=False)
+        y3 = bn3(x3)
+        y3.backward(gy.float())
+        got3 = dict(y=y3.detach().cpu(), gx=x3.grad.cpu(), gw=bn3.weight.grad.cpu(), gb=bn3.bias.grad.cpu(),
+                    rm=bn3.running_mean.cpu(), rv=bn3.running_var.cpu())
+        errs.update({k + "_f32": float((got3[k] - want[k]).norm() / (want[k].norm() + 1e-12)) for k in got3})
+        q.put((rank, errs))
     finally:
         dist.destroy_process_group()
 
@@ -149,6 +221,7 @@ def test_rank_averaged_statistics_two_ranks_on_one_gpu(cuda):
         assert errs["y"] < 4e-3 and errs["gx"] < 1e-2, (rank, errs)
         assert errs["gw"] < 3e-3 and errs["gb"] < 3e-3, (rank, errs)
         assert errs["rm"] < 1e-3 and errs["rv"] < 1e-3, (rank, errs)
+        assert all(errs[k + "_f32"] < 2e-5 for k in ("y", "gx", "gw", "gb", "rm", "rv")), (rank, errs)
 
 
 def _ddp_worker(rank, world, port, q, dual):
@@ -191,3 +264,72 @@ def test_two_rank_ddp_step_with_synced_batch_norm_on_one_gpu(cuda, dual):
     for rank, (losses, _) in res.items():
         assert all(np.isfinite(losses)), (rank, losses)
     assert abs(res[0][1] - res[1][1]) <= 1e-6 * max(abs(res[0][1]), 1.0), (res[0][1], res[1][1])
+
+
+def _torch_syncbn_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path[:0] = [root, os.path.join(root, "omnihd-scenes_amd")]
+        from omnihd_amd.mm.bricks import ConvModule
+        dev = torch.device("cuda:0")
+        out = {}
+        for dtype in (torch.float32, torch.bfloat16):
+            torch.manual_seed(3)
+            m = ConvModule(16, 32, 3, padding=1, norm_cfg=dict(type="SyncBN", eps=1e-3, momentum=0.1)).to(dev).train()
+            assert isinstance(m.bn, torch.nn.SyncBatchNorm)
+            g = torch.Generator().manual_seed(50 + rank)
+            x = (torch.randn(2, 16, 10, 12, generator=g) * (1 + rank) + 0.3 * rank).to(dev)
+            gy = torch.randn(2, 32, 10, 12, generator=g).to(dev)
+            xin = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+                y = m(xin)
+            y.float().backward(gy)
+            got = dict(y=y.detach().float().cpu(), gx=xin.grad.cpu(), gw=m.conv.weight.grad.cpu(), gg=m.bn.weight.grad.cpu(),
+                       rm=m.bn.running_mean.cpu(), rv=m.bn.running_var.cpu())
+            # the same layer on torch's own SyncBatchNorm in float64 on the CPU ranks (gloo), same weights
+            torch.manual_seed(3)
+            r = ConvModule(16, 32, 3, padding=1, norm_cfg=dict(type="SyncBN", eps=1e-3, momentum=0.1)).double().train()
+            x2 = x.cpu().double().requires_grad_()
+            z = r.conv(x2)
+            mean = z.mean(dim=(0, 2, 3)); msq = (z * z).mean(dim=(0, 2, 3))
+            from omnihd_amd.mm.sync_bn import AllReduceSum
+            vec = AllReduceSum.apply(torch.cat([mean, msq])) / world
+            mu, var = vec[:32], vec[32:] - vec[:32] ** 2
+            zn = (z - mu.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + 1e-3)
+            y2 = (zn * r.bn.weight.view(1, -1, 1, 1) + r.bn.bias.view(1, -1, 1, 1)).relu()
+            y2.backward(gy.cpu().double())
+            n_tot = world * z.numel() / 32
+            want = dict(y=y2.detach(), gx=x2.grad, gw=r.conv.weight.grad, gg=r.bn.weight.grad,
+                        rm=0.1 * mu.detach(), rv=0.9 + 0.1 * var.detach() * n_tot / (n_tot - 1))
+            out[str(dtype)] = {k: float((got[k].double() - want[k]).norm() / (want[k].norm() + 1e-30)) for k in got}
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_syncbn_config_type_is_synchronised_on_the_fused_path(cuda):
+    """norm_cfg type 'SyncBN' (the reference's stage-1 camera config) builds nn.SyncBatchNorm: its statistics must be
+    exchanged between ranks on the fused path too (bf16 and fp32), with torch's unbiased running variance over all rows."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30200 + os.getpid() % 1000
+    procs = [ctx.Process(target=_torch_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out = q.get(timeout=300)
+        res[rank] = out
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res.items():
+        f32, bf = out["torch.float32"], out["torch.bfloat16"]
+        assert all(v < 5e-5 for v in f32.values()), (rank, f32)
+        # bf16 convolution + bf16 activations against float64: rounding of the 16-channel products dominates
+        assert bf["y"] < 1e-2 and bf["gx"] < 8e-2 and bf["gw"] < 8e-2 and bf["rm"] < 1e-2 and bf["rv"] < 1e-2, (rank, bf)

@@ -332,3 +332,51 @@ def test_tiny_detector_simple_test_on_cpu_with_oracle_ops():
         assert float(d["scores_3d"].min()) > 0.05 and set(d["labels_3d"].tolist()) <= {0, 1}
         yaw = d["boxes_3d"].yaw                      # direction fix-up: yaw in [dir_offset, dir_offset + 2pi)
         assert float(yaw.min()) >= 0.7854 - 1e-4 and float(yaw.max()) < 0.7854 + 2 * math.pi + 1e-4
+
+
+def test_plan_cache_key_covers_every_transform_that_shapes_the_geometry(lss_small=None):
+    """A caller that changes only post_trans / extra_rots (image or BEV augmentation) must get a fresh pooling plan; the
+    same transforms again hit the cache."""
+    from oracle.torch_shim import oracle_ops
+    from projects.mmdet3d_plugin.bevfusion.detectors import LiftSplatShoot
+    from tests.test_lss_plain_cpu import CFG
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lss_golden.npz"))
+    rots, trans = torch.from_numpy(g["l1_rots"]), torch.from_numpy(g["l1_trans"])
+    B, N = trans.shape[:2]
+    with oracle_ops():
+        net = LiftSplatShoot(**CFG)
+        none = (None, None, None, None)
+        p0 = net._plan_for(rots, trans, none)
+        assert net._plan_for(rots, trans, none) is p0
+        pt = torch.zeros(B, N, 3)
+        p1 = net._plan_for(rots, trans, (None, pt, None, None))
+        assert p1 is not p0 and net._plan_for(rots, trans, (None, pt.clone(), None, None)) is p1
+        pt2 = pt.clone(); pt2[..., 0] = 1.5
+        p2 = net._plan_for(rots, trans, (None, pt2, None, None))
+        assert p2 is not p1 and p2.tabs[0] is not None and not np.array_equal(p2.tabs[1], p1.tabs[1])
+        er = torch.eye(3).repeat(B, N, 1, 1)
+        er[..., 0, 0] = -1.0                                        # a BEV flip handed in as extra_rots
+        p3 = net._plan_for(rots, trans, (None, None, er, None))
+        assert p3 is not p0 and not np.array_equal(p3.tabs[0], p0.tabs[0])
+        # the same bytes in a different slot are a different geometry
+        assert net._plan_for(rots, trans, (None, None, None, pt2)) is not p2
+
+
+def test_radar_side_thread_is_refused_when_another_branch_also_synchronises(monkeypatch):
+    """Dual-stream forward: safe on one rank always; on several ranks only while every synchronised norm layer sits in
+    the radar branch (whose collectives then all come from the one side thread)."""
+    import torch.distributed as dist
+    from omnihd_amd.harness import tiny_model_cfg
+    from omnihd_amd.mm.config import build_detector
+    from omnihd_amd.mm.sync_bn import NaiveSyncBatchNorm2d
+    m = build_detector(tiny_model_cfg(7))
+    assert m._side_thread_is_safe()                               # no process group
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    assert m._side_thread_is_safe()                               # naiveSyncBN only inside pts_* modules
+    m2 = build_detector(tiny_model_cfg(7))
+    m2.reduc_conv.bn = NaiveSyncBatchNorm2d(m2.reduc_conv.bn.num_features)
+    assert not m2._side_thread_is_safe()
+    m3 = build_detector(tiny_model_cfg(7))
+    m3.img_neck.add_module("extra_sync", torch.nn.SyncBatchNorm(8))
+    assert not m3._side_thread_is_safe()

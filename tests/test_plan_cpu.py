@@ -93,3 +93,15 @@ def test_pixel_schedule_lists_every_pixel_once_with_its_points():
     empty = pixel_schedule(torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32),
                            10, feat_hw=None)
     assert sorted(empty[empty[:, 0] >= 0][:, 0].tolist()) == list(range(10)) and int(empty[:, 2].sum()) == 0
+
+
+def test_patch_schedule_lists_every_patch_once():
+    from omnihd_amd.plan import patch_schedule
+    for n_img, hw in ((6, (64, 176)), (3, (8, 12)), (2, (5, 12)), (1, (3, 7))):
+        sched = patch_schedule(n_img, hw)
+        ppi = (hw[0] * hw[1] + 15) // 16
+        assert sched.dtype == torch.int32 and sched.numel() % 8 == 0
+        assert sorted(sched[sched >= 0].tolist()) == list(range(n_img * ppi))
+        per = sched.numel() // 8
+        counts = [(sched[k * per:(k + 1) * per] >= 0).sum().item() for k in range(8)]
+        assert max(counts) - min(counts) <= 1                                           # equal work per XCD
