@@ -11,8 +11,10 @@ in HBM.  Workloads (`--workload`):
             FPNC, DepthNet, LSS pooling, BEV encoder, radar voxelise + pillars + SECOND/FPN, fusion
             conv + SE, Anchor3DHead losses, KL depth loss): forward + backward + grad-clip + AdamW,
             at the BASELINE resolution R1 = 6 x (3 x 256 x 704) images + one merged (N x 7) radar
-            cloud per frame (`--res r2` = the repo's 544 x 960 / 8 radar channels).  Dense convs in
-            bf16 autocast (MIOpen), pooling / voxelisation / losses fp32 (hand-written HIP).
+            cloud per frame (`--res r2` = the repo's 544 x 960 / 8 radar channels).  Timed twice by
+            default: in fp32, the reference's arithmetic (`value`, `dtype` "f32"), and with the dense
+            convolutions under bf16 autocast (`bf16_autocast`); pooling / voxelisation / losses are fp32
+            (hand-written HIP) in both.
   bev_ops   only the north_star operators (pooling fwd+bwd, voxelise, scatter), no conv layers.
 Besides the whole-job rate the line carries
   roofline      achieved HBM GB/s of the dominant kernel (bev_pool_v2 forward, dense), computed
@@ -73,7 +75,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fusion", choices=["fusion", "bev_ops"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="both", choices=["both", "bf16", "fp32"],
+                    help="fusion workload: 'fp32' = the reference's arithmetic (it trains in fp32), 'bf16' = dense convolutions "
+                         "under bf16 autocast; 'both' (default) times K steps of each, `value` is the fp32 rate and the bf16 "
+                         "rate is carried in `bf16_autocast`")
     ap.add_argument("--res", default="r1", choices=list(RES))
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,6 +159,7 @@ class BevOps:
         self.tiled = True
         self.lean = os.environ.get("OMNIHD_POOL_LEAN", "1") != "0"      # one-table forward kernel (default)
         self.sched_bwd = True
+        self.patch_bwd = os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"   # k_pool_bwd_patch (C = 64), the default
         self.scheduled = True
         H, W, _ = RES[res]
         self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
@@ -174,7 +180,7 @@ class BevOps:
             tabs = [x.clone() for x in (self.plan.ranks_depth, self.plan.ranks_feat, self.plan.row_ptr,
                                         self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
                                         self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_desc, self.plan.ranks_row,
-                                        self.plan.pix_desc)]
+                                        self.plan.pix_desc, self.plan.pix_ptr, self.plan.patch_order)]
             self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
         rng = np.random.default_rng(seed)
         self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
@@ -189,6 +195,9 @@ class BevOps:
 
     def pool_bwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
+        if self.patch_bwd:
+            self.ops.bev_pool_v2_backward_patch(og, depth, feat, tb[3], tb[5], tb[11], tb[12], dg, fg)
+            return
         dg.zero_()
         if self.sched_bwd:
             self.ops.bev_pool_v2_backward_sched(og, depth, feat, tb[3], tb[5], tb[10], dg, fg)
@@ -214,6 +223,23 @@ class BevOps:
         self.pool_bwd(s)
         self.radar()
 
+    def fwd_kernel_name(self):
+        if self.tiled and self.lean:
+            return "k_pool_fwd_lean2<16,4>" if os.environ.get("OMNIHD_POOL_LEAN2", "1") != "0" else "k_pool_fwd_lean<16,4>"
+        return "k_pool_fwd_tiles<16,4>" if self.tiled else "k_pool_fwd<16,true>"
+
+    def bwd_kernel_name(self):
+        return "k_pool_bwd_patch" if self.patch_bwd else ("k_pool_bwd_sched<16,4> + memset" if self.sched_bwd else "k_pool_bwd<16> + 2 memsets")
+
+    def bwd_algorithmic_bytes(self):
+        """3 per-point tables + backward interval tables + depth gather + feature rows + touched out_grad rows
+        + dense depth_grad + feat_grad."""
+        npts, nint = self.plan.n_points, self.plan.n_intervals
+        npix = self.batch * self.N * self.fH * self.fW
+        ntot = npix * self.D
+        nint_bp = int(self.plan.bp_starts.numel())
+        return 4 * 3 * npts + 4 * 2 * nint_bp + 4 * npts + 4 * self.C * npix + 4 * self.C * nint + 4 * ntot + 4 * self.C * npix
+
     # ---- algorithmic bytes of the dense forward kernel, SURVEY.md 8(d) formula ----------------
     def fwd_algorithmic_bytes(self):
         npts, nint = self.plan.n_points, self.plan.n_intervals   # (the kernel reads row_ptr+ranks_row instead of
@@ -236,6 +262,23 @@ def time_kernel(fn, n_sets, launches):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / launches
+
+
+def time_kernel_cold(fn, n_sets, launches=12):
+    """Mean duration of single launches each preceded by a 512 MiB read sweep (inputs AND tables cold in HBM; the
+    back-to-back loop of `time_kernel` keeps the ~50 MB a launch reads resident in the 256 MiB Infinity Cache even with four
+    rotating buffer sets: nt stores do not allocate there, scripts/lab/pool_context.py)."""
+    sweep = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    total = 0.0
+    for k in range(launches):
+        sweep.sum()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(k % n_sets)
+        e1.record()
+        torch.cuda.synchronize()
+        total += e0.elapsed_time(e1)
+    return total * 1e-3 / launches
 
 
 def cpu_baseline(res, budget_s=20.0):
@@ -340,56 +383,92 @@ def main():
     # Dominant north_star kernel (bev_pool_v2 forward): timed FIRST, on the same frame geometry with rotating buffer
     # sets, before the training loop heats the chip (the same kernel inside the step runs ~15 % slower: DVFS
     # after MFMA-heavy convolutions and a polluted L2 — see profiles/ for the in-step rocprofv3 average).
-    kernel_times = None
+    kernel_times = kernel_cold = None
     if rank == 0:
         ops_wl = BevOps(a.res, a.batch, dev, seed=1234)
+        kernel_cold = time_kernel_cold(ops_wl.pool_fwd, len(ops_wl.sets))
         kernel_times = (time_kernel(ops_wl.pool_fwd, len(ops_wl.sets), a.kernel_launches),
                         time_kernel(ops_wl.pool_bwd, len(ops_wl.sets), a.kernel_launches),
-                        ops_wl.fwd_algorithmic_bytes(), ops_wl.plan.n_points, ops_wl.plan.n_intervals, ops_wl.fH, ops_wl.fW)
+                        ops_wl.fwd_algorithmic_bytes(), ops_wl.plan.n_points, ops_wl.plan.n_intervals, ops_wl.fH, ops_wl.fW,
+                        ops_wl.fwd_kernel_name(), ops_wl.bwd_kernel_name(), ops_wl.bwd_algorithmic_bytes())
         del ops_wl
         torch.cuda.empty_cache()
-    if a.workload == "fusion":
-        from omnihd_amd.harness import FusionTrainStep
-        wl = FusionTrainStep(res=a.res, batch=a.batch, radar_dims=radar_dims, device=f"cuda:{local}", seed=1234 + rank,
-                             dtype=a.dtype, ddp=world > 1, miopen_find=True)
-        # set-up, not warm-up: MIOpen's find step and the per-geometry weight-gradient measurement run during the first
-        # two or three steps (each geometry once); they are finished before the W warm-up steps start
-        for _ in range(3):
-            wl.step()
-    else:
-        wl = BevOps(a.res, a.batch, dev, seed=1234 + rank)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        wl.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.step()
-    barrier()
-    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
+    def timed(wl):
+        """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.  An event after every step
+        gives the spread of the individual steps (no synchronisation inside the timed region)."""
+        for _ in range(a.warmup):
+            wl.step()
+        barrier()
+        import omnihd_amd.plan as plan_mod
+        plan_mod.TIMING = []                 # events around every pooling kernel launched inside the timed steps
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for k in range(a.steps):
+            wl.step()
+            marks[k + 1].record()
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
+        q = lambda f: per[min(len(per) - 1, int(f * len(per)))]
+        pool = {}
+        for kind, e0, e1 in plan_mod.TIMING:
+            pool.setdefault(kind, []).append(e0.elapsed_time(e1) * 1e-3)
+        plan_mod.TIMING = None
+        in_step = {k: sum(v) / len(v) for k, v in pool.items() if v}
+        return float(el.item()), {"median": round(q(0.5), 3), "p10": round(q(0.1), 3), "p90": round(q(0.9), 3)}, in_step
+
+    runs = {}
+    if a.workload == "fusion":
+        from omnihd_amd.harness import FusionTrainStep
+        for dt in (["fp32", "bf16"] if a.dtype == "both" else [a.dtype]):
+            wl = FusionTrainStep(res=a.res, batch=a.batch, radar_dims=radar_dims, device=f"cuda:{local}", seed=1234 + rank,
+                                 dtype=dt, ddp=world > 1, miopen_find=True)
+            # set-up, not warm-up: MIOpen's find step and the per-geometry weight-gradient measurement run during the first
+            # two or three steps (each geometry once); they are finished before the W warm-up steps start
+            for _ in range(3):
+                wl.step()
+            runs[dt] = timed(wl)
+            del wl
+            torch.cuda.empty_cache()
+        main_dt = "fp32" if a.dtype == "both" else a.dtype
+    else:
+        runs["f32"] = timed(BevOps(a.res, a.batch, dev, seed=1234 + rank))
+        main_dt = "f32"
+    el, spread, in_step = runs[main_dt]
 
     if rank == 0:
-        t_fwd, t_bwd, fwd_bytes, n_points, n_intervals, fH, fW = kernel_times
-        ach = fwd_bytes / t_fwd / 1e9
+        t_fwd, t_bwd, fwd_bytes, n_points, n_intervals, fH, fW, fwd_kernel, bwd_kernel, bwd_bytes = kernel_times
+        cold_fwd = kernel_cold
+        # `achieved` is computed from the launches INSIDE the timed steps when the workload has them (events around the kernel
+        # on its launching stream); the isolated loops are reported beside it
+        t_step = in_step.get("fwd") if a.workload == "fusion" else None
+        t_main = t_step if t_step else t_fwd
+        ach = fwd_bytes / t_main / 1e9
         # HBM-side bytes per launch from rocprofv3 PMC passes (scripts/pmc_traffic.sh): FETCH_SIZE x the factor
         # calibrated on a 128 MiB read of the same width (2.0 on gfx950, as the microarch guide says) + WRITE_SIZE
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_bev_pool_fwd.json")
+        # (a pointer to a committed measurement of THIS kernel, not a counter read in this run: PMC passes need rocprofv3)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "round2", "pmc_pool_r1.json")
         if os.path.exists(pmc) and a.res == "r1" and a.batch == 1:
-            traffic = round(json.load(open(pmc)).get("hbm_bytes_per_launch"))
+            rec = json.load(open(pmc))
+            k = rec.get("fwd_lean", {})
+            if fwd_kernel.startswith(rec.get("fwd_kernel", "?")) and "read_bytes_corrected" in k and "write_bytes" in k:
+                traffic = round(k["read_bytes_corrected"] + k["write_bytes"])
+                traffic_src = "profiles/round2/pmc_pool_r1.json (rocprofv3 --pmc passes of scripts/lab/pmc_bwd.sh on %s, commit %s)" % (
+                    rec.get("fwd_kernel"), rec.get("commit", "?"))
         line = {
             "metric": "frames/sec (6-cam+6-radar BEV fwd+bwd)", "value": round(a.batch * world * a.steps / el, 3),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": ("bf16" if (a.workload == "fusion" and a.dtype == "bf16") else "f32"),
+            "step_ms": spread, "vs_baseline": None, "dtype": ("bf16" if main_dt == "bf16" else "f32"),
             "data": "synthetic",
             "config": {"workload": (f"fusion@{a.res}: BEVFUSION_depth (reference config bevfusion_NewScenes/bevfusion.py) training step "
                                     f"fwd+bwd+clip+AdamW; 6 cams {RES[a.res][0]}x{RES[a.res][1]}, R50+FPNC, LSS D=59 C=64, BEV 240x160x16, "
@@ -402,11 +481,25 @@ def main():
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
                                        "overlapped with backward) + naiveSyncBN stat exchange" if a.workload == "fusion"
                                        else f"dp{world} (independent frames, no data-path collective)")},
-            "roofline": {"kernel": "k_pool_fwd_lean<16,4> (bev_pool_v2 forward, dense, balanced tiles, azimuth XCD schedule, one rank table)", "bound": "hbm",
+            "roofline": {"kernel": fwd_kernel + " (bev_pool_v2 forward, dense, balanced tiles, azimuth XCD schedule)", "bound": "hbm",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_fwd * 1e6, 2),
-                         "bwd_mean_launch_us": round(t_bwd * 1e6, 2)},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_main * 1e6, 2),
+                         "measured": ("launches inside the %d timed steps (HIP events on the launching stream)" % a.steps
+                                      if t_step else "isolated back-to-back launches"),
+                         "isolated_cache_warm_us": round(t_fwd * 1e6, 2), "isolated_cold_us": round(cold_fwd * 1e6, 2),
+                         "bwd_kernel": bwd_kernel, "bwd_mean_launch_us": round((in_step.get("bwd") or t_bwd) * 1e6, 2),
+                         "bwd_isolated_us": round(t_bwd * 1e6, 2),
+                         "bwd_frac": round(bwd_bytes / (in_step.get("bwd") or t_bwd) / 1e9 / HBM_PEAK_GBS, 4),
+                         "bwd_algorithmic_bytes": bwd_bytes},
         }
+        if a.workload == "fusion" and a.dtype == "both":
+            e2, sp2, _ = runs["bf16"]
+            line["bf16_autocast"] = {"value": round(a.batch * world * a.steps / e2, 3), "unit": "frames/s",
+                                     "ms_per_step": round(e2 / a.steps * 1e3, 4), "step_ms": sp2,
+                                     "note": "dense convolutions under bf16 autocast (MIOpen + the MFMA weight-gradient chain), "
+                                             "pooling / voxelisation / losses fp32; deviation from the fp32 step bounded in "
+                                             "tests/test_detector_gpu.py::test_bf16_step_deviation_from_the_fp32_step"}
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would sit in the
             if a.workload == "fusion":                # closing barrier for minutes while the host cores are busy
                 line["cpu_baseline"] = run_cpu_baseline_child(a.res, radar_dims)

@@ -43,6 +43,11 @@ const char* omnihd_last_error(void);
 /* Number of HIP devices visible to the library (0 when no GPU): lets host code fail loudly. */
 int omnihd_device_count(void);
 
+/* Streaming read of up to 4 device buffers (16-byte aligned, `bytes[i]` each) on `stream`: brings static tables (the
+ * pooling plan's rank tables) into the L2 / Infinity Cache ahead of the kernel that walks them.  A hint only — results
+ * never depend on it.  (No reference counterpart: the reference rebuilds its tables every forward.)                  */
+int omnihd_prefetch(const void* const* ptrs, const size_t* bytes, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * bev_pool_v2 — LSS "BEVPoolv2" (depth x feature gather by rank tables, segment-sum per voxel)
  * ---------------------------------------------------------------------------------------- */
@@ -320,6 +325,25 @@ int omnihd_nms_rotated(const float* boxes, int n, float thresh, long long* keep,
 /* out[i*nb+j] = rotated BEV IoU(boxes_a[i], boxes_b[j]) with the same arithmetic as the NMS
  * (upstream `boxes_iou_bev_gpu`).                                                                   */
 int omnihd_iou_bev_matrix(const float* boxes_a, int na, const float* boxes_b, int nb, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense stride-1 "same" convolutions on the matrix cores: forward and data gradient (implicit GEMM, NHWC)
+ * ref: the BEV encoder  bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:201-214 (nn.Conv2d 3x3, padding 1,
+ *      bias=False, 1024->1024->512->512->256 at 160x240), the fusion conv bevf_faster_rcnn_bevdepth.py:61-72 (640->384),
+ *      and every other 1x1 / 3x3 stride-1 convolution with padding = dilation * (k / 2) — torch.nn.functional.conv2d.
+ * ---------------------------------------------------------------------------------------- */
+
+/* 1 when omnihd_conv_fwd_bf16 takes the geometry: k in {1, 3}, Cin % 64 == 0, Cout % 8 == 0.                   */
+int omnihd_conv_fwd_supported(int batch, int h, int w, int cin, int cout, int ksize, int dil);
+/* y[b,y,x,n] = bias[n] + sum_{ky,kx,c} x[b, y+(ky-k/2)*dil, x+(kx-k/2)*dil, c] * w[n,ky,kx,c]   (zero outside the image)
+ *   x_nhwc (batch,h,w,cin) bf16, w_ohwi (cout,k,k,cin) bf16 (= a torch weight in channels_last memory format),
+ *   bias (cout) f32 or NULL, y_nhwc (batch,h,w,cout) bf16.  fp32 accumulation, one rounding to bf16.
+ *   tile: 0 = choose, 128 = 128x128 tile / 4 wavefronts, 256 = 256x128 tile / 8 wavefronts.                       */
+int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, const float* bias, void* y_nhwc, int batch, int h,
+                         int w, int cin, int cout, int ksize, int dil, int tile, void* stream);
+/* wt[c,k-1-ky,k-1-kx,n] = w[n,ky,kx,c]: the weights with which the DATA GRADIENT of the convolution above is the same
+ * convolution applied to the output gradient:  omnihd_conv_fwd_bf16(gout, wt, NULL, gx, batch, h, w, cout, cin, ...).  */
+int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frozen-BatchNorm epilogue of a convolution (image backbone, bevfusion.py:76-85)

@@ -674,7 +674,8 @@ template <int C4, int U>
 __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
     const float* __restrict__ depth, const float* __restrict__ feat, unsigned feat_bytes,
     const int* __restrict__ ranks_depth, const int* __restrict__ row_ptr, const int4* __restrict__ tile_desc,
-    float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw, float inv_dfhw) {
+    float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw, float inv_dfhw, unsigned depth_bytes,
+    int pf_blocks) {
   static_assert(U == 4, "the record reads below are written for 4 points per step");
   constexpr int G = kBlock / C4;
   constexpr int GPW = 64 / C4;
@@ -695,10 +696,31 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
   OMNIHD_STAMP(0);
   const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
   const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
-  if (nrows <= 0) return;
+  const int tid = threadIdx.x;
+  // Read-ahead of the gather tables: depth and feat were written by the kernels right in front of this one and are NOT
+  // cache-resident for it (measured: 45 us per launch with them resident, 62 us inside the training step, 73 us with the
+  // rank tables cold as well).  The workgroups of the first residency round each stream one slice of [depth | feat] (33 MB
+  // at R1 over 2048 workgroups: 4 loads per lane) while they wait for their own descriptor / table loads anyway; every
+  // later gather, on any XCD, is then served from the Infinity Cache instead of a dependent HBM round trip.
+  unsigned pf_acc = 0;
+  if ((int)blockIdx.x < pf_blocks) {
+    const size_t d16 = depth_bytes / 16, f16 = feat_bytes / 16, per = (d16 + f16 + pf_blocks - 1) / pf_blocks;
+    const uint4* dp = reinterpret_cast<const uint4*>(depth);
+    const uint4* fp = reinterpret_cast<const uint4*>(feat);
+    for (size_t i = tid; i < per; i += kBlock) {
+      const size_t idx = (size_t)blockIdx.x * per + i;
+      if (idx < d16 + f16) {
+        const uint4 v = idx < d16 ? dp[idx] : fp[idx - d16];
+        pf_acc ^= v.x ^ v.w;
+      }
+    }
+  }
+  if (nrows <= 0) {
+    asm volatile("" ::"v"(pf_acc));                                  // the read-ahead loads have a consumer
+    return;
+  }
   OMNIHD_STAMP(1);
 
-  const int tid = threadIdx.x;
   const int sub = tid % C4;
   const int grp = tid / C4;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -753,6 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
     s_row[npts - 1] = (int)0x80000000;             // the single row of the tile (offset 0) closes at its last point
   }
   OMNIHD_STAMP(2);
+  asm volatile("" ::"v"(pf_acc));                                    // the read-ahead loads are consumed here at the latest
   if (npts == 0) return;
 
   float4 acc = zero4;
@@ -831,10 +854,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
       __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)Ra * (C4 * 4)), 0, nrows << SH, 0x00020000);
   const unsigned lane_off = (unsigned)sub << 4;
   const int i0 = grp * Wp;
-  // `pending`: my first point continues a row that an earlier piece started, so the first row I close holds only a
-  // HEAD partial.  It is stored like any other row (and kept in LDS); the fix-up below stores the full sum over it
-  // (same lanes, same address, later in program order).  `pend` is the wave's mask of still-pending lanes: the head
-  // branch is skipped by a scalar test once every group of the wave has closed a row.
+  // `pend`: the wave's mask of lanes whose first point continues a row that an earlier piece started; the first row such a
+  // group closes holds only a HEAD partial, kept in LDS and completed with the earlier pieces' tails after the loop.
   const bool was_pending = (i0 > 0 && i0 < npts && s_row[i0 - 1] >= 0);
   unsigned long long pend = __builtin_amdgcn_ballot_w64(was_pending);
   const int lane = tid & 63;
@@ -868,15 +889,12 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
       const bool closing = cl[u] < 0;                    // this point closes its output row
       const unsigned long long cm = __builtin_amdgcn_ballot_w64(closing);
       if (closing) {
-        if (!(OMNIHD_POOL_ABL & 4) || acc.x == 1.2345e30f) {
+        if ((pend >> lane) & 1ull) {                     // head partial of a continued row: completed after the loop
+          s_head[tid] = acc;
+          if (sub == 0) s_head_row[grp] = cl[u];
+        } else if (!(OMNIHD_POOL_ABL & 4) || acc.x == 1.2345e30f) {
           const u32x4v o = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
           __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)cl[u] << SH) | lane_off, 0, 2 /* nt */);
-        }
-        if ((pend & cm) != 0ull) {                       // wave-uniform: a closing group still owes its head partial
-          if ((pend >> lane) & 1ull) {
-            s_head[tid] = acc;
-            if (sub == 0) s_head_row[grp] = cl[u];
-          }
         }
         acc = zero4;
       }
@@ -1365,12 +1383,16 @@ extern "C" int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat
   // names, and the wrapper passes its size in rows through n_feat_rows (0: unknown -> first lean kernel).
   static const bool lean2 = [] { const char* e = getenv("OMNIHD_POOL_LEAN2"); return !(e && e[0] == '0'); }();
   const long long feat_bytes = (long long)n_feat_rows * c * 4;
+  // read-ahead of depth + feat by the first residency round (OMNIHD_POOL_READAHEAD=0 turns it off)
+  static const bool readahead = [] { const char* e = getenv("OMNIHD_POOL_READAHEAD"); return !(e && e[0] == '0'); }();
+  const long long depth_bytes = (long long)n_feat_rows * d_bins * 4;
+  const int pf_blocks = (readahead && depth_bytes < (1ll << 32)) ? (n_tiles < 2048 ? n_tiles : 2048) : 0;
   if (lean2 && n_feat_rows > 0 && feat_bytes < (1ll << 31)) {
 #define OMNIHD_LEAN2_CASE(C4)                                                                                     \
   case C4:                                                                                                        \
     hipLaunchKernelGGL((k_pool_fwd_lean2<C4, 4>), grid, dim3(kBlock), 0, st, depth, feat, (unsigned)feat_bytes,   \
                        ranks_depth, row_ptr, td, out, tiles_per_xcd, fhw, dfhw, 1.0f / (float)fhw,               \
-                       1.0f / (float)dfhw);                                                                       \
+                       1.0f / (float)dfhw, (unsigned)depth_bytes, pf_blocks);                                     \
     break;
     switch (c / 4) {
       OMNIHD_LEAN2_CASE(1)

@@ -1,0 +1,280 @@
+// Forward and data gradient of the dense stride-1 convolutions on the gfx950 matrix cores: implicit GEMM over NHWC.
+//
+// Where it sits: the BEV encoder of the camera stream (3x3 convs 1024->1024->512->512->256 at 160x240, reference
+// bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:201-214), the fusion conv 640->384
+// (bevf_faster_rcnn_bevdepth.py:61-72) and every other "same" 1x1 / 3x3 convolution of the detector.  north_star: "the
+// BEV conv encoder written for gfx950 ... MFMA used only for the dense BEV convs".
+//
+//   y[m][n] = sum over taps t = (ky, kx) and channels c of  x[(b, y + (ky-k/2)*d, x + (kx-k/2)*d)][c] * w[n][t][c]
+//
+// With channels-last activations AND channels-last weights ((Cout, kh, kw, Cin) memory) both operands of that GEMM are
+// already contiguous along the reduction index (t, c): no im2col buffer, no layout pass.  M = pixels, N = Cout,
+// K = taps * Cin.  A-tile rows are the pixels of the output tile shifted by the tap; a lane whose source pixel lies outside
+// the image fetches from a 256-byte zero page instead (LDS-DMA takes a per-lane global address).
+// The data gradient is the same kernel applied to the output gradient with the weights laid out (Cin, kh, kw, Cout) and
+// the taps mirrored: gx[m][c] = sum_{t,n} g[shift_{-t}(m)][n] * w[n][t][c]  (omnihd_conv_dgrad_weights does that re-layout).
+//
+// Kernel: TM x TN output tile per workgroup of WM x WN wavefronts, each wavefront a 64x64 quadrant as 2x2
+// v_mfma_f32_32x32x16_bf16 tiles; K stepped by 64 through a ring of LDS stages filled by LDS-DMA
+// (`global_load_lds`, 16 B per lane, no VGPR round trip), rows XOR-swizzled on the global source chunk and again on the
+// fragment read (conflict-free ds_read_b128), hand-counted s_waitcnt vmcnt + raw s_barrier (as csrc/conv_wgrad.hip).
+// Tile shapes: 256x128 with 8 wavefronts (two per SIMD: one multiplies while the other waits on LDS; 85 FLOP per
+// operand byte) for the BEV-sized layers, 128x128 with 4 wavefronts for narrow ones.  fp32 accumulation, one rounding to
+// bf16 in the epilogue (+ optional fp32 bias).  Workgroups are numbered so that one XCD keeps ONE band of output channels:
+// its weight slab (TN x K bf16 = 2.4 MB for K = 9216) stays in that XCD's 4 MiB L2 while the activations stream by.
+#include "common.h"
+
+namespace omnihd {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef __attribute__((address_space(1))) const void gbl_ptr_t;
+
+constexpr int kBK = 64;        // reduction elements per K-step
+
+__device__ __forceinline__ unsigned short f2bf_rn(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <int WM, int WN, int STAGES, bool SPREAD, bool PRIO = false>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
+    const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
+    const float* __restrict__ bias, unsigned short* __restrict__ Y, int M, int H, int W, int Cin, int Cout, int ksize,
+    int dil, int tiles_m, int tiles_n, int tiles_per_xcd) {
+  constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN;
+  constexpr int A_CALLS = TM / (8 * NW), B_CALLS = TN / (8 * NW);     // 8-row LDS-DMA calls per wavefront and stage
+  constexpr int CALLS = A_CALLS + B_CALLS;
+  static_assert(TM % (8 * NW) == 0 && TN % (8 * NW) == 0, "rows must split evenly over the wavefronts");
+  // one LDS object only (a second one makes hipcc drain the DMA queue before every ds_read)
+  __shared__ __attribute__((aligned(16))) unsigned short sm[STAGES][TM + TN][kBK];
+
+  // workgroup -> tile: XCD x (= block % 8, observed dispatch rule, speed only) walks a contiguous run of the n-major tile
+  // list, i.e. stays on one band of output channels
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t = xcd * tiles_per_xcd + slot;
+  if (slot >= tiles_per_xcd || t >= tiles_m * tiles_n) return;
+  const int nt = t / tiles_m, mt = t - nt * tiles_m;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int taps = ksize * ksize;
+  const int half = ksize / 2;
+  const int K = taps * Cin;
+
+  // ---- loader state: this lane's rows of A (pixels) and of B (output channels) -------------------------------
+  const int lr = lane >> 3;                       // row inside an 8-row call
+  const int pos = lane & 7;                       // 16-byte slot inside the 128-byte LDS row
+  const int c_even = pos ^ ((lane >> 4) & 7);     // global chunk for even calls; odd calls use c_even ^ 4
+  int a_y[A_CALLS], a_x[A_CALLS];                 // pixel coordinates (y = -1: row beyond M)
+  size_t a_pix[A_CALLS];
+#pragma unroll
+  for (int i = 0; i < A_CALLS; ++i) {
+    const int m = mt * TM + wave * (8 * A_CALLS) + 8 * i + lr;
+    if (m < M) {
+      const int xx = m % W, r = m / W;
+      a_x[i] = xx; a_y[i] = r % H; a_pix[i] = (size_t)m;
+    } else {
+      a_x[i] = 0; a_y[i] = -(1 << 20); a_pix[i] = 0;
+    }
+  }
+  const unsigned short* b_row[B_CALLS];
+#pragma unroll
+  for (int i = 0; i < B_CALLS; ++i) {
+    const int n = nt * TN + wave * (8 * B_CALLS) + 8 * i + lr;
+    b_row[i] = (n < Cout) ? Wt + (size_t)n * K : nullptr;
+  }
+
+  int k_tap = 0, k_c = 0;                         // position of the NEXT K-step to issue
+  // one LDS-DMA call (8 rows x 128 B) of the K-step at (k_tap, k_c): calls 0..A_CALLS-1 fetch A rows, the rest B rows
+  auto issue_call = [&](int stage, bool real, int call) {
+    const int c = (call & 1) ? (c_even ^ 4) : c_even;          // A_CALLS is even: the parity of a B call is that of its index
+    if (call < A_CALLS) {
+      const int i = call;
+      const int dy = (k_tap / ksize - half) * dil, dx = (k_tap % ksize - half) * dil;
+      const bool ok = real && (unsigned)(a_y[i] + dy) < (unsigned)H && (unsigned)(a_x[i] + dx) < (unsigned)W;
+      const unsigned short* g = ok ? X + (a_pix[i] + (ptrdiff_t)dy * W + dx) * Cin + k_c + c * 8 : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][wave * (8 * A_CALLS) + 8 * i][0], 16, 0, 0);
+    } else {
+      const int i = call - A_CALLS;
+      const unsigned short* g = (real && b_row[i]) ? b_row[i] + (size_t)k_tap * Cin + k_c + c * 8 : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][TM + wave * (8 * B_CALLS) + 8 * i][0], 16, 0, 0);
+    }
+  };
+  // channels OUTER, taps INNER: the nine taps of one 64-channel slice read the same pixels' 128-byte lines (shifted), so a
+  // line fetched for the first tap is an L2 hit for the other eight; with taps outer every tap re-fetched 2 KB-strided lines
+  // that had long left the 4 MiB L2 (753 -> 793 TFLOP/s on 1024->1024 at 160x240; L2 hit rate 90 %)
+  auto advance = [&]() { if (++k_tap == taps) { k_tap = 0; k_c += kBK; } };
+  auto issue = [&](int stage, bool real) {
+#pragma unroll
+    for (int call = 0; call < CALLS; ++call) issue_call(stage, real, call);
+    advance();
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  const int n_steps = K / kBK;
+
+  // prologue: STAGES-1 K-steps in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s, s < n_steps);
+  int stage = 0;
+  for (int step = 0; step < n_steps; ++step) {
+    // the oldest K-step has landed when at most (STAGES-2) younger ones (CALLS DMA calls each) are outstanding
+    if (STAGES == 4) {
+      if (CALLS == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      if (CALLS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const int fill = (stage + STAGES - 1) % STAGES;             // its buffer was last read before this barrier
+    const bool fill_real = step + STAGES - 1 < n_steps;
+    if (!SPREAD) issue(fill, fill_real);
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + frow;
+        const int rb = wn * 64 + i * 32 + frow;
+        const int c = ks * 2 + fhalf;
+        a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+        b[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+      }
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+      if (SPREAD) {
+        // the DMA calls of the next fill are issued BEHIND this slice's MFMAs (their issue time, 60-185 cycles each, then
+        // overlaps the matrix pipe instead of preceding it): CALLS calls over the kBK/16 slices
+        constexpr int PER = (CALLS + kBK / 16 - 1) / (kBK / 16);
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
+      }
+    }
+    if (SPREAD) advance();
+    stage = (stage + 1) % STAGES;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail loads before the epilogue stores
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31 (B row = output channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nt * TN + wn * 64 + j * 32 + (lane & 31);
+    const float bv = (bias && n < Cout) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && n < Cout) Y[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
+      }
+  }
+}
+
+// w (Cout, k, k, Cin) -> wt (Cin, k, k, Cout) with mirrored taps: the weights of the data-gradient convolution
+__global__ __launch_bounds__(256) void k_dgrad_weights(const unsigned short* __restrict__ w, unsigned short* __restrict__ wt,
+                                                       int cout, int cin, int taps) {
+  __shared__ unsigned short s[64][64 + 2];
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tap = blockIdx.z;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int n = i / 64, c = i % 64;
+    s[n][c] = (n0 + n < cout && c0 + c < cin) ? w[((size_t)(n0 + n) * taps + tap) * cin + c0 + c] : (unsigned short)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i / 64, n = i % 64;
+    if (c0 + c < cin && n0 + n < cout) wt[((size_t)(c0 + c) * taps + (taps - 1 - tap)) * cout + n0 + n] = s[n][c];
+  }
+}
+
+const unsigned short* igemm_zero_page() {
+  static void* pages[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!pages[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;      // synchronous, once per device and process
+    pages[dev] = p;
+  }
+  return static_cast<const unsigned short*>(pages[dev]);
+}
+
+}  // namespace
+}  // namespace omnihd
+
+using namespace omnihd;
+
+extern "C" int omnihd_conv_fwd_supported(int batch, int h, int w, int cin, int cout, int ksize, int dil) {
+  return batch > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && (ksize == 1 || ksize == 3) && dil >= 1 && cin % 64 == 0 &&
+         cout % 8 == 0 && (long long)batch * h * w < (1ll << 31) / 2;
+}
+
+extern "C" int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, const float* bias, void* y_nhwc, int batch,
+                                    int h, int w, int cin, int cout, int ksize, int dil, int tile, void* stream) {
+  OMNIHD_REQUIRE(omnihd_conv_fwd_supported(batch, h, w, cin, cout, ksize, dil),
+                 "conv_fwd: square 1x1 / 3x3 kernel, stride 1, 'same' padding, Cin a multiple of 64, Cout of 8");
+  OMNIHD_REQUIRE(x_nhwc && w_ohwi && y_nhwc, "null pointer");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_ohwi)) & 15u) == 0, "16-byte alignment");
+  const unsigned short* zero_page = igemm_zero_page();
+  OMNIHD_REQUIRE(zero_page != nullptr, "could not allocate the zero page");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = batch * h * w;
+  const unsigned short* X = static_cast<const unsigned short*>(x_nhwc);
+  const unsigned short* Wt = static_cast<const unsigned short*>(w_ohwi);
+  unsigned short* Y = static_cast<unsigned short*>(y_nhwc);
+  // tile 0 = choose: 256x128 when that still fills the chip several times over, else 128x128
+  const long long big_tiles = (long long)((M + 255) / 256) * ((cout + 127) / 128);
+  const bool big = tile == 256 || (tile == 0 && big_tiles >= 2 * kCUs);
+  if (tile == 255) {   // lab: the 256x128 kernel with s_setprio(1) around the MFMA groups
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
+                       ksize, dil, tiles_m, tiles_n, per);
+  } else if (tile == 254) {   // lab: 128x256 tile (2 x 4 wavefronts): half the A traffic per flop, twice the weights'
+    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 255) / 256;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<2, 4, 3, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
+                       ksize, dil, tiles_m, tiles_n, per);
+  } else if (big) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
+                       ksize, dil, tiles_m, tiles_n, per);
+  } else {
+    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<2, 2, 4, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
+                       ksize, dil, tiles_m, tiles_n, per);
+  }
+  return check_launch("conv_fwd_bf16");
+}
+
+extern "C" int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream) {
+  OMNIHD_REQUIRE(w_ohwi && wt_ihwo && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "arguments");
+  hipLaunchKernelGGL(k_dgrad_weights, dim3((cout + 63) / 64, (cin + 63) / 64, ksize * ksize), dim3(256), 0,
+                     (hipStream_t)stream, static_cast<const unsigned short*>(w_ohwi), static_cast<unsigned short*>(wt_ihwo),
+                     cout, cin, ksize * ksize);
+  return check_launch("conv_dgrad_weights");
+}

@@ -12,6 +12,7 @@ PROTOTYPES = {
     "omnihd_version": (c_char_p, []),
     "omnihd_last_error": (c_char_p, []),
     "omnihd_device_count": (c_int, []),
+    "omnihd_prefetch": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "omnihd_bev_pool_v2_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_fwd_csr": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -44,6 +45,9 @@ PROTOTYPES = {
     "omnihd_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
     "omnihd_conv1x1_wgrad_workspace_bytes": (c_size_t, [c_int] * 3),
     "omnihd_conv1x1_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+    "omnihd_conv_fwd_supported": (c_int, [c_int] * 7),
+    "omnihd_conv_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
+    "omnihd_conv_dgrad_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "omnihd_dcn3x3_sample_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "omnihd_dcn3x3_sample_bwd": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "omnihd_pillar_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -139,8 +139,9 @@ def run_fused(seq, x):
 
 
 class BevConv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters / state-dict keys) whose bf16 training path takes its weight gradient from
-    the hand-written MFMA kernel (omnihd_conv_wgrad_bf16); forward and data gradient stay on MIOpen."""
+    """nn.Conv2d (same parameters / state-dict keys) whose bf16 training path runs on the hand-written MFMA kernels of this
+    library where they measure faster than MIOpen for the layer's geometry: forward and data gradient on the implicit-GEMM
+    kernel (omnihd_conv_fwd_bf16), weight gradient on the k-major chain (omnihd_conv_wgrad_bf16)."""
 
     def _conv_forward(self, x, weight, bias):
         from .. import ops
@@ -148,8 +149,8 @@ class BevConv2d(nn.Conv2d):
                 and self.padding_mode == "zeros" and not isinstance(self.padding, str)):
             # once a geometry has been measured in MIOpen's favour the layer is a plain convolution again
             # (no Python in its backward); unmeasured geometries go through the function that measures
-            if ops.wgrad_choice_for(x.shape, weight.shape[0], weight.shape[2], self.stride[0], self.padding[0],
-                                    self.dilation[0], x.device.index) == "miopen":
+            if ops.conv_all_miopen(x.shape, weight.shape[0], weight.shape[2], self.stride[0], self.padding[0],
+                                   self.dilation[0], x.device.index):
                 return super()._conv_forward(x, weight, bias)
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             if ops.conv_wgrad_supported(xb, weight, self.stride, self.padding, self.dilation):

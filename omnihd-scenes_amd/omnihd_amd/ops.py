@@ -123,6 +123,29 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
               "omnihd_bev_pool_v2_fwd_csr")
 
 
+_PREFETCH_STREAMS = {}
+
+
+def prefetch(tensors):
+    """Read-ahead of up to 4 static device tensors into the L2 / Infinity Cache on a side stream (a hint: see
+    include/omnihd_hip.h, omnihd_prefetch).  Returns immediately; nothing waits for it."""
+    ts = [t for t in tensors if t is not None and t.is_cuda and t.numel() > 0][:4]
+    if not ts:
+        return
+    dev = ts[0].device
+    side = _PREFETCH_STREAMS.get(dev.index)
+    if side is None:
+        side = _PREFETCH_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    sizes = (ctypes.c_size_t * len(ts))(*[t.numel() * t.element_size() for t in ts])
+    # ordered behind the work already enqueued on the calling stream (the host runs milliseconds ahead of the device: an
+    # unordered read-ahead would execute right away and be evicted again long before its consumer starts)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with _on(dev):
+        check(lib().omnihd_prefetch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(sizes, ctypes.c_void_p), len(ts),
+                                    ctypes.c_void_p(side.cuda_stream)), "omnihd_prefetch")
+
+
 def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, depth_bins, feat_hw, gen=2):
     """Dense tiled forward reading one per-point table (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_lean).
     ``gen=1`` asks for the first-generation kernel (64-bit addressing; bit-identical to the three-table kernel)."""
@@ -532,6 +555,42 @@ def conv3x3_wgrad_supported(x, weight):
     return conv_wgrad_supported(x, weight, (1, 1), (1, 1))
 
 
+def conv_fwd_supported(x_shape, cout, k, stride, padding, dilation):
+    """Geometries the implicit-GEMM forward / data-gradient kernel takes: stride 1, 'same' padding, k in {1,3},
+    Cin a multiple of 64, Cout a multiple of 8."""
+    B, cin, H, W = x_shape
+    return (stride == 1 and k in (1, 3) and padding == dilation * (k // 2) and
+            bool(lib().omnihd_conv_fwd_supported(B, H, W, cin, cout, k, dilation)))
+
+
+def conv_fwd(x, w_cl, bias=None, dilation=1, tile=0):
+    """y = conv2d(x, w, bias, stride 1, padding = dilation*(k//2)) on the matrix cores (csrc/conv_igemm.hip).
+    x (B,Cin,H,W) bf16 channels-last, w_cl (Cout,Cin,k,k) bf16 in channels_last memory format ((Cout,k,k,Cin) memory),
+    bias (Cout,) fp32 or None -> (B,Cout,H,W) bf16 channels-last."""
+    _want_cl(x, "x")
+    if w_cl.dtype != torch.bfloat16 or w_cl.dim() != 4 or not w_cl.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError("w must be a 4-D bf16 tensor in channels_last memory format")
+    B, cin, H, W = x.shape
+    cout, k = w_cl.shape[0], w_cl.shape[2]
+    y = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    with _on(x.device):
+        check(lib().omnihd_conv_fwd_bf16(x.data_ptr(), w_cl.data_ptr(), None if bias is None else _f32c(bias).data_ptr(),
+                                         y.data_ptr(), B, H, W, cin, cout, k, int(dilation), int(tile), _raw_stream()),
+              "omnihd_conv_fwd_bf16")
+    return y.permute(0, 3, 1, 2)
+
+
+def conv_dgrad_weights(w_cl):
+    """(Cout,Cin,k,k) channels_last bf16 -> (Cin,Cout,k,k) channels_last bf16 with mirrored taps: the weights with which
+    the data gradient is ``conv_fwd(grad_out, wt)``."""
+    cout, cin, k, _ = w_cl.shape
+    wt = torch.empty((cin, k, k, cout), dtype=torch.bfloat16, device=w_cl.device)
+    with _on(w_cl.device):
+        check(lib().omnihd_conv_dgrad_weights(w_cl.data_ptr(), wt.data_ptr(), cout, cin, k, _raw_stream()),
+              "omnihd_conv_dgrad_weights")
+    return wt.permute(0, 3, 1, 2)
+
+
 # Which implementation computes the weight gradient of a given convolution geometry: the MFMA kernel chain of
 # this library ("hip") or MIOpen ("miopen").  The staged GEMM wins by 2-4x on the BEV-sized convolutions and on
 # small feature maps, MIOpen's direct implicit GEMM wins where the pixel axis is long and the channel counts are
@@ -583,6 +642,24 @@ def wgrad_choice_for(x_shape, cout, k, stride, padding, dilation, device_index):
     return _WGRAD_CHOICE.get((tuple(x_shape), cout, k, stride, padding, dilation, device_index))
 
 
+def conv_all_miopen(x_shape, cout, k, stride, padding, dilation, device_index):
+    """True once EVERY direction of a convolution geometry has been measured in MIOpen's favour (or cannot run here):
+    the layer is then a plain torch convolution again (no Python in its backward)."""
+    if wgrad_choice_for(x_shape, cout, k, stride, padding, dilation, device_index) != "miopen":
+        return False
+    if os.environ.get("OMNIHD_CONV_POLICY", "tune") == "miopen":
+        return True
+    B, cin, H, W = x_shape
+    same = stride == 1 and k in (1, 3) and padding == dilation * (k // 2)
+    if same and cin % 64 == 0 and cout % 8 == 0:
+        if _CONV_CHOICE.get(("fwd", tuple(x_shape), cout, k, dilation, device_index)) != "miopen":
+            return False
+    if same and cout % 64 == 0 and cin % 8 == 0:
+        if _CONV_CHOICE.get(("dgrad", (B, cout, H, W), cin, k, dilation, device_index)) != "miopen":
+            return False
+    return True
+
+
 def wgrad_choices():
     """{geometry: 'hip' | 'miopen'} decided so far (for logs and DESIGN.md tables)."""
     return dict(_WGRAD_CHOICE)
@@ -623,9 +700,56 @@ def refresh_bf16_shadows():
     return len(src)
 
 
+# Forward and data gradient of the stride-1 "same" convolutions: the implicit-GEMM MFMA kernel of this library
+# (csrc/conv_igemm.hip, two tile shapes) or MIOpen — like the weight gradient, a measured choice per geometry and direction
+# (OMNIHD_CONV_POLICY = tune (default) | hip | miopen).  Measured at the BEV sizes (scripts/lab/conv_bench.py): the data
+# gradient is ours on every 3x3 geometry (854 vs 700 TFLOP/s on 1024->1024 at 160x240), the forward is a close race
+# (861 vs 875-966), 1x1 convolutions stay on MIOpen.
+_CONV_CHOICE = {}
+_CONV_IMPLS = ("hip256", "hip128x256", "miopen")
+
+
+def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen):
+    """Run one direction ('fwd': x = input, w_cl = weights; 'dgrad': x = grad_out, w_cl = data-gradient weights) with the
+    implementation chosen for its geometry."""
+    k = w_cl.shape[2]
+    policy = os.environ.get("OMNIHD_CONV_POLICY", "tune")
+    ours = (x.dtype == torch.bfloat16 and conv_fwd_supported(x.shape, w_cl.shape[0], k, stride[0], padding[0], dilation[0])
+            and stride[0] == stride[1] and padding[0] == padding[1] and dilation[0] == dilation[1])
+    if not ours or policy == "miopen":
+        return run_miopen()
+    run_hip = lambda tile: conv_fwd(x, w_cl, None, dilation[0], tile)
+    if policy == "hip":
+        return run_hip(0)
+    key = (direction, tuple(x.shape), w_cl.shape[0], k, dilation[0], x.device.index)
+    choice = _CONV_CHOICE.get(key)
+    if choice is None:
+        def clock(fn):
+            fn(); fn()
+            torch.cuda.synchronize(x.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(x.device)
+            return e0.elapsed_time(e1)
+        times = {"hip256": clock(lambda: run_hip(256)), "hip128x256": clock(lambda: run_hip(254)), "miopen": clock(run_miopen)}
+        choice = min(times, key=times.get)
+        _CONV_CHOICE[key] = choice
+    if choice == "miopen":
+        return run_miopen()
+    return run_hip(256 if choice == "hip256" else 254)
+
+
+def conv_choices():
+    """{(direction, geometry...): implementation} decided so far (for logs and DESIGN.md tables)."""
+    return dict(_CONV_CHOICE)
+
+
 class _ConvHipWgrad(torch.autograd.Function):
-    """Convolution whose forward and data gradient run on MIOpen and whose WEIGHT gradient runs on the
-    hand-written MFMA kernel (the slowest dense kernels of the training step under MIOpen)."""
+    """Convolution of the bf16 training path: forward and data gradient on the implicit-GEMM MFMA kernel of this library or
+    on MIOpen (measured per geometry), weight gradient on the k-major MFMA chain or MIOpen (measured per geometry)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
@@ -636,8 +760,13 @@ class _ConvHipWgrad(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.conv = (list(stride), list(padding), list(dilation))
         ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
-        return torch.nn.functional.conv2d(x, wb, None if bias is None else bias.detach().to(x.dtype), stride, padding,
-                                          dilation)
+        bt = None if bias is None else bias.detach().to(x.dtype)
+        run_miopen = lambda: torch.nn.functional.conv2d(x, wb, None, stride, padding, dilation)
+        if x.dtype == torch.bfloat16 and x.dim() == 4:
+            y = _conv_impl("fwd", x, wb.contiguous(memory_format=torch.channels_last), stride, padding, dilation, run_miopen)
+        else:
+            y = run_miopen()
+        return y if bt is None else y + bt.view(1, -1, 1, 1)
 
     @staticmethod
     def backward(ctx, g):
@@ -646,8 +775,16 @@ class _ConvHipWgrad(torch.autograd.Function):
         gx = gw = gb = None
         g = g.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            run_miopen = lambda: torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0],
+                                                                     1, [True, False, False])[0]
+            k = weight.shape[2]
+            if (g.dtype == torch.bfloat16 and stride[0] == 1 and weight.shape[0] % 64 == 0 and weight.shape[1] % 8 == 0
+                    and k in (1, 3) and padding[0] == dilation[0] * (k // 2)
+                    and os.environ.get("OMNIHD_CONV_POLICY", "tune") != "miopen"):
+                wt = conv_dgrad_weights(weight.contiguous(memory_format=torch.channels_last))
+                gx = _conv_impl("dgrad", g, wt, stride, padding, dilation, run_miopen)
+            else:
+                gx = run_miopen()
         if ctx.needs_input_grad[1]:
             gw = _tuned_wgrad(x.contiguous(memory_format=torch.channels_last), g, weight, stride, padding,
                               dilation).to(ctx.param_dtypes[0])

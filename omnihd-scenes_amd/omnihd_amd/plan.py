@@ -242,6 +242,21 @@ def _patch_backward():
     return os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"
 
 
+# bench.py sets this to a list to collect (start, end) event pairs around every pooling forward / backward kernel launched
+# inside the training step (the in-step launch duration the roofline line is computed from); None = no events
+TIMING = None
+
+
+def _timed(kind, launch):
+    if TIMING is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    TIMING.append((kind, e0, e1))
+
+
 class _PlannedPool(torch.autograd.Function):
     """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order."""
 
@@ -251,8 +266,8 @@ class _PlannedPool(torch.autograd.Function):
         feat = feat.contiguous().float()
         out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
         if plan.depth_bins > 0 and plan.tile_desc is not None and plan.n_points > 0 and _lean_forward():
-            ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, out,
-                                         plan.depth_bins, plan.feat_hw)
+            _timed("fwd", lambda: ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, out,
+                                                               plan.depth_bins, plan.feat_hw))
         else:
             ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
                                         plan.ranks_row, plan.tile_desc)
@@ -269,8 +284,9 @@ class _PlannedPool(torch.autograd.Function):
         if (c == 64 and plan.patch_order is not None and plan.depth_bins > 0 and depth.dim() == 5
                 and plan.n_rows * 256 < 2 ** 32 and _patch_backward()):
             depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)   # both written densely
-            ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat, plan.bp_ranks_depth,
-                                           plan.bp_ranks_row, plan.pix_ptr, plan.patch_order, depth_grad, feat_grad)
+            _timed("bwd", lambda: ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat,
+                                                                 plan.bp_ranks_depth, plan.bp_ranks_row, plan.pix_ptr,
+                                                                 plan.patch_order, depth_grad, feat_grad))
             return depth_grad, feat_grad, None
         depth_grad = torch.zeros_like(depth)
         if plan.pix_desc is not None and c in (4, 8, 16, 32, 64):

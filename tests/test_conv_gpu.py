@@ -248,3 +248,36 @@ def test_transposed_conv_weight_gradient(cuda, cin, cout, k, H, W):
     torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=2e-2)
     assert float((w.grad - wr.grad).abs().max()) <= 2e-3 * float(wr.grad.abs().max())
     assert float((x.grad.float() - xr.grad).abs().max()) <= 2e-2 * float(xr.grad.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dil,tile", [(1, 160, 240, 128, 256, 3, 1, 0), (1, 160, 240, 128, 256, 3, 1, 128),
+                                                          (2, 20, 30, 64, 72, 3, 1, 0), (1, 33, 47, 192, 136, 3, 2, 128),
+                                                          (1, 33, 47, 192, 136, 3, 2, 256), (3, 16, 44, 256, 64, 1, 1, 0),
+                                                          (1, 64, 176, 256, 256, 3, 6, 256)])
+def test_igemm_conv_forward_and_data_gradient_match_fp32_reference(cuda, B, H, W, cin, cout, k, dil, tile):
+    """csrc/conv_igemm.hip against torch.nn.functional.conv2d in fp32 on the same bf16-rounded operands: forward with bias,
+    and the data gradient as the same kernel on mirrored / transposed weights.  Bound: one bf16 rounding of the result
+    (2^-8 relative) on top of fp32 accumulation in a different order."""
+    from omnihd_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * H + cin + cout + k)
+    x = torch.randn(B, cin, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(cuda).bfloat16()
+    w = w.contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, generator=g).to(cuda)
+    gy = torch.randn(B, cout, H, W, generator=g).to(cuda).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert ops.conv_fwd_supported(x.shape, cout, k, 1, dil * (k // 2), dil)
+    y = ops.conv_fwd(x, w, bias, dilation=dil, tile=tile)
+    xr = x.float().requires_grad_()
+    yr = torch.nn.functional.conv2d(xr, w.float(), bias, stride=1, padding=dil * (k // 2), dilation=dil)
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    err = (y.float() - yr).abs()
+    assert float(err.max()) <= 2 ** -7 * float(yr.abs().max()), float(err.max() / yr.abs().max())
+    assert float((y.float() - yr).norm() / yr.norm()) < 3e-3
+    assert torch.equal(y, ops.conv_fwd(x, w, bias, dilation=dil, tile=tile))                    # deterministic
+    if cout % 64 == 0:
+        wt = ops.conv_dgrad_weights(w)
+        assert wt.shape == (cin, cout, k, k)
+        gx = ops.conv_fwd(gy, wt, None, dilation=dil, tile=tile)
+        yr.backward(gy.float())
+        assert float((gx.float() - xr.grad).norm() / xr.grad.norm()) < 3e-3
+        assert float((gx.float() - xr.grad).abs().max()) <= 2 ** -7 * float(xr.grad.abs().max())

@@ -125,3 +125,42 @@ def test_ddp_wrapped_step_on_one_gpu(cuda):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DDP_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_bf16_step_deviation_from_the_fp32_step(cuda):
+    """The reference trains in fp32; the bf16-autocast step is the fast variant.  Same weights (seeded init), same R1
+    frame, train-mode BatchNorm in both: the fused BEV feature, the box-regression map and the losses of the bf16 step
+    stay within the stated bounds of the fp32 step (measured: see DESIGN.md section 5; north_star's 1e-3 is an fp32
+    claim, checked against the oracle in test_tiny_detector_hip_ops_match_oracle_ops).  The rank tables and the voxel
+    assignment are dtype-independent and must be identical."""
+    from omnihd_amd.harness import FusionTrainStep
+    outs = {}
+    for dt in ("fp32", "bf16"):
+        st = FusionTrainStep(res="r1", batch=1, radar_dims=7, device="cuda:0", dtype=dt, sets=1, seed=77)
+        m, b = st.raw_model, st.batches[0]
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == "bf16"):
+            fd = m.extract_feat(b["points"], img=b["img"], img_metas=b["img_metas"])
+            cls, reg, dirc = m.pts_bbox_head(fd["pts_feats"])
+            losses = m.pts_bbox_head.loss(cls, reg, dirc, b["gt_bboxes_3d"], b["gt_labels_3d"], b["img_metas"])
+            depth_loss, _ = m.lift_splat_shot_vis.get_depth_loss(b["img_depth"], fd["depth_dist"], "kld")
+        plan = next(iter(m.lift_splat_shot_vis._plans.values()))
+        outs[dt] = dict(bev=fd["pts_feats"][0].float().cpu(), reg=reg[0].float().cpu(), cls=cls[0].float().cpu(),
+                        depth=fd["depth_dist"].float().cpu(), ranks=plan.ranks_depth.cpu(), rows=plan.ranks_row.cpu(),
+                        losses={k: float(v[0]) for k, v in losses.items()}, depth_loss=float(depth_loss))
+        del st, m
+        torch.cuda.empty_cache()
+    a, b_ = outs["fp32"], outs["bf16"]
+    assert torch.equal(a["ranks"], b_["ranks"]) and torch.equal(a["rows"], b_["rows"])      # indexing never depends on the dtype
+    nrm = lambda x, y: float((x - y).norm() / (y.norm() + 1e-12))
+    dev = {k: nrm(b_[k], a[k]) for k in ("bev", "reg", "cls", "depth")}
+    dev.update({k: abs(b_["losses"][k] - a["losses"][k]) / max(abs(a["losses"][k]), 1e-6) for k in a["losses"]})
+    dev["depth_loss"] = abs(b_["depth_loss"] - a["depth_loss"]) / abs(a["depth_loss"])
+    print("bf16 vs fp32 deviation (relative L2 / relative loss):", {k: round(v, 5) for k, v in dev.items()})
+    # measured on MI355X (round 2, random-init weights): bev 6.7e-2, reg 6.8e-2, depth 6.8e-2, cls 2.2e-3 relative L2;
+    # losses 1e-5 .. 1.2e-3 relative.  ~50 bf16 convolutions deep, each rounding its output to 8 mantissa bits.
+    assert dev["bev"] < 1e-1 and dev["depth"] < 1e-1 and dev["reg"] < 1e-1, dev
+    assert dev["cls"] < 1e-2, dev
+    assert all(dev[k] < 5e-3 for k in list(a["losses"]) + ["depth_loss"]), dev
