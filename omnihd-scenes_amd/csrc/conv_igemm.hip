@@ -23,6 +23,7 @@
 // bf16 in the epilogue (+ optional fp32 bias).  Workgroups are numbered so that one XCD keeps ONE band of output channels:
 // its weight slab (TN x K bf16 = 2.4 MB for K = 9216) stays in that XCD's 4 MiB L2 while the activations stream by.
 #include "common.h"
+#include <type_traits>
 
 namespace omnihd {
 namespace {
@@ -40,7 +41,8 @@ __device__ __forceinline__ unsigned short f2bf_rn(float f) {
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int WM, int WN, int STAGES, bool SPREAD, bool PRIO = false>
+// ABL (lab only, tile codes 251/252 of omnihd_conv_fwd_bf16): 1 = no MFMAs (pure operand streaming), 2 = no LDS-DMA (pure MFMA + LDS reads)
+template <int WM, int WN, int STAGES, bool SPREAD, bool PRIO = false, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
     const float* __restrict__ bias, unsigned short* __restrict__ Y, int M, int H, int W, int Cin, int Cout, int ksize,
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
   int k_tap = 0, k_c = 0;                         // position of the NEXT K-step to issue
   // one LDS-DMA call (8 rows x 128 B) of the K-step at (k_tap, k_c): calls 0..A_CALLS-1 fetch A rows, the rest B rows
   auto issue_call = [&](int stage, bool real, int call) {
+    if (ABL == 2) return;
     const int c = (call & 1) ? (c_even ^ 4) : c_even;          // A_CALLS is even: the parity of a B call is that of its index
     if (call < A_CALLS) {
       const int i = call;
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          if (ABL != 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          else acc[i][j][0] += (float)a[i][0] + (float)b[j][0];
       if (PRIO) __builtin_amdgcn_s_setprio(0);
       if (SPREAD) {
         // the DMA calls of the next fill are issued BEHIND this slice's MFMAs (their issue time, 60-185 cycles each, then
@@ -187,6 +191,195 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && n < Cout) Y[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 variant with ROW-SHIFT REUSE of the activation tile (k_conv_igemm_rs).
+// Ablation of k_conv_igemm on 1024->1024 at 160x240 (tile codes 251/252): operand streaming alone 0.688 ms, MFMAs + LDS
+// reads alone 0.337 ms, together 0.854 ms — the kernel is bound by the bytes it streams into LDS (12 TB/s out of the L2s,
+// 90 % hits), not by the matrix pipes.  Two thirds of those bytes are the A tile, and the three taps of one kernel row
+// read the SAME pixels shifted by one: here the A tile of a (channel slice, ky) pair is staged ONCE with a halo of 8 pixels
+// on either side (272 rows) and the taps kx = 0,1,2 read it at row offsets 8-d, 8, 8+d; a fragment row whose source pixel
+// x + dx falls outside the image row is zeroed in registers (the raster neighbour belongs to another image row).  Only the
+// weights are streamed per tap.  Bytes per three K-steps: 40 + 3*16 = 88 KB instead of 144 KB.
+// LDS: two A buffers (272 rows + 8 junk rows for the padding calls) + a ring of four B buffers = 134 KB; per wavefront and
+// group of three K-steps 5 A calls + 3 x 2 B calls in a fixed program order, so the waits are literal counts:
+// vmcnt(4) before the first K-step of a group, vmcnt(9) before the other two.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHalo = 8;
+
+template <bool SPREAD>
+__global__ __launch_bounds__(512) void k_conv_igemm_rs(
+    const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
+    const float* __restrict__ bias, unsigned short* __restrict__ Y, int M, int H, int W, int Cin, int Cout, int dil,
+    int tiles_m, int tiles_n, int tiles_per_xcd) {
+  constexpr int TM = 256, TN = 128, WN = 2;
+  constexpr int A_ROWS = TM + 2 * kHalo;              // 272 = 34 calls; every wavefront issues 5 (the last 6 are padding)
+  constexpr int A_BUF = A_ROWS + 8;                   // + one junk block the padding calls write to
+  __shared__ __attribute__((aligned(16))) unsigned short sm[2 * A_BUF + 4 * TN][kBK];
+  auto a_buf = [&](int slot) { return sm + slot * A_BUF; };
+  auto b_buf = [&](int slot) { return sm + 2 * A_BUF + slot * TN; };
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int t = xcd * tiles_per_xcd + slot;
+  if (slot >= tiles_per_xcd || t >= tiles_m * tiles_n) return;
+  const int nt = t / tiles_m, mt = t - nt * tiles_m;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int K = 9 * Cin;
+  const int lr = lane >> 3;
+  const int pos = lane & 7;
+  const int chunk = pos ^ (((wave & 1) << 2) | ((lane >> 4) & 3));   // call index parity == wave parity for A and B calls
+
+  // A calls of this wavefront: call index ca = wave + 8*q (q = 0..4), rows 8*ca .. 8*ca+7 of the A buffer,
+  // row j <-> pixel m0 - kHalo + j
+  int a_y[5];
+  long long a_pix[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int ca = wave + 8 * q;
+    const long long m = (long long)mt * TM - kHalo + 8 * ca + lr;
+    if (ca < A_ROWS / 8 && m >= 0 && m < M) {
+      a_pix[q] = m;
+      a_y[q] = (int)((m / W) % H);
+    } else {
+      a_pix[q] = 0;
+      a_y[q] = -(1 << 20);
+    }
+  }
+  const unsigned short* b_row[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int n = nt * TN + 8 * (wave + 8 * q) + lr;
+    b_row[q] = (n < Cout) ? Wt + (size_t)n * K : nullptr;
+  }
+
+  // fragment rows of this lane and the x coordinate of their pixels (for the border mask)
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  int fx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long long m = (long long)mt * TM + wm * 64 + i * 32 + frow;
+    fx[i] = (int)(m % W);
+  }
+
+  const int n_c = Cin / kBK;
+  const int n_groups = n_c * 3;
+  const int n_steps = n_groups * 3;
+
+  auto issue_a = [&](int g, int q) {                  // call q (0..4) of the A fill of group g = (c, ky)
+    const bool real = g < n_groups;
+    const int c = g / 3, ky = g - 3 * c;
+    const int dy = (ky - 1) * dil;
+    const int ca = wave + 8 * q;
+    const bool ok = real && (unsigned)(a_y[q] + dy) < (unsigned)H;
+    const unsigned short* src = ok ? X + (size_t)(a_pix[q] + (long long)dy * W) * Cin + c * kBK + chunk * 8 : zero_page;
+    unsigned short(*dst)[kBK] = a_buf(g & 1) + (ca < A_ROWS / 8 ? 8 * ca : A_ROWS);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
+  };
+  auto issue_b = [&](int k, int q) {                  // call q (0..1) of the B fill of K-step k = (c, ky, kx)
+    const bool real = k < n_steps;
+    const int g = k / 3, kx = k - 3 * g;
+    const int c = g / 3, ky = g - 3 * c;
+    const unsigned short* src = (real && b_row[q]) ? b_row[q] + (size_t)(ky * 3 + kx) * Cin + c * kBK + chunk * 8 : zero_page;
+    unsigned short(*dst)[kBK] = b_buf(k & 3) + 8 * (wave + 8 * q);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue, program order A(0), B(0), B(1), B(2)
+#pragma unroll
+  for (int q = 0; q < 5; ++q) issue_a(0, q);
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    issue_b(kk, 0);
+    issue_b(kk, 1);
+  }
+
+  auto kstep = [&](int k, int g, auto kx_tag) {
+    constexpr int KX = decltype(kx_tag)::value;
+    if (KX == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int dx = (KX - 1) * dil;
+    const unsigned short(*A)[kBK] = a_buf(g & 1);
+    const unsigned short(*B)[kBK] = b_buf(k & 3);
+    bool ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ok[i] = (KX == 1) || ((unsigned)(fx[i] + dx) < (unsigned)W);
+    if (!SPREAD) {
+      if (KX == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) issue_a(g + 1, q);
+      }
+      issue_b(k + 3, 0);
+      issue_b(k + 3, 1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + frow + kHalo + dx;          // row of the A buffer
+        const int rb = wn * 64 + i * 32 + frow;
+        const int c = ks * 2 + fhalf;
+        a[i] = *reinterpret_cast<const bf16x8*>(&A[ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+        b[i] = *reinterpret_cast<const bf16x8*>(&B[rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+        if (KX != 1 && !ok[i]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[i][e] = (__bf16)0.0f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (SPREAD) {
+        // program order of the fills: [A(g+1) x5 when KX == 0], B(k+3) x2 — spread behind the MFMAs of the four slices
+        if (KX == 0) {
+          if (ks == 0) { issue_a(g + 1, 0); issue_a(g + 1, 1); }
+          if (ks == 1) { issue_a(g + 1, 2); issue_a(g + 1, 3); }
+          if (ks == 2) { issue_a(g + 1, 4); issue_b(k + 3, 0); }
+          if (ks == 3) { issue_b(k + 3, 1); }
+        } else {
+          if (ks == 0) issue_b(k + 3, 0);
+          if (ks == 1) issue_b(k + 3, 1);
+        }
+      }
+    }
+  };
+
+  for (int g = 0; g < n_groups; ++g) {
+    kstep(3 * g + 0, g, std::integral_constant<int, 0>{});
+    kstep(3 * g + 1, g, std::integral_constant<int, 1>{});
+    kstep(3 * g + 2, g, std::integral_constant<int, 2>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nt * TN + wn * 64 + j * 32 + (lane & 31);
+    const float bv = (bias && n < Cout) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = (long long)mt * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < M && n < Cout) Y[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
       }
   }
@@ -247,7 +440,23 @@ extern "C" int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, cons
   // tile 0 = choose: 256x128 when that still fills the chip several times over, else 128x128
   const long long big_tiles = (long long)((M + 255) / 256) * ((cout + 127) / 128);
   const bool big = tile == 256 || (tile == 0 && big_tiles >= 2 * kCUs);
-  if (tile == 255) {   // lab: the 256x128 kernel with s_setprio(1) around the MFMA groups
+  if (tile == 300 || (tile == 0 && ksize == 3 && dil <= kHalo && big_tiles >= 2 * kCUs)) {
+    // 3x3 with row-shift reuse of the activation tile
+    OMNIHD_REQUIRE(ksize == 3 && dil <= kHalo, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm_rs<true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout, dil,
+                       tiles_m, tiles_n, per);
+  } else if (tile == 251 || tile == 252) {   // lab: 256x128 without MFMAs (251) / without LDS-DMA (252); results are garbage
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    if (tile == 251)
+      hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, false, 1>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin,
+                         cout, ksize, dil, tiles_m, tiles_n, per);
+    else
+      hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, false, 2>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin,
+                         cout, ksize, dil, tiles_m, tiles_n, per);
+  } else if (tile == 255) {   // lab: the 256x128 kernel with s_setprio(1) around the MFMA groups
     const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
     hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,

@@ -572,23 +572,24 @@ def conv_fwd(x, w_cl, bias=None, dilation=1, tile=0):
         raise TypeError("w must be a 4-D bf16 tensor in channels_last memory format")
     B, cin, H, W = x.shape
     cout, k = w_cl.shape[0], w_cl.shape[2]
-    y = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=x.device)
+    # (B,Cout,H,W) with channels-last strides = NHWC memory; not a view of anything (a custom Function must not hand out views)
+    y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     with _on(x.device):
         check(lib().omnihd_conv_fwd_bf16(x.data_ptr(), w_cl.data_ptr(), None if bias is None else _f32c(bias).data_ptr(),
                                          y.data_ptr(), B, H, W, cin, cout, k, int(dilation), int(tile), _raw_stream()),
               "omnihd_conv_fwd_bf16")
-    return y.permute(0, 3, 1, 2)
+    return y
 
 
 def conv_dgrad_weights(w_cl):
     """(Cout,Cin,k,k) channels_last bf16 -> (Cin,Cout,k,k) channels_last bf16 with mirrored taps: the weights with which
     the data gradient is ``conv_fwd(grad_out, wt)``."""
     cout, cin, k, _ = w_cl.shape
-    wt = torch.empty((cin, k, k, cout), dtype=torch.bfloat16, device=w_cl.device)
+    wt = torch.empty((cin, cout, k, k), dtype=torch.bfloat16, device=w_cl.device, memory_format=torch.channels_last)
     with _on(w_cl.device):
         check(lib().omnihd_conv_dgrad_weights(w_cl.data_ptr(), wt.data_ptr(), cout, cin, k, _raw_stream()),
               "omnihd_conv_dgrad_weights")
-    return wt.permute(0, 3, 1, 2)
+    return wt
 
 
 # Which implementation computes the weight gradient of a given convolution geometry: the MFMA kernel chain of
@@ -706,10 +707,10 @@ def refresh_bf16_shadows():
 # gradient is ours on every 3x3 geometry (854 vs 700 TFLOP/s on 1024->1024 at 160x240), the forward is a close race
 # (861 vs 875-966), 1x1 convolutions stay on MIOpen.
 _CONV_CHOICE = {}
-_CONV_IMPLS = ("hip256", "hip128x256", "miopen")
+_CONV_IMPLS = ("hip", "hip128x256", "miopen")
 
 
-def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen):
+def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=None):
     """Run one direction ('fwd': x = input, w_cl = weights; 'dgrad': x = grad_out, w_cl = data-gradient weights) with the
     implementation chosen for its geometry."""
     k = w_cl.shape[2]
@@ -718,7 +719,7 @@ def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen):
             and stride[0] == stride[1] and padding[0] == padding[1] and dilation[0] == dilation[1])
     if not ours or policy == "miopen":
         return run_miopen()
-    run_hip = lambda tile: conv_fwd(x, w_cl, None, dilation[0], tile)
+    run_hip = lambda tile: conv_fwd(x, w_cl, bias, dilation[0], tile)          # fp32 bias added before the one rounding
     if policy == "hip":
         return run_hip(0)
     key = (direction, tuple(x.shape), w_cl.shape[0], k, dilation[0], x.device.index)
@@ -734,12 +735,14 @@ def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen):
             e1.record()
             torch.cuda.synchronize(x.device)
             return e0.elapsed_time(e1)
-        times = {"hip256": clock(lambda: run_hip(256)), "hip128x256": clock(lambda: run_hip(254)), "miopen": clock(run_miopen)}
+        # "hip": the library's own pick (3x3 with dilation <= 8 at BEV sizes: the row-shift kernel, else the 256x128 tile,
+        # 128x128 for small problems); "hip128x256": the wide-N tile
+        times = {"hip": clock(lambda: run_hip(0)), "hip128x256": clock(lambda: run_hip(254)), "miopen": clock(run_miopen)}
         choice = min(times, key=times.get)
         _CONV_CHOICE[key] = choice
     if choice == "miopen":
         return run_miopen()
-    return run_hip(256 if choice == "hip256" else 254)
+    return run_hip(0 if choice == "hip" else 254)
 
 
 def conv_choices():
@@ -760,13 +763,12 @@ class _ConvHipWgrad(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.conv = (list(stride), list(padding), list(dilation))
         ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
-        bt = None if bias is None else bias.detach().to(x.dtype)
-        run_miopen = lambda: torch.nn.functional.conv2d(x, wb, None, stride, padding, dilation)
+        run_miopen = lambda: torch.nn.functional.conv2d(x, wb, None if bias is None else bias.detach().to(x.dtype), stride,
+                                                         padding, dilation)
         if x.dtype == torch.bfloat16 and x.dim() == 4:
-            y = _conv_impl("fwd", x, wb.contiguous(memory_format=torch.channels_last), stride, padding, dilation, run_miopen)
-        else:
-            y = run_miopen()
-        return y if bt is None else y + bt.view(1, -1, 1, 1)
+            return _conv_impl("fwd", x, wb.contiguous(memory_format=torch.channels_last), stride, padding, dilation, run_miopen,
+                              None if bias is None else bias.detach())
+        return run_miopen()
 
     @staticmethod
     def backward(ctx, g):

@@ -10,7 +10,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/p[123]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_conv_igemm" in r["Kernel_Name"]:
+        if "k_conv_igemm" in r["Kernel_Name"]:  # either kernel of csrc/conv_igemm.hip
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:34s} {sum(v[-5:])/len(v[-5:]):16.0f}")

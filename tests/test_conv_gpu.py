@@ -220,7 +220,9 @@ def test_bevconv2d_module_gradients_match_plain_conv(cuda):
         x2 = x1.detach().clone().requires_grad_()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y1, y2 = ref(x1), mod(x2)
-        assert torch.equal(y1, y2)
+        # the forward runs on whichever implementation measured faster for the geometry (MIOpen: identical bits; the
+        # implicit-GEMM kernel: fp32 accumulation in another order, one bf16 rounding)
+        assert float((y1.float() - y2.float()).abs().max()) <= 2 ** -7 * float(y1.float().abs().max())
         gy = torch.randn_like(y1)
         y1.backward(gy); y2.backward(gy)
         torch.testing.assert_close(x2.grad, x1.grad, rtol=2e-2, atol=2e-2)
@@ -253,7 +255,9 @@ def test_transposed_conv_weight_gradient(cuda, cin, cout, k, H, W):
 @pytest.mark.parametrize("B,H,W,cin,cout,k,dil,tile", [(1, 160, 240, 128, 256, 3, 1, 0), (1, 160, 240, 128, 256, 3, 1, 128),
                                                           (2, 20, 30, 64, 72, 3, 1, 0), (1, 33, 47, 192, 136, 3, 2, 128),
                                                           (1, 33, 47, 192, 136, 3, 2, 256), (3, 16, 44, 256, 64, 1, 1, 0),
-                                                          (1, 64, 176, 256, 256, 3, 6, 256)])
+                                                          (1, 64, 176, 256, 256, 3, 6, 256), (1, 160, 240, 128, 256, 3, 1, 300),
+                                                          (2, 20, 30, 64, 72, 3, 1, 300), (1, 33, 47, 192, 136, 3, 2, 300),
+                                                          (1, 64, 176, 256, 256, 3, 6, 300), (3, 17, 9, 64, 64, 3, 8, 300)])
 def test_igemm_conv_forward_and_data_gradient_match_fp32_reference(cuda, B, H, W, cin, cout, k, dil, tile):
     """csrc/conv_igemm.hip against torch.nn.functional.conv2d in fp32 on the same bf16-rounded operands: forward with bias,
     and the data gradient as the same kernel on mirrored / transposed weights.  Bound: one bf16 rounding of the result
