@@ -120,16 +120,42 @@ __global__ __launch_bounds__(256) void k_bn_reduce(const float* __restrict__ par
   if (lane == 0) sums[out] = s * mult;
 }
 
+// Sum of the per-block partials of one output column, in block order (the same order for every launch: deterministic).
+// 16 lanes per column: lane l adds blocks l, l+16, ... and a fixed xor tree combines the 16 strands — every lane of the
+// group returns the total.
+__device__ __forceinline__ float sum_partials(const float* __restrict__ partial, int n_blocks, int c2, int col, int l16) {
+  float s = 0.f;
+#pragma unroll 4
+  for (int b = l16; b < n_blocks; b += 16) s += partial[(size_t)b * c2 + col];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+  return s;
+}
+
 // stats = (mean, meansqr) [2c] possibly summed over ranks -> * rank_mult; constants of the forward pass.
-__global__ __launch_bounds__(256) void k_bn_fwd_consts(const float* __restrict__ stats, float rank_mult,
+// With n_blocks > 0 `stats` is the PARTIAL array of k_bn_partial ([n_blocks][2c]) and the second reduction stage happens
+// here (single-rank path: one launch less per layer and direction; the reduced statistics are also written to stats_out).
+__global__ __launch_bounds__(256) void k_bn_fwd_consts(const float* __restrict__ stats, float rank_mult, int n_blocks,
+                                                       float* __restrict__ stats_out,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, float momentum, float var_correction, int c,
                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        float* __restrict__ scale, float* __restrict__ shift,
                                                        float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  // launch: n_blocks > 0 -> 16 channels per workgroup (16 lanes each), else 256 channels per workgroup
+  const int i = n_blocks > 0 ? blockIdx.x * 16 + threadIdx.x / 16 : blockIdx.x * 256 + threadIdx.x;
+  const int l16 = threadIdx.x % 16;
   if (i >= c) return;
-  const float mean = stats[i] * rank_mult, msq = stats[c + i] * rank_mult;
+  float mean, msq;
+  if (n_blocks > 0) {
+    mean = sum_partials(stats, n_blocks, 2 * c, i, l16) * rank_mult;
+    msq = sum_partials(stats, n_blocks, 2 * c, c + i, l16) * rank_mult;
+    if (l16 != 0) return;
+    if (stats_out) { stats_out[i] = mean; stats_out[c + i] = msq; }
+  } else {
+    mean = stats[i] * rank_mult;
+    msq = stats[c + i] * rank_mult;
+  }
   const float var = fmaxf(msq - mean * mean, 0.f);          // E[x^2] - E[x]^2 can cancel below zero for |mean| >> std
   const float invstd = rsqrtf(var + eps);
   const float sc = gamma[i] * invstd;
@@ -146,18 +172,27 @@ __global__ __launch_bounds__(256) void k_bn_fwd_consts(const float* __restrict__
 // local [2c] = this rank's (sum g', sum g'x); global [2c] = the same summed over ranks.
 // dgamma, dbeta from the local sums; coefficients of gx = g'*A + x*B + C from the global ones.
 __global__ __launch_bounds__(256) void k_bn_bwd_consts(const float* __restrict__ local, const float* __restrict__ global,
-                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       int n_blocks, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float inv_count, int c,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                        float* __restrict__ coefA, float* __restrict__ coefB,
                                                        float* __restrict__ coefC) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = n_blocks > 0 ? blockIdx.x * 16 + threadIdx.x / 16 : blockIdx.x * 256 + threadIdx.x;
+  const int l16 = threadIdx.x % 16;
   if (i >= c) return;
   const float mu = mean[i], is = invstd[i], g = gamma[i];
-  const float l1 = local[i], l2 = local[c + i];
+  float l1, l2, t1, t2;
+  if (n_blocks > 0) {                                          // single rank: local == global == the partials, reduced here
+    l1 = t1 = sum_partials(local, n_blocks, 2 * c, i, l16);
+    l2 = t2 = sum_partials(local, n_blocks, 2 * c, c + i, l16);
+    if (l16 != 0) return;
+  } else {
+    l1 = local[i]; l2 = local[c + i];
+    t1 = global[i]; t2 = global[c + i];
+  }
   dbeta[i] = l1;
   dgamma[i] = is * (l2 - mu * l1);
-  const float t1 = global[i], t2 = global[c + i];
   const float dot = g * (t2 - mu * t1) * is * is * is;      // gamma * sum g'(x - mu) * invstd^3
   const float dmu = -g * is * t1 + dot * mu;                 // dL/dmu
   const float dq = -0.5f * dot;                              // dL/d(meansqr)
@@ -217,7 +252,8 @@ extern "C" size_t omnihd_bn_workspace_bytes(long long rows, int c) {
 namespace {
 template <typename T>
 int channel_sums_t(const void* a, const void* b, const void* mask, const float* fwd_scale_shift, float* sums, long long rows,
-                   int c, int mode, float mult, void* workspace, size_t workspace_bytes, void* stream) {
+                   int c, int mode, float mult, void* workspace, size_t workspace_bytes, void* stream,
+                   int* partial_blocks = nullptr) {
   OMNIHD_REQUIRE(rows > 0 && c > 0 && c % 8 == 0 && c <= 2048, "rows > 0, C a multiple of 8, C <= 2048");
   OMNIHD_REQUIRE(a && sums && workspace && (mode == 0 || b), "null pointer");
   OMNIHD_REQUIRE(workspace_bytes >= omnihd_bn_workspace_bytes(rows, c), "workspace too small");
@@ -231,7 +267,8 @@ int channel_sums_t(const void* a, const void* b, const void* mask, const float* 
   else
     hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)a, (const T*)b, (const T*)mask,
                        fwd_scale_shift, partial, rows, c / 8, per);
-  hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 3) / 4), dim3(256), 0, st, partial, blocks, c, mult, sums);
+  if (partial_blocks) *partial_blocks = blocks;                 // the caller's constants kernel reduces the partials itself
+  else hipLaunchKernelGGL(k_bn_reduce, dim3((2 * c + 3) / 4), dim3(256), 0, st, partial, blocks, c, mult, sums);
   return check_launch("bn_channel_sums");
 }
 
@@ -268,8 +305,9 @@ extern "C" int omnihd_bn_fwd_consts(const float* stats, float rank_mult, const f
                                     void* stream) {
   OMNIHD_REQUIRE(c > 0 && stats && gamma && beta && scale && shift && mean && invstd, "null pointer");
   OMNIHD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running stats: both or neither");
-  hipLaunchKernelGGL(k_bn_fwd_consts, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, rank_mult, gamma,
-                     beta, eps, momentum, var_correction, c, running_mean, running_var, scale, shift, mean, invstd);
+  hipLaunchKernelGGL(k_bn_fwd_consts, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, rank_mult, 0,
+                     (float*)nullptr, gamma, beta, eps, momentum, var_correction, c, running_mean, running_var, scale, shift,
+                     mean, invstd);
   return check_launch("bn_fwd_consts");
 }
 
@@ -278,7 +316,7 @@ extern "C" int omnihd_bn_bwd_consts(const float* local_sums, const float* global
                                     float* dbeta, float* coef_a, float* coef_b, float* coef_c, void* stream) {
   OMNIHD_REQUIRE(c > 0 && local_sums && global_sums && gamma && mean && invstd && dgamma && dbeta && coef_a && coef_b &&
                      coef_c, "null pointer");
-  hipLaunchKernelGGL(k_bn_bwd_consts, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, local_sums, global_sums,
+  hipLaunchKernelGGL(k_bn_bwd_consts, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, local_sums, global_sums, 0,
                      gamma, mean, invstd, inv_count, c, dgamma, dbeta, coef_a, coef_b, coef_c);
   return check_launch("bn_bwd_consts");
 }
@@ -300,11 +338,15 @@ template <typename T>
 int train_fwd_t(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, float momentum, float eps, float var_correction, int relu, void* y, float* stats2c,
                 float* consts4c, long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = channel_sums_t<T>(x, nullptr, nullptr, nullptr, stats2c, rows, c, 0, 1.0f / (float)rows, workspace,
-                             workspace_bytes, stream);
+  int blocks = 0;
+  int rc = channel_sums_t<T>(x, nullptr, nullptr, nullptr, stats2c, rows, c, 0, 1.0f, workspace, workspace_bytes, stream,
+                             &blocks);
   if (rc) return rc;
-  rc = omnihd_bn_fwd_consts(stats2c, 1.0f, gamma, beta, eps, momentum, var_correction, c, running_mean, running_var,
-                            consts4c, consts4c + c, consts4c + 2 * c, consts4c + 3 * c, stream);
+  OMNIHD_REQUIRE(gamma && beta && consts4c && stats2c, "null pointer");
+  hipLaunchKernelGGL(k_bn_fwd_consts, dim3((c + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const float*>(workspace), 1.0f / (float)rows, blocks, stats2c, gamma, beta, eps, momentum,
+                     var_correction, c, running_mean, running_var, consts4c, consts4c + c, consts4c + 2 * c, consts4c + 3 * c);
+  rc = check_launch("bn_fwd_consts");
   if (rc) return rc;
   if (sizeof(T) == 2) return omnihd_affine_act_fwd(x, consts4c, consts4c + c, res, y, rows, c, relu, stream);
   return omnihd_affine_act_fwd_f32((const float*)x, consts4c, consts4c + c, (const float*)res, (float*)y, rows, c, relu, stream);
@@ -315,10 +357,14 @@ int train_bwd_t(const void* gy, const void* y_mask, int relu_from_x, const void*
                 void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
                 size_t workspace_bytes, void* stream) {
   const float* fss = (relu_from_x && !y_mask) ? consts4c : nullptr;    // consts4c starts with scale, shift
-  int rc = channel_sums_t<T>(gy, x, y_mask, fss, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream);
+  int blocks = 0;
+  int rc = channel_sums_t<T>(gy, x, y_mask, fss, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream, &blocks);
   if (rc) return rc;
-  rc = omnihd_bn_bwd_consts(sums2c, sums2c, gamma, consts4c + 2 * c, consts4c + 3 * c, 1.0f / (float)rows, c, out5c,
-                            out5c + c, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, stream);
+  const float* partial = static_cast<const float*>(workspace);
+  hipLaunchKernelGGL(k_bn_bwd_consts, dim3((c + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial, partial, blocks, gamma,
+                     consts4c + 2 * c, consts4c + 3 * c, 1.0f / (float)rows, c, out5c, out5c + c, out5c + 2 * c, out5c + 3 * c,
+                     out5c + 4 * c);
+  rc = check_launch("bn_bwd_consts");
   if (rc) return rc;
   return bwd_apply_t<T>(gy, y_mask, fss, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream);
 }

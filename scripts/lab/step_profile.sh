@@ -1,0 +1,32 @@
+#!/bin/bash
+# Steady-state kernel statistics of the bf16 training step (MIOpen db seeded, immediate find lookups): launches per step
+# and GPU time by kernel.  Usage: bash scripts/lab/step_profile.sh [bf16|fp32] [steps]
+export TMPDIR=/tmp; DT=${1:-bf16}; N=${2:-10}; out=gpurun_out/r2v_$DT; mkdir -p $out
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/prof -o st -- python3 scripts/lab/step_few.py $DT $N > $out/run.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+f = glob.glob("$out/prof/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+# steady-state region: the last N steps = launches after the (3+...) warm-up; split by the optimizer kernel count
+names = [r["Kernel_Name"] for r in rows]
+opt = [i for i, n in enumerate(names) if "multi_tensor_apply" in n and "adam" in n.lower()]
+print("total launches", len(rows), "adam launches", len(opt))
+# take the last $N steps: find boundaries by the last adam kernel of each step (fused adamw = a few launches per step)
+per_step = max(1, len(opt) // ($N + 3))
+cut = opt[-per_step * $N - 1] + 1 if len(opt) > per_step * $N else 0
+ss = rows[cut:]
+t0, t1 = int(ss[0]["Start_Timestamp"]), int(ss[-1]["End_Timestamp"])
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ss)
+print(f"steady region: {len(ss)} launches over $N steps = {len(ss)/$N:.0f} per step; wall {(t1-t0)/1e6/$N:.2f} ms/step; sum of kernel durations {busy/1e6/$N:.2f} ms/step")
+agg = collections.defaultdict(lambda: [0, 0])
+for r in ss:
+    k = r["Kernel_Name"].split("(")[0][:70]
+    agg[k][0] += 1; agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+print("--- by GPU time")
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+    print(f"{t/1e6/$N:7.3f} ms/step {c/$N:7.1f} calls/step  {k}")
+print("--- by launch count")
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:22]:
+    print(f"{c/$N:7.1f} calls/step {t/1e6/$N:7.3f} ms/step  {k}")
+PY
+find $out/prof -type f -size +2M -delete
