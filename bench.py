@@ -18,8 +18,9 @@ in HBM.  Workloads (`--workload`):
   bev_ops   only the north_star operators (pooling fwd+bwd, voxelise, scatter), no conv layers.
 Besides the whole-job rate the line carries
   roofline      achieved HBM GB/s of the dominant kernel (bev_pool_v2 forward, dense), computed
-                from ALGORITHMIC bytes / mean launch duration measured here with
-                HIP events over back-to-back launches on rotating buffer sets (> Infinity Cache);
+                from ALGORITHMIC bytes / mean duration of the kernel's launches INSIDE
+                the timed steps (HIP events on the launching stream); the isolated loops (back-to-back on
+                rotating buffer sets = Infinity-Cache-warm reads; after a 512 MiB sweep = cold) beside it;
   cpu_baseline  the CPU oracle (a port of the reference algorithm; the reference has no CPU
                 kernels) timed on this host's cores on a bounded sample of the same workload.
 """
