@@ -376,10 +376,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # OMNIHD_BENCH_SHARE_GPU=1: every rank on cuda:0 over gloo — a functional check of the multi-rank path (DDP, SyncBN
+    # exchange, max-over-ranks timing) on a one-GPU box; RCCL refuses two ranks on one device.  Not a measurement.
+    share = os.environ.get("OMNIHD_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     radar_dims = 7 if a.res == "r1" else 8
     # Dominant north_star kernel (bev_pool_v2 forward): timed FIRST, on the same frame geometry with rotating buffer
     # sets, before the training loop heats the chip (the same kernel inside the step runs ~15 % slower: DVFS

@@ -303,6 +303,12 @@ int omnihd_dcn3x3_sample_fwd(const void* x_nhwc_bf16, const float* offset_nhwc, 
 int omnihd_dcn3x3_sample_bwd(const void* x_nhwc_bf16, const float* offset_nhwc, const void* gcol_bf16,
                              const int* max_abs_offset_ceil, void* gx_nhwc_bf16, float* goffset_nhwc,
                              int batch, int h, int w, int c, int stride, int pad, int dil, void* stream);
+/* The same with fp32 x / col / gcol / gx (the reference's arithmetic). */
+int omnihd_dcn3x3_sample_fwd_f32(const float* x_nhwc, const float* offset_nhwc, float* col, int batch, int h, int w,
+                                 int c, int stride, int pad, int dil, void* stream);
+int omnihd_dcn3x3_sample_bwd_f32(const float* x_nhwc, const float* offset_nhwc, const float* gcol,
+                                 const int* max_abs_offset_ceil, float* gx_nhwc, float* goffset_nhwc, int batch, int h,
+                                 int w, int c, int stride, int pad, int dil, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Test-time post-process: rotated BEV NMS

@@ -16,27 +16,33 @@
 // the (grouped) weight stays a bf16 GEMM in the caller.  Zero padding outside the image, offset
 // channel order (tap, (dy, dx)) as in mmcv.
 #include "common.h"
+#include "bn_vec.h"
 
 namespace omnihd {
 namespace {
 
 constexpr int kBlock = 256;
 
-__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);       // round to nearest even
-  return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+// eight consecutive channels (vector i of a row-major array) as fp32: bf16 rows 16 B per lane, fp32 rows 32 B per lane;
+// plain (cached) accesses — every input row is gathered by ~36 (pixel, tap, corner) samples
+__device__ __forceinline__ void ld8(const bf16_t* __restrict__ p, size_t i, float (&f)[8]) {
+  const uint4 v = reinterpret_cast<const uint4*>(p)[i];
   f[0] = bf2f(v.x & 0xffff); f[1] = bf2f(v.x >> 16); f[2] = bf2f(v.y & 0xffff); f[3] = bf2f(v.y >> 16);
   f[4] = bf2f(v.z & 0xffff); f[5] = bf2f(v.z >> 16); f[6] = bf2f(v.w & 0xffff); f[7] = bf2f(v.w >> 16);
 }
-__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+__device__ __forceinline__ void ld8(const float* __restrict__ p, size_t i, float (&f)[8]) {
+  const float4 a = reinterpret_cast<const float4*>(p)[2 * i], b = reinterpret_cast<const float4*>(p)[2 * i + 1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void st8(bf16_t* __restrict__ p, size_t i, const float (&f)[8]) {
   uint4 v;
   v.x = f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16); v.y = f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
   v.z = f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16); v.w = f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
-  return v;
+  reinterpret_cast<uint4*>(p)[i] = v;
+}
+__device__ __forceinline__ void st8(float* __restrict__ p, size_t i, const float (&f)[8]) {
+  reinterpret_cast<float4*>(p)[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
+  reinterpret_cast<float4*>(p)[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
 }
 
 struct Geo { int B, H, W, Ho, Wo, stride, pad, dil; };
@@ -71,31 +77,29 @@ __device__ __forceinline__ Sample make_sample(const Geo& g, const float* __restr
   return s;
 }
 
-template <int C8>
-__global__ __launch_bounds__(kBlock) void k_dcn_fwd(const uint4* __restrict__ x8, const float* __restrict__ off,
-                                                    Geo g, long n_bags, uint4* __restrict__ col8) {
+template <typename T, int C8>
+__global__ __launch_bounds__(kBlock) void k_dcn_fwd(const T* __restrict__ x, const float* __restrict__ off,
+                                                    Geo g, long n_bags, T* __restrict__ col) {
   constexpr int G = kBlock / C8;
   const int sub = threadIdx.x % C8, grp = threadIdx.x / C8;
   for (long bag = (long)blockIdx.x * G + grp; bag < n_bags; bag += (long)gridDim.x * G) {
     const Sample s = make_sample(g, off, bag / 9, (int)(bag % 9));
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint4 v[4];
+    float f[4][8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = x8[(size_t)max(s.row[k], 0) * C8 + sub];
+    for (int k = 0; k < 4; ++k) ld8(x, (size_t)max(s.row[k], 0) * C8 + sub, f[k]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float f[8];
-      unpack8(v[k], f);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] = fmaf(s.w[k], f[c], acc[c]);
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(s.w[k], f[k][c], acc[c]);
     }
-    col8[(size_t)bag * C8 + sub] = pack8(acc);
+    st8(col, (size_t)bag * C8 + sub, acc);
   }
 }
 
-template <int C8>
-__global__ __launch_bounds__(kBlock) void k_dcn_bwd_off(const uint4* __restrict__ x8, const float* __restrict__ off,
-                                                        const uint4* __restrict__ gcol8, Geo g, long n_bags,
+template <typename T, int C8>
+__global__ __launch_bounds__(kBlock) void k_dcn_bwd_off(const T* __restrict__ x, const float* __restrict__ off,
+                                                        const T* __restrict__ gcol, Geo g, long n_bags,
                                                         float* __restrict__ goff) {
   constexpr int G = kBlock / C8;
   const int sub = threadIdx.x % C8, grp = threadIdx.x / C8;
@@ -104,12 +108,12 @@ __global__ __launch_bounds__(kBlock) void k_dcn_bwd_off(const uint4* __restrict_
     const int t = (int)(bag % 9);
     const Sample s = make_sample(g, off, p, t);
     float gc[8];
-    unpack8(gcol8[(size_t)bag * C8 + sub], gc);
+    ld8(gcol, (size_t)bag * C8 + sub, gc);
     float d[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float f[8];
-      unpack8(x8[(size_t)max(s.row[k], 0) * C8 + sub], f);
+      ld8(x, (size_t)max(s.row[k], 0) * C8 + sub, f);
       float a = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) a = fmaf(gc[c], f[c], a);
@@ -128,10 +132,10 @@ __global__ __launch_bounds__(kBlock) void k_dcn_bwd_off(const uint4* __restrict_
   }
 }
 
-template <int C8>
-__global__ __launch_bounds__(kBlock) void k_dcn_bwd_in(const float* __restrict__ off, const uint4* __restrict__ gcol8,
+template <typename T, int C8>
+__global__ __launch_bounds__(kBlock) void k_dcn_bwd_in(const float* __restrict__ off, const T* __restrict__ gcol,
                                                        Geo g, const int* __restrict__ radius_ptr, long n_in,
-                                                       uint4* __restrict__ gx8) {
+                                                       T* __restrict__ gx) {
   constexpr int G = kBlock / C8;
   const int sub = threadIdx.x % C8, grp = threadIdx.x / C8;
   const int R = *radius_ptr + 1;                      // candidate window half-width
@@ -153,14 +157,14 @@ __global__ __launch_bounds__(kBlock) void k_dcn_bwd_in(const float* __restrict__
           if (ay < 1.f && ax < 1.f) {
             const float w = (1.f - ay) * (1.f - ax);
             float f[8];
-            unpack8(gcol8[(size_t)(p * 9 + t) * C8 + sub], f);
+            ld8(gcol, (size_t)(p * 9 + t) * C8 + sub, f);
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] = fmaf(w, f[c], acc[c]);
           }
         }
       }
     }
-    gx8[(size_t)q * C8 + sub] = pack8(acc);
+    st8(gx, (size_t)q * C8 + sub, acc);
   }
 }
 
@@ -171,12 +175,12 @@ bool c8_ok(int c) { return c == 256 || c == 128 || c == 64 || c == 32; }
 
 using namespace omnihd;
 
-#define OMNIHD_DCN_DISPATCH(KERNEL, GRID, ...)                                                        \
-  switch (c / 8) {                                                                                     \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;         \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;         \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;           \
-    default: hipLaunchKernelGGL((KERNEL<4>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;          \
+#define OMNIHD_DCN_DISPATCH(KERNEL, T, GRID, ...)                                                        \
+  switch (c / 8) {                                                                                       \
+    case 32: hipLaunchKernelGGL((KERNEL<T, 32>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;        \
+    case 16: hipLaunchKernelGGL((KERNEL<T, 16>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;        \
+    case 8: hipLaunchKernelGGL((KERNEL<T, 8>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;          \
+    default: hipLaunchKernelGGL((KERNEL<T, 4>), GRID, dim3(kBlock), 0, st, __VA_ARGS__); break;         \
   }
 
 static int dcn_geo(Geo* g, int b, int h, int w, int stride, int pad, int dil) {
@@ -186,38 +190,61 @@ static int dcn_geo(Geo* g, int b, int h, int w, int stride, int pad, int dil) {
   return g->Ho > 0 && g->Wo > 0;
 }
 
-extern "C" int omnihd_dcn3x3_sample_fwd(const void* x_nhwc_bf16, const float* offset_nhwc, void* col_bf16, int batch,
-                                        int h, int w, int c, int stride, int pad, int dil, void* stream) {
+template <typename T>
+static int dcn_fwd_t(const void* x_nhwc, const float* offset_nhwc, void* col, int batch, int h, int w, int c, int stride,
+                     int pad, int dil, void* stream, const char* what) {
   hipStream_t st = (hipStream_t)stream;
   Geo g;
   OMNIHD_REQUIRE(batch > 0 && c8_ok(c) && dcn_geo(&g, batch, h, w, stride, pad, dil), "shape (C in {32,64,128,256})");
-  OMNIHD_REQUIRE(x_nhwc_bf16 && offset_nhwc && col_bf16, "null pointer");
+  OMNIHD_REQUIRE(x_nhwc && offset_nhwc && col, "null pointer");
   const long n_bags = (long)batch * g.Ho * g.Wo * 9;
   const dim3 grid(grid_for(n_bags, kBlock / (c / 8) * 4));
-  OMNIHD_DCN_DISPATCH(k_dcn_fwd, grid, static_cast<const uint4*>(x_nhwc_bf16), offset_nhwc, g, n_bags,
-                      static_cast<uint4*>(col_bf16))
-  return check_launch("dcn3x3_sample_fwd");
+  OMNIHD_DCN_DISPATCH(k_dcn_fwd, T, grid, static_cast<const T*>(x_nhwc), offset_nhwc, g, n_bags, static_cast<T*>(col))
+  return check_launch(what);
+}
+
+template <typename T>
+static int dcn_bwd_t(const void* x_nhwc, const float* offset_nhwc, const void* gcol, const int* max_abs_offset_ceil,
+                     void* gx_nhwc, float* goffset_nhwc, int batch, int h, int w, int c, int stride, int pad, int dil,
+                     void* stream, const char* what) {
+  hipStream_t st = (hipStream_t)stream;
+  Geo g;
+  OMNIHD_REQUIRE(batch > 0 && c8_ok(c) && dcn_geo(&g, batch, h, w, stride, pad, dil), "shape (C in {32,64,128,256})");
+  OMNIHD_REQUIRE(stride == 1, "the input-gradient gather assumes stride 1");
+  OMNIHD_REQUIRE(x_nhwc && offset_nhwc && gcol && max_abs_offset_ceil, "null pointer");
+  const long n_bags = (long)batch * g.Ho * g.Wo * 9;
+  const long n_in = (long)batch * h * w;
+  if (goffset_nhwc) {
+    const dim3 grid(grid_for(n_bags, kBlock / (c / 8) * 4));
+    OMNIHD_DCN_DISPATCH(k_dcn_bwd_off, T, grid, static_cast<const T*>(x_nhwc), offset_nhwc, static_cast<const T*>(gcol), g,
+                        n_bags, goffset_nhwc)
+  }
+  if (gx_nhwc) {
+    const dim3 grid(grid_for(n_in, kBlock / (c / 8)));
+    OMNIHD_DCN_DISPATCH(k_dcn_bwd_in, T, grid, offset_nhwc, static_cast<const T*>(gcol), g, max_abs_offset_ceil, n_in,
+                        static_cast<T*>(gx_nhwc))
+  }
+  return check_launch(what);
+}
+
+extern "C" int omnihd_dcn3x3_sample_fwd(const void* x_nhwc_bf16, const float* offset_nhwc, void* col_bf16, int batch,
+                                        int h, int w, int c, int stride, int pad, int dil, void* stream) {
+  return dcn_fwd_t<bf16_t>(x_nhwc_bf16, offset_nhwc, col_bf16, batch, h, w, c, stride, pad, dil, stream, "dcn3x3_sample_fwd");
+}
+extern "C" int omnihd_dcn3x3_sample_fwd_f32(const float* x_nhwc, const float* offset_nhwc, float* col, int batch, int h,
+                                            int w, int c, int stride, int pad, int dil, void* stream) {
+  return dcn_fwd_t<float>(x_nhwc, offset_nhwc, col, batch, h, w, c, stride, pad, dil, stream, "dcn3x3_sample_fwd_f32");
 }
 
 extern "C" int omnihd_dcn3x3_sample_bwd(const void* x_nhwc_bf16, const float* offset_nhwc, const void* gcol_bf16,
                                         const int* max_abs_offset_ceil, void* gx_nhwc_bf16, float* goffset_nhwc,
                                         int batch, int h, int w, int c, int stride, int pad, int dil, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  Geo g;
-  OMNIHD_REQUIRE(batch > 0 && c8_ok(c) && dcn_geo(&g, batch, h, w, stride, pad, dil), "shape (C in {32,64,128,256})");
-  OMNIHD_REQUIRE(stride == 1, "the input-gradient gather assumes stride 1");
-  OMNIHD_REQUIRE(x_nhwc_bf16 && offset_nhwc && gcol_bf16 && max_abs_offset_ceil, "null pointer");
-  const long n_bags = (long)batch * g.Ho * g.Wo * 9;
-  const long n_in = (long)batch * h * w;
-  if (goffset_nhwc) {
-    const dim3 grid(grid_for(n_bags, kBlock / (c / 8) * 4));
-    OMNIHD_DCN_DISPATCH(k_dcn_bwd_off, grid, static_cast<const uint4*>(x_nhwc_bf16), offset_nhwc,
-                        static_cast<const uint4*>(gcol_bf16), g, n_bags, goffset_nhwc)
-  }
-  if (gx_nhwc_bf16) {
-    const dim3 grid(grid_for(n_in, kBlock / (c / 8)));
-    OMNIHD_DCN_DISPATCH(k_dcn_bwd_in, grid, offset_nhwc, static_cast<const uint4*>(gcol_bf16), g, max_abs_offset_ceil,
-                        n_in, static_cast<uint4*>(gx_nhwc_bf16))
-  }
-  return check_launch("dcn3x3_sample_bwd");
+  return dcn_bwd_t<bf16_t>(x_nhwc_bf16, offset_nhwc, gcol_bf16, max_abs_offset_ceil, gx_nhwc_bf16, goffset_nhwc, batch, h, w,
+                           c, stride, pad, dil, stream, "dcn3x3_sample_bwd");
+}
+extern "C" int omnihd_dcn3x3_sample_bwd_f32(const float* x_nhwc, const float* offset_nhwc, const float* gcol,
+                                            const int* max_abs_offset_ceil, float* gx_nhwc, float* goffset_nhwc, int batch,
+                                            int h, int w, int c, int stride, int pad, int dil, void* stream) {
+  return dcn_bwd_t<float>(x_nhwc, offset_nhwc, gcol, max_abs_offset_ceil, gx_nhwc, goffset_nhwc, batch, h, w, c, stride, pad,
+                          dil, stream, "dcn3x3_sample_bwd_f32");
 }

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "omnihd_conv_dgrad_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "omnihd_dcn3x3_sample_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "omnihd_dcn3x3_sample_bwd": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "omnihd_dcn3x3_sample_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "omnihd_dcn3x3_sample_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "omnihd_pillar_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p]),
     "omnihd_nms_rotated_workspace_bytes": (c_size_t, [c_int]),

@@ -79,6 +79,25 @@ def frozen_bn_constants(bn):
     return cached[1], cached[2]
 
 
+def _flush_batches_tracked(bn, *_):
+    n = getattr(bn, "_omnihd_pending_batches", 0)
+    if n and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(n)
+    bn._omnihd_pending_batches = 0
+
+
+def _count_batch(bn):
+    """``num_batches_tracked += 1`` without a kernel per layer and step (37 launches per step in the fusion detector): the
+    fused path uses a fixed momentum and never reads the counter, so increments are kept on the host and written into the
+    buffer when it is needed — before ``state_dict()`` (checkpoints carry the same value torch would) and when the layer
+    leaves training mode through ``bn_act``'s plain branch."""
+    if not hasattr(bn, "_omnihd_pending_batches"):
+        bn._omnihd_pending_batches = 0
+        bn.register_state_dict_pre_hook(lambda mod, prefix, keep_vars: _flush_batches_tracked(mod))
+        bn.register_load_state_dict_post_hook(lambda mod, incompatible: setattr(mod, "_omnihd_pending_batches", 0))
+    bn._omnihd_pending_batches += 1
+
+
 def bn_act(x, bn, relu=True, residual=None, inplace=True):
     """``relu(bn(x) + residual)``.  A frozen BatchNorm (eval mode, affine parameters without gradient) on a bf16 or fp32
     device tensor is an affine map with constant coefficients: ONE fused channels-last pass each way
@@ -113,9 +132,11 @@ def bn_act(x, bn, relu=True, residual=None, inplace=True):
                 return F.relu(out, inplace=inplace) if relu else out
             unbiased_sync = True
         if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            _count_batch(bn)
         return ops.bn_train_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, group,
                                 residual, unbiased_sync)
+    if getattr(bn, "_omnihd_pending_batches", 0):
+        _flush_batches_tracked(bn)                # torch's own forward may read the counter (momentum=None)
     out = bn(x)
     if residual is not None:
         out = out + residual
@@ -151,7 +172,9 @@ class BevConv2d(nn.Conv2d):
             # (no Python in its backward); unmeasured geometries go through the function that measures
             if ops.conv_all_miopen(x.shape, weight.shape[0], weight.shape[2], self.stride[0], self.padding[0],
                                    self.dilation[0], x.device.index):
-                return super()._conv_forward(x, weight, bias)
+                # MIOpen in all three directions: a plain convolution, fed with the bf16 image of the master weight that
+                # the step refreshes with one fused copy (no per-layer cast kernel of autocast)
+                return super()._conv_forward(x, ops.bf16_weight(weight), bias)
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             if ops.conv_wgrad_supported(xb, weight, self.stride, self.padding, self.dilation):
                 return ops.conv_hip_wgrad(xb, weight, bias, self.stride, self.padding, self.dilation)

@@ -35,24 +35,25 @@ class DeformConv2dPack(nn.Module):
     def forward(self, x):
         offset = self.conv_offset(x)                                   # (B, dg*2*k*k, Ho, Wo)
         gemm_dtype = torch.bfloat16 if (torch.is_autocast_enabled() and x.is_cuda) else torch.float32
-        if gemm_dtype == torch.bfloat16:
+        if x.is_cuda and x.dtype in (torch.bfloat16, torch.float32):
             from .. import ops
             if ops.dcn3x3_supported(x, self.k, self.stride, self.deform_groups):
                 with torch.autocast(x.device.type, enabled=False):
-                    return self._hip_sample_and_gemm(x, offset)
+                    return self._hip_sample_and_gemm(x, offset, gemm_dtype)
         with torch.autocast(x.device.type, enabled=False):             # sampling positions need fp32
             if self.deform_groups == 1:
                 return self._gather_and_gemm(x.float(), offset.float(), gemm_dtype).to(x.dtype)
             return self._sample_and_contract(x.float(), offset.float()).to(x.dtype)
 
-    def _hip_sample_and_gemm(self, x, offset):
-        """bf16 training path: hand-written HIP row-gather kernels (omnihd_dcn3x3_sample_*) + one bf16 GEMM."""
+    def _hip_sample_and_gemm(self, x, offset, gemm_dtype):
+        """Training path on the GPU: hand-written HIP row-gather kernels (omnihd_dcn3x3_sample_*) + one GEMM, in bf16
+        under autocast and in fp32 otherwise."""
         from .. import ops
         B, C, H, W = x.shape
-        xb = x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()               # (B,H,W,C): a view for channels-last x
+        xb = x.to(gemm_dtype).permute(0, 2, 3, 1).contiguous()                   # (B,H,W,C): a view for channels-last x
         ob = offset.float().permute(0, 2, 3, 1).contiguous()                     # (B,Ho,Wo,18), channel = tap*2 + (dy,dx)
         col = ops.dcn3x3_sample(xb, ob, self.stride, self.padding, self.dilation)
-        out = col @ self._grouped_weight().to(torch.bfloat16)
+        out = col @ self._grouped_weight().to(gemm_dtype)
         Ho, Wo = ob.shape[1:3]
         return out.view(B, Ho, Wo, self.out_channels).permute(0, 3, 1, 2).to(x.dtype)
 

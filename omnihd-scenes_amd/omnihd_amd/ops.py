@@ -685,6 +685,25 @@ def bf16_of(weight):
     return shadow
 
 
+class _Bf16Weight(torch.autograd.Function):
+    """The cached bf16 image of an fp32 master weight as a differentiable function of it (gradient cast back)."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        ctx.wdtype = weight.dtype
+        return bf16_of(weight).view_as(weight)          # a fresh alias: the cached tensor itself must not get a grad_fn
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.wdtype)
+
+
+def bf16_weight(weight):
+    if weight.dtype == torch.bfloat16 or not weight.is_cuda:
+        return weight
+    return _Bf16Weight.apply(weight) if weight.requires_grad and torch.is_grad_enabled() else bf16_of(weight)
+
+
 def refresh_bf16_shadows():
     """Bring every stale bf16 image up to date with one fused copy; returns how many were refreshed."""
     src, dst, keys = [], [], []
@@ -851,16 +870,17 @@ def deconv_hip_wgrad(x, weight, k):
 # deformable 3x3 sampling (DepthNet's DCN)
 # ---------------------------------------------------------------------------------------------
 class _DcnSample(torch.autograd.Function):
-    """x (B,H,W,C) bf16, offset (B,Ho,Wo,18) fp32 -> col (B*Ho*Wo, 9*C) bf16 (row gathers, no atomics)."""
+    """x (B,H,W,C) bf16 or fp32, offset (B,Ho,Wo,18) fp32 -> col (B*Ho*Wo, 9*C) in x's type (row gathers, no atomics)."""
 
     @staticmethod
     def forward(ctx, x, offset, stride, pad, dil):
         B, H, W, C = x.shape
         Ho, Wo = offset.shape[1:3]
-        col = torch.empty((B * Ho * Wo, 9 * C), dtype=torch.bfloat16, device=x.device)
+        col = torch.empty((B * Ho * Wo, 9 * C), dtype=x.dtype, device=x.device)
+        sfx = "_f32" if x.dtype == torch.float32 else ""
         with torch.cuda.device(x.device):
-            check(lib().omnihd_dcn3x3_sample_fwd(_ptr(x), _ptr(offset), _ptr(col), B, H, W, C, stride, pad, dil, _stream()),
-                  "omnihd_dcn3x3_sample_fwd")
+            check(getattr(lib(), "omnihd_dcn3x3_sample_fwd" + sfx)(_ptr(x), _ptr(offset), _ptr(col), B, H, W, C, stride, pad,
+                                                                   dil, _stream()), "omnihd_dcn3x3_sample_fwd" + sfx)
         ctx.save_for_backward(x, offset)
         ctx.geo = (stride, pad, dil)
         return col
@@ -870,19 +890,21 @@ class _DcnSample(torch.autograd.Function):
         x, offset = ctx.saved_tensors
         stride, pad, dil = ctx.geo
         B, H, W, C = x.shape
-        gcol = gcol.contiguous().to(torch.bfloat16)
+        gcol = gcol.contiguous().to(x.dtype)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         goff = torch.empty_like(offset) if ctx.needs_input_grad[1] else None
         radius = offset.abs().amax().ceil().to(torch.int32).reshape(1)          # stays on the device
+        sfx = "_f32" if x.dtype == torch.float32 else ""
         with torch.cuda.device(x.device):
-            check(lib().omnihd_dcn3x3_sample_bwd(_ptr(x), _ptr(offset), _ptr(gcol), _ptr(radius), _ptr(gx), _ptr(goff),
-                                                 B, H, W, C, stride, pad, dil, _stream()), "omnihd_dcn3x3_sample_bwd")
+            check(getattr(lib(), "omnihd_dcn3x3_sample_bwd" + sfx)(_ptr(x), _ptr(offset), _ptr(gcol), _ptr(radius), _ptr(gx),
+                                                                   _ptr(goff), B, H, W, C, stride, pad, dil, _stream()),
+                  "omnihd_dcn3x3_sample_bwd" + sfx)
         return gx, goff, None, None, None
 
 
 def dcn3x3_sample(x_nhwc, offset_nhwc, stride=1, pad=1, dil=1):
-    if not (x_nhwc.is_cuda and x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous()):
-        raise TypeError("x must be a contiguous (B,H,W,C) bf16 CUDA(HIP) tensor")
+    if not (x_nhwc.is_cuda and x_nhwc.dtype in (torch.bfloat16, torch.float32) and x_nhwc.is_contiguous()):
+        raise TypeError("x must be a contiguous (B,H,W,C) bf16 or fp32 CUDA(HIP) tensor")
     if not (offset_nhwc.dtype == torch.float32 and offset_nhwc.is_contiguous() and offset_nhwc.shape[-1] == 18):
         raise TypeError("offset must be a contiguous (B,Ho,Wo,18) fp32 tensor")
     return _DcnSample.apply(x_nhwc, offset_nhwc, int(stride), int(pad), int(dil))

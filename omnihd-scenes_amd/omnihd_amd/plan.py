@@ -12,6 +12,7 @@ grid, yet the reference rebuilds them in every forward
 for one of two row numberings: ``'bzyx'`` (the reference's (B,Z,Y,X,C) buffer) or ``'byxz'``
 ((B,Y,X,Z,C) memory = the channels-last layout of the s2c tensor (B, Z*C, Y, X)).
 """
+import os
 from dataclasses import dataclass
 
 import torch
@@ -279,10 +280,15 @@ class _PlannedPool(torch.autograd.Function):
     def backward(ctx, out_grad):
         depth, feat = ctx.saved_tensors
         plan = ctx.plan
-        out_grad = out_grad.contiguous().float()
         c = feat.size(-1)
-        if (c == 64 and plan.patch_order is not None and plan.depth_bins > 0 and depth.dim() == 5
-                and plan.n_rows * 256 < 2 ** 32 and _patch_backward()):
+        patch = (c == 64 and plan.patch_order is not None and plan.depth_bins > 0 and depth.dim() == 5
+                 and plan.n_rows * 256 < 2 ** 32 and _patch_backward())
+        if patch and out_grad.dtype != torch.float32 and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0":
+            # the forward's tensors and the backward tables have long left the Infinity Cache: read them ahead on the side
+            # stream while the cast of the incoming gradient runs (bf16 step; in the fp32 step nothing precedes the kernel)
+            ops.prefetch([plan.bp_ranks_depth, plan.bp_ranks_row, depth, feat])
+        out_grad = out_grad.contiguous().float()
+        if patch:
             depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)   # both written densely
             _timed("bwd", lambda: ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat,
                                                                  plan.bp_ranks_depth, plan.bp_ranks_row, plan.pix_ptr,

@@ -333,3 +333,24 @@ def test_torch_syncbn_config_type_is_synchronised_on_the_fused_path(cuda):
         assert all(v < 5e-5 for v in f32.values()), (rank, f32)
         # bf16 convolution + bf16 activations against float64: rounding of the 16-channel products dominates
         assert bf["y"] < 1e-2 and bf["gx"] < 8e-2 and bf["gw"] < 8e-2 and bf["rm"] < 1e-2 and bf["rv"] < 1e-2, (rank, bf)
+
+
+def test_batch_counter_is_kept_on_the_host_and_flushed_into_checkpoints(cuda):
+    """The fused training path does not launch `num_batches_tracked += 1` per layer; the count reaches the buffer when a
+    state dict is taken (what a checkpoint stores is what torch's own BatchNorm would have stored) and a loaded state
+    dict resets the pending count."""
+    from omnihd_amd.mm import bricks
+    bn = torch.nn.BatchNorm2d(64).to(cuda).train()
+    x = torch.randn(2, 64, 8, 10, device=cuda).contiguous(memory_format=torch.channels_last)
+    for _ in range(3):
+        bricks.bn_act(x, bn, relu=True, inplace=False)
+    assert int(bn.state_dict()["num_batches_tracked"]) == 3
+    bricks.bn_act(x, bn, relu=True, inplace=False)
+    sd = {k: v.clone() for k, v in bn.state_dict().items()}
+    assert int(sd["num_batches_tracked"]) == 4
+    bricks.bn_act(x, bn, relu=True, inplace=False)
+    bn.load_state_dict(sd)
+    assert int(bn.state_dict()["num_batches_tracked"]) == 4
+    bn.eval()
+    bricks.bn_act(x, bn, relu=True, inplace=False)               # plain branch: nothing pending, counter untouched
+    assert int(bn.num_batches_tracked) == 4

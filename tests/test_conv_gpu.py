@@ -68,7 +68,7 @@ def test_dcn_hip_sampling_matches_torch_formulation(cuda):
     torch.nn.init.normal_(m.conv_offset.bias, std=1.2)
     x = torch.randn(2, 64, 12, 20, device=cuda).to(torch.bfloat16).float().contiguous(memory_format=torch.channels_last).requires_grad_()
     off = m.conv_offset(x).detach().requires_grad_()
-    a = m._hip_sample_and_gemm(x, off)
+    a = m._hip_sample_and_gemm(x, off, torch.bfloat16)
     b = m._gather_and_gemm(x, off, torch.float32)
     scale = float(b.abs().max())
     assert float((a - b).abs().max()) <= 2e-2 * scale
@@ -77,8 +77,39 @@ def test_dcn_hip_sampling_matches_torch_formulation(cuda):
     gb = torch.autograd.grad(b, [x, off, m.weight], g)
     for u, v, name in zip(ga, gb, ("x", "offset", "weight")):
         assert float((u - v).abs().max()) <= 3e-2 * float(v.abs().max()), name
-    again = m._hip_sample_and_gemm(x, off)
+    again = m._hip_sample_and_gemm(x, off, torch.bfloat16)
     assert torch.equal(a, again)
+
+
+@pytest.mark.parametrize("c,H,W", [(64, 12, 20), (256, 16, 44), (32, 5, 7)])
+def test_dcn_hip_sampling_fp32_matches_torch_formulation(cuda, c, H, W):
+    """The fp32 form of the sampling kernels (the reference's arithmetic; what the fp32 training step runs) against the
+    embedding_bag formulation in fp32: forward, grad wrt input, offsets and weight to fp32 rounding (1e-5 of the largest
+    value; the offset gradient sums C products per sample in a different order: 5e-5)."""
+    from omnihd_amd.mm.dcn import DeformConv2dPack
+    torch.manual_seed(c)
+    m = DeformConv2dPack(c, 64, 3, padding=1, groups=4).to(cuda)
+    torch.nn.init.normal_(m.conv_offset.weight, std=0.05)
+    torch.nn.init.normal_(m.conv_offset.bias, std=1.2)
+    x = torch.randn(2, c, H, W, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+    off = m.conv_offset(x).detach().requires_grad_()
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        a = m._hip_sample_and_gemm(x, off, torch.float32)
+        b = m._gather_and_gemm(x, off, torch.float32)
+        assert a.dtype == torch.float32
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        g = torch.randn_like(b)
+        ga = torch.autograd.grad(a, [x, off, m.weight], g, retain_graph=True)
+        gb = torch.autograd.grad(b, [x, off, m.weight], g)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    for u, v, name in zip(ga, gb, ("x", "offset", "weight")):
+        assert float((u - v).abs().max()) <= 5e-5 * float(v.abs().max()), name
+    y = m(x)                                           # the module takes the HIP path in fp32 too
+    assert y.dtype == torch.float32 and float((y - m._gather_and_gemm(x, m.conv_offset(x), torch.float32)).abs().max()) \
+        <= 1e-5 * float(y.abs().max())
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,stride", [(2, 8, 22, 512, 128, 1), (6, 16, 44, 256, 1024, 1), (1, 9, 13, 128, 256, 2), (3, 7, 5, 2048, 512, 1)])
