@@ -132,6 +132,10 @@ __global__ __launch_bounds__(kBlock) void k_dcn_bwd_off(const T* __restrict__ x,
   }
 }
 
+// The C8 lanes that own one input pixel search its candidate window TOGETHER: lane l tests candidates l, l + C8, ...
+// (candidate = (tap, window position), in the order (tap, yo, xo) ascending), the hits of a round are collected with a
+// ballot and then visited in ascending order by all lanes — four gradient rows in flight.  The summation order is the
+// serial one, so the result does not depend on C8.
 template <typename T, int C8>
 __global__ __launch_bounds__(kBlock) void k_dcn_bwd_in(const float* __restrict__ off, const T* __restrict__ gcol,
                                                        Geo g, const int* __restrict__ radius_ptr, long n_in,
@@ -139,32 +143,66 @@ __global__ __launch_bounds__(kBlock) void k_dcn_bwd_in(const float* __restrict__
   constexpr int G = kBlock / C8;
   const int sub = threadIdx.x % C8, grp = threadIdx.x / C8;
   const int R = *radius_ptr + 1;                      // candidate window half-width
-  for (long q = (long)blockIdx.x * G + grp; q < n_in; q += (long)gridDim.x * G) {
-    const int b = (int)(q / (g.H * g.W));
-    const int rem = (int)(q % (g.H * g.W));
+  const int win = 2 * R + 1;
+  const int n_cand = 9 * win * win;
+  const int shift = (threadIdx.x & 63) / C8 * C8;     // first lane of this group inside its wavefront
+  const unsigned long long gmask = (C8 == 64) ? ~0ull : ((1ull << C8) - 1ull);
+  for (long q0 = (long)blockIdx.x * G; q0 < n_in; q0 += (long)gridDim.x * G) {
+    const long q = q0 + grp;
+    const bool live = q < n_in;                       // whole groups drop out together; ballots stay wave-wide
+    const long qq = live ? q : 0;
+    const int b = (int)(qq / (g.H * g.W));
+    const int rem = (int)(qq % (g.H * g.W));
     const int y = rem / g.W, x = rem % g.W;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < 9; ++t) {
-      const int ky = t / 3, kx = t % 3;
-      // stride 1: the undeformed sample of output pixel (yo, xo) sits at (yo - pad + ky*dil, ...)
-      const int cy = y + g.pad - ky * g.dil, cx = x + g.pad - kx * g.dil;
-      for (int yo = max(cy - R, 0); yo <= min(cy + R, g.Ho - 1); ++yo) {
-        for (int xo = max(cx - R, 0); xo <= min(cx + R, g.Wo - 1); ++xo) {
+    for (int c0 = 0; c0 < n_cand; c0 += C8) {
+      const int idx = c0 + sub;
+      float w = 0.f;
+      long row = 0;
+      if (live && idx < n_cand) {
+        const int t = idx / (win * win), r2 = idx - t * win * win;
+        const int wy = r2 / win, wx = r2 - wy * win;
+        const int ky = t / 3, kx = t - ky * 3;
+        // stride 1: the undeformed sample of output pixel (yo, xo) sits at (yo - pad + ky*dil, ...)
+        const int yo = y + g.pad - ky * g.dil - R + wy, xo = x + g.pad - kx * g.dil - R + wx;
+        if (yo >= 0 && yo < g.Ho && xo >= 0 && xo < g.Wo) {
           const long p = ((long)b * g.Ho + yo) * g.Wo + xo;
-          const float py = (float)(yo * g.stride - g.pad + ky * g.dil) + off[p * 18 + 2 * t];
-          const float px = (float)(xo * g.stride - g.pad + kx * g.dil) + off[p * 18 + 2 * t + 1];
+          const float2 o = *reinterpret_cast<const float2*>(off + p * 18 + 2 * t);
+          const float py = (float)(yo * g.stride - g.pad + ky * g.dil) + o.x;
+          const float px = (float)(xo * g.stride - g.pad + kx * g.dil) + o.y;
           const float ay = fabsf(py - (float)y), ax = fabsf(px - (float)x);
-          if (ay < 1.f && ax < 1.f) {
-            const float w = (1.f - ay) * (1.f - ax);
-            float f[8];
-            ld8(gcol, (size_t)(p * 9 + t) * C8 + sub, f);
+          if (ay < 1.f && ax < 1.f) { w = (1.f - ay) * (1.f - ax); row = p * 9 + t; }
+        }
+      }
+      // a hit with weight exactly 0 adds nothing in the serial order either
+      unsigned long long m = (__ballot(w != 0.f) >> shift) & gmask;
+      while (m) {
+        int src[4];
+        float ws[4];
+        long rows[4];
+        float f[4][8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = fmaf(w, f[c], acc[c]);
+        for (int u = 0; u < 4; ++u) {
+          src[u] = m ? __builtin_ctzll(m) : -1;
+          if (m) m &= m - 1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sl = src[u] < 0 ? 0 : src[u];
+          ws[u] = __shfl(w, sl, C8);
+          rows[u] = __shfl(row, sl, C8);
+          if (src[u] >= 0) ld8(gcol, (size_t)rows[u] * C8 + sub, f[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (src[u] >= 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = fmaf(ws[u], f[u][c], acc[c]);
           }
         }
       }
     }
-    st8(gx, (size_t)q * C8 + sub, acc);
+    if (live) st8(gx, (size_t)q * C8 + sub, acc);
   }
 }
 
