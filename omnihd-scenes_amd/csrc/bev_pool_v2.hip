@@ -1186,8 +1186,10 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
   extern __shared__ float s_dyn[];                 // [0, D*16) depth values of the patch, [D*16, 2*D*16) depth gradients
   const int slot = (int)(blockIdx.x >> 3);
   if (slot >= patches_per_xcd) return;
+  OMNIHD_STAMP(0);
   const int patch = patch_order[(size_t)(blockIdx.x & 7) * patches_per_xcd + slot];
   if (patch < 0) return;
+  OMNIHD_STAMP(1);
   const int tid = threadIdx.x;
   const int sub = tid % C4;
   const int grp = tid / C4;
@@ -1219,7 +1221,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
   ml = max(ml, __shfl_xor(ml, 16));
   ml = max(ml, __shfl_xor(ml, 32));
   const int wave_len = __builtin_amdgcn_readfirstlane(ml);
+  OMNIHD_STAMP(2);
   __syncthreads();
+  OMNIHD_STAMP(3);
 
   const __amdgpu_buffer_rsrc_t og_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)og_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)sub << 4;
@@ -1258,12 +1262,15 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
     if (cb + 8 < wave_len) patch_batch8<8>(og_rsrc, lane_off, rr, dval, x, fg, mydot, sub);
     if (inb) s_dg[dk * kPatch + grp] = mydot;
   }
+  OMNIHD_STAMP(4);
   if (valid) feat_grad4[(size_t)f * C4 + sub] = fg;
   __syncthreads();
+  OMNIHD_STAMP(5);
   for (int i = tid; i < n_cell; i += kBlock) {
     const int d = i / kPatch, px = i % kPatch;
     if (px < npx) depth_grad[img_base + (size_t)d * fhw + px] = s_dg[i];
   }
+  OMNIHD_STAMP(6);
 }
 
 __global__ __launch_bounds__(kBlock) void k_pool_bwd_generic(
@@ -1598,3 +1605,4 @@ extern "C" int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* 
                      patches_per_img, fhw, d_bins, 1.0f / (float)fhw, depth_grad, reinterpret_cast<float4*>(feat_grad));
   return check_launch("bev_pool_v2_bwd_patch");
 }
+

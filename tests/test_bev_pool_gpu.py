@@ -419,6 +419,13 @@ def test_patch_backward_matches_oracle(cuda, fH, fW, B):
     ops.bev_pool_v2_backward_patch(t(og.reshape(n_rows, c), cuda), t(depth, cuda), t(feat, cuda), t(brd, cuda), t(brb, cuda),
                                    pix_ptr, sched.to(cuda), dg2, fg2)
     assert torch.equal(dg, dg2) and torch.equal(fg, fg2)                                # run-to-run identical
+    # the cost-balanced, heaviest-first schedule (what the plan hands to the kernel): same bits
+    sched2 = patch_schedule(B * N, (fH, fW), pix_ptr=pix_ptr).to(cuda)
+    assert sorted(sched2[sched2 >= 0].tolist()) == sorted(sched[sched >= 0].tolist())
+    dg3 = torch.full_like(dg, float("nan")); fg3 = torch.full_like(fg, float("nan"))
+    ops.bev_pool_v2_backward_patch(t(og.reshape(n_rows, c), cuda), t(depth, cuda), t(feat, cuda), t(brd, cuda), t(brb, cuda),
+                                   pix_ptr, sched2, dg3, fg3)
+    assert torch.equal(dg, dg3) and torch.equal(fg, fg3)
 
 
 def test_patch_backward_full_size_against_the_reference_api_kernel(cuda):

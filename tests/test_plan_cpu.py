@@ -105,3 +105,38 @@ def test_patch_schedule_lists_every_patch_once():
         per = sched.numel() // 8
         counts = [(sched[k * per:(k + 1) * per] >= 0).sum().item() for k in range(8)]
         assert max(counts) - min(counts) <= 1                                           # equal work per XCD
+
+
+def test_cost_balanced_patch_schedule_is_a_permutation_with_equal_cost_runs():
+    """With the points per pixel the runs of the patch schedule carry (nearly) equal cost and start with their heaviest
+    4-row blocks; still every patch exactly once."""
+    from omnihd_amd.plan import PATCH, PATCH_FIXED_COST, patch_schedule
+    g = torch.Generator().manual_seed(3)
+    n_img, (fH, fW) = 6, (64, 176)
+    fhw = fH * fW
+    # points per pixel: heavy band in the middle rows of every image, nothing at the top
+    rows = torch.arange(fH).view(1, fH, 1).expand(n_img, fH, fW)
+    lens = (59.0 * torch.exp(-((rows - 40.0) / 12.0) ** 2)).long() + torch.randint(0, 3, (n_img, fH, fW), generator=g)
+    lens[:, :8] = 0
+    pix_ptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.view(-1).cumsum(0)]).int()
+    sched = patch_schedule(n_img, (fH, fW), pix_ptr=pix_ptr)
+    ppi = fhw // PATCH
+    live = sched[sched >= 0]
+    assert sched.numel() % 8 == 0 and sorted(live.tolist()) == list(range(n_img * ppi))
+    cost = lens.view(n_img, ppi, PATCH).sum(-1).view(-1) + PATCH_FIXED_COST
+    per = sched.numel() // 8
+    run_cost = []
+    for k in range(8):
+        run = sched[k * per:(k + 1) * per]
+        run = run[run >= 0].long()
+        assert run.numel() > 0
+        run_cost.append(float(cost[run].sum()))
+        # heaviest first: the first quarter of a run costs more per patch than its last quarter
+        q = max(1, run.numel() // 4)
+        assert float(cost[run[:q]].float().mean()) >= float(cost[run[-q:]].float().mean())
+    assert max(run_cost) <= 1.03 * min(run_cost)
+    # the count-balanced schedule of the same frame is worse
+    flat = patch_schedule(n_img, (fH, fW))
+    per0 = flat.numel() // 8
+    c0 = [float(cost[flat[k * per0:(k + 1) * per0][flat[k * per0:(k + 1) * per0] >= 0].long()].sum()) for k in range(8)]
+    assert max(c0) / min(c0) > max(run_cost) / min(run_cost)
