@@ -282,6 +282,126 @@ __global__ __launch_bounds__(kBlock) void k_sum_slabs(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Three taps per workgroup (3x3, stride 1, pad == dil): the taps (ky, 0..2) of one kernel row multiply the SAME G tile with
+// the three dx-shifted copies of X at the same row offset, so G is streamed once per three taps.  The one-tap kernel keeps
+// 96 KB of operands in flight per CU and is bound by that (12 TB/s out of the L2s at ~2 us of loaded latency = what 24 MB
+// in flight can deliver): the same bytes in flight now feed 1.5x the MFMAs (4 operand tiles per 3 tile products instead
+// of 6).  K-step of 32 pixels (64-byte LDS rows, 16-byte chunks XOR-swizzled by ((row >> 2) & 3): conflict-free
+// ds_read_b128), ring of 4 stages x 4 tiles x 8 KB = 128 KB, one 4-wave workgroup per CU, 192 accumulator registers.
+// Per wave and stage: 2 DMA calls for G + 3 x 2 for X = 8, so vmcnt(16) leaves two younger stages in flight.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBK3 = 32;
+constexpr int kStages3 = 4;
+
+__global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds3(const unsigned short* __restrict__ Gt,
+                                                             const unsigned short* __restrict__ Xt,
+                                                             const unsigned short* __restrict__ zero_page,
+                                                             float* __restrict__ slab, int Cout, int Cin, int Coutp,
+                                                             int Cinp, int M, int Mp, int H, int W, int n_split,
+                                                             int k_per_split, int dil) {
+  __shared__ __attribute__((aligned(16))) unsigned short sm[kStages3][4][kTile][kBK3];   // tile 0 = G, 1..3 = X copies
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tiles_c = Cinp / kTile, tiles_n = Coutp / kTile;
+  int bid = blockIdx.x;
+  const int ct = bid % tiles_c; bid /= tiles_c;
+  const int nt = bid % tiles_n; bid /= tiles_n;
+  const int ky = bid % 3;
+  const int split = bid / 3;
+  const int dy = (ky - 1) * dil;
+  const int k0 = split * k_per_split;
+  const int k1 = min(k0 + k_per_split, Mp);
+
+  // loader: one DMA call = 16 rows of 64 B; wave w owns rows [32w, 32w+32) of every tile: two calls per tile
+  const int lr = lane >> 2;                        // row inside the call
+  const int gch = (lane & 3) ^ ((lane >> 4) & 3);  // global 16-byte chunk this lane fetches (LDS slot lane & 3)
+  const unsigned short* a_row = Gt + (size_t)(nt * kTile + wave * 32 + lr) * Mp;
+  const unsigned short* b_row = Xt + ((size_t)ct * kTile + wave * 32 + lr) * Mp + (ptrdiff_t)dy * W;
+  const size_t copy_pitch = (size_t)Cinp * Mp;
+  int px = (k0 + gch * 8) % W, py = ((k0 + gch * 8) / W) % H;
+
+  auto issue = [&](int k, int stage) {
+    const bool real = k < k1;
+    const bool ok = real && (k + gch * 8 < M) && (py + dy >= 0) && (py + dy < H);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned short* ga = real ? a_row + (size_t)(16 * i) * Mp + k + gch * 8 : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)ga, (lds_ptr_t*)&sm[stage][0][wave * 32 + 16 * i][0], 16, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const unsigned short* gb = ok ? b_row + c * copy_pitch + (size_t)(16 * i) * Mp + k + gch * 8 : zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t*)gb, (lds_ptr_t*)&sm[stage][1 + c][wave * 32 + 16 * i][0], 16, 0, 0);
+      }
+    }
+    px += kBK3; while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
+  };
+
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+
+  issue(k0, 0);
+  issue(k0 + kBK3, 1);
+  issue(k0 + 2 * kBK3, 2);
+  int stage = 0;
+  for (int k = k0; k < k1; k += kBK3) {
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(k + 3 * kBK3, (stage + 3) % kStages3);
+#pragma unroll
+    for (int ks = 0; ks < kBK3 / 16; ++ks) {
+      bf16x8 a[2], b[3][2];
+      const int c = ks * 2 + fhalf;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + frow;
+        const int rb = wn * 64 + i * 32 + frow;
+        a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][(c ^ ((ra >> 2) & 3)) * 8]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          b[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1 + t][rb][(c ^ ((rb >> 2) & 3)) * 8]);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[t][j], acc[t][i][j], 0, 0, 0);
+    }
+    stage = (stage + 1) % kStages3;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* dst = slab + (size_t)split * Cout * 9 * Cin;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = ky * 3 + t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nt * kTile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int cc = ct * kTile + wn * 64 + j * 32 + (lane & 31);
+          if (n < Cout && cc < Cin) dst[((size_t)n * 9 + tap) * Cin + cc] = acc[t][i][j][r];
+        }
+  }
+}
+
 // Row pitch of the pixel-major operands.  A pitch that is a multiple of 1 KiB (38400 px * 2 B = 75 KiB)
 // maps every row of a tile onto the same few L2 channels; an ODD number of 128-byte lines per row
 // rotates the rows over all channels.
@@ -303,6 +423,29 @@ int pick_split(int coutp, int cinp, int mp, int taps) {
 }
 
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// Split of the three-taps kernel: one workgroup per CU is resident (128 KB of LDS), so the launch is a whole number of
+// "rounds" of kCUs workgroups; pick the smallest split whose rounds are within 10 % of the fullest.  0 = too few
+// workgroups to fill three quarters of the chip: the one-tap kernel (two workgroups per CU, three times the tiles) is used.
+int pick_split3(int coutp, int cinp, int mp) {
+  const int tiles = (coutp / kTile) * (cinp / kTile) * 3;
+  int max_s = mp / (kBK * 8);
+  if (max_s > 16) max_s = 16;
+  if (max_s < 1) max_s = 1;
+  if (tiles * max_s < (3 * kCUs) / 4) return 0;
+  auto eff_of = [&](int sp) {
+    const int blocks = tiles * sp;
+    const int rounds = (blocks + kCUs - 1) / kCUs;
+    return blocks >= (3 * kCUs) / 4 ? (double)blocks / ((double)rounds * kCUs) : 0.0;
+  };
+  double best_eff = 0.0;
+  for (int sp = 1; sp <= max_s; ++sp) best_eff = eff_of(sp) > best_eff ? eff_of(sp) : best_eff;
+  if (best_eff <= 0.0) return 0;
+  // every split costs one more fp32 slab written and read back: the smallest split within 10 % of the fullest rounds
+  for (int sp = 1; sp <= max_s; ++sp)
+    if (eff_of(sp) >= 0.9 * best_eff) return sp;
+  return 0;
+}
 
 // 256 zero bytes per device, allocated once: the source of every masked LDS-DMA row (borders, K tail).
 const unsigned short* zero_page_for_current_device() {
@@ -327,6 +470,7 @@ struct WgradPlan {
   int mpix;        // valid extent of the pixel axis
   int mp;          // its padded pitch
   int coutp, cinp, split;
+  int split3;      // split of the three-taps-per-workgroup kernel (mode 0, 3x3), 0 = not applicable
   size_t gt_bytes, xt_bytes, slab_bytes, guard;
 };
 
@@ -351,9 +495,10 @@ bool make_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int k
   }
   p->mp = padded_pixels((size_t)p->mpix);
   p->split = pick_split(p->coutp, p->cinp, p->mp, p->taps);
+  p->split3 = (p->mode == 0 && p->taps == 9) ? pick_split3(p->coutp, p->cinp, p->mp) : 0;
   p->gt_bytes = align_up((size_t)p->coutp * p->mp * 2, 256);
   p->xt_bytes = align_up((size_t)p->copies * p->cinp * p->mp * 2, 256);
-  p->slab_bytes = align_up((size_t)p->split * cout * p->taps * cin * 4, 256);
+  p->slab_bytes = align_up((size_t)(p->split3 > p->split ? p->split3 : p->split) * cout * p->taps * cin * 4, 256);
   p->guard = align_up((size_t)dil * p->wp * 2 + 256, 256);
   return true;
 }
@@ -412,12 +557,22 @@ extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc,
     hipLaunchKernelGGL(k_taps_kmajor, dim3(p.mp / 64, p.cinp / 64, p.taps), dim3(kBlock), 0, st, xs, batch, h, w, cin,
                        p.cinp, ho, wo, p.mp, kw, stride, pad, dil, Xt);
   }
-  const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * p.taps * p.split;
-  hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, p.split > 1 ? slab : dw,
-                     cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, p.split, k_per_split, p.taps, p.mode, dil);
-  if (p.split > 1) {
+  static const bool three_taps = [] { const char* e = getenv("OMNIHD_WGRAD_3TAPS"); return !(e && e[0] == '0'); }();
+  int n_split = p.split;
+  if (p.split3 > 0 && three_taps) {
+    n_split = p.split3;
+    const int k_per_split3 = ((p.mp / kBK + n_split - 1) / n_split) * kBK;
+    const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * 3 * n_split;
+    hipLaunchKernelGGL(k_wgrad_mfma_glds3, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, n_split > 1 ? slab : dw, cout,
+                       cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil);
+  } else {
+    const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * p.taps * p.split;
+    hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, p.split > 1 ? slab : dw,
+                       cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, p.split, k_per_split, p.taps, p.mode, dil);
+  }
+  if (n_split > 1) {
     const size_t n = (size_t)cout * p.taps * cin;
-    hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, p.split, n, dw);
+    hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, n_split, n, dw);
   }
   return check_launch("conv_wgrad_bf16");
 }

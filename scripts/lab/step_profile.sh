@@ -20,10 +20,10 @@ busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ss)
 print(f"steady region: {len(ss)} launches over $N steps = {len(ss)/$N:.0f} per step; wall {(t1-t0)/1e6/$N:.2f} ms/step; sum of kernel durations {busy/1e6/$N:.2f} ms/step")
 agg = collections.defaultdict(lambda: [0, 0])
 for r in ss:
-    k = r["Kernel_Name"].split("(")[0][:70]
+    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
     agg[k][0] += 1; agg[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 print("--- by GPU time")
-for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{t/1e6/$N:7.3f} ms/step {c/$N:7.1f} calls/step  {k}")
 print("--- by launch count")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:22]:
