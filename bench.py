@@ -506,7 +506,7 @@ def main():
             e2, sp2, _ = runs["bf16"]
             line["bf16_autocast"] = {"value": round(a.batch * world * a.steps / e2, 3), "unit": "frames/s",
                                      "ms_per_step": round(e2 / a.steps * 1e3, 4), "step_ms": sp2,
-                                     "note": "dense convolutions under bf16 autocast (MIOpen + the MFMA weight-gradient chain), "
+                                     "note": "dense convolutions under bf16 autocast (our implicit-GEMM MFMA kernels for forward / data / weight gradient or MIOpen, measured per geometry), "
                                              "pooling / voxelisation / losses fp32; deviation from the fp32 step bounded in "
                                              "tests/test_detector_gpu.py::test_bf16_step_deviation_from_the_fp32_step"}
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would sit in the
