@@ -736,19 +736,30 @@ _CONV_CHOICE = {}
 _CONV_IMPLS = ("hip", "hip128x256", "miopen")
 
 
-def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=None):
+def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=None, n_out=None, k=None):
     """Run one direction ('fwd': x = input, w_cl = weights; 'dgrad': x = grad_out, w_cl = data-gradient weights) with the
-    implementation chosen for its geometry."""
-    k = w_cl.shape[2]
+    implementation chosen for its geometry.  ``w_cl`` may be a function returning the weights (with ``n_out`` = their
+    output channels and ``k``): the data gradient's mirrored / transposed weights are then only made when our kernel runs."""
+    lazy = callable(w_cl)
+    weights = (lambda: w_cl()) if lazy else (lambda: w_cl)
+    if not lazy:
+        n_out, k = w_cl.shape[0], w_cl.shape[2]
     policy = os.environ.get("OMNIHD_CONV_POLICY", "tune")
-    ours = (x.dtype == torch.bfloat16 and conv_fwd_supported(x.shape, w_cl.shape[0], k, stride[0], padding[0], dilation[0])
+    ours = (x.dtype == torch.bfloat16 and conv_fwd_supported(x.shape, n_out, k, stride[0], padding[0], dilation[0])
             and stride[0] == stride[1] and padding[0] == padding[1] and dilation[0] == dilation[1])
     if not ours or policy == "miopen":
         return run_miopen()
-    run_hip = lambda tile: conv_fwd(x, w_cl, bias, dilation[0], tile)          # fp32 bias added before the one rounding
+    made = []
+
+    def run_hip(tile, timing=False):                        # fp32 bias added before the one rounding
+        if timing and lazy:                                 # the measurement pays for the weight transform every time
+            return conv_fwd(x, weights(), bias, dilation[0], tile)
+        if not made:
+            made.append(weights())
+        return conv_fwd(x, made[0], bias, dilation[0], tile)
     if policy == "hip":
         return run_hip(0)
-    key = (direction, tuple(x.shape), w_cl.shape[0], k, dilation[0], x.device.index)
+    key = (direction, tuple(x.shape), n_out, k, dilation[0], x.device.index)
     choice = _CONV_CHOICE.get(key)
     if choice is None:
         def clock(fn):
@@ -763,7 +774,7 @@ def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=N
             return e0.elapsed_time(e1)
         # "hip": the library's own pick (3x3 with dilation <= 8 at BEV sizes: the row-shift kernel, else the 256x128 tile,
         # 128x128 for small problems); "hip128x256": the wide-N tile
-        times = {"hip": clock(lambda: run_hip(0)), "hip128x256": clock(lambda: run_hip(254)), "miopen": clock(run_miopen)}
+        times = {"hip": clock(lambda: run_hip(0, True)), "hip128x256": clock(lambda: run_hip(254, True)), "miopen": clock(run_miopen)}
         choice = min(times, key=times.get)
         _CONV_CHOICE[key] = choice
     if choice == "miopen":
@@ -809,8 +820,8 @@ class _ConvHipWgrad(torch.autograd.Function):
             if (g.dtype == torch.bfloat16 and stride[0] == 1 and weight.shape[0] % 64 == 0 and weight.shape[1] % 8 == 0
                     and k in (1, 3) and padding[0] == dilation[0] * (k // 2)
                     and os.environ.get("OMNIHD_CONV_POLICY", "tune") != "miopen"):
-                wt = conv_dgrad_weights(weight.contiguous(memory_format=torch.channels_last))
-                gx = _conv_impl("dgrad", g, wt, stride, padding, dilation, run_miopen)
+                wt = lambda: conv_dgrad_weights(weight.contiguous(memory_format=torch.channels_last))
+                gx = _conv_impl("dgrad", g, wt, stride, padding, dilation, run_miopen, n_out=weight.shape[1], k=k)
             else:
                 gx = run_miopen()
         if ctx.needs_input_grad[1]:
