@@ -140,3 +140,27 @@ def test_head_test_time_branch_matches_the_vendored_head():
     assert torch.equal(seen["dir_scores"], t("tt_nms_in_dir_scores")) and seen["thr_max"] == g["tt_nms_in_thr_max"].tolist()
     assert torch.allclose(boxes.tensor, t("tt_boxes"), rtol=1e-6, atol=1e-6)
     assert torch.allclose(scores, t("tt_scores"), rtol=1e-6, atol=1e-7) and torch.equal(labels, t("tt_labels"))
+
+
+def test_lazy_batch_counter_reaches_state_dict_and_resets_on_load():
+    """bricks._count_batch keeps `num_batches_tracked` increments on the host (no kernel per layer and step on the fused
+    GPU path); a state dict carries the value torch's own BatchNorm would have stored, loading one drops pending counts,
+    deep copies keep their own counters."""
+    import copy
+    from omnihd_amd.mm import bricks
+    bn = torch.nn.BatchNorm2d(8)
+    for _ in range(3):
+        bricks._count_batch(bn)
+    assert int(bn.num_batches_tracked) == 0 and bn._omnihd_pending_batches == 3
+    twin = copy.deepcopy(bn)
+    bricks._count_batch(twin)
+    assert int(bn.state_dict()["num_batches_tracked"]) == 3 and bn._omnihd_pending_batches == 0
+    assert int(twin.state_dict()["num_batches_tracked"]) == 4
+    bricks._count_batch(bn)
+    bn.load_state_dict(twin.state_dict())
+    assert bn._omnihd_pending_batches == 0 and int(bn.state_dict()["num_batches_tracked"]) == 4
+    # the plain (torch) branch of bn_act flushes before torch's own forward reads the counter
+    bricks._count_batch(bn)
+    bn.train()
+    bricks.bn_act(torch.randn(2, 8, 3, 3), bn, relu=False)
+    assert int(bn.num_batches_tracked) == 6          # 4 + 1 pending + torch's own increment
