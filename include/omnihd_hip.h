@@ -431,6 +431,13 @@ int omnihd_bn_train_bwd_f32(const float* gy, const float* y_mask, int relu_from_
                             const float* consts4c, float* gx, float* gres, float* sums2c, float* out5c, long long rows,
                             int c, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Column sums of a row-major [rows][c] bf16 (is_f32 = 0) or fp32 matrix for ANY c, in fp32, two stages in a fixed order:
+ * the bias gradient of a convolution whose channel count is not a multiple of 8 (sum over N, H, W of the NHWC output
+ * gradient; torch's reduction takes 0.36 ms for DepthNet's 59 depth logits at 6 x 64 x 176).                          */
+size_t omnihd_column_sums_workspace_bytes(long long rows, int c);
+int omnihd_column_sums(const void* a, int is_f32, long long rows, int c, float* sums, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Radar input format: sweep merge + ego-motion compensation on the device
  * ---------------------------------------------------------------------------------------- */

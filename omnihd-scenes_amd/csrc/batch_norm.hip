@@ -242,6 +242,93 @@ int plan_blocks(long long rows, int c8, long long* rows_per_block) {
 
 using namespace omnihd;
 
+// ---------------------------------------------------------------------------------------------------------------
+// Column sums of a row-major [rows][c] matrix for ANY c (scalar element loads, lanes along the columns): the bias gradient
+// of a convolution whose channel count is not a multiple of 8.  torch's reduction of an NHWC gradient with an odd channel
+// count (DepthNet's 59 depth logits) takes 0.36 ms for 8 MB.  Two stages in a fixed order, like the vector kernels above.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float elem_f32(const T* p, size_t i);
+template <>
+__device__ __forceinline__ float elem_f32<bf16_t>(const bf16_t* p, size_t i) { return bf2f(p[i]); }
+template <>
+__device__ __forceinline__ float elem_f32<float>(const float* p, size_t i) { return p[i]; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_partial(const T* __restrict__ a, float* __restrict__ partial, long long rows,
+                                                     int c, int cw, long long rows_per_block) {
+  __shared__ float red[256];
+  const int t = threadIdx.x;
+  const int rl_n = 256 / cw;                        // row lanes of the workgroup
+  const int cl = t % cw, rl = t / cw;
+  const long long begin = (long long)blockIdx.x * rows_per_block;
+  const long long end = min(begin + rows_per_block, rows);
+  for (int c0 = 0; c0 < c; c0 += cw) {              // one pass per strip of cw columns (one pass for c <= 128)
+    const int col = c0 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < c && rl < rl_n) {
+      long long r = begin + rl;
+      for (; r + 3 * rl_n < end; r += 4 * rl_n) {
+        s0 += elem_f32<T>(a, (size_t)r * c + col);
+        s1 += elem_f32<T>(a, (size_t)(r + rl_n) * c + col);
+        s2 += elem_f32<T>(a, (size_t)(r + 2 * rl_n) * c + col);
+        s3 += elem_f32<T>(a, (size_t)(r + 3 * rl_n) * c + col);
+      }
+      for (; r < end; r += rl_n) s0 += elem_f32<T>(a, (size_t)r * c + col);
+    }
+    red[t] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && col < c) {
+      float s = red[cl];
+      for (int k = 1; k < rl_n; ++k) s += red[k * cw + cl];
+      partial[(size_t)blockIdx.x * c + col] = s;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ partial, int n_blocks, int c, float* __restrict__ sums) {
+  const int out = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (out >= c) return;
+  float s = 0.f;
+  for (int b = lane; b < n_blocks; b += 64) s += partial[(size_t)b * c + out];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) sums[out] = s;
+}
+
+constexpr int kColBlocks = 512;
+
+extern "C" size_t omnihd_column_sums_workspace_bytes(long long rows, int c) {
+  (void)rows;
+  return c > 0 ? (size_t)kColBlocks * c * sizeof(float) : 0;
+}
+
+extern "C" int omnihd_column_sums(const void* a, int is_f32, long long rows, int c, float* sums, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  OMNIHD_REQUIRE(rows > 0 && c > 0, "sizes");
+  OMNIHD_REQUIRE(a && sums && workspace, "null pointer");
+  OMNIHD_REQUIRE(workspace_bytes >= omnihd_column_sums_workspace_bytes(rows, c), "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int cw = 32;
+  while (cw < c && cw < 256) cw <<= 1;              // lanes along the columns: 32, 64, 128 or 256
+  long long per = (rows + kColBlocks - 1) / kColBlocks;
+  const int rl_n = 256 / cw;
+  if (per < 4 * rl_n) per = 4 * rl_n;               // at least one unrolled trip per row lane
+  const int blocks = (int)((rows + per - 1) / per);
+  float* partial = static_cast<float*>(workspace);
+  if (is_f32) {
+    hipLaunchKernelGGL((k_col_partial<float>), dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a), partial, rows, c, cw,
+                       per);
+  } else {
+    hipLaunchKernelGGL((k_col_partial<bf16_t>), dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t*>(a), partial, rows, c,
+                       cw, per);
+  }
+  hipLaunchKernelGGL(k_col_reduce, dim3((c + 3) / 4), dim3(256), 0, st, partial, blocks, c, sums);
+  return check_launch("column_sums");
+}
+
 extern "C" size_t omnihd_bn_workspace_bytes(long long rows, int c) {
   if (rows <= 0 || c <= 0 || c % 8 || c > 2048) return 0;
   long long per;

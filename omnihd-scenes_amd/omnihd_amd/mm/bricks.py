@@ -178,6 +178,14 @@ class BevConv2d(nn.Conv2d):
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             if ops.conv_wgrad_supported(xb, weight, self.stride, self.padding, self.dilation):
                 return ops.conv_hip_wgrad(xb, weight, bias, self.stride, self.padding, self.dilation)
+        if bias is not None and x.is_cuda and weight.shape[0] % 8 != 0 and bias.requires_grad and torch.is_grad_enabled():
+            # odd channel counts (DepthNet's 59 depth logits): the bias is still added inside the convolution, its gradient
+            # comes from the column-sum kernel instead of torch's element-wise NHWC reduction (0.36 ms -> 10 us)
+            from .. import ops
+            y = super()._conv_forward(x, weight, bias.detach())
+            if ops.bias_grad_supported(y, bias):
+                return ops._BiasGrad.apply(y, bias)
+            return super()._conv_forward(x, weight, bias)
         return super()._conv_forward(x, weight, bias)
 
 
@@ -203,7 +211,9 @@ def use_bev_conv(module):
     n = 0
     for m in module.modules():
         if type(m) is nn.Conv2d and m.groups == 1 and m.kernel_size in ((1, 1), (3, 3)) \
-                and m.in_channels % 8 == 0 and m.out_channels % 8 == 0:
+                and m.in_channels % 8 == 0 and (m.out_channels % 8 == 0 or m.bias is not None):
+            # (an output channel count that is not a multiple of 8 stays on MIOpen; the class then only takes over the
+            # bias gradient, which torch reduces element by element for such widths)
             m.__class__ = BevConv2d
             n += 1
         elif type(m) is nn.ConvTranspose2d and m.groups == 1 and m.kernel_size == m.stride and m.bias is None:

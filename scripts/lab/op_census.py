@@ -17,6 +17,7 @@ for _ in range(4):
 torch.cuda.synchronize()
 torch.autograd.set_multithreading_enabled(False)
 counts = collections.Counter()
+reductions = []
 SKIP = ("aten.view", "aten.permute", "aten.detach", "aten.t.", "aten.expand", "aten.reshape", "aten._unsafe_view", "aten.alias",
         "aten.slice", "aten.select", "aten.unsqueeze", "aten.squeeze", "aten.transpose", "aten.as_strided", "aten.unbind",
         "aten.split", "aten.sym_", "aten.is_", "aten.stride", "aten.size", "aten.empty", "aten.new_empty", "aten.lift_fresh",
@@ -33,6 +34,9 @@ class Census(TorchDispatchMode):
                     site = f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} {fr.name}"
                     break
             counts[(name, site)] += 1
+            if any(k in name for k in ("aten.sum", "aten.mean", "aten.linalg_vector_norm", "aten.norm", "aten.amax", "aten.max")):
+                shapes = [(tuple(a.shape), str(a.dtype).replace("torch.", ""), a.stride()) for a in args if torch.is_tensor(a)]
+                reductions.append((name, site, shapes, [a for a in args[1:] if not torch.is_tensor(a)]))
         return func(*args, **(kwargs or {}))
 
 
@@ -47,3 +51,8 @@ for name, c in by_op.most_common(28):
     print(f"{c:5d}  {name}")
     for (n2, site), c2 in sorted(((k, v) for k, v in counts.items() if k[0] == name), key=lambda kv: -kv[1])[:6]:
         print(f"        {c2:4d}  {site}")
+
+print("--- reductions with big inputs")
+for name, site, shapes, rest in reductions:
+    if shapes and max((torch.tensor(sh[0]).prod().item() if sh[0] else 1) for sh in shapes) >= 1 << 20:
+        print(name, site, shapes, rest)

@@ -25,6 +25,16 @@ for r in ss:
 print("--- by GPU time")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{t/1e6/$N:7.3f} ms/step {c/$N:7.1f} calls/step  {k}")
+import os
+probe = os.environ.get("STEP_PROFILE_PROBE")           # print the neighbours of the first steady-state launch matching this
+if probe:
+    short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "")[:150]
+    hits = [i for i, r in enumerate(ss) if probe in r["Kernel_Name"]][:2]
+    for i in hits:
+        print("--- neighbours of", probe)
+        for j in range(max(0, i - 5), min(len(ss), i + 4)):
+            r = ss[j]
+            print(("  >> " if j == i else "     ") + f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp']))/1e3:8.1f} us  grid {r.get('Grid_Size', '?')}  {short(r['Kernel_Name'])}")
 print("--- by launch count")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:22]:
     print(f"{c/$N:7.1f} calls/step {t/1e6/$N:7.3f} ms/step  {k}")

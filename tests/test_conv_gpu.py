@@ -316,3 +316,42 @@ def test_igemm_conv_forward_and_data_gradient_match_fp32_reference(cuda, B, H, W
         yr.backward(gy.float())
         assert float((gx.float() - xr.grad).norm() / xr.grad.norm()) < 3e-3
         assert float((gx.float() - xr.grad).abs().max()) <= 2 ** -7 * float(xr.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,c", [(67584, 59), (4099, 123), (513, 7), (2000, 300), (3, 1)])
+def test_column_sums_any_width(cuda, dtype, rows, c):
+    """omnihd_column_sums (bias gradient for channel counts that are not multiples of 8) against the float64 sums."""
+    from omnihd_amd import ops
+    a = torch.randn(rows, c, device=cuda, generator=torch.Generator(device=cuda).manual_seed(rows + c)).to(dtype)
+    got = ops.column_sums(a)
+    want = a.double().sum(0)
+    scale = float(a.double().abs().sum(0).max())
+    assert got.dtype == torch.float32 and got.shape == (c,)
+    assert float((got.double() - want).abs().max()) <= 2e-6 * scale
+    assert torch.equal(got, ops.column_sums(a))                        # fixed order: run-to-run identical
+
+
+@pytest.mark.parametrize("autocast", [True, False])
+def test_odd_channel_conv_bias_gradient(cuda, autocast):
+    """A BevConv2d with 59 output channels (DepthNet's depth logits): same output and the same three gradients as
+    nn.Conv2d — its bias gradient comes from the column-sum kernel."""
+    from omnihd_amd.mm.bricks import BevConv2d
+    torch.manual_seed(3)
+    ref = torch.nn.Conv2d(64, 59, 1, bias=True).to(cuda).to(memory_format=torch.channels_last)
+    m = BevConv2d(64, 59, 1, bias=True).to(cuda).to(memory_format=torch.channels_last)
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(3, 64, 10, 14, device=cuda).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(3, 59, 10, 14, device=cuda)
+    outs = []
+    for mod in (m, ref):
+        xi = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            y = mod(xi)
+        grads = torch.autograd.grad(y, [xi, mod.weight, mod.bias], g.to(y.dtype))
+        outs.append((y, *grads))
+    assert "BiasGrad" in type(outs[0][0].grad_fn).__name__
+    tol = 2e-2 if autocast else 1e-5
+    for a, b in zip(*outs):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        assert float((a.float() - b.float()).abs().max()) <= tol * float(b.float().abs().max())

@@ -164,3 +164,28 @@ def test_lazy_batch_counter_reaches_state_dict_and_resets_on_load():
     bn.train()
     bricks.bn_act(torch.randn(2, 8, 3, 3), bn, relu=False)
     assert int(bn.num_batches_tracked) == 6          # 4 + 1 pending + torch's own increment
+
+
+def test_aspp_broadcast_branch_has_the_gradient_of_a_plain_expand(monkeypatch):
+    """ASPP's image-pooling branch is broadcast through a custom function (packed reduction in its backward on the GPU);
+    its gradients equal those of `pooled.expand(...)`."""
+    import projects.mmdet3d_plugin.bevfusion.detectors.cam_stream_lss_bevpoolv2_depthnet as mod
+    torch.manual_seed(0)
+    m = mod.ASPP(16, 16, norm_cfg=NORM).train()
+    m.dropout.p = 0.0
+    x = torch.randn(2, 16, 7, 9, requires_grad=True)
+    g = torch.randn(2, 16, 7, 9)
+    params = [p for p in m.parameters()]
+    y1 = m(x)
+    got = torch.autograd.grad(y1, [x] + params, g)
+
+    class Plain:
+        @staticmethod
+        def apply(pooled, h, w):
+            return pooled.expand(-1, -1, h, w)
+    monkeypatch.setattr(mod, "_BroadcastHW", Plain)
+    y2 = m(x)
+    want = torch.autograd.grad(y2, [x] + params, g)
+    assert torch.equal(y1, y2)
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
