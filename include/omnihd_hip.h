@@ -104,10 +104,14 @@ int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
  * (rf = (rd / (d_bins*fhw)) * fhw + rd % fhw, i.e. depth (B,N,D,fH,fW) and feat (B,N,fH,fW,C) of the same frames)
  * and the closing point of every output row comes from row_ptr.  tile_desc: 8*k slots as above (required).
  * n_feat_rows = B*N*fH*fW, the number of rows of `feat` (the kernel gathers them with range-checked buffer loads:
- * n_feat_rows*c*4 must stay below 2 GiB; 0 = unknown selects the first-generation kernel with 64-bit addressing). */
+ * n_feat_rows*c*4 must stay below 2 GiB; 0 = unknown selects the first-generation kernel with 64-bit addressing).
+ * empty_rows_kept != 0: `out` is the buffer of an earlier launch with the SAME tables (or a zero-filled one) that nobody
+ * has written to since — its empty rows (no point falls into them: a property of the tables) are zero already and are
+ * not stored again; only the rows that collect points are written (at R1: 94 MB instead of 157 MB per launch).  The
+ * result in `out` is the same dense tensor either way.  Needs n_feat_rows > 0. */
 int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int* ranks_depth, const int* row_ptr,
                                 const int* tile_desc, int n_tiles, float* out, int c, int n_rows, int n_points,
-                                int d_bins, int fhw, int n_feat_rows, void* stream);
+                                int d_bins, int fhw, int n_feat_rows, int empty_rows_kept, void* stream);
 
 /* Schedule descriptors for the call above from a tile table (omnihd_csr_tiles) and an optional
  * tile order (8*ceil(n_tiles/8) ints, -1 = idle slot, NULL = tiles in index order).          */
@@ -350,6 +354,30 @@ int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, const float* bi
 /* wt[c,k-1-ky,k-1-kx,n] = w[n,ky,kx,c]: the weights with which the DATA GRADIENT of the convolution above is the same
  * convolution applied to the output gradient:  omnihd_conv_fwd_bf16(gout, wt, NULL, gx, batch, h, w, cout, cin, ...).  */
 int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Depth-head epilogue of the LSS camera stream: softmax over D + depth / context split + pooling layouts
+ * ref: CamEncode.get_depth_dist / get_depth_feat  bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:134-143
+ *      (x[:, :D].softmax(dim=1), x[:, D:D+C]), the layout copy in front of the pooling  :290
+ *      (feat.permute(0,1,3,4,2).contiguous()) and the fp32 casts of ops/bev_pool_v2/bev_pool.py:20-21.
+ * ---------------------------------------------------------------------------------------- */
+
+/* logits  [n_img*fhw rows, d_bins] with row pitch ld_logits ELEMENTS (channels-last depth logits; the pitch lets a channel
+ *         slice of a wider tensor be passed), context [rows, c] with pitch ld_context, both bf16 (is_f32 = 0) or fp32.
+ * depth      [n_img, d_bins, fhw] f32 = softmax over d_bins per pixel  (the (B,N,D,fH,fW) tensor bev_pool_v2 gathers from)
+ * depth_rows [rows, d_bins]       f32, the same values pixel-major (what the KL depth loss reads), or NULL
+ * feat       [rows, c]            f32 = the context rows               (the (B,N,fH,fW,C) tensor bev_pool_v2 gathers from);
+ *            context == NULL skips it (an fp32, packed context tensor IS feat already).
+ * fp32 arithmetic: exp(x - max) / sum.  c % 4 == 0, d_bins <= 160, n_img <= 65535.                                        */
+int omnihd_depth_head_fwd(const void* logits, long long ld_logits, const void* context, long long ld_context, int is_f32,
+                          int n_img, int fhw, int d_bins, int c, float* depth, float* depth_rows, float* feat,
+                          void* stream);
+/* Backward: g = g_depth [n_img, d_bins, fhw] (+ g_rows [rows, d_bins]), either may be NULL;
+ * g_logits[p][d] = y * (g - sum_d g * y) with y = depth (the forward output), written with row pitch ld_g_logits in the
+ * logits' element type; g_context = g_feat cast to that type (pitch ld_g_context), skipped when g_context == NULL.       */
+int omnihd_depth_head_bwd(const float* depth, const float* g_depth, const float* g_rows, const float* g_feat, int is_f32,
+                          int n_img, int fhw, int d_bins, int c, void* g_logits, long long ld_g_logits, void* g_context,
+                          long long ld_g_context, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frozen-BatchNorm epilogue of a convolution (image backbone, bevfusion.py:76-85)

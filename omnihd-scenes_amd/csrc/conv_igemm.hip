@@ -22,6 +22,15 @@
 // operand byte) for the BEV-sized layers, 128x128 with 4 wavefronts for narrow ones.  fp32 accumulation, one rounding to
 // bf16 in the epilogue (+ optional fp32 bias).  Workgroups are numbered so that one XCD keeps ONE band of output channels:
 // its weight slab (TN x K bf16 = 2.4 MB for K = 9216) stays in that XCD's 4 MiB L2 while the activations stream by.
+//
+// SPLIT = true (round 3): the same kernels at fp32-grade accuracy for the reference-precision (fp32) training step.  Every
+// fp32 operand is handed over as TWO bf16 planes, hi = bf16(v) and lo = bf16(v - hi) (omnihd_split_f32), and a product is
+//     x * w  ~=  x_hi*w_hi + x_hi*w_lo + x_lo*w_hi            (fp32 accumulation; the dropped x_lo*w_lo is 2^-16 of the product)
+// i.e. three bf16 MFMAs instead of one fp32 MFMA that runs at 1/16 of their rate.  One LDS row (128 B) then holds 32 channels
+// of the hi plane followed by the same 32 channels of the lo plane — the LDS-DMA source address is per lane, so the loader
+// only picks the plane by the 16-byte slot — and everything else (stage ring, swizzle, DMA call counts, waits) is unchanged:
+// a K-step covers 32 channels, reads 8 fragments (4 hi, 4 lo) per 16-deep slice and issues 12 MFMAs on them (0.67 LDS reads
+// per MFMA against 1.0 in the bf16 kernel, which is bound by the bytes streamed into LDS).  The result is written in fp32.
 #include "common.h"
 #include <type_traits>
 
@@ -41,12 +50,13 @@ __device__ __forceinline__ unsigned short f2bf_rn(float f) {
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// ABL (lab only, tile codes 251/252 of omnihd_conv_fwd_bf16): 1 = no MFMAs (pure operand streaming), 2 = no LDS-DMA (pure MFMA + LDS reads)
-template <int WM, int WN, int STAGES, bool SPREAD, bool PRIO = false, int ABL = 0>
+template <int WM, int WN, int STAGES, bool SPREAD, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
-    const float* __restrict__ bias, unsigned short* __restrict__ Y, int M, int H, int W, int Cin, int Cout, int ksize,
-    int dil, int tiles_m, int tiles_n, int tiles_per_xcd) {
+    const float* __restrict__ bias, void* __restrict__ Yv, int M, int H, int W, int Cin, int Cout, int ksize,
+    int dil, int tiles_m, int tiles_n, int tiles_per_xcd, const unsigned short* __restrict__ X2 = nullptr,
+    const unsigned short* __restrict__ Wt2 = nullptr) {
+  constexpr int kCS = SPLIT ? 32 : 64;            // channels per K-step
   constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN;
   constexpr int A_CALLS = TM / (8 * NW), B_CALLS = TN / (8 * NW);     // 8-row LDS-DMA calls per wavefront and stage
   constexpr int CALLS = A_CALLS + B_CALLS;
@@ -94,24 +104,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
   int k_tap = 0, k_c = 0;                         // position of the NEXT K-step to issue
   // one LDS-DMA call (8 rows x 128 B) of the K-step at (k_tap, k_c): calls 0..A_CALLS-1 fetch A rows, the rest B rows
   auto issue_call = [&](int stage, bool real, int call) {
-    if (ABL == 2) return;
     const int c = (call & 1) ? (c_even ^ 4) : c_even;          // A_CALLS is even: the parity of a B call is that of its index
+    // SPLIT: slots 0-3 of the row come from the hi plane, slots 4-7 from the lo plane (the same 32 channels)
+    const ptrdiff_t lo_plane_a = SPLIT && c >= 4 ? X2 - X : 0, lo_plane_b = SPLIT && c >= 4 ? Wt2 - Wt : 0;
+    const int cc = SPLIT ? (c & 3) : c;
     if (call < A_CALLS) {
       const int i = call;
       const int dy = (k_tap / ksize - half) * dil, dx = (k_tap % ksize - half) * dil;
       const bool ok = real && (unsigned)(a_y[i] + dy) < (unsigned)H && (unsigned)(a_x[i] + dx) < (unsigned)W;
-      const unsigned short* g = ok ? X + (a_pix[i] + (ptrdiff_t)dy * W + dx) * Cin + k_c + c * 8 : zero_page;
+      const unsigned short* g = ok ? X + lo_plane_a + (a_pix[i] + (ptrdiff_t)dy * W + dx) * Cin + k_c + cc * 8 : zero_page;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][wave * (8 * A_CALLS) + 8 * i][0], 16, 0, 0);
     } else {
       const int i = call - A_CALLS;
-      const unsigned short* g = (real && b_row[i]) ? b_row[i] + (size_t)k_tap * Cin + k_c + c * 8 : zero_page;
+      const unsigned short* g = (real && b_row[i]) ? b_row[i] + lo_plane_b + (size_t)k_tap * Cin + k_c + cc * 8 : zero_page;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][TM + wave * (8 * B_CALLS) + 8 * i][0], 16, 0, 0);
     }
   };
   // channels OUTER, taps INNER: the nine taps of one 64-channel slice read the same pixels' 128-byte lines (shifted), so a
   // line fetched for the first tap is an L2 hit for the other eight; with taps outer every tap re-fetched 2 KB-strided lines
   // that had long left the 4 MiB L2 (753 -> 793 TFLOP/s on 1024->1024 at 160x240; L2 hit rate 90 %)
-  auto advance = [&]() { if (++k_tap == taps) { k_tap = 0; k_c += kBK; } };
+  auto advance = [&]() { if (++k_tap == taps) { k_tap = 0; k_c += kCS; } };
   auto issue = [&](int stage, bool real) {
 #pragma unroll
     for (int call = 0; call < CALLS; ++call) issue_call(stage, real, call);
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
-  const int n_steps = K / kBK;
+  const int n_steps = K / kCS;
 
   // prologue: STAGES-1 K-steps in flight
 #pragma unroll
@@ -148,32 +160,60 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
     const int fill = (stage + STAGES - 1) % STAGES;             // its buffer was last read before this barrier
     const bool fill_real = step + STAGES - 1 < n_steps;
     if (!SPREAD) issue(fill, fill_real);
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int ks = 0; ks < kBK / 16; ++ks) {
-      bf16x8 a[2], b[2];
+      for (int ks = 0; ks < kCS / 16; ++ks) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + frow;
-        const int rb = wn * 64 + i * 32 + frow;
-        const int c = ks * 2 + fhalf;
-        a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
-        b[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wm * 64 + i * 32 + frow;
+          const int rb = wn * 64 + i * 32 + frow;
+          const int c = ks * 2 + fhalf;                              // hi slots 0..3, lo slots 4..7
+          ah[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+          al[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][(((c + 4) ^ ((ra >> 1) & 7)) * 8)]);
+          bh[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+          bl[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][(((c + 4) ^ ((rb >> 1) & 7)) * 8)]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+        if (SPREAD) {
+          constexpr int PER = (CALLS + kCS / 16 - 1) / (kCS / 16);
+#pragma unroll
+          for (int q = 0; q < PER; ++q)
+            if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
+        }
       }
-      if (PRIO) __builtin_amdgcn_s_setprio(1);
+    } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int ks = 0; ks < kBK / 16; ++ks) {
+        bf16x8 a[2], b[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (ABL != 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-          else acc[i][j][0] += (float)a[i][0] + (float)b[j][0];
-      if (PRIO) __builtin_amdgcn_s_setprio(0);
-      if (SPREAD) {
-        // the DMA calls of the next fill are issued BEHIND this slice's MFMAs (their issue time, 60-185 cycles each, then
-        // overlaps the matrix pipe instead of preceding it): CALLS calls over the kBK/16 slices
-        constexpr int PER = (CALLS + kBK / 16 - 1) / (kBK / 16);
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wm * 64 + i * 32 + frow;
+          const int rb = wn * 64 + i * 32 + frow;
+          const int c = ks * 2 + fhalf;
+          a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+          b[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+        }
 #pragma unroll
-        for (int q = 0; q < PER; ++q)
-          if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (SPREAD) {
+          // the DMA calls of the next fill are issued BEHIND this slice's MFMAs (their issue time, 60-185 cycles each, then
+          // overlaps the matrix pipe instead of preceding it): CALLS calls over the kBK/16 slices
+          constexpr int PER = (CALLS + kBK / 16 - 1) / (kBK / 16);
+#pragma unroll
+          for (int q = 0; q < PER; ++q)
+            if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
+        }
       }
     }
     if (SPREAD) advance();
@@ -191,7 +231,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < Cout) Y[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
+        if (m < M && n < Cout) {
+          if constexpr (SPLIT) static_cast<float*>(Yv)[(size_t)m * Cout + n] = acc[i][j][r] + bv;
+          else static_cast<unsigned short*>(Yv)[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
+        }
       }
   }
 }
@@ -211,12 +254,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
 // ---------------------------------------------------------------------------------------------
 constexpr int kHalo = 8;
 
-template <bool SPREAD>
+template <bool SPREAD, bool SPLIT = false>
 __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
-    const float* __restrict__ bias, unsigned short* __restrict__ Y, int M, int H, int W, int Cin, int Cout, int dil,
-    int tiles_m, int tiles_n, int tiles_per_xcd) {
+    const float* __restrict__ bias, void* __restrict__ Yv, int M, int H, int W, int Cin, int Cout, int dil,
+    int tiles_m, int tiles_n, int tiles_per_xcd, const unsigned short* __restrict__ X2 = nullptr,
+    const unsigned short* __restrict__ Wt2 = nullptr) {
   constexpr int TM = 256, TN = 128, WN = 2;
+  constexpr int kCS = SPLIT ? 32 : 64;                // channels per K-step (SPLIT: 32 of the hi plane + the same 32 of the lo plane)
   constexpr int A_ROWS = TM + 2 * kHalo;              // 272 = 34 calls; every wavefront issues 5 (the last 6 are padding)
   constexpr int A_BUF = A_ROWS + 8;                   // + one junk block the padding calls write to
   __shared__ __attribute__((aligned(16))) unsigned short sm[2 * A_BUF + 4 * TN][kBK];
@@ -235,6 +280,9 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
   const int lr = lane >> 3;
   const int pos = lane & 7;
   const int chunk = pos ^ (((wave & 1) << 2) | ((lane >> 4) & 3));   // call index parity == wave parity for A and B calls
+  // SPLIT: slots 0-3 of a row come from the hi plane, slots 4-7 from the lo plane
+  const ptrdiff_t lo_plane_a = SPLIT && chunk >= 4 ? X2 - X : 0, lo_plane_b = SPLIT && chunk >= 4 ? Wt2 - Wt : 0;
+  const int cchunk = SPLIT ? (chunk & 3) : chunk;
 
   // A calls of this wavefront: call index ca = wave + 8*q (q = 0..4), rows 8*ca .. 8*ca+7 of the A buffer,
   // row j <-> pixel m0 - kHalo + j
@@ -270,7 +318,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     fx[i] = (int)(m % W);
   }
 
-  const int n_c = Cin / kBK;
+  const int n_c = Cin / kCS;
   const int n_groups = n_c * 3;
   const int n_steps = n_groups * 3;
 
@@ -280,7 +328,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const int dy = (ky - 1) * dil;
     const int ca = wave + 8 * q;
     const bool ok = real && (unsigned)(a_y[q] + dy) < (unsigned)H;
-    const unsigned short* src = ok ? X + (size_t)(a_pix[q] + (long long)dy * W) * Cin + c * kBK + chunk * 8 : zero_page;
+    const unsigned short* src = ok ? X + lo_plane_a + (size_t)(a_pix[q] + (long long)dy * W) * Cin + c * kCS + cchunk * 8 : zero_page;
     unsigned short(*dst)[kBK] = a_buf(g & 1) + (ca < A_ROWS / 8 ? 8 * ca : A_ROWS);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
   };
@@ -288,7 +336,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const bool real = k < n_steps;
     const int g = k / 3, kx = k - 3 * g;
     const int c = g / 3, ky = g - 3 * c;
-    const unsigned short* src = (real && b_row[q]) ? b_row[q] + (size_t)(ky * 3 + kx) * Cin + c * kBK + chunk * 8 : zero_page;
+    const unsigned short* src = (real && b_row[q]) ? b_row[q] + lo_plane_b + (size_t)(ky * 3 + kx) * Cin + c * kCS + cchunk * 8 : zero_page;
     unsigned short(*dst)[kBK] = b_buf(k & 3) + 8 * (wave + 8 * q);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
   };
@@ -328,6 +376,45 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
       }
       issue_b(k + 3, 0);
       issue_b(k + 3, 1);
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < kCS / 16; ++ks) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ra = wm * 64 + i * 32 + frow + kHalo + dx;        // row of the A buffer
+          const int rb = wn * 64 + i * 32 + frow;
+          const int c = ks * 2 + fhalf;                                // hi slots 0..3, lo slots 4..7
+          ah[i] = *reinterpret_cast<const bf16x8*>(&A[ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+          al[i] = *reinterpret_cast<const bf16x8*>(&A[ra][(((c + 4) ^ ((ra >> 1) & 7)) * 8)]);
+          bh[i] = *reinterpret_cast<const bf16x8*>(&B[rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+          bl[i] = *reinterpret_cast<const bf16x8*>(&B[rb][(((c + 4) ^ ((rb >> 1) & 7)) * 8)]);
+          if (KX != 1 && !ok[i]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ah[i][e] = (__bf16)0.0f; al[i][e] = (__bf16)0.0f; }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+        if (SPREAD) {
+          // same program order of the fills as below, spread over the two 16-deep slices
+          if (KX == 0) {
+            if (ks == 0) { issue_a(g + 1, 0); issue_a(g + 1, 1); issue_a(g + 1, 2); }
+            if (ks == 1) { issue_a(g + 1, 3); issue_a(g + 1, 4); issue_b(k + 3, 0); issue_b(k + 3, 1); }
+          } else {
+            if (ks == 0) issue_b(k + 3, 0);
+            if (ks == 1) issue_b(k + 3, 1);
+          }
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int ks = 0; ks < kBK / 16; ++ks) {
@@ -380,7 +467,10 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long long m = (long long)mt * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && n < Cout) Y[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
+        if (m < M && n < Cout) {
+          if constexpr (SPLIT) static_cast<float*>(Yv)[(size_t)m * Cout + n] = acc[i][j][r] + bv;
+          else static_cast<unsigned short*>(Yv)[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
+        }
       }
   }
 }
@@ -398,6 +488,37 @@ __global__ __launch_bounds__(256) void k_dgrad_weights(const unsigned short* __r
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int c = i / 64, n = i % 64;
     if (c0 + c < cin && n0 + n < cout) wt[((size_t)(c0 + c) * taps + (taps - 1 - tap)) * cout + n0 + n] = s[n][c];
+  }
+}
+
+// v (fp32) -> hi = bf16(v) (round to nearest even), lo = bf16(v - hi): v = hi + lo up to 2^-17 |v|.  8 values per lane.
+__global__ __launch_bounds__(256) void k_split_f32(const float* __restrict__ x, long long n, unsigned short* __restrict__ hi,
+                                                   unsigned short* __restrict__ lo) {
+  const long long n8 = n / 8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      h[k] = f2bf_rn(v[k]);
+      const float hv = __uint_as_float((unsigned)h[k] << 16);
+      const bool finite = (h[k] & 0x7f80) != 0x7f80;                    // inf / nan stay in the hi plane alone
+      l[k] = finite ? f2bf_rn(v[k] - hv) : (unsigned short)0;
+    }
+    uint4 ph, pl;
+    ph.x = h[0] | ((unsigned)h[1] << 16); ph.y = h[2] | ((unsigned)h[3] << 16); ph.z = h[4] | ((unsigned)h[5] << 16); ph.w = h[6] | ((unsigned)h[7] << 16);
+    pl.x = l[0] | ((unsigned)l[1] << 16); pl.y = l[2] | ((unsigned)l[3] << 16); pl.z = l[4] | ((unsigned)l[5] << 16); pl.w = l[6] | ((unsigned)l[7] << 16);
+    reinterpret_cast<uint4*>(hi)[i] = ph;
+    reinterpret_cast<uint4*>(lo)[i] = pl;
+  }
+  if (blockIdx.x == 0) {                                                 // tail of fewer than 8 values
+    const long long i = n8 * 8 + threadIdx.x;
+    if (i < n) {
+      const unsigned short h = f2bf_rn(x[i]);
+      hi[i] = h;
+      lo[i] = ((h & 0x7f80) != 0x7f80) ? f2bf_rn(x[i] - __uint_as_float((unsigned)h << 16)) : (unsigned short)0;
+    }
   }
 }
 
@@ -445,37 +566,23 @@ extern "C" int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, cons
     OMNIHD_REQUIRE(ksize == 3 && dil <= kHalo, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
     const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm_rs<true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout, dil,
-                       tiles_m, tiles_n, per);
-  } else if (tile == 251 || tile == 252) {   // lab: 256x128 without MFMAs (251) / without LDS-DMA (252); results are garbage
-    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
-    const int per = (tiles_m * tiles_n + 7) / 8;
-    if (tile == 251)
-      hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, false, 1>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin,
-                         cout, ksize, dil, tiles_m, tiles_n, per);
-    else
-      hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, false, 2>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin,
-                         cout, ksize, dil, tiles_m, tiles_n, per);
-  } else if (tile == 255) {   // lab: the 256x128 kernel with s_setprio(1) around the MFMA groups
-    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
-    const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
-                       ksize, dil, tiles_m, tiles_n, per);
-  } else if (tile == 254) {   // lab: 128x256 tile (2 x 4 wavefronts): half the A traffic per flop, twice the weights'
+    hipLaunchKernelGGL((k_conv_igemm_rs<true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout, dil,
+                       tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
+  } else if (tile == 254) {   // 128x256 tile (2 x 4 wavefronts): half the A traffic per flop, twice the weights'
     const int tiles_m = (M + 127) / 128, tiles_n = (cout + 255) / 256;
     const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm<2, 4, 3, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
-                       ksize, dil, tiles_m, tiles_n, per);
+    hipLaunchKernelGGL((k_conv_igemm<2, 4, 3, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout,
+                       ksize, dil, tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
   } else if (big) {
     const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
-                       ksize, dil, tiles_m, tiles_n, per);
+    hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout,
+                       ksize, dil, tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
   } else {
     const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm<2, 2, 4, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, Y, M, h, w, cin, cout,
-                       ksize, dil, tiles_m, tiles_n, per);
+    hipLaunchKernelGGL((k_conv_igemm<2, 2, 4, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout,
+                       ksize, dil, tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
   }
   return check_launch("conv_fwd_bf16");
 }
@@ -486,4 +593,55 @@ extern "C" int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int 
                      (hipStream_t)stream, static_cast<const unsigned short*>(w_ohwi), static_cast<unsigned short*>(wt_ihwo),
                      cout, cin, ksize * ksize);
   return check_launch("conv_dgrad_weights");
+}
+
+extern "C" int omnihd_split_f32(const float* x, long long n, void* hi, void* lo, void* stream) {
+  OMNIHD_REQUIRE(n >= 0 && (n == 0 || (x && hi && lo)), "arguments");
+  if (n == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15u) == 0,
+                 "16-byte alignment");
+  hipLaunchKernelGGL(k_split_f32, dim3(grid_for(n / 8 + 1, 256 * 2)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     static_cast<unsigned short*>(hi), static_cast<unsigned short*>(lo));
+  return check_launch("split_f32");
+}
+
+extern "C" int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                     float* y_nhwc, int batch, int h, int w, int cin, int cout, int ksize, int dil, int tile,
+                                     void* stream) {
+  OMNIHD_REQUIRE(omnihd_conv_fwd_supported(batch, h, w, cin, cout, ksize, dil),
+                 "conv_fwd_split: square 1x1 / 3x3 kernel, stride 1, 'same' padding, Cin a multiple of 64, Cout of 8");
+  OMNIHD_REQUIRE(x_hi && x_lo && w_hi && w_lo && y_nhwc, "null pointer");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo) | reinterpret_cast<uintptr_t>(w_hi) |
+                   reinterpret_cast<uintptr_t>(w_lo)) & 15u) == 0, "16-byte alignment");
+  const unsigned short* zero_page = igemm_zero_page();
+  OMNIHD_REQUIRE(zero_page != nullptr, "could not allocate the zero page");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = batch * h * w;
+  const unsigned short *X = static_cast<const unsigned short*>(x_hi), *X2 = static_cast<const unsigned short*>(x_lo);
+  const unsigned short *Wt = static_cast<const unsigned short*>(w_hi), *Wt2 = static_cast<const unsigned short*>(w_lo);
+  const long long big_tiles = (long long)((M + 255) / 256) * ((cout + 127) / 128);
+  const bool big = tile == 256 || (tile == 0 && big_tiles >= 2 * kCUs);
+  if (tile == 300 || (tile == 0 && ksize == 3 && dil <= kHalo && big_tiles >= 2 * kCUs)) {
+    OMNIHD_REQUIRE(ksize == 3 && dil <= kHalo, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm_rs<true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc, M, h, w, cin,
+                       cout, dil, tiles_m, tiles_n, per, X2, Wt2);
+  } else if (tile == 254) {
+    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 255) / 256;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<2, 4, 3, true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc,
+                       M, h, w, cin, cout, ksize, dil, tiles_m, tiles_n, per, X2, Wt2);
+  } else if (big) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc,
+                       M, h, w, cin, cout, ksize, dil, tiles_m, tiles_n, per, X2, Wt2);
+  } else {
+    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<2, 2, 4, true, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc,
+                       M, h, w, cin, cout, ksize, dil, tiles_m, tiles_n, per, X2, Wt2);
+  }
+  return check_launch("conv_fwd_split");
 }

@@ -1,7 +1,7 @@
 """ctypes binding of libomnihd_hip.so — one prototype per symbol of include/omnihd_hip.h."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # OMNIHD_LIB_PATH: load another build of the same library (experiments such as scripts/pool_traffic_abl.sh)
@@ -16,7 +16,7 @@ PROTOTYPES = {
     "omnihd_bev_pool_v2_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_fwd_csr": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "omnihd_bev_pool_v2_fwd_lean": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omnihd_bev_pool_v2_fwd_lean": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_bwd_sched": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "omnihd_column_sums_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "omnihd_column_sums": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -76,6 +76,10 @@ PROTOTYPES = {
                                         c_int, c_void_p, c_size_t, c_void_p]),
     "omnihd_bn_train_bwd_f32": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "omnihd_radar_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omnihd_depth_head_fwd": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omnihd_depth_head_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_longlong, c_void_p, c_longlong, c_void_p]),
     "omnihd_iou_bev_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
 }
 

@@ -333,6 +333,15 @@ class FusionTrainStep:
                 b["gt_occ"] = synthetic_occupancy(batch, nx, ny, 16, 12, self.device, seed + 1000 * i)
         self.i = 0
         self.last_losses = None
+        self.ddp = bool(ddp)
+
+    def sync_choices(self):
+        """After the set-up steps of a multi-rank run: every rank takes rank 0's measured per-geometry kernel choices, so all
+        ranks (and the bf16 summation order of their convolutions) agree from here on."""
+        if self.ddp and self.device.type == "cuda":
+            from . import ops
+            return ops.sync_tuned_choices()
+        return 0
 
     def step(self):
         b = self.batches[self.i % len(self.batches)]

@@ -86,15 +86,37 @@ def _flush_batches_tracked(bn, *_):
     bn._omnihd_pending_batches = 0
 
 
+def _state_dict_pre_hook(mod, prefix, keep_vars):          # module-level functions: a model carrying the hooks pickles
+    _flush_batches_tracked(mod)
+
+
+def _load_state_dict_post_hook(mod, incompatible):
+    mod._omnihd_pending_batches = 0
+
+
+def flush_batch_counters(model):
+    """Write every BatchNorm's host-side batch count into its ``num_batches_tracked`` buffer.  ``state_dict()`` and leaving
+    training mode through ``bn_act`` do this by themselves; call it before anything that reads the buffers WITHOUT going
+    through ``nn.Module.state_dict`` — mmcv's ``get_state_dict`` walks ``_save_to_state_dict`` directly, ``torch.save(model)``
+    pickles the buffers, DDP with ``broadcast_buffers=True`` sends them."""
+    n = 0
+    for m in model.modules():
+        if getattr(m, "_omnihd_pending_batches", 0):
+            _flush_batches_tracked(m)
+            n += 1
+    return n
+
+
 def _count_batch(bn):
     """``num_batches_tracked += 1`` without a kernel per layer and step (37 launches per step in the fusion detector): the
     fused path uses a fixed momentum and never reads the counter, so increments are kept on the host and written into the
-    buffer when it is needed — before ``state_dict()`` (checkpoints carry the same value torch would) and when the layer
-    leaves training mode through ``bn_act``'s plain branch."""
+    buffer when it is needed — before ``state_dict()`` (checkpoints carry the same value torch would), when the layer runs in
+    eval mode or through ``bn_act``'s plain branch, and by ``flush_batch_counters(model)`` for checkpoint writers that bypass
+    ``nn.Module.state_dict`` (see there)."""
     if not hasattr(bn, "_omnihd_pending_batches"):
         bn._omnihd_pending_batches = 0
-        bn.register_state_dict_pre_hook(lambda mod, prefix, keep_vars: _flush_batches_tracked(mod))
-        bn.register_load_state_dict_post_hook(lambda mod, incompatible: setattr(mod, "_omnihd_pending_batches", 0))
+        bn.register_state_dict_pre_hook(_state_dict_pre_hook)
+        bn.register_load_state_dict_post_hook(_load_state_dict_post_hook)
     bn._omnihd_pending_batches += 1
 
 
@@ -106,6 +128,8 @@ def bn_act(x, bn, relu=True, residual=None, inplace=True):
     channel counts that are not multiples of 8, eval-mode layers with trainable affine parameters — is the plain torch
     composition."""
     from .. import ops
+    if not bn.training and getattr(bn, "_omnihd_pending_batches", 0):
+        _flush_batches_tracked(bn)                # the layer has left training mode: its counter buffer is made current
     if (isinstance(bn, nn.modules.batchnorm._BatchNorm) and not bn.training and bn.track_running_stats and bn.affine
             and not bn.weight.requires_grad and not bn.bias.requires_grad and ops.affine_act_supported(x, residual)):
         scale, shift = frozen_bn_constants(bn)
@@ -178,14 +202,18 @@ class BevConv2d(nn.Conv2d):
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             if ops.conv_wgrad_supported(xb, weight, self.stride, self.padding, self.dilation):
                 return ops.conv_hip_wgrad(xb, weight, bias, self.stride, self.padding, self.dilation)
-        if bias is not None and x.is_cuda and weight.shape[0] % 8 != 0 and bias.requires_grad and torch.is_grad_enabled():
-            # odd channel counts (DepthNet's 59 depth logits): the bias is still added inside the convolution, its gradient
-            # comes from the column-sum kernel instead of torch's element-wise NHWC reduction (0.36 ms -> 10 us)
-            from .. import ops
-            y = super()._conv_forward(x, weight, bias.detach())
-            if ops.bias_grad_supported(y, bias):
-                return ops._BiasGrad.apply(y, bias)
-            return super()._conv_forward(x, weight, bias)
+        if (bias is not None and weight.shape[0] % 8 != 0 and x.is_cuda and x.dim() == 4 and self.padding_mode == "zeros"
+                and not isinstance(self.padding, str) and bias.requires_grad and torch.is_grad_enabled()):
+            # odd channel counts (DepthNet's 59 depth logits): bias gradient from the column-sum kernel instead of torch's
+            # element-wise NHWC reduction (0.36 ms -> 10 us).  The convolution runs inside the function (fresh output tensor);
+            # under autocast the operands are cast here as autocast would cast them
+            xe, we = x, weight
+            if torch.is_autocast_enabled():
+                dt = torch.get_autocast_dtype("cuda")
+                xe = x.to(dt)
+                we = ops.bf16_weight(weight) if dt == torch.bfloat16 else weight.to(dt)
+            if ops.conv_bias_colsum_supported(xe, we, bias):
+                return ops.conv_bias_colsum(xe, we, bias, self.stride, self.padding, self.dilation, self.groups)
         return super()._conv_forward(x, weight, bias)
 
 

@@ -153,9 +153,11 @@ def prefetch(tensors):
                                     ctypes.c_void_p(side.cuda_stream)), "omnihd_prefetch")
 
 
-def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, depth_bins, feat_hw, gen=2):
+def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, depth_bins, feat_hw, gen=2, empty_rows_kept=False):
     """Dense tiled forward reading one per-point table (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_lean).
-    ``gen=1`` asks for the first-generation kernel (64-bit addressing; bit-identical to the three-table kernel)."""
+    ``gen=1`` asks for the first-generation kernel (64-bit addressing; bit-identical to the three-table kernel).
+    ``empty_rows_kept``: ``out`` already holds zeros in every row no point falls into (an earlier result of the same tables
+    or a zero-filled buffer): those rows are not written again."""
     _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
     _want(ranks_depth, torch.int32, "ranks_depth"); _want(row_ptr, torch.int32, "row_ptr")
     _want(tile_desc, torch.int32, "tile_desc")
@@ -163,11 +165,15 @@ def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, 
     n_rows = row_ptr.numel() - 1
     if out.numel() != n_rows * c:
         raise ValueError(f"out has {out.numel()} elements, expected {n_rows}*{c}")
+    if depth.numel() != (feat.numel() // c) * int(depth_bins) or (feat.numel() // c) % int(feat_hw):
+        raise ValueError(f"depth ({depth.numel()} values) must hold depth_bins={depth_bins} values per pixel row of feat "
+                         f"({feat.numel() // c} rows, feat_hw={feat_hw})")
     dev = _same_device(depth, feat, out, ranks_depth, row_ptr, tile_desc)
     with _on(dev):
         check(lib().omnihd_bev_pool_v2_fwd_lean(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(row_ptr), _ptr(tile_desc),
                                                 tile_desc.size(0), _ptr(out), c, n_rows, ranks_depth.numel(), int(depth_bins),
-                                                int(feat_hw), feat.numel() // c if gen != 1 else 0, _stream()), "omnihd_bev_pool_v2_fwd_lean")
+                                                int(feat_hw), feat.numel() // c if gen != 1 else 0, 1 if empty_rows_kept else 0,
+                                                _stream()), "omnihd_bev_pool_v2_fwd_lean")
 
 
 def bev_pool_v2_backward_sched(out_grad, depth, feat, ranks_depth, ranks_row, pix_desc, depth_grad, feat_grad):
@@ -239,6 +245,101 @@ def csr_tiles(row_ptr, tile_items=768, long_len=512):
                                      ctypes.cast(ctypes.pointer(h), ctypes.c_void_p), _ptr(ws), ws.numel(), _stream()),
               "omnihd_csr_tiles")
     return tile_row[:h.value + 1].clone()
+
+
+# ---------------------------------------------------------------------------------------------
+# depth-head epilogue: softmax over D + depth / context split + the pooling's layouts (csrc/depth_head.hip)
+# ---------------------------------------------------------------------------------------------
+def _nhwc_rows(t, align_bytes):
+    """(M, ch, H, W) tensor -> (tensor, row pitch in elements) such that pixel p's channels are the ``ch`` contiguous elements
+    at p * pitch (channels-last memory, or a channel slice of a wider channels-last tensor); anything else is packed."""
+    M, ch, H, W = t.shape
+    P = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else (t.stride(0) if M > 1 else ch))
+    ok = ((ch == 1 or t.stride(1) == 1) and P >= ch and (W == 1 or t.stride(3) == P) and (H == 1 or t.stride(2) == W * P)
+          and (M == 1 or t.stride(0) == H * W * P)
+          and (t.data_ptr() % align_bytes == 0 and (P * t.element_size()) % align_bytes == 0))
+    if ok:
+        return t, P
+    t = t.contiguous(memory_format=torch.channels_last)
+    if t.data_ptr() % align_bytes or not t.is_contiguous(memory_format=torch.channels_last):
+        t = t.clone(memory_format=torch.channels_last)
+    return t, ch
+
+
+class _DepthHead(torch.autograd.Function):
+    """logits (M,D,H,W), context (M,C,H,W) or None, bf16 or fp32 ->
+    depth (M,D,H,W) fp32 contiguous (= softmax(logits, 1)), depth_rows (M,H,W,D) fp32 or None, feat (M,H,W,C) fp32 or None."""
+
+    @staticmethod
+    def forward(ctx, logits, context, want_rows):
+        M, D, H, W = logits.shape
+        dev = logits.device
+        is_f32 = logits.dtype == torch.float32
+        lg, ld_l = _nhwc_rows(logits, 4 if is_f32 else 2)
+        cx = ld_c = feat = None
+        C = 0
+        if context is not None:
+            C = context.shape[1]
+            cx, ld_c = _nhwc_rows(context, 16 if is_f32 else 8)
+            feat = torch.empty((M, H, W, C), dtype=torch.float32, device=dev)
+        depth = torch.empty((M, D, H, W), dtype=torch.float32, device=dev)
+        rows = torch.empty((M, H, W, D), dtype=torch.float32, device=dev) if want_rows else None
+        with _on(dev):
+            check(lib().omnihd_depth_head_fwd(_ptr(lg), ld_l, _ptr(cx), ld_c or 0, 1 if is_f32 else 0, M, H * W, D, C,
+                                              _ptr(depth), _ptr(rows), _ptr(feat), _stream()), "omnihd_depth_head_fwd")
+        ctx.save_for_backward(depth)
+        ctx.meta = (M, D, H, W, C, logits.dtype, context is not None)
+        ctx.set_materialize_grads(False)
+        return depth, rows, feat
+
+    @staticmethod
+    def backward(ctx, g_depth, g_rows, g_feat):
+        (depth,) = ctx.saved_tensors
+        M, D, H, W, C, dtype, has_ctx = ctx.meta
+        dev = depth.device
+        g_logits = g_ctx = None
+        f32 = lambda t: None if t is None else t.contiguous().float()
+        g_depth, g_rows, g_feat = f32(g_depth), f32(g_rows), f32(g_feat)
+        want_ctx = has_ctx and ctx.needs_input_grad[1]
+        if want_ctx:
+            g_ctx = torch.empty((M, C, H, W), dtype=dtype, device=dev, memory_format=torch.channels_last)
+            if g_feat is None:
+                g_ctx.zero_()
+        if ctx.needs_input_grad[0]:
+            g_logits = torch.empty((M, D, H, W), dtype=dtype, device=dev, memory_format=torch.channels_last)
+        if g_logits is not None or (want_ctx and g_feat is not None):
+            scratch = g_logits if g_logits is not None else torch.empty((M, D, H, W), dtype=dtype, device=dev,
+                                                                       memory_format=torch.channels_last)
+            with _on(dev):
+                check(lib().omnihd_depth_head_bwd(_ptr(depth), _ptr(g_depth), _ptr(g_rows), _ptr(g_feat),
+                                                  1 if dtype == torch.float32 else 0, M, H * W, D, C, _ptr(scratch), D,
+                                                  _ptr(g_ctx) if (want_ctx and g_feat is not None) else None, C, _stream()),
+                      "omnihd_depth_head_bwd")
+        return g_logits, g_ctx, None
+
+
+def depth_head_supported(logits, context):
+    return (logits.is_cuda and logits.dim() == 4 and logits.dtype in (torch.bfloat16, torch.float32) and logits.shape[1] <= 160
+            and logits.shape[0] <= 65535 and context.dim() == 4 and context.dtype == logits.dtype and context.shape[1] % 4 == 0
+            and context.shape[0] == logits.shape[0] and context.shape[2:] == logits.shape[2:])
+
+
+def depth_head(logits, context, want_rows=False):
+    """Depth-head epilogue of the LSS camera stream (reference cam_stream_lss_bevpoolv2_depthnet.py:134-143, :290):
+    depth logits (M,D,H,W) + context (M,C,H,W), bf16 or fp32 ->
+      depth      (M,D,H,W) fp32 contiguous, softmax over D             (view it (B,N,D,H,W): what bev_pool_v2 gathers from)
+      depth_rows (M,H,W,D) fp32, the same values pixel-major, or None   (what the KL depth loss reads)
+      feat       (M,H,W,C) fp32 contiguous context rows                 (view it (B,N,H,W,C): what bev_pool_v2 gathers from).
+    A packed fp32 channels-last context tensor already IS ``feat``: it is returned as a view, no copy."""
+    if not depth_head_supported(logits, context):
+        raise TypeError("depth_head: (M,D,H,W) logits with D <= 160 and (M,C,H,W) context, C % 4 == 0, both bf16 or both fp32, "
+                        "CUDA(HIP) tensors")
+    M, C, H, W = context.shape
+    if (context.dtype == torch.float32 and context.data_ptr() % 16 == 0 and C > 1 and H * W > 1
+            and context.is_contiguous(memory_format=torch.channels_last)):
+        depth, rows, _ = _DepthHead.apply(logits, None, bool(want_rows))
+        return depth, rows, context.permute(0, 2, 3, 1)
+    return _DepthHead.apply(logits, context, bool(want_rows))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -787,6 +888,28 @@ def conv_choices():
     return dict(_CONV_CHOICE)
 
 
+def sync_tuned_choices(group=None, src=0):
+    """Make every rank of ``group`` use rank ``src``'s measured kernel choices (convolution forward / data gradient / weight
+    gradient per geometry).  The measurements run inside forward / backward on each rank separately and a noisy one could put
+    two ranks on kernels with different bf16 summation orders; call this once after the set-up steps (the harness does) from
+    the thread that owns the process group, outside forward / backward.  Device indices in the keys are mapped to the local
+    device.  Returns the number of entries that changed on this rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    me = _current_device() if torch.cuda.is_available() else None
+    strip = lambda table: {k[:-1]: v for k, v in table.items()}
+    payload = [(strip(_CONV_CHOICE), strip(_WGRAD_CHOICE))] if dist.get_rank(group) == src else [None]
+    dist.broadcast_object_list(payload, src=src, group=group)
+    changed = 0
+    for table, theirs in ((_CONV_CHOICE, payload[0][0]), (_WGRAD_CHOICE, payload[0][1])):
+        for k, v in theirs.items():
+            if table.get(k + (me,)) != v:
+                table[k + (me,)] = v
+                changed += 1
+    return changed
+
+
 def column_sums(rows2d):
     """fp32 column sums of a contiguous (rows, c) bf16 / fp32 device matrix, any c (omnihd_column_sums)."""
     if not (rows2d.is_cuda and rows2d.dim() == 2 and rows2d.is_contiguous() and rows2d.dtype in (torch.bfloat16, torch.float32)):
@@ -804,27 +927,41 @@ def column_sums(rows2d):
     return sums
 
 
-class _BiasGrad(torch.autograd.Function):
-    """Identity on ``y`` = conv(x, w, bias.detach()) that gives ``bias`` its gradient sum_{n,h,w} g from the column-sum kernel.
-    For channel counts that are not a multiple of 8 torch reduces the NHWC gradient element by element (0.36 ms for the
-    59 depth logits of DepthNet at 6 x 64 x 176; 10 us here)."""
+class _ConvBiasColsum(torch.autograd.Function):
+    """y = conv2d(x, w, bias) for output widths that are not a multiple of 8 (DepthNet's 59 depth logits): the convolution and
+    its data / weight gradients are torch's (MIOpen), the BIAS gradient sum_{n,h,w} g comes from the column-sum kernel — torch
+    reduces such an NHWC gradient element by element (0.36 ms at 6 x 59 x 64 x 176; 10 us here).  The convolution runs INSIDE
+    the function, so the result is a fresh tensor that in-place consumers (ReLU(inplace=True), sigmoid_()) may overwrite."""
 
     @staticmethod
-    def forward(ctx, y, bias):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, weight)
+        ctx.conv = (list(stride), list(padding), list(dilation), int(groups))
         ctx.bdtype = bias.dtype
-        return y.view_as(y)
+        return torch.nn.functional.conv2d(x, weight, bias.to(x.dtype), stride, padding, dilation, groups)
 
     @staticmethod
     def backward(ctx, g):
-        gc = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
-        n, c, h, w = gc.shape
-        rows = gc.permute(0, 2, 3, 1).reshape(n * h * w, c)            # a view of the NHWC memory
-        return g, column_sums(rows).to(ctx.bdtype)
+        x, weight = ctx.saved_tensors
+        stride, padding, dilation, groups = ctx.conv
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], groups,
+                                                            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        if ctx.needs_input_grad[2]:
+            gc = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
+            n, c, h, w = gc.shape
+            gb = column_sums(gc.permute(0, 2, 3, 1).reshape(n * h * w, c)).to(ctx.bdtype)    # a view of the NHWC memory
+        return gx, gw, gb, None, None, None, None
 
 
-def bias_grad_supported(y, bias):
-    return (bias is not None and bias.requires_grad and torch.is_grad_enabled() and y.is_cuda and y.dim() == 4
-            and y.dtype in (torch.bfloat16, torch.float32) and y.shape[1] % 8 != 0)
+def conv_bias_colsum_supported(x, weight, bias):
+    return (bias is not None and bias.requires_grad and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+            and x.dtype in (torch.bfloat16, torch.float32) and weight.shape[0] % 8 != 0 and weight.dtype == x.dtype)
+
+
+def conv_bias_colsum(x, weight, bias, stride, padding, dilation, groups=1):
+    return _ConvBiasColsum.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), int(groups))
 
 
 class _ConvHipWgrad(torch.autograd.Function):
@@ -864,6 +1001,9 @@ class _ConvHipWgrad(torch.autograd.Function):
                 gx = _conv_impl("dgrad", g, wt, stride, padding, dilation, run_miopen, n_out=weight.shape[1], k=k)
             else:
                 gx = run_miopen()
+        else:
+            # no data gradient asked for (first trainable layer behind a frozen trunk): nothing to measure in this direction
+            _CONV_CHOICE.setdefault(("dgrad", tuple(g.shape), weight.shape[1], weight.shape[2], dilation[0], g.device.index), "miopen")
         if ctx.needs_input_grad[1]:
             gw = _tuned_wgrad(x.contiguous(memory_format=torch.channels_last), g, weight, stride, padding,
                               dilation).to(ctx.param_dtypes[0])

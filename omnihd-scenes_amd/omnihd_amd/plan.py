@@ -287,17 +287,78 @@ def _timed(kind, launch):
     TIMING.append((kind, e0, e1))
 
 
+def _check_plan_matches(plan, depth, feat):
+    """A plan built from one frustum must not be run on tensors of another shape: the kernels index depth / feat by the
+    plan's tables (an out-of-range rank is a wild device read, not an exception)."""
+    if plan.depth_bins <= 0:
+        return                                       # foreign tables (plan_from_tables): the caller vouches for them
+    c = feat.size(-1)
+    n_feat_rows = feat.numel() // max(c, 1)
+    if depth.dim() != 5 or depth.size(2) != plan.depth_bins or depth.size(3) * depth.size(4) != plan.feat_hw:
+        raise ValueError(f"depth {tuple(depth.shape)} does not match the pooling plan (D={plan.depth_bins}, fH*fW={plan.feat_hw})")
+    if depth.numel() != n_feat_rows * plan.depth_bins:
+        raise ValueError(f"depth {tuple(depth.shape)} and feat {tuple(feat.shape)} disagree on the number of image pixels")
+    if plan.pix_ptr is not None and plan.pix_ptr.numel() != n_feat_rows + 1:
+        raise ValueError(f"feat {tuple(feat.shape)} has {n_feat_rows} pixel rows, the plan was built for {plan.pix_ptr.numel() - 1}")
+
+
+def _storage_users(t):
+    """How many owners the tensor's storage has right now (tensors, views, saved tensors of autograd nodes); None when this
+    torch build does not expose the count."""
+    try:
+        return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+    except (AttributeError, RuntimeError, TypeError):
+        return None
+
+
+MAX_KEPT_OUTPUTS = 2      # output buffers kept per plan (one in flight between forward and backward + one spare)
+
+
+def _kept_output(plan, c, device):
+    """An output buffer of this plan whose EMPTY rows are zero already, or None.
+
+    40 % of the BEV rows of a camera rig collect no frustum point at all (248 596 of 614 400 at R1) — which ones is a property
+    of the plan, i.e. of the calibration.  The dense forward has to leave zeros there; the reference zero-fills the whole
+    tensor every forward (ops/bev_pool_v2/bev_pool.py:27).  A buffer that a previous forward of the SAME plan produced
+    still holds those zeros as long as nobody wrote to it, so the kernel stores only the rows that collect points (94 MB
+    instead of 157 MB per launch at R1).  A buffer is handed out again only when every other owner of its storage is gone
+    (the result tensor, its views, the copy the next layer saved for its backward): while a result is alive its memory is
+    never touched, whatever the caller does with it.  Callers that WRITE into the result in place must not opt in."""
+    kept = getattr(plan, "_kept_outputs", None)
+    if kept is None:
+        kept = plan._kept_outputs = []
+    for keeper, base in kept:
+        if keeper.shape[1] == c and keeper.device == device and _storage_users(keeper) == base:
+            return keeper
+    if len(kept) >= MAX_KEPT_OUTPUTS:
+        return None
+    keeper = torch.zeros((plan.n_rows, c), dtype=torch.float32, device=device)          # zero-filled once
+    base = _storage_users(keeper)
+    if base is None:
+        return None
+    kept.append((keeper, base))
+    return keeper
+
+
 class _PlannedPool(torch.autograd.Function):
     """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order."""
 
     @staticmethod
-    def forward(ctx, depth, feat, plan):
+    def forward(ctx, depth, feat, plan, keep_empty_rows=False):
         depth = depth.contiguous().float()
         feat = feat.contiguous().float()
-        out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
-        if plan.depth_bins > 0 and plan.tile_desc is not None and plan.n_points > 0 and _lean_forward():
+        _check_plan_matches(plan, depth, feat)
+        lean = plan.depth_bins > 0 and plan.tile_desc is not None and plan.n_points > 0 and _lean_forward()
+        keeper = _kept_output(plan, feat.size(-1), feat.device) if (keep_empty_rows and lean) else None
+        if keeper is not None:
+            # a fresh tensor object over the kept storage (not a view: nothing ties it to the keeper in autograd)
+            out = torch.empty(0, dtype=torch.float32, device=feat.device).set_(keeper.untyped_storage(), 0, keeper.shape,
+                                                                              keeper.stride())
+        else:
+            out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
+        if lean:
             _timed("fwd", lambda: ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, out,
-                                                               plan.depth_bins, plan.feat_hw))
+                                                               plan.depth_bins, plan.feat_hw, empty_rows_kept=keeper is not None))
         else:
             ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
                                         plan.ranks_row, plan.tile_desc)
@@ -310,8 +371,12 @@ class _PlannedPool(torch.autograd.Function):
         depth, feat = ctx.saved_tensors
         plan = ctx.plan
         c = feat.size(-1)
+        # the limits of omnihd_bev_pool_v2_bwd_patch (csrc/bev_pool_v2.hip): C = 64, 32-bit gather offsets into out_grad and a
+        # 24-bit row field, both D x 16 LDS blocks within 64 KiB, 16-byte aligned row tensors; anything else takes the
+        # scheduled kernel
         patch = (c == 64 and plan.patch_order is not None and plan.depth_bins > 0 and depth.dim() == 5
-                 and plan.n_rows * 256 < 2 ** 32 and _patch_backward())
+                 and plan.n_rows * 256 < 2 ** 32 and plan.n_rows < 0xffffff and plan.depth_bins <= 512
+                 and feat.data_ptr() % 16 == 0 and _patch_backward())
         if patch and out_grad.dtype != torch.float32 and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0":
             # the forward's tensors and the backward tables have long left the Infinity Cache: read them ahead on the side
             # stream while the cast of the incoming gradient runs (bf16 step; in the fp32 step nothing precedes the kernel)
@@ -322,7 +387,7 @@ class _PlannedPool(torch.autograd.Function):
             _timed("bwd", lambda: ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat,
                                                                  plan.bp_ranks_depth, plan.bp_ranks_row, plan.pix_ptr,
                                                                  plan.patch_order, depth_grad, feat_grad))
-            return depth_grad, feat_grad, None
+            return depth_grad, feat_grad, None, None
         depth_grad = torch.zeros_like(depth)
         if plan.pix_desc is not None and c in (4, 8, 16, 32, 64):
             feat_grad = torch.empty_like(feat)          # written densely by the scheduled kernel
@@ -333,17 +398,19 @@ class _PlannedPool(torch.autograd.Function):
             og5 = out_grad.view(1, 1, 1, plan.n_rows, c)
             ops.bev_pool_v2_backward(og5, depth_grad, feat_grad, depth, feat, plan.bp_ranks_depth,
                                      plan.bp_ranks_feat, plan.bp_ranks_row, plan.bp_lengths, plan.bp_starts)
-        return depth_grad, feat_grad, None
+        return depth_grad, feat_grad, None, None
 
 
-def planned_pool(depth, feat, plan):
+def planned_pool(depth, feat, plan, keep_empty_rows=False):
     """Returns the pooled BEV tensor with logical shape (B, C, Z, Y, X) (what the reference's
     ``bev_pool_v2`` returns, ops/bev_pool_v2/bev_pool.py:86-92).  For ``layout='byxz'`` it is a
-    zero-copy view over (B,Y,X,Z,C) memory, so ``cat(unbind(dim=2), 1)`` (s2c) is a reshape."""
+    zero-copy view over (B,Y,X,Z,C) memory, so ``cat(unbind(dim=2), 1)`` (s2c) is a reshape.
+    ``keep_empty_rows``: reuse an output buffer of the same plan whose empty rows are zero already (see ``_kept_output``);
+    only for callers that never write into the result in place."""
     B, Z, Y, X = plan.grid
     C = feat.size(-1)
     # fp32 like the reference (bev_pool.py:20-21); the casts are autograd ops so bf16 callers get bf16 grads
-    rows = _PlannedPool.apply(depth.float(), feat.float(), plan)
+    rows = _PlannedPool.apply(depth.float(), feat.float(), plan, bool(keep_empty_rows))
     if plan.layout == "bzyx":
         return rows.view(B, Z, Y, X, C).permute(0, 4, 1, 2, 3)
     return rows.view(B, Y, X, Z, C).permute(0, 4, 3, 1, 2)

@@ -128,9 +128,15 @@ class DepthNet(nn.Module):
                                   padding=1, groups=4, im2col_step=128)),
             nn.Conv2d(mid_channels, depth_channels, 1, stride=1, padding=0))
 
-    def forward(self, x):
+    def heads(self, x):
+        """(depth logits (M,D,H,W), context (M,C,H,W)) before the reference's concatenation; the context head runs last so
+        that both tensors the pooling gathers from are written by the launches right in front of it."""
         x = run_fused(self.reduce_conv, x)
-        return torch.cat([self.depth_conv(x), self.context_conv(x)], dim=1)
+        logits = self.depth_conv(x)
+        return logits, self.context_conv(x)
+
+    def forward(self, x):
+        return torch.cat(self.heads(x), dim=1)
 
 
 class CamEncode(nn.Module):
@@ -144,7 +150,20 @@ class CamEncode(nn.Module):
         return x.softmax(dim=1)
 
     def get_depth_feat(self, x):
-        x = self.depthnet(x)
+        """(depth distribution (M,D,H,W), context features (M,C,H,W)) — reference :137-143.  On the device the concatenation /
+        slicing / softmax / layout copies of the reference are ONE epilogue kernel (csrc/depth_head.hip): the distribution
+        comes back fp32 and contiguous (the (B,N,D,fH,fW) tensor bev_pool_v2 gathers from, as bev_pool.py:20 casts it), the
+        context as a (M,C,H,W)-shaped view of fp32 (M,H,W,C) rows (so that :290's permute + contiguous is a no-op), and the
+        pixel-major copy of the distribution that the KL depth loss reads rides along as ``depth._omnihd_rows``."""
+        if x.is_cuda and os.environ.get("OMNIHD_DEPTH_HEAD", "1") != "0":
+            logits, context = self.depthnet.heads(x)
+            if _ops.depth_head_supported(logits, context):
+                depth, rows, feat = _ops.depth_head(logits, context, want_rows=torch.is_grad_enabled())
+                depth._omnihd_rows = rows
+                return depth, feat.permute(0, 3, 1, 2)
+            x = torch.cat([logits, context], dim=1)
+        else:
+            x = self.depthnet(x)
         return self.get_depth_dist(x[:, :self.D]), x[:, self.D:(self.D + self.C)]
 
     def forward(self, x):
@@ -242,7 +261,11 @@ class LiftSplatShoot_Depth(nn.Module):
         B, N, C, H, W = x.shape
         x, depth = self.camencode(x.view(B * N, C, H, W))
         assert depth.shape[1:] == self.frustum.shape[:3]
-        return x.view(B, N, self.camC, H, W), depth.view(B, N, self.D, H, W)
+        rows = getattr(depth, "_omnihd_rows", None)
+        depth = depth.view(B, N, self.D, H, W)
+        if rows is not None:
+            depth._omnihd_rows = rows           # (B*N, H, W, D) fp32: the same distribution pixel-major, for the depth loss
+        return x.view(B, N, self.camC, H, W), depth
 
     # ---- rank tables ------------------------------------------------------------------------
     def voxel_pooling_prepare_v2(self, coor):
@@ -286,7 +309,9 @@ class LiftSplatShoot_Depth(nn.Module):
         if plan.n_points == 0:   # defect D4: the reference would crash; defined here as all-zero BEV
             B = depth.shape[0]
             return feat.new_zeros(B, self.camC, int(self.nx[2]), int(self.nx[1]), int(self.nx[0]))
-        return planned_pool(depth, feat, plan)
+        # the pooled tensor goes straight into the BEV encoder's first convolution (read-only): its empty rows can be kept
+        # from the previous forward of this plan instead of being zero-filled again
+        return planned_pool(depth, feat, plan, keep_empty_rows=os.environ.get("OMNIHD_POOL_KEEP_ZEROS", "1") != "0")
 
     def get_voxels(self, x, rots=None, trans=None, post_rots=None, post_trans=None, extra_rots=None,
                    extra_trans=None, plan_key=None):
@@ -327,7 +352,11 @@ class LiftSplatShoot_Depth(nn.Module):
         # "batchmean" over the foreground pixels, written with a mask instead of a boolean gather (a gather
         # needs the pixel count on the host: one device synchronisation per step)
         target = target.view(-1, self.D)
-        pred = depth_preds.float().permute(0, 1, 3, 4, 2).contiguous().view(-1, self.D)
+        rows = getattr(depth_preds, "_omnihd_rows", None)      # the depth-head kernel's pixel-major copy (same values)
+        if rows is not None and rows.numel() == depth_preds.numel():
+            pred = rows.view(-1, self.D)
+        else:
+            pred = depth_preds.float().permute(0, 1, 3, 4, 2).contiguous().view(-1, self.D)
         kl = F.kl_div(torch.log(pred + 1e-4), target, reduction="none", log_target=False)
         loss = (kl * fg.unsqueeze(-1)).sum() / fg.sum()
         return loss, depth_values.clone()

@@ -43,7 +43,7 @@ class _CpuPool(torch.autograd.Function):
         return torch.from_numpy(dg), torch.from_numpy(fg), None
 
 
-def planned_pool(depth, feat, plan):
+def planned_pool(depth, feat, plan, keep_empty_rows=False):
     out = _CpuPool.apply(depth.float().contiguous(), feat.float().contiguous(), plan)
     return out.permute(0, 4, 1, 2, 3).contiguous()               # ops/bev_pool_v2/bev_pool.py:91
 

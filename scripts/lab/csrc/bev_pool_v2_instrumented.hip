@@ -1,3 +1,5 @@
+// LAB COPY (round 2, commit e90a151) of omnihd-scenes_amd/csrc/bev_pool_v2.hip with its OMNIHD_POOL_ABL / OMNIHD_POOL_TRACE hooks;
+// built only by scripts/build_abl.sh.  Not part of the product library.
 // bev_pool_v2 forward / backward for gfx950 (MI355X).
 //
 // What the reference computes: ops/bev_pool_v2/src/bev_pool_cuda.cu:21-48 (forward, one CUDA
@@ -22,8 +24,27 @@
 #include "common.h"
 #include <stdlib.h>
 
-// (The traffic-attribution and phase-timeline builds of rounds 1-2 live in a lab copy of this file,
-// scripts/lab/csrc/bev_pool_v2_instrumented.hip; the product source carries no instrumentation.)
+// Traffic attribution builds (scripts/pool_traffic_abl.sh): -DOMNIHD_POOL_ABL=1 replaces the depth gather by a
+// constant, =2 folds every feature gather onto 1024 L2-resident rows, =3 both; +4 drops the stores of pooled rows, +8 the zero-fill stores, +16 the feature gathers altogether (timing skeletons only).  Never defined in the product.
+#ifndef OMNIHD_POOL_ABL
+#define OMNIHD_POOL_ABL 0
+#endif
+
+// Phase-timeline builds (scripts/lab/pool_trace.py): -DOMNIHD_POOL_TRACE makes thread 0 of every workgroup of the lean
+// forward write wall_clock64() at its phase boundaries into a device buffer set by omnihd_lab_set_trace().  Never defined
+// in the product.
+#ifdef OMNIHD_POOL_TRACE
+__device__ unsigned long long* g_omnihd_trace = nullptr;
+#define OMNIHD_STAMP(k)                                                                         \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && g_omnihd_trace) g_omnihd_trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
+  } while (0)
+extern "C" int omnihd_lab_set_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_omnihd_trace), &p, sizeof(p));
+}
+#else
+#define OMNIHD_STAMP(k) do {} while (0)
+#endif
 
 namespace omnihd {
 namespace {
@@ -325,9 +346,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
   for (int k = 0; k < kPer; ++k) {
     const int i = tid + k * kBlock;
     if (i < npts) {
-      const float dv = depth[l_rd[k]];
+      const float dv = (OMNIHD_POOL_ABL & 1) ? 1.0f : depth[l_rd[k]];
       const int last = (l_row[k] != l_nxt[k]) ? (int)0x80000000 : 0;
-      s_rfd[i] = make_int2(l_rf[k] | last, __float_as_int(dv));
+      s_rfd[i] = make_int2(((OMNIHD_POOL_ABL & 2) ? (l_rf[k] & 1023) : l_rf[k]) | last, __float_as_int(dv));
       s_row[i] = l_row[k];
     }
   }
@@ -423,9 +444,11 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
   float4* s_tail = reinterpret_cast<float4*>(s_mem);
 
   if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+  OMNIHD_STAMP(0);
   const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
   const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
   if (nrows <= 0) return;
+  OMNIHD_STAMP(1);
 
   const int tid = threadIdx.x;
   const int sub = tid % C4;
@@ -476,7 +499,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
       for (int k = 0; k < 64; k += GPW) {
         const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
         if (window == 0ull) continue;
-        if ((m >> (k + gw)) & 1ull)
+        if (((m >> (k + gw)) & 1ull) && !(OMNIHD_POOL_ABL & 8))
           store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
       }
     }
@@ -484,6 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
     l_close[0] = npts - 1;                         // the single row of the tile closes at its last point
     l_crow[0] = Ra;
   }
+  OMNIHD_STAMP(2);
   if (npts == 0) return;
 
   float4 acc = zero4;
@@ -543,11 +567,13 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
   for (int k = 0; k < kPer; ++k) {
     const int i = tid + k * kBlock;
     if (i < npts) {
-      s_rfd[i] = make_int2(pixel_row(l_rd[k]), __float_as_int(depth[l_rd[k]]));
+      const int px = (OMNIHD_POOL_ABL & 2) ? (pixel_row(l_rd[k]) & 1023) : pixel_row(l_rd[k]);
+      s_rfd[i] = make_int2(px, __float_as_int((OMNIHD_POOL_ABL & 1) ? 1.0f : depth[l_rd[k]]));
     }
   }
   if (tid < G) s_head_row[tid] = -1;
   __syncthreads();
+  OMNIHD_STAMP(3);
   // ---- closing flags + row ids from the CSR boundaries (each closing record has exactly one owner) ----
 #pragma unroll
   for (int j = 0; j < kRowsPerLane; ++j)
@@ -556,6 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
       s_row[l_close[j]] = l_crow[j];
     }
   __syncthreads();
+  OMNIHD_STAMP(4);
 
   // ---- phase P: equal pieces of the point list, one per group ----------------------------------
   const int w = (npts + G - 1) / G;
@@ -572,7 +599,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
       const int2 rc = s_rfd[min(i + u, i1 - 1)];
       d[u] = __int_as_float(rc.y);
       fl[u] = rc.x;
-      v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
+      if (OMNIHD_POOL_ABL & 16) { const float t = (float)(rc.x & 0xffff); v[u] = make_float4(t, t, t, t); }
+      else v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -585,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
             s_head[tid] = acc;
             if (sub == 0) s_head_row[grp] = row;
             head_pending = false;
-          } else {
+          } else if (!(OMNIHD_POOL_ABL & 4) || acc.x == 1.2345e30f) {
             store_row(out4 + (size_t)row * C4 + sub, acc, true);
           }
           acc = zero4;
@@ -595,7 +623,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
   }
   // piece ends inside a row (or is empty: then it is "inside" whatever row surrounds it, with a zero partial)
   const bool open_end = (i1 <= i0) || (s_rfd[i1 - 1].x >= 0);
+  OMNIHD_STAMP(5);
   __syncthreads();
+  OMNIHD_STAMP(6);   // every group is done with the records: their LDS is reused for the tails
   s_tail[tid] = acc;
   if (sub == 0) s_tail_flags[grp] = (open_end ? 1 : 0) | (closed_any ? 0 : 2);
   __syncthreads();
@@ -616,6 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
     tsum = add4(tsum, s_head[tid]);
     store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
   }
+  OMNIHD_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -645,7 +676,8 @@ template <int C4, int U>
 __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
     const float* __restrict__ depth, const float* __restrict__ feat, unsigned feat_bytes,
     const int* __restrict__ ranks_depth, const int* __restrict__ row_ptr, const int4* __restrict__ tile_desc,
-    float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw, float inv_dfhw, int empty_rows_kept) {
+    float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw, float inv_dfhw, unsigned depth_bytes,
+    int pf_blocks) {
   static_assert(U == 4, "the record reads below are written for 4 points per step");
   constexpr int G = kBlock / C4;
   constexpr int GPW = 64 / C4;
@@ -663,10 +695,33 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
   float4* s_tail = reinterpret_cast<float4*>(s_mem);              // after the point loop
 
   if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+  OMNIHD_STAMP(0);
   const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
   const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
   const int tid = threadIdx.x;
-  if (nrows <= 0) return;
+  // Read-ahead of the gather tables: depth and feat were written by the kernels right in front of this one and are NOT
+  // cache-resident for it (measured: 45 us per launch with them resident, 62 us inside the training step, 73 us with the
+  // rank tables cold as well).  The workgroups of the first residency round each stream one slice of [depth | feat] (33 MB
+  // at R1 over 2048 workgroups: 4 loads per lane) while they wait for their own descriptor / table loads anyway; every
+  // later gather, on any XCD, is then served from the Infinity Cache instead of a dependent HBM round trip.
+  unsigned pf_acc = 0;
+  if ((int)blockIdx.x < pf_blocks) {
+    const size_t d16 = depth_bytes / 16, f16 = feat_bytes / 16, per = (d16 + f16 + pf_blocks - 1) / pf_blocks;
+    const uint4* dp = reinterpret_cast<const uint4*>(depth);
+    const uint4* fp = reinterpret_cast<const uint4*>(feat);
+    for (size_t i = tid; i < per; i += kBlock) {
+      const size_t idx = (size_t)blockIdx.x * per + i;
+      if (idx < d16 + f16) {
+        const uint4 v = idx < d16 ? dp[idx] : fp[idx - d16];
+        pf_acc ^= v.x ^ v.w;
+      }
+    }
+  }
+  if (nrows <= 0) {
+    asm volatile("" ::"v"(pf_acc));                                  // the read-ahead loads have a consumer
+    return;
+  }
+  OMNIHD_STAMP(1);
 
   const int sub = tid % C4;
   const int grp = tid / C4;
@@ -708,21 +763,21 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
         empty = e0 == s0;
         if (!empty && staged) s_row[e0 - 1 - Pa] = i | (int)0x80000000;   // row offset inside the tile
       }
-      // empty_rows_kept: the caller hands in a buffer whose empty rows (a property of the plan) are zero already — the
-      // buffer of an earlier launch of the SAME plan, which only ever wrote the non-empty rows — so they are not stored again
-      const unsigned long long m = empty_rows_kept ? 0ull : __ballot(empty);
+      const unsigned long long m = __ballot(empty);
       if (m == 0ull) continue;
       const int wave_row0 = Ra + base + (tid & ~63);
       for (int k = 0; k < 64; k += GPW) {
         const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
         if (window == 0ull) continue;
-        if ((m >> (k + gw)) & 1ull)
+        if (((m >> (k + gw)) & 1ull) && !(OMNIHD_POOL_ABL & 8))
           store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
       }
     }
   } else if (tid == 0 && staged) {
     s_row[npts - 1] = (int)0x80000000;             // the single row of the tile (offset 0) closes at its last point
   }
+  OMNIHD_STAMP(2);
+  asm volatile("" ::"v"(pf_acc));                                    // the read-ahead loads are consumed here at the latest
   if (npts == 0) return;
 
   float4 acc = zero4;
@@ -785,11 +840,14 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
   for (int k = 0; k < kPer; ++k) {
     const int i = tid + k * kBlock;
     if (i < npts) {
-      s_rec[i] = make_int2(pixel_row(l_rd[k]), __float_as_int(depth[l_rd[k]]));
+      const int px = (OMNIHD_POOL_ABL & 2) ? (pixel_row(l_rd[k]) & 1023) : pixel_row(l_rd[k]);
+      s_rec[i] = make_int2(px, __float_as_int((OMNIHD_POOL_ABL & 1) ? 1.0f : depth[l_rd[k]]));
     }
   }
   for (int i = npts + tid; i < n_rec; i += kBlock) s_rec[i] = make_int2(0x7fffffff, 0);   // offset beyond the buffer
   __syncthreads();
+  OMNIHD_STAMP(3);
+  OMNIHD_STAMP(4);
 
   // ---- phase P: Wp points per group, U per step, no bounds tests -------------------------------
   const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
@@ -819,8 +877,13 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
     float4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const u32x4v raw = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, ((unsigned)px[u] << SH) | lane_off, 0, 0);
-      v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+      if (OMNIHD_POOL_ABL & 16) {
+        const float t = (float)(px[u] & 0xffff);
+        v[u] = make_float4(t, t, t, t);
+      } else {
+        const u32x4v raw = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, ((unsigned)px[u] << SH) | lane_off, 0, 0);
+        v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -831,7 +894,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
         if ((pend >> lane) & 1ull) {                     // head partial of a continued row: completed after the loop
           s_head[tid] = acc;
           if (sub == 0) s_head_row[grp] = cl[u];
-        } else {
+        } else if (!(OMNIHD_POOL_ABL & 4) || acc.x == 1.2345e30f) {
           const u32x4v o = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
           __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)cl[u] << SH) | lane_off, 0, 2 /* nt */);
         }
@@ -844,7 +907,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
   // piece ends inside a row (or is empty: then it lies "inside" whatever row surrounds it, with a zero partial)
   const int i1 = min(i0 + Wp, npts);
   const bool open_end = (i1 <= i0) || (s_row[i1 - 1] >= 0);
+  OMNIHD_STAMP(5);
   __syncthreads();   // every group is done with the records: their LDS is reused for the tails
+  OMNIHD_STAMP(6);
   s_tail[tid] = acc;
   // bit0: the piece ends inside a row; bit1: the piece lies entirely inside one row that started before it
   if (sub == 0) s_tail_flags[grp] = (open_end ? 1 : 0) | ((pending || i1 <= i0) ? 2 : 0);
@@ -866,6 +931,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
     const u32x4v o = {__float_as_uint(tsum.x), __float_as_uint(tsum.y), __float_as_uint(tsum.z), __float_as_uint(tsum.w)};
     __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)s_head_row[grp] << SH) | lane_off, 0, 2);
   }
+  OMNIHD_STAMP(7);
 }
 
 // schedule slot -> {first row, #rows, first point, #points}; idle slots get #rows = 0
@@ -1122,8 +1188,10 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
   extern __shared__ float s_dyn[];                 // [0, D*16) depth values of the patch, [D*16, 2*D*16) depth gradients
   const int slot = (int)(blockIdx.x >> 3);
   if (slot >= patches_per_xcd) return;
+  OMNIHD_STAMP(0);
   const int patch = patch_order[(size_t)(blockIdx.x & 7) * patches_per_xcd + slot];
   if (patch < 0) return;
+  OMNIHD_STAMP(1);
   const int tid = threadIdx.x;
   const int sub = tid % C4;
   const int grp = tid / C4;
@@ -1155,7 +1223,9 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
   ml = max(ml, __shfl_xor(ml, 16));
   ml = max(ml, __shfl_xor(ml, 32));
   const int wave_len = __builtin_amdgcn_readfirstlane(ml);
+  OMNIHD_STAMP(2);
   __syncthreads();
+  OMNIHD_STAMP(3);
 
   const __amdgpu_buffer_rsrc_t og_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)og_bytes, 0x00020000);
   const unsigned lane_off = (unsigned)sub << 4;
@@ -1194,12 +1264,15 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
     if (cb + 8 < wave_len) patch_batch8<8>(og_rsrc, lane_off, rr, dval, x, fg, mydot, sub);
     if (inb) s_dg[dk * kPatch + grp] = mydot;
   }
+  OMNIHD_STAMP(4);
   if (valid) feat_grad4[(size_t)f * C4 + sub] = fg;
   __syncthreads();
+  OMNIHD_STAMP(5);
   for (int i = tid; i < n_cell; i += kBlock) {
     const int d = i / kPatch, px = i % kPatch;
     if (px < npx) depth_grad[img_base + (size_t)d * fhw + px] = s_dg[i];
   }
+  OMNIHD_STAMP(6);
 }
 
 __global__ __launch_bounds__(kBlock) void k_pool_bwd_generic(
@@ -1314,7 +1387,7 @@ extern "C" int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const i
 extern "C" int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int* ranks_depth,
                                            const int* row_ptr, const int* tile_desc, int n_tiles, float* out, int c,
                                            int n_rows, int n_points, int d_bins, int fhw, int n_feat_rows,
-                                           int empty_rows_kept, void* stream) {
+                                           int /*empty_rows_kept: round-3 argument, ignored by this round-2 lab copy*/, void* stream) {
   OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles > 0 && n_points >= 0 && d_bins > 0 && fhw > 0 && n_feat_rows >= 0, "sizes");
   if (n_rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(depth && feat && row_ptr && out && tile_desc && (n_points == 0 || ranks_depth), "null pointer");
@@ -1333,14 +1406,16 @@ extern "C" int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat
   // names, and the wrapper passes its size in rows through n_feat_rows (0: unknown -> first lean kernel).
   static const bool lean2 = [] { const char* e = getenv("OMNIHD_POOL_LEAN2"); return !(e && e[0] == '0'); }();
   const long long feat_bytes = (long long)n_feat_rows * c * 4;
-  OMNIHD_REQUIRE(!empty_rows_kept || (lean2 && n_feat_rows > 0 && feat_bytes < (1ll << 31)),
-                 "empty_rows_kept needs the second-generation kernel (n_feat_rows given, feature table below 2 GiB)");
+  // read-ahead of depth + feat by the first residency round (OMNIHD_POOL_READAHEAD=0 turns it off)
+  static const bool readahead = [] { const char* e = getenv("OMNIHD_POOL_READAHEAD"); return !(e && e[0] == '0'); }();
+  const long long depth_bytes = (long long)n_feat_rows * d_bins * 4;
+  const int pf_blocks = (readahead && depth_bytes < (1ll << 32)) ? (n_tiles < 2048 ? n_tiles : 2048) : 0;
   if (lean2 && n_feat_rows > 0 && feat_bytes < (1ll << 31)) {
 #define OMNIHD_LEAN2_CASE(C4)                                                                                     \
   case C4:                                                                                                        \
     hipLaunchKernelGGL((k_pool_fwd_lean2<C4, 4>), grid, dim3(kBlock), 0, st, depth, feat, (unsigned)feat_bytes,   \
                        ranks_depth, row_ptr, td, out, tiles_per_xcd, fhw, dfhw, 1.0f / (float)fhw,               \
-                       1.0f / (float)dfhw, empty_rows_kept);                                                      \
+                       1.0f / (float)dfhw, (unsigned)depth_bytes, pf_blocks);                                     \
     break;
     switch (c / 4) {
       OMNIHD_LEAN2_CASE(1)

@@ -43,7 +43,7 @@ def _seed_everything():
     # Backend switches are process-global: a test that flips one changes the arithmetic of every later test.  Round 1's
     # red GPU suite was exactly that — `torch.backends.cudnn.allow_tf32 = False`, set by one detector test, makes MIOpen on
     # this ROCm build pick fp32 backward kernels that are off by 1e-2 (default: 6e-7 against the reference golden, measured
-    # with scripts/repro_lss_test.py).  Every test therefore starts from torch's defaults.
+    # with scripts/repro_lss_grad.py).  Every test therefore starts from torch's defaults.
     torch.backends.cudnn.allow_tf32 = True
     torch.backends.cudnn.benchmark = False
     torch.backends.cudnn.deterministic = False

@@ -92,3 +92,38 @@ def test_plan_layouts_agree(cuda, golden):
     x, y, z, b = rb % X, (rb // X) % Y, (rb // (X * Y)) % Z, rb // (X * Y * Z)
     perm = ((b * Y + y) * X + x) * Z + z
     assert np.array_equal(np.sort(perm), q.ranks_row.cpu().numpy())
+
+
+@pytest.mark.parametrize("tag,H,W", [("r1", 256, 704), ("r2", 544, 960)])
+def test_device_geometry_of_the_lss_module_is_bit_exact_and_its_plan_reproduces_the_reference_checksums(cuda, golden, tag, H, W):
+    """the tables north_star wants bit-exact are built from the geometry the PRODUCT computes on the
+    device (LiftSplatShoot_Depth.get_geometry, three broadcast multiply-adds per axis), not from a host geometry.  For the
+    6-camera R1 and R2 rigs: the device geometry equals the oracle's (= the reference's torch-CPU get_geometry,
+    cam_stream_lss_bevpoolv2_depthnet.py:235-264) bit for bit, the plan the module builds from it through its own cache
+    path (`_plan_for`) carries the reference's point / interval counts and table checksums (:302-362, recorded from the
+    reference in tests/golden/make_golden.py), and the reference-format tables from the same device geometry do too."""
+    from omnihd_amd import ops
+    from projects.mmdet3d_plugin.bevfusion.detectors.cam_stream_lss_bevpoolv2_depthnet import LiftSplatShoot_Depth
+    from tests.helpers import PC_RANGE
+    net = LiftSplatShoot_Depth(final_dim=(H, W), camera_depth_range=[1, 60, 1], pc_range=PC_RANGE, downsample=4, grid=0.5,
+                               inputC=256, camC=64, norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01))
+    net.frustum.data = net.frustum.data.to(cuda)               # only the geometry path is exercised: no need to move the convs
+    rots, trans = t(golden[f"full_{tag}_rots"], cuda), t(golden[f"full_{tag}_trans"], cuda)
+    with torch.no_grad():
+        geom = net.get_geometry(rots, trans)
+    want, dx, bx, nx = full_size_geometry(tag)
+    assert geom.dtype == torch.float32 and tuple(geom.shape) == want.shape
+    assert torch.equal(geom.cpu(), torch.from_numpy(want)), "device geometry differs from the reference's torch-CPU geometry"
+    cs_ref = golden[f"full_{tag}_checksums"].tolist()
+    tabs = ops.voxel_pooling_prepare_v2(geom.contiguous(), dx, bx, nx)
+    cs = [tabs[0].numel(), tabs[3].numel()] + [int(x.long().sum()) for x in tabs] + [int(tabs[4].max())]
+    assert cs == cs_ref
+    plan = net._plan_for(rots, trans, (None, None, None, None))
+    assert plan.layout == "byxz" and plan.n_points == cs_ref[0] and plan.n_intervals == cs_ref[1]
+    assert int(plan.ranks_depth.long().sum()) == cs_ref[3] and int(plan.ranks_feat.long().sum()) == cs_ref[4]
+    assert int(plan.interval_lengths.long().sum()) == cs_ref[6] and int(plan.interval_lengths.max()) == cs_ref[7]
+    # the plan numbers rows (b,y,x,z); mapped back to the reference's (b,z,y,x) numbering the row sum is the reference's too
+    X, Y, Z = (int(v) for v in nx)
+    r = plan.ranks_row.long()
+    z, x, y, b = r % Z, (r // Z) % X, (r // (Z * X)) % Y, r // (Z * X * Y)
+    assert int((((b * Z + z) * Y + y) * X + x).sum()) == cs_ref[2]
