@@ -164,6 +164,7 @@ class BevOps:
         self.sched_bwd = True
         self.patch_bwd = os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"   # k_pool_bwd_patch (C = 64), the default
         self.scheduled = True
+        self.keep_empty = os.environ.get("OMNIHD_POOL_KEEP_ZEROS", "1") != "0"
         H, W, _ = RES[res]
         self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
         dx, bx, nx, frustum = lss_constants(res)
@@ -178,7 +179,7 @@ class BevOps:
             depth = torch.rand(batch, self.N, self.D, self.fH, self.fW, device=dev, generator=g).softmax(2)
             feat = torch.randn(batch, self.N, self.fH, self.fW, self.C, device=dev, generator=g)
             og = torch.randn(self.plan.n_rows, self.C, device=dev, generator=g)
-            out = torch.empty(self.plan.n_rows, self.C, device=dev)
+            out = torch.zeros(self.plan.n_rows, self.C, device=dev)
             # private copies of the tables too, so that nothing is served from the Infinity Cache
             tabs = [x.clone() for x in (self.plan.ranks_depth, self.plan.ranks_feat, self.plan.row_ptr,
                                         self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
@@ -192,7 +193,9 @@ class BevOps:
     def pool_fwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
         if self.tiled and self.lean:
-            self.ops.bev_pool_v2_forward_lean(depth, feat, tb[0], tb[2], tb[8], out, self.D, self.fH * self.fW)
+            # as the product launches it: the empty rows of `out` are zero already (same plan, nobody wrote to it) and are kept
+            self.ops.bev_pool_v2_forward_lean(depth, feat, tb[0], tb[2], tb[8], out, self.D, self.fH * self.fW,
+                                              empty_rows_kept=self.keep_empty)
         else:
             self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out, tb[9], tb[8] if self.tiled else None)
 

@@ -348,12 +348,38 @@ int omnihd_conv_fwd_supported(int batch, int h, int w, int cin, int cout, int ks
 /* y[b,y,x,n] = bias[n] + sum_{ky,kx,c} x[b, y+(ky-k/2)*dil, x+(kx-k/2)*dil, c] * w[n,ky,kx,c]   (zero outside the image)
  *   x_nhwc (batch,h,w,cin) bf16, w_ohwi (cout,k,k,cin) bf16 (= a torch weight in channels_last memory format),
  *   bias (cout) f32 or NULL, y_nhwc (batch,h,w,cout) bf16.  fp32 accumulation, one rounding to bf16.
- *   tile: 0 = choose, 128 = 128x128 tile / 4 wavefronts, 256 = 256x128 tile / 8 wavefronts.                       */
+ *   tile: 0 = choose, 128 = 128x128 tile / 4 wavefronts, 256 = 256x128 tile / 8 wavefronts, 254 = 128x256 tile,
+ *         300 = 3x3 row-shift kernel (256x128 tile, dilation <= 8).                                                 */
 int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, const float* bias, void* y_nhwc, int batch, int h,
                          int w, int cin, int cout, int ksize, int dil, int tile, void* stream);
 /* wt[c,k-1-ky,k-1-kx,n] = w[n,ky,kx,c]: the weights with which the DATA GRADIENT of the convolution above is the same
  * convolution applied to the output gradient:  omnihd_conv_fwd_bf16(gout, wt, NULL, gx, batch, h, w, cout, cin, ...).  */
 int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream);
+
+/* The same convolutions at fp32-grade accuracy on the bf16 matrix cores (the reference trains in fp32:
+ * projects/configs/bevfusion_NewScenes/bevfusion.py:223-268 has no fp16 hook; gfx950's fp32 MFMA runs at 1/16 of the bf16
+ * rate and has no TF32 form).  Every fp32 operand is split into two bf16 planes, hi = bf16(v), lo = bf16(v - hi), and
+ *     x * w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi   with fp32 accumulation
+ * (the dropped lo*lo term is 2^-16 of a product: results agree with an fp32 convolution to ~1e-5 relative).               */
+
+/* hi[i] = bf16(x[i]) (round to nearest even), lo[i] = bf16(x[i] - hi[i]) for n fp32 values (any layout: element-wise);
+ * inf / nan stay in the hi plane.  16-byte aligned buffers.                                                               */
+int omnihd_split_f32(const float* x, long long n, void* hi, void* lo, void* stream);
+/* omnihd_conv_fwd_bf16 on split operands: x_hi/x_lo (batch,h,w,cin) bf16, w_hi/w_lo (cout,k,k,cin) bf16, bias f32 or NULL,
+ * y (batch,h,w,cout) F32.  Same geometries (omnihd_conv_fwd_supported) and tile codes.  The data gradient is the same call
+ * on the split output gradient with both weight planes re-laid by omnihd_conv_dgrad_weights.                              */
+int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                          float* y_nhwc, int batch, int h, int w, int cin, int cout, int ksize, int dil, int tile,
+                          void* stream);
+
+/* Weight gradient of the same convolutions from split operands (see omnihd_conv_wgrad_bf16 for the geometry arguments):
+ * dW = G_hi*X_hi + G_hi*X_lo + G_lo*X_hi with fp32 accumulation — the four planes are staged once and one GEMM launch runs
+ * its pixel loop three times into the same tiles.  dw (cout,kh,kw,cin) f32.                                               */
+size_t omnihd_conv_wgrad_split_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw,
+                                               int stride, int pad, int dil);
+int omnihd_conv_wgrad_split(const void* x_hi, const void* x_lo, const void* g_hi, const void* g_lo, float* dw, int batch, int h,
+                            int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad, int dil,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Depth-head epilogue of the LSS camera stream: softmax over D + depth / context split + pooling layouts

@@ -174,14 +174,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
           bh[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
           bl[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][(((c + 4) ^ ((rb >> 1) & 7)) * 8)]);
         }
+        // term-major order: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         if (SPREAD) {
           constexpr int PER = (CALLS + kCS / 16 - 1) / (kCS / 16);
 #pragma unroll
@@ -395,14 +400,19 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
             for (int e = 0; e < 8; ++e) { ah[i][e] = (__bf16)0.0f; al[i][e] = (__bf16)0.0f; }
           }
         }
+        // term-major order: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         if (SPREAD) {
           // same program order of the fills as below, spread over the two 16-deep slices
           if (KX == 0) {

@@ -171,7 +171,10 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
                                                             float* __restrict__ slab, int Cout, int Cin,
                                                             int Coutp, int Cinp, int M, int Mp, int H, int W,
                                                             int n_split, int k_per_split, int taps, int mode,
-                                                            int dil) {
+                                                            int dil, const unsigned short* __restrict__ Gt2,
+                                                            const unsigned short* __restrict__ Xt2, int n_terms) {
+  // n_terms == 3 (fp32-grade split operands): Gt / Xt are the hi planes, Gt2 / Xt2 the lo planes, and the K loop runs three
+  // times over the split's pixel range, accumulating  G_hi*X_hi + G_hi*X_lo + G_lo*X_hi  into the same tile
   // one LDS object only (a second one makes hipcc drain the DMA queue before every ds_read)
   __shared__ __attribute__((aligned(16))) unsigned short sm[kStages][2][kTile][kBK];
   const int tid = threadIdx.x;
@@ -193,14 +196,22 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
   const int lr = lane >> 3;                       // row inside the 8-row call
   const int pos = lane & 7;                       // 16-byte slot inside the LDS row
   const int c_even = pos ^ ((lane >> 4) & 7);     // global chunk for calls 0,2 ; calls 1,3 use c_even ^ 4
-  const unsigned short* a_row = Gt + (size_t)(nt * kTile + wave * 32 + lr) * Mp;
-  const unsigned short* b_row = Xt + ((size_t)copy * Cinp + ct * kTile + wave * 32 + lr) * Mp + (ptrdiff_t)dy * W;
+  const size_t a_off = (size_t)(nt * kTile + wave * 32 + lr) * Mp;
+  const ptrdiff_t b_off = (ptrdiff_t)(((size_t)copy * Cinp + ct * kTile + wave * 32 + lr) * Mp) + (ptrdiff_t)dy * W;
+  const unsigned short* a_row = Gt + a_off;
+  const unsigned short* b_row = Xt + b_off;
   // image row of this lane's two chunk positions at K-step k0 (chunks never straddle rows: W % 8 == 0)
-  int px0 = (k0 + c_even * 8) % W, py0 = ((k0 + c_even * 8) / W) % H;
-  int px1 = (k0 + (c_even ^ 4) * 8) % W, py1 = ((k0 + (c_even ^ 4) * 8) / W) % H;
+  const int px0_0 = (k0 + c_even * 8) % W, py0_0 = ((k0 + c_even * 8) / W) % H;
+  const int px1_0 = (k0 + (c_even ^ 4) * 8) % W, py1_0 = ((k0 + (c_even ^ 4) * 8) / W) % H;
+  int px0 = px0_0, py0 = py0_0, px1 = px1_0, py1 = py1_0;
+  const int n_it = (k1 - k0 + kBK - 1) / kBK;      // K-steps per term
+  const int total = n_it * n_terms;
+  int it_issue = 0, it_in_term = 0, term = 0;
 
-  auto issue = [&](int k, int stage) {
-    const bool real = k < k1;
+  // issues the next K-step in (term, pixel) order; beyond the last one: zero-page dummies (keeps the wait counts uniform)
+  auto issue = [&](int stage) {
+    const bool real = it_issue < total;
+    const int k = k0 + it_in_term * kBK;
     const bool ok0 = real && (k + c_even * 8 < M) && (py0 + dy >= 0) && (py0 + dy < H);
     const bool ok1 = real && (k + (c_even ^ 4) * 8 < M) && (py1 + dy >= 0) && (py1 + dy < H);
 #pragma unroll
@@ -214,6 +225,13 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
     }
     px0 += kBK; while (px0 >= W) { px0 -= W; py0 = (py0 + 1 == H) ? 0 : py0 + 1; }
     px1 += kBK; while (px1 >= W) { px1 -= W; py1 = (py1 + 1 == H) ? 0 : py1 + 1; }
+    ++it_issue;
+    if (++it_in_term == n_it && it_issue < total) {   // next term: rewind the pixel range, switch operand planes
+      it_in_term = 0; ++term;
+      px0 = px0_0; py0 = py0_0; px1 = px1_0; py1 = py1_0;
+      a_row = (term == 2 ? Gt2 : Gt) + a_off;
+      b_row = (term == 1 ? Xt2 : Xt) + b_off;
+    }
   };
 
   f32x16 acc[2][2];
@@ -229,15 +247,15 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
   const int fhalf = lane >> 5;
 
   // prologue: three K-steps in flight
-  issue(k0, 0);
-  issue(k0 + kBK, 1);
-  issue(k0 + 2 * kBK, 2);
+  issue(0);
+  issue(1);
+  issue(2);
   int stage = 0;
-  for (int k = k0; k < k1; k += kBK) {
+  for (int it = 0; it < total; ++it) {
     // the oldest K-step (8 DMA calls per wave) has landed when at most 16 younger calls are outstanding
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(k + 3 * kBK, (stage + 3) % kStages);      // its buffer was last read two barriers ago
+    issue((stage + 3) % kStages);                   // its buffer was last read two barriers ago
 #pragma unroll
     for (int ks = 0; ks < kBK / 16; ++ks) {
       bf16x8 a[2], b[2];
@@ -299,7 +317,9 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds3(const unsigned shor
                                                              const unsigned short* __restrict__ zero_page,
                                                              float* __restrict__ slab, int Cout, int Cin, int Coutp,
                                                              int Cinp, int M, int Mp, int H, int W, int n_split,
-                                                             int k_per_split, int dil) {
+                                                             int k_per_split, int dil, const unsigned short* __restrict__ Gt2,
+                                                             const unsigned short* __restrict__ Xt2, int n_terms) {
+  // n_terms == 3: split operands, three passes over the pixel range (see k_wgrad_mfma_glds)
   __shared__ __attribute__((aligned(16))) unsigned short sm[kStages3][4][kTile][kBK3];   // tile 0 = G, 1..3 = X copies
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -317,13 +337,20 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds3(const unsigned shor
   // loader: one DMA call = 16 rows of 64 B; wave w owns rows [32w, 32w+32) of every tile: two calls per tile
   const int lr = lane >> 2;                        // row inside the call
   const int gch = (lane & 3) ^ ((lane >> 4) & 3);  // global 16-byte chunk this lane fetches (LDS slot lane & 3)
-  const unsigned short* a_row = Gt + (size_t)(nt * kTile + wave * 32 + lr) * Mp;
-  const unsigned short* b_row = Xt + ((size_t)ct * kTile + wave * 32 + lr) * Mp + (ptrdiff_t)dy * W;
+  const size_t a_off = (size_t)(nt * kTile + wave * 32 + lr) * Mp;
+  const ptrdiff_t b_off = (ptrdiff_t)(((size_t)ct * kTile + wave * 32 + lr) * Mp) + (ptrdiff_t)dy * W;
+  const unsigned short* a_row = Gt + a_off;
+  const unsigned short* b_row = Xt + b_off;
   const size_t copy_pitch = (size_t)Cinp * Mp;
-  int px = (k0 + gch * 8) % W, py = ((k0 + gch * 8) / W) % H;
+  const int px_0 = (k0 + gch * 8) % W, py_0 = ((k0 + gch * 8) / W) % H;
+  int px = px_0, py = py_0;
+  const int n_it = (k1 - k0 + kBK3 - 1) / kBK3;
+  const int total = n_it * n_terms;
+  int it_issue = 0, it_in_term = 0, term = 0;
 
-  auto issue = [&](int k, int stage) {
-    const bool real = k < k1;
+  auto issue = [&](int stage) {
+    const bool real = it_issue < total;
+    const int k = k0 + it_in_term * kBK3;
     const bool ok = real && (k + gch * 8 < M) && (py + dy >= 0) && (py + dy < H);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -336,6 +363,13 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds3(const unsigned shor
       }
     }
     px += kBK3; while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
+    ++it_issue;
+    if (++it_in_term == n_it && it_issue < total) {
+      it_in_term = 0; ++term;
+      px = px_0; py = py_0;
+      a_row = (term == 2 ? Gt2 : Gt) + a_off;
+      b_row = (term == 1 ? Xt2 : Xt) + b_off;
+    }
   };
 
   f32x16 acc[3][2][2];
@@ -352,14 +386,14 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds3(const unsigned shor
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
 
-  issue(k0, 0);
-  issue(k0 + kBK3, 1);
-  issue(k0 + 2 * kBK3, 2);
+  issue(0);
+  issue(1);
+  issue(2);
   int stage = 0;
-  for (int k = k0; k < k1; k += kBK3) {
+  for (int it = 0; it < total; ++it) {
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(k + 3 * kBK3, (stage + 3) % kStages3);
+    issue((stage + 3) % kStages3);
 #pragma unroll
     for (int ks = 0; ks < kBK3 / 16; ++ks) {
       bf16x8 a[2], b[3][2];
@@ -381,6 +415,140 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds3(const unsigned shor
           for (int j = 0; j < 2; ++j)
             acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[t][j], acc[t][i][j], 0, 0, 0);
     }
+    stage = (stage + 1) % kStages3;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* dst = slab + (size_t)split * Cout * 9 * Cin;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = ky * 3 + t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nt * kTile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int cc = ct * kTile + wn * 64 + j * 32 + (lane & 31);
+          if (n < Cout && cc < Cin) dst[((size_t)n * 9 + tap) * Cin + cc] = acc[t][i][j][r];
+        }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Three taps per workgroup on SPLIT operands (fp32-grade weight gradient of the reference-precision step): per K-step of
+// 16 pixels one stage holds G_hi, G_lo and the three dx-shifted copies of X_hi and X_lo (8 tiles of 128 rows x 32 B = 32 KB,
+// the ring of 4 stages is the same 128 KB) and feeds  3 taps x 3 terms x 4 = 36 MFMAs  from 16 fragment reads:
+//     dW[tap] += G_hi*X_hi[tap] + G_hi*X_lo[tap] + G_lo*X_hi[tap].
+// Running k_wgrad_mfma_glds3 three times over the pixel range (one launch, n_terms = 3) streams 12 operand tiles through LDS
+// for the same 9 tile products and measured 2.97 ms on 1024->1024 at 160x240; here it is 8.
+// 32-byte LDS rows: slot = 16-byte chunk ^ ((row >> 3) & 1)  (conflict-free ds_read_b128, checked per 16-lane group).
+// Per wave and stage: 8 DMA calls (one per tile), so vmcnt(16) leaves two younger stages in flight.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBKS = 16;
+
+__global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* __restrict__ Gt, const unsigned short* __restrict__ Gt2,
+                                                         const unsigned short* __restrict__ Xt, const unsigned short* __restrict__ Xt2,
+                                                         const unsigned short* __restrict__ zero_page, float* __restrict__ slab,
+                                                         int Cout, int Cin, int Coutp, int Cinp, int M, int Mp, int H, int W,
+                                                         int n_split, int k_per_split, int dil) {
+  // tiles: 0 = G_hi, 1 = G_lo, 2..4 = X_hi copies, 5..7 = X_lo copies
+  __shared__ __attribute__((aligned(16))) unsigned short sm[kStages3][8][kTile][kBKS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tiles_c = Cinp / kTile, tiles_n = Coutp / kTile;
+  int bid = blockIdx.x;
+  const int ct = bid % tiles_c; bid /= tiles_c;
+  const int nt = bid % tiles_n; bid /= tiles_n;
+  const int ky = bid % 3;
+  const int split = bid / 3;
+  const int dy = (ky - 1) * dil;
+  const int k0 = split * k_per_split;
+  const int k1 = min(k0 + k_per_split, Mp);
+
+  // loader: one DMA call = 32 rows of 32 B; wave w owns rows [32w, 32w+32) of every tile: one call per tile
+  const int lr = lane >> 1;                          // row inside the call
+  const int gch = (lane & 1) ^ ((lr >> 3) & 1);      // global 16-byte chunk this lane fetches (LDS slot lane & 1)
+  const size_t a_off = (size_t)(nt * kTile + wave * 32 + lr) * Mp;
+  const ptrdiff_t b_off = (ptrdiff_t)(((size_t)ct * kTile + wave * 32 + lr) * Mp) + (ptrdiff_t)dy * W;
+  const size_t copy_pitch = (size_t)Cinp * Mp;
+  int px = (k0 + gch * 8) % W, py = ((k0 + gch * 8) / W) % H;
+
+  auto issue = [&](int k, int stage) {
+    const bool real = k < k1;
+    const bool ok = real && (k + gch * 8 < M) && (py + dy >= 0) && (py + dy < H);
+    const size_t ka = (size_t)k + gch * 8;
+    const unsigned short* g0 = real ? Gt + a_off + ka : zero_page;
+    const unsigned short* g1 = real ? Gt2 + a_off + ka : zero_page;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g0, (lds_ptr_t*)&sm[stage][0][wave * 32][0], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g1, (lds_ptr_t*)&sm[stage][1][wave * 32][0], 16, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned short* x0 = ok ? Xt + b_off + c * copy_pitch + ka : zero_page;
+      const unsigned short* x1 = ok ? Xt2 + b_off + c * copy_pitch + ka : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)x0, (lds_ptr_t*)&sm[stage][2 + c][wave * 32][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)x1, (lds_ptr_t*)&sm[stage][5 + c][wave * 32][0], 16, 0, 0);
+    }
+    px += kBKS; while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
+  };
+
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+
+  issue(k0, 0);
+  issue(k0 + kBKS, 1);
+  issue(k0 + 2 * kBKS, 2);
+  int stage = 0;
+  for (int k = k0; k < k1; k += kBKS) {
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(k + 3 * kBKS, (stage + 3) % kStages3);
+    bf16x8 ah[2], al[2], bh[3][2], bl[3][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = wm * 64 + i * 32 + frow;
+      const int rb = wn * 64 + i * 32 + frow;
+      const int sa = (fhalf ^ ((ra >> 3) & 1)) * 8, sb = (fhalf ^ ((rb >> 3) & 1)) * 8;
+      ah[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][sa]);
+      al[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1][ra][sa]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        bh[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][2 + t][rb][sb]);
+        bl[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][5 + t][rb][sb]);
+      }
+    }
+    // term-major: consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[t][j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[t][j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[t][j], acc[t][i][j], 0, 0, 0);
     stage = (stage + 1) % kStages3;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -515,17 +683,21 @@ extern "C" size_t omnihd_conv_wgrad_workspace_bytes(int batch, int h, int w, int
   return 256 + p.gt_bytes + p.xt_bytes + p.slab_bytes + 4 * p.guard;
 }
 
-extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw, int batch, int h, int w,
-                                      int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad,
-                                      int dil, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// x_lo / g_lo == nullptr: plain bf16 operands.  Otherwise the fp32-grade three-term form on split operands: all four planes
+// are staged k-major once and ONE GEMM launch runs the K loop three times (hi*hi, hi*lo, lo*hi) into the same tiles.
+int wgrad_impl(const void* x_nhwc, const void* x_lo, const void* gout_nhwc, const void* g_lo, float* dw, int batch, int h, int w,
+               int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad, int dil, void* workspace,
+               size_t workspace_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  const bool split = x_lo != nullptr;
   WgradPlan p;
   if (!make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, &p)) {
     set_error("conv_wgrad: unsupported geometry (square 1x1/3x3 kernels, channels multiples of 8, consistent output size)");
     return OMNIHD_ERR_ARG;
   }
-  OMNIHD_REQUIRE(x_nhwc && gout_nhwc && dw && workspace, "null pointer");
-  const size_t need = omnihd_conv_wgrad_workspace_bytes(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil);
+  OMNIHD_REQUIRE(x_nhwc && gout_nhwc && dw && workspace && (!split || g_lo), "null pointer");
+  const size_t need = (split ? 2 : 1) * (p.gt_bytes + p.xt_bytes + 2 * p.guard) + 256 + p.slab_bytes + 2 * p.guard;
   if (workspace_bytes < need) {
     set_error("conv_wgrad: workspace %zu < required %zu", workspace_bytes, need);
     return OMNIHD_ERR_WORKSPACE;
@@ -538,24 +710,35 @@ extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc,
   q += p.gt_bytes + p.guard;
   unsigned short* Xt = reinterpret_cast<unsigned short*>(q);
   q += p.xt_bytes + p.guard;
+  unsigned short *Gt2 = nullptr, *Xt2 = nullptr;
+  if (split) {
+    Gt2 = reinterpret_cast<unsigned short*>(q);
+    q += p.gt_bytes + p.guard;
+    Xt2 = reinterpret_cast<unsigned short*>(q);
+    q += p.xt_bytes + p.guard;
+  }
   float* slab = reinterpret_cast<float*>(q);
-  const unsigned short* xs = static_cast<const unsigned short*>(x_nhwc);
-  const unsigned short* gs = static_cast<const unsigned short*>(gout_nhwc);
+  const int n_terms = split ? 3 : 1;
 
   const int cmax = p.coutp > p.cinp ? p.coutp : p.cinp;
-  const StageArgs aG{gs, Gt, cout, p.coutp, 1};
-  if (p.mode == 0 && p.taps == 9) {
-    // G and X share the padded raster (b, y, x) with row pitch wp
-    const StageArgs aX{xs, Xt, cin, p.cinp, 3};
-    hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, cmax / 64, 2), dim3(kBlock), 0, st, aG, aX, batch * h * w, w, p.wp, p.mp, dil);
-  } else if (p.mode == 0) {
-    // 1x1: the raster is the plain pixel index (one "row" of mp pixels, nothing to shift)
-    const StageArgs aX{xs, Xt, cin, p.cinp, 1};
-    hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, cmax / 64, 2), dim3(kBlock), 0, st, aG, aX, p.mpix, p.mpix, p.mp, p.mp, 1);
-  } else {
-    hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, p.coutp / 64, 1), dim3(kBlock), 0, st, aG, aG, p.mpix, p.mpix, p.mp, p.mp, 1);
-    hipLaunchKernelGGL(k_taps_kmajor, dim3(p.mp / 64, p.cinp / 64, p.taps), dim3(kBlock), 0, st, xs, batch, h, w, cin,
-                       p.cinp, ho, wo, p.mp, kw, stride, pad, dil, Xt);
+  for (int plane = 0; plane < (split ? 2 : 1); ++plane) {
+    const unsigned short* xs = static_cast<const unsigned short*>(plane ? x_lo : x_nhwc);
+    const unsigned short* gs = static_cast<const unsigned short*>(plane ? g_lo : gout_nhwc);
+    unsigned short *gt = plane ? Gt2 : Gt, *xt = plane ? Xt2 : Xt;
+    const StageArgs aG{gs, gt, cout, p.coutp, 1};
+    if (p.mode == 0 && p.taps == 9) {
+      // G and X share the padded raster (b, y, x) with row pitch wp
+      const StageArgs aX{xs, xt, cin, p.cinp, 3};
+      hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, cmax / 64, 2), dim3(kBlock), 0, st, aG, aX, batch * h * w, w, p.wp, p.mp, dil);
+    } else if (p.mode == 0) {
+      // 1x1: the raster is the plain pixel index (one "row" of mp pixels, nothing to shift)
+      const StageArgs aX{xs, xt, cin, p.cinp, 1};
+      hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, cmax / 64, 2), dim3(kBlock), 0, st, aG, aX, p.mpix, p.mpix, p.mp, p.mp, 1);
+    } else {
+      hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, p.coutp / 64, 1), dim3(kBlock), 0, st, aG, aG, p.mpix, p.mpix, p.mp, p.mp, 1);
+      hipLaunchKernelGGL(k_taps_kmajor, dim3(p.mp / 64, p.cinp / 64, p.taps), dim3(kBlock), 0, st, xs, batch, h, w, cin,
+                         p.cinp, ho, wo, p.mp, kw, stride, pad, dil, xt);
+    }
   }
   static const bool three_taps = [] { const char* e = getenv("OMNIHD_WGRAD_3TAPS"); return !(e && e[0] == '0'); }();
   int n_split = p.split;
@@ -563,18 +746,47 @@ extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc,
     n_split = p.split3;
     const int k_per_split3 = ((p.mp / kBK + n_split - 1) / n_split) * kBK;
     const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * 3 * n_split;
-    hipLaunchKernelGGL(k_wgrad_mfma_glds3, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, n_split > 1 ? slab : dw, cout,
-                       cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil);
+    static const bool fused8 = [] { const char* e = getenv("OMNIHD_WGRAD_SPLIT8"); return !(e && e[0] == '0'); }();
+    if (split && fused8)
+      hipLaunchKernelGGL(k_wgrad_split3, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2, zero_page, n_split > 1 ? slab : dw, cout,
+                         cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil);
+    else
+      hipLaunchKernelGGL(k_wgrad_mfma_glds3, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, n_split > 1 ? slab : dw, cout,
+                         cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil, Gt2, Xt2, n_terms);
   } else {
     const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * p.taps * p.split;
     hipLaunchKernelGGL(k_wgrad_mfma_glds, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, p.split > 1 ? slab : dw,
-                       cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, p.split, k_per_split, p.taps, p.mode, dil);
+                       cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, p.split, k_per_split, p.taps, p.mode, dil,
+                       Gt2, Xt2, n_terms);
   }
   if (n_split > 1) {
     const size_t n = (size_t)cout * p.taps * cin;
     hipLaunchKernelGGL(k_sum_slabs, dim3(grid_for((int64_t)n, kBlock * 4)), dim3(kBlock), 0, st, slab, n_split, n, dw);
   }
-  return check_launch("conv_wgrad_bf16");
+  return check_launch(split ? "conv_wgrad_split" : "conv_wgrad_bf16");
+}
+}  // namespace
+
+extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw, int batch, int h, int w,
+                                      int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad,
+                                      int dil, void* workspace, size_t workspace_bytes, void* stream) {
+  return wgrad_impl(x_nhwc, nullptr, gout_nhwc, nullptr, dw, batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, workspace,
+                    workspace_bytes, stream);
+}
+
+extern "C" size_t omnihd_conv_wgrad_split_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh,
+                                                          int kw, int stride, int pad, int dil) {
+  WgradPlan p;
+  if (!make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, &p)) return 0;
+  return 256 + 2 * (p.gt_bytes + p.xt_bytes + 2 * p.guard) + p.slab_bytes + 2 * p.guard;
+}
+
+extern "C" int omnihd_conv_wgrad_split(const void* x_hi, const void* x_lo, const void* g_hi, const void* g_lo, float* dw,
+                                       int batch, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                                       int pad, int dil, void* workspace, size_t workspace_bytes, void* stream) {
+  OMNIHD_REQUIRE(x_lo && g_lo, "null pointer");
+  return wgrad_impl(x_hi, x_lo, g_hi, g_lo, dw, batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, workspace,
+                    workspace_bytes, stream);
 }
 
 // The two original entry points, kept as names for the common cases.

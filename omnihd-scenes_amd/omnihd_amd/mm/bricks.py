@@ -1,4 +1,6 @@
 """Layer builders with mmcv's call signatures: build_norm_layer, build_conv_layer, ConvModule."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -202,6 +204,15 @@ class BevConv2d(nn.Conv2d):
             xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             if ops.conv_wgrad_supported(xb, weight, self.stride, self.padding, self.dilation):
                 return ops.conv_hip_wgrad(xb, weight, bias, self.stride, self.padding, self.dilation)
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.groups == 1
+                and self.padding_mode == "zeros" and not isinstance(self.padding, str)
+                and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen"
+                and ops.conv_split_supported(x, weight, self.stride, self.padding, self.dilation)
+                and not ops.conv_split_all_miopen(x.shape, weight.shape[0], weight.shape[2], self.stride, self.padding,
+                                                  self.dilation, x.device.index)):
+            # the reference-precision (fp32) step: fp32-grade result from three bf16 MFMA products per term
+            # (csrc/conv_igemm.hip, SPLIT), where that measures faster than MIOpen's fp32 kernel for the geometry
+            return ops.conv_split(x, weight, bias, self.stride, self.padding, self.dilation)
         if (bias is not None and weight.shape[0] % 8 != 0 and x.is_cuda and x.dim() == 4 and self.padding_mode == "zeros"
                 and not isinstance(self.padding, str) and bias.requires_grad and torch.is_grad_enabled()):
             # odd channel counts (DepthNet's 59 depth logits): bias gradient from the column-sum kernel instead of torch's

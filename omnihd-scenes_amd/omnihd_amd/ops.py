@@ -630,6 +630,30 @@ def conv_wgrad(x, grad_out, kernel_size, stride=1, padding=0, dilation=1):
     return dw.permute(0, 3, 1, 2)
 
 
+def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1):
+    """fp32-grade weight gradient from split operands: xs = (x_hi, x_lo), gs = (g_hi, g_lo) bf16 channels-last ->
+    dW (Cout,Cin,k,k) fp32 in channels-last memory (omnihd_conv_wgrad_split: one staging pass, one three-term GEMM launch)."""
+    for t in (*xs, *gs):
+        _want_cl(t, "operand plane")
+    B, cin, H, W = xs[0].shape
+    _, cout, Ho, Wo = gs[0].shape
+    k = int(kernel_size)
+    dev = xs[0].device
+    dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
+    geo = (B, H, W, cin, Ho, Wo, cout, k, k, int(stride), int(padding), int(dilation))
+    L = lib()
+    with _on(dev):
+        nbytes = _SIZE_CACHE.get(("split",) + geo)
+        if nbytes is None:
+            nbytes = _SIZE_CACHE[("split",) + geo] = L.omnihd_conv_wgrad_split_workspace_bytes(*geo)
+        if nbytes == 0:
+            raise ValueError(f"conv_wgrad_split: unsupported geometry {geo}")
+        ws = _wgrad_workspace(nbytes, dev)
+        check(L.omnihd_conv_wgrad_split(xs[0].data_ptr(), xs[1].data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), dw.data_ptr(), *geo,
+                                        ws.data_ptr(), ws.numel(), _raw_stream()), "omnihd_conv_wgrad_split")
+    return dw.permute(0, 3, 1, 2)
+
+
 def conv3x3_wgrad(x, grad_out):
     """3x3 / stride 1 / pad 1."""
     return conv_wgrad(x, grad_out, 3, 1, 1, 1)
@@ -908,6 +932,200 @@ def sync_tuned_choices(group=None, src=0):
                 table[k + (me,)] = v
                 changed += 1
     return changed
+
+
+# --------------------------------------------------------------------------------------------
+# fp32-grade convolutions on the bf16 matrix cores: 3-term split (hi*hi + hi*lo + lo*hi), fp32 accumulation
+# --------------------------------------------------------------------------------------------
+def split_f32(t):
+    """fp32 tensor (dense in its memory format) -> (hi, lo) bf16 tensors of the same shape and strides with
+    t = hi + lo up to 2^-17 |t| (omnihd_split_f32)."""
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise TypeError("split_f32 takes an fp32 CUDA(HIP) tensor")
+    if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+        t = t.contiguous()
+    hi = torch.empty_like(t, dtype=torch.bfloat16)          # preserve_format: same strides
+    lo = torch.empty_like(t, dtype=torch.bfloat16)
+    with _on(t.device):
+        check(lib().omnihd_split_f32(t.data_ptr(), t.numel(), hi.data_ptr(), lo.data_ptr(), _raw_stream()), "omnihd_split_f32")
+    return hi, lo
+
+
+_SPLIT_SHADOW = {}
+
+
+def split_weight(weight, dgrad=False):
+    """(hi, lo) bf16 planes of an fp32 convolution weight in channels_last memory ((Cout,k,k,Cin)), cached while the
+    parameter's version is unchanged; ``dgrad=True``: the planes re-laid for the data gradient ((Cin,k,k,Cout), taps mirrored)."""
+    key = (id(weight), dgrad)
+    e = _SPLIT_SHADOW.get(key)
+    if e is not None and e[0]() is weight and e[1] == weight._version and e[2][0].device == weight.device:
+        return e[2]
+    if dgrad:
+        hi, lo = split_weight(weight)
+        planes = (conv_dgrad_weights(hi), conv_dgrad_weights(lo))
+    else:
+        planes = split_f32(weight.detach().float().contiguous(memory_format=torch.channels_last))
+    if len(_SPLIT_SHADOW) > 4096:
+        for k in [k for k, v in _SPLIT_SHADOW.items() if v[0]() is None]:
+            del _SPLIT_SHADOW[k]
+    _SPLIT_SHADOW[key] = (weakref.ref(weight), weight._version, planes)
+    return planes
+
+
+def conv_fwd_split(xs, ws, bias=None, dilation=1, tile=0):
+    """fp32-grade y = conv2d(x, w, bias, stride 1, padding = dilation*(k//2)) from split operands: xs = (x_hi, x_lo)
+    (B,Cin,H,W) bf16 channels-last, ws = (w_hi, w_lo) (Cout,Cin,k,k) bf16 channels_last -> (B,Cout,H,W) fp32 channels-last."""
+    for t in xs:
+        _want_cl(t, "x plane")
+    for t in ws:
+        if t.dtype != torch.bfloat16 or t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise TypeError("weight planes must be 4-D bf16 tensors in channels_last memory format")
+    B, cin, H, W = xs[0].shape
+    cout, k = ws[0].shape[0], ws[0].shape[2]
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=xs[0].device, memory_format=torch.channels_last)
+    with _on(y.device):
+        check(lib().omnihd_conv_fwd_split(xs[0].data_ptr(), xs[1].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                          None if bias is None else _f32c(bias).data_ptr(), y.data_ptr(), B, H, W, cin, cout, k,
+                                          int(dilation), int(tile), _raw_stream()), "omnihd_conv_fwd_split")
+    return y
+
+
+def conv_split_geometry(x_shape, cout, k, stride, padding, dilation, groups=1):
+    """(forward ok, data gradient ok, weight gradient ok) for the split kernels on a convolution geometry."""
+    B, cin, H, W = x_shape
+    s, p, d = _pair_same(stride), _pair_same(padding), _pair_same(dilation)
+    if groups != 1 or s is None or p is None or d is None or k not in (1, 3):
+        return False, False, False
+    same = s == 1 and p == d * (k // 2)
+    fwd = same and cin % 64 == 0 and cout % 8 == 0 and B * H * W < 2 ** 30
+    dgrad = same and cout % 64 == 0 and cin % 8 == 0 and B * H * W < 2 ** 30
+    wgrad = cin % 8 == 0 and cout % 8 == 0 and not (k == 3 and s == 1 and p == d and d > 18)
+    return fwd, dgrad, wgrad
+
+
+# per-geometry measured choice between the split kernels and MIOpen's fp32 kernels (OMNIHD_FP32_CONV = tune | split | miopen)
+_SPLIT_CHOICE = {}
+
+
+def _clock(fn, dev, n=3):
+    fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1)
+
+
+def _split_pick(key, run_split, run_miopen, dev):
+    policy = os.environ.get("OMNIHD_FP32_CONV", "tune")
+    if policy == "split":
+        return run_split()
+    if policy == "miopen":
+        return run_miopen()
+    choice = _SPLIT_CHOICE.get(key)
+    if choice is None:
+        choice = _SPLIT_CHOICE[key] = "split" if _clock(run_split, dev) <= _clock(run_miopen, dev) else "miopen"
+    return run_split() if choice == "split" else run_miopen()
+
+
+def split_choices():
+    return dict(_SPLIT_CHOICE)
+
+
+def conv_split_all_miopen(x_shape, cout, k, stride, padding, dilation, device_index):
+    """True once every direction the split kernels could take for this geometry has been measured in MIOpen's favour: the
+    layer is then a plain torch convolution again (no operand split, no Python in its backward)."""
+    if os.environ.get("OMNIHD_FP32_CONV", "tune") != "tune":
+        return False
+    geo = (tuple(x_shape), cout, k, stride[0], padding[0], dilation[0], device_index)
+    oks = conv_split_geometry(x_shape, cout, k, stride, padding, dilation)
+    return all(_SPLIT_CHOICE.get((d,) + geo) == "miopen" for d, ok in zip(("fwd", "dgrad", "wgrad"), oks) if ok)
+
+
+class _ConvSplit(torch.autograd.Function):
+    """fp32 convolution of the reference-precision step on the split kernels: forward and data gradient on
+    omnihd_conv_fwd_split, weight gradient as three launches of the bf16 k-major chain (hi*hi + hi*lo + lo*hi, fp32 slabs);
+    per geometry and direction the measured faster of that and MIOpen's fp32 kernel runs.  The input is saved as its two
+    bf16 planes (the same bytes as the fp32 tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
+        dev = x.device
+        x = x.contiguous(memory_format=torch.channels_last)
+        k = weight.shape[2]
+        geo = (tuple(x.shape), weight.shape[0], k, stride[0], padding[0], dilation[0], dev.index)
+        ok_f, ok_d, ok_w = conv_split_geometry(x.shape, weight.shape[0], k, stride, padding, dilation)
+        xs = split_f32(x)
+        ctx.save_for_backward(xs[0], xs[1], weight)
+        ctx.conv = (list(stride), list(padding), list(dilation), geo, ok_d, ok_w)
+        ctx.has_bias = bias is not None
+        ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
+        run_miopen = lambda: torch.nn.functional.conv2d(x, weight.detach(), None if bias is None else bias.detach(), stride,
+                                                         padding, dilation)
+        if not ok_f:
+            return run_miopen()
+        run_split = lambda: conv_fwd_split(xs, split_weight(weight), None if bias is None else bias.detach(), dilation[0])
+        return _split_pick(("fwd",) + geo, run_split, run_miopen, dev)
+
+    @staticmethod
+    def backward(ctx, g):
+        x_hi, x_lo, weight = ctx.saved_tensors
+        stride, padding, dilation, geo, ok_d, ok_w = ctx.conv
+        dev = g.device
+        g = g.float().contiguous(memory_format=torch.channels_last)
+        gs = split_f32(g) if ((ok_d and ctx.needs_input_grad[0]) or (ok_w and ctx.needs_input_grad[1])) else None
+        gx = gw = gb = None
+        x_f32 = []
+
+        def x_full():                      # only for MIOpen's weight gradient: hi + lo reproduces x to 2^-17
+            if not x_f32:
+                x_f32.append(x_hi.float().add_(x_lo))
+            return x_f32[0]
+
+        if ctx.needs_input_grad[0]:
+            # (an uninitialised fp32 stand-in for the input: only its shape / layout matter to the data gradient; with
+            # torch.nn.grad.conv2d_input's stride-0 stand-in MIOpen took a kernel that was 2e-2 off on a strided 3x3 layer)
+            x_like = lambda: torch.empty(x_hi.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            run_miopen = lambda: torch.ops.aten.convolution_backward(g, x_like(), weight.detach(), None, stride, padding, dilation,
+                                                                     False, [0, 0], 1, [True, False, False])[0]
+            if ok_d:
+                run_split = lambda: conv_fwd_split(gs, split_weight(weight, dgrad=True), None, dilation[0])
+                gx = _split_pick(("dgrad",) + geo, run_split, run_miopen, dev)
+            else:
+                gx = run_miopen()
+        elif ok_d:
+            _SPLIT_CHOICE.setdefault(("dgrad",) + geo, "miopen")          # never asked for: nothing to measure
+        if ctx.needs_input_grad[1]:
+            run_miopen = lambda: torch.ops.aten.convolution_backward(g, x_full(), weight.detach(), None, stride, padding, dilation,
+                                                                     False, [0, 0], 1, [False, True, False])[1]
+            if ok_w:
+                k = weight.shape[2]
+
+                run_split = lambda: conv_wgrad_split((x_hi, x_lo), gs, k, stride[0], padding[0], dilation[0])
+                gw = _split_pick(("wgrad",) + geo, run_split, run_miopen, dev)
+            else:
+                gw = run_miopen()
+            gw = gw.to(ctx.param_dtypes[0])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            n, c, h, w = g.shape
+            gb = column_sums(g.permute(0, 2, 3, 1).reshape(n * h * w, c)).to(ctx.param_dtypes[1])
+        return gx, gw, gb, None, None, None
+
+
+def conv_split_supported(x, weight, stride, padding, dilation, groups=1):
+    """fp32 device activations and at least one direction the split kernels take."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dtype == torch.float32 and weight.dim() == 4
+            and weight.shape[2] == weight.shape[3] and weight.shape[1] == x.shape[1]):
+        return False
+    return any(conv_split_geometry(x.shape, weight.shape[0], weight.shape[2], stride, padding, dilation, groups))
+
+
+def conv_split(x, weight, bias, stride, padding, dilation=(1, 1)):
+    return _ConvSplit.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation))
 
 
 def column_sums(rows2d):

@@ -145,6 +145,7 @@ class CamEncode(nn.Module):
         self.D, self.C = D, C
         self.depthnet = DepthNet(in_channels=inputC, mid_channels=inputC, context_channels=C, depth_channels=D,
                                  norm_cfg=norm_cfg)
+        self.before_epilogue = None            # set by the LSS module around a forward: called once, in front of the epilogue
 
     def get_depth_dist(self, x, eps=1e-20):
         return x.softmax(dim=1)
@@ -158,6 +159,8 @@ class CamEncode(nn.Module):
         if x.is_cuda and os.environ.get("OMNIHD_DEPTH_HEAD", "1") != "0":
             logits, context = self.depthnet.heads(x)
             if _ops.depth_head_supported(logits, context):
+                if self.before_epilogue is not None:
+                    self.before_epilogue()       # the pooling plan's table read-ahead: runs beside the epilogue kernel
                 depth, rows, feat = _ops.depth_head(logits, context, want_rows=torch.is_grad_enabled())
                 depth._omnihd_rows = rows
                 return depth, feat.permute(0, 3, 1, 2)
@@ -208,6 +211,7 @@ class LiftSplatShoot_Depth(nn.Module):
         self._plans = {}
         self._max_plans = 16
         self.pool_layout = "byxz"
+        self._tables_read_ahead = False
 
     def _build_camencode(self):
         return CamEncode(self.D, self.camC, self.inputC, self.norm_cfg)
@@ -296,13 +300,14 @@ class LiftSplatShoot_Depth(nn.Module):
 
     def voxel_pooling_v2(self, coor, depth, feat, plan=None):
         """(B,N,D,H,W) depth x (B,N,C,H,W) features -> (B, C, Z, Y, X) (logical shape)."""
-        if (plan is not None and feat.is_cuda and getattr(plan, "tile_desc", None) is not None
+        if (plan is not None and feat.is_cuda and getattr(plan, "tile_desc", None) is not None and not self._tables_read_ahead
                 and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0"):
-            # the plan's tables were last read a whole step ago: stream them into the caches on a side stream while the
-            # layout copy below runs (the pooling kernel is a chain of dependent reads per tile; 62 us with cold tables
-            # inside the step vs 45 us with resident ones)
+            # the plan's tables were last read a whole step ago: stream them into the caches on a side stream (the pooling
+            # kernel is a chain of dependent reads per tile; 62 us with cold tables inside the step vs 45 us with resident
+            # ones).  With the fused depth-head epilogue this has already happened in front of that kernel (get_voxels).
             _ops.prefetch([plan.tile_desc, plan.row_ptr, plan.ranks_depth])
-        feat = feat.permute(0, 1, 3, 4, 2).contiguous()
+        self._tables_read_ahead = False
+        feat = feat.permute(0, 1, 3, 4, 2).contiguous()      # a no-op behind the depth-head epilogue (pixel rows already)
         if plan is None:
             plan = omnihd_amd.build_plan(coor.contiguous().float(), self.dx.numpy(), self.bx.numpy(),
                                          self.nx.numpy(), layout=self.pool_layout)
@@ -316,7 +321,20 @@ class LiftSplatShoot_Depth(nn.Module):
     def get_voxels(self, x, rots=None, trans=None, post_rots=None, post_trans=None, extra_rots=None,
                    extra_trans=None, plan_key=None):
         plan = self._plan_for(rots, trans, (post_rots, post_trans, extra_rots, extra_trans), plan_key)
-        x, depth = self.get_cam_feats(x)
+
+        def read_tables_ahead():
+            # on the side stream, ordered behind DepthNet's last convolution: runs while the epilogue kernel writes depth / feat
+            # and is finished when the pooling kernel starts (nothing else streams through the caches in between)
+            if (x.is_cuda and getattr(plan, "tile_desc", None) is not None and plan.n_points > 0
+                    and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0"):
+                _ops.prefetch([plan.tile_desc, plan.row_ptr, plan.ranks_depth])
+                self._tables_read_ahead = True
+
+        self.camencode.before_epilogue = read_tables_ahead
+        try:
+            x, depth = self.get_cam_feats(x)
+        finally:
+            self.camencode.before_epilogue = None
         return self.voxel_pooling_v2(None, depth, x, plan=plan), depth
 
     def s2c(self, x):

@@ -8,7 +8,7 @@ import torch
 from omnihd_amd.harness import FusionTrainStep
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype=dt, miopen_find=False)
+st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype=dt, miopen_find=os.environ.get("OMNIHD_STEP_FIND", "1") == "1")
 for _ in range(3):
     st.step()
 torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Steady-state kernel statistics of the bf16 training step (MIOpen db seeded, immediate find lookups): launches per step
 # and GPU time by kernel.  Usage: bash scripts/lab/step_profile.sh [bf16|fp32] [steps]
-export TMPDIR=/tmp; DT=${1:-bf16}; N=${2:-10}; out=gpurun_out/r2v_$DT; mkdir -p $out
+export TMPDIR=/tmp; DT=${1:-bf16}; N=${2:-10}; out=gpurun_out/r3v_$DT; mkdir -p $out
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/prof -o st -- python3 scripts/lab/step_few.py $DT $N > $out/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
@@ -18,6 +18,11 @@ ss = rows[cut:]
 t0, t1 = int(ss[0]["Start_Timestamp"]), int(ss[-1]["End_Timestamp"])
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ss)
 print(f"steady region: {len(ss)} launches over $N steps = {len(ss)/$N:.0f} per step; wall {(t1-t0)/1e6/$N:.2f} ms/step; sum of kernel durations {busy/1e6/$N:.2f} ms/step")
+ours = lambda n: "omnihd::" in n or "_ZN6omnihd" in n
+t_ours = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ss if ours(r["Kernel_Name"]))
+n_ours = sum(1 for r in ss if ours(r["Kernel_Name"]))
+print(f"hand-written (libomnihd_hip.so) kernels: {t_ours/1e6/$N:.2f} ms/step in {n_ours/$N:.0f} launches/step; library / framework kernels (MIOpen, rocBLAS, ATen): "
+      f"{(busy-t_ours)/1e6/$N:.2f} ms/step in {(len(ss)-n_ours)/$N:.0f} launches/step")
 agg = collections.defaultdict(lambda: [0, 0])
 for r in ss:
     k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]

