@@ -38,25 +38,10 @@ for _p in (ROOT, os.path.join(ROOT, "omnihd-scenes_amd")):
 
 
 def _seed_miopen_db():
-    """MIOpen tuning records for the convolution geometries of this workload (find-db, perf-db and the compiled
-    kernels of the chosen solvers), captured on an MI355X with this image: copied to a scratch directory and
-    offered to MIOpen as its user database, so that the find step of a fresh box is a lookup (bench start-up
-    3m52s -> 1m52s measured).  A missing or rejected database only costs the find time back."""
-    src = os.path.join(ROOT, "omnihd-scenes_amd", "miopen_db")
-    if not os.path.isdir(src) or "MIOPEN_USER_DB_PATH" in os.environ:
-        return
-    import shutil
-    import tempfile
-    dst = os.path.join(tempfile.gettempdir(), "omnihd_miopen_%d_%s" % (os.getuid(), os.environ.get("LOCAL_RANK", "0")))
-    try:
-        os.makedirs(dst, exist_ok=True)
-        for name in os.listdir(src):
-            if not os.path.exists(os.path.join(dst, name)):
-                shutil.copy(os.path.join(src, name), os.path.join(dst, name))
-        os.environ["MIOPEN_USER_DB_PATH"] = dst
-        os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = dst
-    except OSError:
-        pass
+    """MIOpen tuning records for this workload's convolution geometries (omnihd_amd.harness.seed_miopen_db): offered to MIOpen as
+    its user database before the first convolution runs, so that the find step of a fresh box is a lookup."""
+    from omnihd_amd.harness import seed_miopen_db
+    seed_miopen_db()
 
 
 _seed_miopen_db()

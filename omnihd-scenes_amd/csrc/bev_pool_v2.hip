@@ -1096,11 +1096,7 @@ __device__ __forceinline__ void patch_point(const u32x4t a, float d, const float
 template <int J0>
 __device__ __forceinline__ void patch_batch8(const __amdgpu_buffer_rsrc_t og_rsrc, unsigned lane_off, int rr, float dval,
                                              const float4 x, float4& fg, float& mydot, int sub) {
-#if defined(OMNIHD_POOL_BWD_ABL) && (OMNIHD_POOL_BWD_ABL & 1)      /* lab build: no out_grad gathers */
-#define OMNIHD_G(K) const unsigned v##K = (unsigned)dpp_row_bcast_i<J0 + K>(rr); const u32x4t a##K = {v##K, v##K, lane_off, v##K};
-#else
 #define OMNIHD_G(K) const u32x4t a##K = __builtin_amdgcn_raw_buffer_load_b128(og_rsrc, ((unsigned)dpp_row_bcast_i<J0 + K>(rr) << 8) | lane_off, 0, 0);
-#endif
   OMNIHD_G(0) OMNIHD_G(1) OMNIHD_G(2) OMNIHD_G(3) OMNIHD_G(4) OMNIHD_G(5) OMNIHD_G(6) OMNIHD_G(7)
 #undef OMNIHD_G
   patch_point<J0 + 0>(a0, dpp_row_bcast_f<J0 + 0>(dval), x, fg, mydot, sub);
@@ -1164,13 +1160,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
   // tables of the first chunk; each chunk's tables are requested one chunk ahead
   int rr_n = 0x00ffffff, rd_n = rd_base;                        // row beyond the buffer: the gather returns zeros
   if (sub < len) {
-#if defined(OMNIHD_POOL_BWD_ABL) && (OMNIHD_POOL_BWD_ABL & 2)      /* lab build: no table loads */
-    rr_n = (f * 5 + sub) & 0x3ffff;
-    rd_n = rd_base + (sub % d_bins) * fhw;
-#else
     rr_n = ranks_row[s + sub];
     rd_n = ranks_depth[s + sub];
-#endif
   }
   for (int cb = 0; cb < wave_len; cb += kPatch) {
     const int mine = cb + sub;
@@ -1180,13 +1171,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
     rr_n = 0x00ffffff;
     rd_n = rd_base;
     if (mine + kPatch < len) {
-#if defined(OMNIHD_POOL_BWD_ABL) && (OMNIHD_POOL_BWD_ABL & 2)
-      rr_n = (f * 5 + mine + kPatch) & 0x3ffff;
-      rd_n = rd_base + ((mine + kPatch) % d_bins) * fhw;
-#else
       rr_n = ranks_row[s + mine + kPatch];
       rd_n = ranks_depth[s + mine + kPatch];
-#endif
     }
     const float dval = inb ? s_dv[dk * kPatch + grp] : 0.f;
     float mydot = 0.f;

@@ -82,41 +82,50 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
   const int lr = lane >> 3;                       // row inside an 8-row call
   const int pos = lane & 7;                       // 16-byte slot inside the 128-byte LDS row
   const int c_even = pos ^ ((lane >> 4) & 7);     // global chunk for even calls; odd calls use c_even ^ 4
+  // per call: the lane's source pointer at tap (0,0) offset, channel slice 0 (SPLIT: slots 0-3 of a row come from the hi
+  // plane, slots 4-7 from the lo plane of the same 32 channels); a fill adds ONE wave-uniform offset to it
   int a_y[A_CALLS], a_x[A_CALLS];                 // pixel coordinates (y = -1: row beyond M)
-  size_t a_pix[A_CALLS];
+  const unsigned short* a_ptr[A_CALLS];
 #pragma unroll
   for (int i = 0; i < A_CALLS; ++i) {
+    const int c = (i & 1) ? (c_even ^ 4) : c_even;
+    const unsigned short* plane = (SPLIT && c >= 4) ? X2 : X;
+    const int cc = SPLIT ? (c & 3) : c;
     const int m = mt * TM + wave * (8 * A_CALLS) + 8 * i + lr;
     if (m < M) {
       const int xx = m % W, r = m / W;
-      a_x[i] = xx; a_y[i] = r % H; a_pix[i] = (size_t)m;
+      a_x[i] = xx; a_y[i] = r % H; a_ptr[i] = plane + (size_t)m * Cin + cc * 8;
     } else {
-      a_x[i] = 0; a_y[i] = -(1 << 20); a_pix[i] = 0;
+      a_x[i] = 0; a_y[i] = -(1 << 20); a_ptr[i] = zero_page;
     }
   }
-  const unsigned short* b_row[B_CALLS];
+  const unsigned short* b_ptr[B_CALLS];
+  bool b_ok[B_CALLS];
 #pragma unroll
   for (int i = 0; i < B_CALLS; ++i) {
+    const int call = A_CALLS + i;                 // A_CALLS is even: the parity of a B call is that of its index
+    const int c = (call & 1) ? (c_even ^ 4) : c_even;
+    const unsigned short* plane = (SPLIT && c >= 4) ? Wt2 : Wt;
+    const int cc = SPLIT ? (c & 3) : c;
     const int n = nt * TN + wave * (8 * B_CALLS) + 8 * i + lr;
-    b_row[i] = (n < Cout) ? Wt + (size_t)n * K : nullptr;
+    b_ok[i] = n < Cout;
+    b_ptr[i] = b_ok[i] ? plane + (size_t)n * K + cc * 8 : zero_page;
   }
 
   int k_tap = 0, k_c = 0;                         // position of the NEXT K-step to issue
   // one LDS-DMA call (8 rows x 128 B) of the K-step at (k_tap, k_c): calls 0..A_CALLS-1 fetch A rows, the rest B rows
   auto issue_call = [&](int stage, bool real, int call) {
-    const int c = (call & 1) ? (c_even ^ 4) : c_even;          // A_CALLS is even: the parity of a B call is that of its index
-    // SPLIT: slots 0-3 of the row come from the hi plane, slots 4-7 from the lo plane (the same 32 channels)
-    const ptrdiff_t lo_plane_a = SPLIT && c >= 4 ? X2 - X : 0, lo_plane_b = SPLIT && c >= 4 ? Wt2 - Wt : 0;
-    const int cc = SPLIT ? (c & 3) : c;
     if (call < A_CALLS) {
       const int i = call;
       const int dy = (k_tap / ksize - half) * dil, dx = (k_tap % ksize - half) * dil;
       const bool ok = real && (unsigned)(a_y[i] + dy) < (unsigned)H && (unsigned)(a_x[i] + dx) < (unsigned)W;
-      const unsigned short* g = ok ? X + lo_plane_a + (a_pix[i] + (ptrdiff_t)dy * W + dx) * Cin + k_c + cc * 8 : zero_page;
+      const ptrdiff_t goff = ((ptrdiff_t)dy * W + dx) * Cin + k_c;             // wave-uniform
+      const unsigned short* g = ok ? a_ptr[i] + goff : zero_page;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][wave * (8 * A_CALLS) + 8 * i][0], 16, 0, 0);
     } else {
       const int i = call - A_CALLS;
-      const unsigned short* g = (real && b_row[i]) ? b_row[i] + lo_plane_b + (size_t)k_tap * Cin + k_c + cc * 8 : zero_page;
+      const ptrdiff_t goff = (ptrdiff_t)k_tap * Cin + k_c;                     // wave-uniform
+      const unsigned short* g = (real && b_ok[i]) ? b_ptr[i] + goff : zero_page;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][TM + wave * (8 * B_CALLS) + 8 * i][0], 16, 0, 0);
     }
   };
@@ -143,6 +152,48 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
   const int fhalf = lane >> 5;
   const int n_steps = K / kCS;
 
+  // one 16-deep slice of fragments: SPLIT: [0..1] a_hi, [2..3] a_lo, [4..5] b_hi, [6..7] b_lo; else [0..1] a, [2..3] b
+  constexpr int NS = kCS / 16;
+  constexpr int NF = SPLIT ? 8 : 4;
+  auto load_slice = [&](int stage, int ks, bf16x8 (&f)[NF]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = wm * 64 + i * 32 + frow;
+      const int rb = wn * 64 + i * 32 + frow;
+      const int c = ks * 2 + fhalf;
+      f[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+      if constexpr (SPLIT) {
+        f[2 + i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][(((c + 4) ^ ((ra >> 1) & 7)) * 8)]);
+        f[4 + i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+        f[6 + i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][(((c + 4) ^ ((rb >> 1) & 7)) * 8)]);
+      } else {
+        f[2 + i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+      }
+    }
+  };
+  auto mma_slice = [&](const bf16x8 (&f)[NF]) {
+    if constexpr (SPLIT) {
+      // term-major order: consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 + i], f[4 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[6 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[4 + j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[2 + j], acc[i][j], 0, 0, 0);
+    }
+  };
+
   // prologue: STAGES-1 K-steps in flight
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s, s < n_steps);
@@ -159,67 +210,31 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
     __builtin_amdgcn_s_barrier();
     const int fill = (stage + STAGES - 1) % STAGES;             // its buffer was last read before this barrier
     const bool fill_real = step + STAGES - 1 < n_steps;
+    // slices software-pipelined by hand (two fragment sets): the reads of slice s+1 are in flight while slice s multiplies;
+    // the DMA calls of the next fill are issued BEHIND each slice's MFMAs (their issue time, 60-185 cycles each, then
+    // overlaps the matrix pipe instead of preceding it): CALLS calls over the NS slices
+    bf16x8 fa[NF], fb[NF];
+    load_slice(stage, 0, fa);
     if (!SPREAD) issue(fill, fill_real);
-    if constexpr (SPLIT) {
+    constexpr int PER = (CALLS + NS - 1) / NS;
+    auto spread = [&](int ks) {
+      if (!SPREAD) return;
 #pragma unroll
-      for (int ks = 0; ks < kCS / 16; ++ks) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+      for (int q = 0; q < PER; ++q)
+        if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
+    };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int ra = wm * 64 + i * 32 + frow;
-          const int rb = wn * 64 + i * 32 + frow;
-          const int c = ks * 2 + fhalf;                              // hi slots 0..3, lo slots 4..7
-          ah[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
-          al[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][(((c + 4) ^ ((ra >> 1) & 7)) * 8)]);
-          bh[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
-          bl[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][(((c + 4) ^ ((rb >> 1) & 7)) * 8)]);
-        }
-        // term-major order: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        if (SPREAD) {
-          constexpr int PER = (CALLS + kCS / 16 - 1) / (kCS / 16);
-#pragma unroll
-          for (int q = 0; q < PER; ++q)
-            if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < kBK / 16; ++ks) {
-        bf16x8 a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int ra = wm * 64 + i * 32 + frow;
-          const int rb = wn * 64 + i * 32 + frow;
-          const int c = ks * 2 + fhalf;
-          a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
-          b[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][TM + rb][((c ^ ((rb >> 1) & 7)) * 8)]);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        if (SPREAD) {
-          // the DMA calls of the next fill are issued BEHIND this slice's MFMAs (their issue time, 60-185 cycles each, then
-          // overlaps the matrix pipe instead of preceding it): CALLS calls over the kBK/16 slices
-          constexpr int PER = (CALLS + kBK / 16 - 1) / (kBK / 16);
-#pragma unroll
-          for (int q = 0; q < PER; ++q)
-            if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
-        }
-      }
+    for (int ks = 0; ks < NS; ks += 2) {
+      load_slice(stage, ks + 1, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_slice(fa);
+      spread(ks);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < NS) load_slice(stage, ks + 2, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_slice(fb);
+      spread(ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (SPREAD) advance();
     stage = (stage + 1) % STAGES;
@@ -259,6 +274,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
 // ---------------------------------------------------------------------------------------------
 constexpr int kHalo = 8;
 
+// Round 3: the slice loop is software-pipelined by hand.  hipcc's schedule of the straightforward loop read two fragments,
+// waited lgkmcnt(0), issued one MFMA, read the next fragment, waited again ... five exposed LDS round trips per 16-deep slice
+// (ISA dump of the first split build); and it computed every LDS-DMA source address with 64-bit multiply chains behind an
+// exec-mask branch.  Now: all fragments of slice s+1 are requested before the MFMAs of slice s are issued (two register
+// sets, pinned with sched_barrier), the per-lane source pointers are precomputed and a fill call adds one scalar offset and
+// selects the zero page with two v_cndmask.
 template <bool SPREAD, bool SPLIT = false>
 __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
@@ -267,6 +288,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const unsigned short* __restrict__ Wt2 = nullptr) {
   constexpr int TM = 256, TN = 128, WN = 2;
   constexpr int kCS = SPLIT ? 32 : 64;                // channels per K-step (SPLIT: 32 of the hi plane + the same 32 of the lo plane)
+  constexpr int NS = kCS / 16;                        // 16-deep slices per K-step
   constexpr int A_ROWS = TM + 2 * kHalo;              // 272 = 34 calls; every wavefront issues 5 (the last 6 are padding)
   constexpr int A_BUF = A_ROWS + 8;                   // + one junk block the padding calls write to
   __shared__ __attribute__((aligned(16))) unsigned short sm[2 * A_BUF + 4 * TN][kBK];
@@ -286,30 +308,33 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
   const int pos = lane & 7;
   const int chunk = pos ^ (((wave & 1) << 2) | ((lane >> 4) & 3));   // call index parity == wave parity for A and B calls
   // SPLIT: slots 0-3 of a row come from the hi plane, slots 4-7 from the lo plane
-  const ptrdiff_t lo_plane_a = SPLIT && chunk >= 4 ? X2 - X : 0, lo_plane_b = SPLIT && chunk >= 4 ? Wt2 - Wt : 0;
   const int cchunk = SPLIT ? (chunk & 3) : chunk;
+  const unsigned short* Xp = (SPLIT && chunk >= 4) ? X2 : X;
+  const unsigned short* Wp = (SPLIT && chunk >= 4) ? Wt2 : Wt;
 
   // A calls of this wavefront: call index ca = wave + 8*q (q = 0..4), rows 8*ca .. 8*ca+7 of the A buffer,
-  // row j <-> pixel m0 - kHalo + j
+  // row j <-> pixel m0 - kHalo + j.  a_ptr = address of (pixel, channel chunk) at channel slice 0, dy = 0.
   int a_y[5];
-  long long a_pix[5];
+  const unsigned short* a_ptr[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const int ca = wave + 8 * q;
     const long long m = (long long)mt * TM - kHalo + 8 * ca + lr;
     if (ca < A_ROWS / 8 && m >= 0 && m < M) {
-      a_pix[q] = m;
+      a_ptr[q] = Xp + (size_t)m * Cin + cchunk * 8;
       a_y[q] = (int)((m / W) % H);
     } else {
-      a_pix[q] = 0;
+      a_ptr[q] = zero_page;
       a_y[q] = -(1 << 20);
     }
   }
-  const unsigned short* b_row[2];
+  const unsigned short* b_ptr[2];
+  bool b_ok[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int n = nt * TN + 8 * (wave + 8 * q) + lr;
-    b_row[q] = (n < Cout) ? Wt + (size_t)n * K : nullptr;
+    b_ok[q] = n < Cout;
+    b_ptr[q] = b_ok[q] ? Wp + (size_t)n * K + cchunk * 8 : zero_page;
   }
 
   // fragment rows of this lane and the x coordinate of their pixels (for the border mask)
@@ -326,6 +351,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
   const int n_c = Cin / kCS;
   const int n_groups = n_c * 3;
   const int n_steps = n_groups * 3;
+  const ptrdiff_t row_pitch = (ptrdiff_t)W * Cin;
 
   auto issue_a = [&](int g, int q) {                  // call q (0..4) of the A fill of group g = (c, ky)
     const bool real = g < n_groups;
@@ -333,7 +359,8 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const int dy = (ky - 1) * dil;
     const int ca = wave + 8 * q;
     const bool ok = real && (unsigned)(a_y[q] + dy) < (unsigned)H;
-    const unsigned short* src = ok ? X + lo_plane_a + (size_t)(a_pix[q] + (long long)dy * W) * Cin + c * kCS + cchunk * 8 : zero_page;
+    const ptrdiff_t goff = (ptrdiff_t)dy * row_pitch + c * kCS;            // wave-uniform
+    const unsigned short* src = ok ? a_ptr[q] + goff : zero_page;
     unsigned short(*dst)[kBK] = a_buf(g & 1) + (ca < A_ROWS / 8 ? 8 * ca : A_ROWS);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
   };
@@ -341,7 +368,8 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const bool real = k < n_steps;
     const int g = k / 3, kx = k - 3 * g;
     const int c = g / 3, ky = g - 3 * c;
-    const unsigned short* src = (real && b_row[q]) ? b_row[q] + lo_plane_b + (size_t)(ky * 3 + kx) * Cin + c * kCS + cchunk * 8 : zero_page;
+    const ptrdiff_t goff = (ptrdiff_t)(ky * 3 + kx) * Cin + c * kCS;       // wave-uniform
+    const unsigned short* src = (real && b_ok[q]) ? b_ptr[q] + goff : zero_page;
     unsigned short(*dst)[kBK] = b_buf(k & 3) + 8 * (wave + 8 * q);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
   };
@@ -363,6 +391,58 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     issue_b(kk, 1);
   }
 
+  // one 16-deep slice of fragments: SPLIT: [0..1] a_hi, [2..3] a_lo, [4..5] b_hi, [6..7] b_lo; else [0..1] a, [2..3] b
+  constexpr int NF = SPLIT ? 8 : 4;
+  auto load_slice = [&](const unsigned short(*A)[kBK], const unsigned short(*B)[kBK], int dx, int ks, bf16x8 (&f)[NF]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = wm * 64 + i * 32 + frow + kHalo + dx;          // row of the A buffer
+      const int rb = wn * 64 + i * 32 + frow;
+      const int c = ks * 2 + fhalf;
+      f[i] = *reinterpret_cast<const bf16x8*>(&A[ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+      if constexpr (SPLIT) {
+        f[2 + i] = *reinterpret_cast<const bf16x8*>(&A[ra][(((c + 4) ^ ((ra >> 1) & 7)) * 8)]);
+        f[4 + i] = *reinterpret_cast<const bf16x8*>(&B[rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+        f[6 + i] = *reinterpret_cast<const bf16x8*>(&B[rb][(((c + 4) ^ ((rb >> 1) & 7)) * 8)]);
+      } else {
+        f[2 + i] = *reinterpret_cast<const bf16x8*>(&B[rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+      }
+    }
+  };
+  auto mma_slice = [&](bf16x8 (&f)[NF], const bool (&ok)[2], bool masked) {
+    if (masked) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (!ok[i]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            f[i][e] = (__bf16)0.0f;
+            if constexpr (SPLIT) f[2 + i][e] = (__bf16)0.0f;
+          }
+        }
+    }
+    if constexpr (SPLIT) {
+      // term-major order: consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 + i], f[4 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[6 + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[4 + j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[2 + j], acc[i][j], 0, 0, 0);
+    }
+  };
+
   auto kstep = [&](int k, int g, auto kx_tag) {
     constexpr int KX = decltype(kx_tag)::value;
     if (KX == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -374,6 +454,8 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     bool ok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) ok[i] = (KX == 1) || ((unsigned)(fx[i] + dx) < (unsigned)W);
+    bf16x8 fa[NF], fb[NF];
+    load_slice(A, B, dx, 0, fa);
     if (!SPREAD) {
       if (KX == 0) {
 #pragma unroll
@@ -382,82 +464,36 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
       issue_b(k + 3, 0);
       issue_b(k + 3, 1);
     }
-    if constexpr (SPLIT) {
+    // the fills of the next group / K-step in their fixed program order [A(g+1) x5 when KX == 0], B(k+3) x2, spread behind
+    // the MFMA groups of the slices
+    auto fill = [&](int part, int parts) {
+      if (!SPREAD) return;
+      if (KX == 0) {
+        constexpr int N = 7;
+        const int lo = part * N / parts, hi = (part + 1) * N / parts;
 #pragma unroll
-      for (int ks = 0; ks < kCS / 16; ++ks) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
+        for (int c = 0; c < N; ++c)
+          if (c >= lo && c < hi) { if (c < 5) issue_a(g + 1, c); else issue_b(k + 3, c - 5); }
+      } else {
+        const int lo = part * 2 / parts, hi = (part + 1) * 2 / parts;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int ra = wm * 64 + i * 32 + frow + kHalo + dx;        // row of the A buffer
-          const int rb = wn * 64 + i * 32 + frow;
-          const int c = ks * 2 + fhalf;                                // hi slots 0..3, lo slots 4..7
-          ah[i] = *reinterpret_cast<const bf16x8*>(&A[ra][((c ^ ((ra >> 1) & 7)) * 8)]);
-          al[i] = *reinterpret_cast<const bf16x8*>(&A[ra][(((c + 4) ^ ((ra >> 1) & 7)) * 8)]);
-          bh[i] = *reinterpret_cast<const bf16x8*>(&B[rb][((c ^ ((rb >> 1) & 7)) * 8)]);
-          bl[i] = *reinterpret_cast<const bf16x8*>(&B[rb][(((c + 4) ^ ((rb >> 1) & 7)) * 8)]);
-          if (KX != 1 && !ok[i]) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ah[i][e] = (__bf16)0.0f; al[i][e] = (__bf16)0.0f; }
-          }
-        }
-        // term-major order: consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        if (SPREAD) {
-          // same program order of the fills as below, spread over the two 16-deep slices
-          if (KX == 0) {
-            if (ks == 0) { issue_a(g + 1, 0); issue_a(g + 1, 1); issue_a(g + 1, 2); }
-            if (ks == 1) { issue_a(g + 1, 3); issue_a(g + 1, 4); issue_b(k + 3, 0); issue_b(k + 3, 1); }
-          } else {
-            if (ks == 0) issue_b(k + 3, 0);
-            if (ks == 1) issue_b(k + 3, 1);
-          }
-        }
+        for (int c = 0; c < 2; ++c)
+          if (c >= lo && c < hi) issue_b(k + 3, c);
       }
-      return;
-    }
+    };
 #pragma unroll
-    for (int ks = 0; ks < kBK / 16; ++ks) {
-      bf16x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + frow + kHalo + dx;          // row of the A buffer
-        const int rb = wn * 64 + i * 32 + frow;
-        const int c = ks * 2 + fhalf;
-        a[i] = *reinterpret_cast<const bf16x8*>(&A[ra][((c ^ ((ra >> 1) & 7)) * 8)]);
-        b[i] = *reinterpret_cast<const bf16x8*>(&B[rb][((c ^ ((rb >> 1) & 7)) * 8)]);
-        if (KX != 1 && !ok[i]) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a[i][e] = (__bf16)0.0f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      if (SPREAD) {
-        // program order of the fills: [A(g+1) x5 when KX == 0], B(k+3) x2 — spread behind the MFMAs of the four slices
-        if (KX == 0) {
-          if (ks == 0) { issue_a(g + 1, 0); issue_a(g + 1, 1); }
-          if (ks == 1) { issue_a(g + 1, 2); issue_a(g + 1, 3); }
-          if (ks == 2) { issue_a(g + 1, 4); issue_b(k + 3, 0); }
-          if (ks == 3) { issue_b(k + 3, 1); }
-        } else {
-          if (ks == 0) issue_b(k + 3, 0);
-          if (ks == 1) issue_b(k + 3, 1);
-        }
-      }
+    for (int ks = 0; ks < NS; ks += 2) {
+      // slice ks is in `fa`; request slice ks+1 into `fb`, multiply slice ks, then the other way round
+      load_slice(A, B, dx, ks + 1, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_slice(fa, ok, KX != 1);
+      fill(ks, NS);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < NS) load_slice(A, B, dx, ks + 2, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_slice(fb, ok, KX != 1);
+      fill(ks + 1, NS);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 

@@ -256,23 +256,27 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds(const unsigned short
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue((stage + 3) % kStages);                   // its buffer was last read two barriers ago
+    // all fragments of the K-step are requested before its first MFMA (see k_wgrad_mfma_glds3)
+    bf16x8 a[kBK / 16][2], b[kBK / 16][2];
 #pragma unroll
     for (int ks = 0; ks < kBK / 16; ++ks) {
-      bf16x8 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ra = wm * 64 + i * 32 + frow;
         const int rb = wn * 64 + i * 32 + frow;
         const int c = ks * 2 + fhalf;
-        a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
-        b[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1][rb][((c ^ ((rb >> 1) & 7)) * 8)]);
+        a[ks][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][((c ^ ((ra >> 1) & 7)) * 8)]);
+        b[ks][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1][rb][((c ^ ((rb >> 1) & 7)) * 8)]);
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
     stage = (stage + 1) % kStages;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail loads before the epilogue stores
@@ -394,26 +398,32 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_mfma_glds3(const unsigned shor
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue((stage + 3) % kStages3);
+    // both 16-deep slices are requested before the first MFMA and slice 1's reads are in flight while slice 0 multiplies
+    // (hipcc's own schedule interleaved reads and MFMAs with full lgkmcnt(0) waits)
+    bf16x8 a[2][2], b[2][3][2];
 #pragma unroll
     for (int ks = 0; ks < kBK3 / 16; ++ks) {
-      bf16x8 a[2], b[3][2];
       const int c = ks * 2 + fhalf;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ra = wm * 64 + i * 32 + frow;
         const int rb = wn * 64 + i * 32 + frow;
-        a[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][(c ^ ((ra >> 2) & 3)) * 8]);
+        a[ks][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][(c ^ ((ra >> 2) & 3)) * 8]);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-          b[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1 + t][rb][(c ^ ((rb >> 2) & 3)) * 8]);
+          b[ks][t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1 + t][rb][(c ^ ((rb >> 2) & 3)) * 8]);
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < kBK3 / 16; ++ks) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[t][j], acc[t][i][j], 0, 0, 0);
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][t][j], acc[t][i][j], 0, 0, 0);
     }
     stage = (stage + 1) % kStages3;
   }
@@ -530,6 +540,9 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
         bl[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][5 + t][rb][sb]);
       }
     }
+    // all 16 fragment reads are requested before the first MFMA (hipcc otherwise interleaves them with four lgkmcnt(0) waits
+    // per K-step: one wavefront per SIMD has nobody to cover an exposed LDS round trip)
+    __builtin_amdgcn_sched_barrier(0);
     // term-major: consecutive MFMAs go to different accumulators
 #pragma unroll
     for (int t = 0; t < 3; ++t)

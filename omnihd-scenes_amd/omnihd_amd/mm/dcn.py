@@ -11,6 +11,8 @@ a sort + segmented sum, no atomics), followed by one dense GEMM with a block-dia
 as a plain grouped conv), zero padding outside the image, offset channel order
 (deform_group, tap, (dy, dx)) as in mmcv.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -53,8 +55,17 @@ class DeformConv2dPack(nn.Module):
         xb = x.to(gemm_dtype).permute(0, 2, 3, 1).contiguous()                   # (B,H,W,C): a view for channels-last x
         ob = offset.float().permute(0, 2, 3, 1).contiguous()                     # (B,Ho,Wo,18), channel = tap*2 + (dy,dx)
         col = ops.dcn3x3_sample(xb, ob, self.stride, self.padding, self.dilation)
-        out = col @ self._grouped_weight().to(gemm_dtype)
         Ho, Wo = ob.shape[1:3]
+        wmat = self._grouped_weight()                                            # (9*Cin, Cout) fp32, block-diagonal
+        if (gemm_dtype == torch.float32 and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen"
+                and col.shape[1] % 64 == 0 and self.out_channels % 8 == 0):
+            # the fp32 step: the contraction is a 1x1 convolution over the column rows — on the fp32-grade split kernels
+            # (3-term bf16 MFMA, csrc/conv_igemm.hip) where they measure faster than the fp32 GEMM library
+            rows = col.view(1, B * Ho * Wo, 1, col.shape[1]).permute(0, 3, 1, 2)   # (1, 9*Cin, M, 1) over (M, 9*Cin) memory
+            w4 = wmat.t().reshape(self.out_channels, col.shape[1], 1, 1)
+            out = ops.conv_split(rows, w4, None, (1, 1), (0, 0), (1, 1))            # (1, Cout, M, 1) channels-last
+            return out.permute(0, 2, 3, 1).reshape(B, Ho, Wo, self.out_channels).permute(0, 3, 1, 2).to(x.dtype)
+        out = col @ wmat.to(gemm_dtype)
         return out.view(B, Ho, Wo, self.out_channels).permute(0, 3, 1, 2).to(x.dtype)
 
     def _grouped_weight(self):

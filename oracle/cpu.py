@@ -121,3 +121,21 @@ def nms_rotated(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
         order = order[:pre_maxsize]
     kept = order[nms_rotated_sorted(np.asarray(boxes)[order], thresh)]
     return kept if post_max_size is None else kept[:post_max_size]
+
+
+def deform_conv(x, offset, weight, stride=1, pad=1, dil=1, groups=1, deform_groups=1, grad_out=None):
+    """mmcv 1.4.0 deformable convolution v1 (oracle/dcn_oracle.c): x (B,C,H,W), offset (B,DG*2*K*K,Ho,Wo), weight
+    (N,C/G,K,K) -> out (B,N,Ho,Wo); with ``grad_out`` also (grad_x, grad_offset, grad_weight)."""
+    x, offset, weight = _f32(x), _f32(offset), _f32(weight)
+    B, C, H, W = x.shape
+    N, _, K, _ = weight.shape
+    Ho, Wo = offset.shape[2:]
+    out = np.zeros((B, N, Ho, Wo), dtype=np.float32)
+    geo = [ctypes.c_int(v) for v in (B, C, H, W, N, K, stride, pad, dil, groups, deform_groups, Ho, Wo)]
+    lib().oracle_deform_conv_fwd(_p(x), _p(offset), _p(weight), _p(out), *geo)
+    if grad_out is None:
+        return out
+    g = _f32(grad_out)
+    gx, go, gw = np.zeros_like(x), np.zeros_like(offset), np.zeros_like(weight)
+    lib().oracle_deform_conv_bwd(_p(x), _p(offset), _p(weight), _p(g), _p(gx), _p(go), _p(gw), *geo)
+    return out, gx, go, gw

@@ -27,6 +27,8 @@ def cuda():
         pytest.fail("this test is marked gpu but no GPU is visible (HIP path has no CPU fallback)")
     import omnihd_amd
     omnihd_amd.require_gpu()
+    from omnihd_amd.harness import seed_miopen_db
+    seed_miopen_db()                      # MIOpen's kernel builds for the full-size geometries become lookups
     return torch.device("cuda:0")
 
 

@@ -112,6 +112,36 @@ def test_dcn_hip_sampling_fp32_matches_torch_formulation(cuda, c, H, W):
         <= 1e-5 * float(y.abs().max())
 
 
+@pytest.mark.parametrize("c,H,W", [(32, 9, 14), (64, 6, 11)])
+def test_dcn_hip_path_matches_the_independent_c_oracle(cuda, c, H, W):
+    """the HIP deformable-sampling kernels + GEMM (fp32 form) against oracle/dcn_oracle.c — an
+    independent C restatement of mmcv 1.4.0's deformable_im2col (channel order (dy, dx) per tap, `> -1 / < H` border rule,
+    corner-wise zero padding; its own known answers are in tests/test_oracle.py) — not against the product's torch formulation:
+    forward and the gradients with respect to input, offsets and weight; offsets up to several pixels, reaching outside the
+    image.  1e-5 of the largest value (5e-5 for the offset gradient: C products per sample summed in another order)."""
+    from omnihd_amd.mm.dcn import DeformConv2dPack
+    from oracle import cpu as OC
+    torch.manual_seed(c + H)
+    m = DeformConv2dPack(c, 32, 3, padding=1, groups=4).to(cuda)
+    x = torch.randn(2, c, H, W, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+    off = (torch.randn(2, 18, H, W, device=cuda) * 1.5 + 0.01).requires_grad_()
+    off.data[0, :, 0, 0] = -3.0                                  # far outside: zero sample, zero gradients
+    g = torch.randn(2, 32, H, W, device=cuda)
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        y = m._hip_sample_and_gemm(x, off, torch.float32)
+        gx, go, gw = torch.autograd.grad(y, [x, off, m.weight], g)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    want = OC.deform_conv(x.detach().cpu().numpy(), off.detach().cpu().numpy(), m.weight.detach().cpu().numpy(), 1, 1, 1, groups=4,
+                          grad_out=g.cpu().numpy())
+    for got, w, name, tol in zip((y, gx, go, gw), want, ("output", "grad input", "grad offset", "grad weight"), (1e-5, 1e-5, 5e-5, 1e-5)):
+        w = torch.from_numpy(w)
+        assert got.shape == w.shape, name
+        assert float((got.detach().cpu() - w).abs().max()) <= tol * float(w.abs().max()), name
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,stride", [(2, 8, 22, 512, 128, 1), (6, 16, 44, 256, 1024, 1), (1, 9, 13, 128, 256, 2), (3, 7, 5, 2048, 512, 1)])
 def test_wgrad_1x1_matches_fp32_reference(cuda, B, H, W, cin, cout, stride):
     from omnihd_amd import ops

@@ -143,6 +143,42 @@ def test_full_size_r1_fp32_forward_matches_the_oracle_ops_run(cuda, policy, monk
     assert _close(gpu["reg"], cpu["reg"]) and _close(gpu["cls"], cpu["cls"]), "box regressions / class logits"
 
 
+def test_camera_only_config1_trains_and_detects_at_full_size(cuda):
+    """BASELINE.json configs[1] (the reference's camera-only stage-1 config, cam_stream/LSS.py:30-123: torch SyncBN everywhere,
+    lc_fusion=False, head on the 256-channel camera BEV) on the GPU: two bf16 training steps at R1 with the reference's four
+    loss keys, then the test-time path (decode + rotated NMS) on one frame.  SyncBN in training mode needs a process group:
+    a one-rank RCCL group in a child process, as the reference's own benchmark tool sets one up
+    (tools/analysis_tools/benchmark.py:16-18)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, math, torch, torch.distributed as dist\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'omnihd-scenes_amd')!r}]\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "from omnihd_amd.harness import FusionTrainStep, seed_miopen_db\n"
+        "seed_miopen_db()\n"
+        "st = FusionTrainStep(res='r1', batch=1, radar_dims=7, device='cuda:0', dtype='bf16', sets=1, task='camera')\n"
+        "m = st.raw_model\n"
+        "assert not hasattr(m, 'reduc_conv') and m.pts_bbox_head.conv_cls.in_channels == 256\n"
+        "assert any(isinstance(x, torch.nn.SyncBatchNorm) for x in m.img_backbone.modules())\n"
+        "l = [float(st.step().detach()) for _ in range(2)]\n"
+        "assert all(math.isfinite(v) for v in l), l\n"
+        "assert set(st.last_losses) == {'loss_cls', 'loss_bbox', 'loss_dir', 'img_depth_loss'}, list(st.last_losses)\n"
+        "m.eval()\n"
+        "torch.nn.init.constant_(m.pts_bbox_head.conv_cls.bias, -2.0)\n"
+        "b = st.batches[0]\n"
+        "with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):\n"
+        "    out = m(return_loss=False, rescale=True, points=[b['points']], img_metas=[b['img_metas']], img=[b['img']])\n"
+        "boxes = out[0]['pts_bbox']['boxes_3d'].tensor\n"
+        "assert len(out) == 1 and boxes.shape[-1] == 9 and len(boxes) <= 500, boxes.shape\n"
+        "dist.destroy_process_group()\n"
+        "print('CAMERA_OK', l, len(boxes))\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "CAMERA_OK" in out.stdout, out.stderr[-3000:]
+
+
 def test_full_size_detector_bf16_step_runs_and_is_finite(cuda):
     """One R1 training step of the reference config (bf16 autocast, channels-last): finite losses with the
     reference's four loss keys; plan cache hit on the second step."""

@@ -380,3 +380,24 @@ def test_radar_side_thread_is_refused_when_another_branch_also_synchronises(monk
     m3 = build_detector(tiny_model_cfg(7))
     m3.img_neck.add_module("extra_sync", torch.nn.SyncBatchNorm(8))
     assert not m3._side_thread_is_safe()
+
+
+def test_camera_only_config_is_the_reference_stage1_config():
+    """BASELINE.json configs[1]: harness.camera_model_cfg restates projects/configs/bevfusion_NewScenes/cam_stream/LSS.py:30-123
+    (lc_fusion=False, SyncBN everywhere, head on the 256-channel camera BEV): same dict as the reference file (geometry keys
+    aside) and the same state-dict keys / parameter count when built."""
+    from omnihd_amd import harness
+    from omnihd_amd.mm.config import build_detector, load_config
+    cfg = harness.camera_model_cfg(harness.reference_model_cfg())
+    assert cfg["lc_fusion"] is False and cfg["norm_cfg"]["type"] == "SyncBN" and cfg["pts_bbox_head"]["in_channels"] == 256
+    assert "pts_voxel_encoder" not in cfg and cfg["img_backbone"]["norm_eval"] is False
+    ref_file = "/root/reference/projects/configs/bevfusion_NewScenes/cam_stream/LSS.py"
+    if os.path.exists(ref_file):
+        ref = load_config(ref_file)["model"]
+        assert set(ref) == set(cfg)
+        for k in ref:
+            if k not in ("final_dim", "img_neck", "pc_range", "pts_bbox_head"):
+                assert ref[k] == cfg[k], k
+        a, b = build_detector(cfg), build_detector(ref)
+        assert list(a.state_dict()) == list(b.state_dict())
+        assert sum(p.numel() for p in a.parameters()) == sum(p.numel() for p in b.parameters())

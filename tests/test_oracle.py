@@ -239,3 +239,79 @@ def test_nms_oracle_greedy_semantics():
     assert OC.nms_rotated(boxes, scores, 0.2, pre_maxsize=2).tolist() == [3, 0]
     assert OC.nms_rotated(boxes, scores, 0.4, post_max_size=1).tolist() == [3]
     assert OC.nms_rotated(np.zeros((0, 5), np.float32), np.zeros(0, np.float32), 0.2).tolist() == []
+
+
+# ---- deformable convolution v1 (mmcv 1.4.0, un-vendored): hand-computed cases; parity unpinned by the reference ----
+def _dcn_inputs(rng, B=2, C=8, H=6, W=7, N=8, G=4):
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = rng.standard_normal((N, C // G, 3, 3)).astype(np.float32)
+    return x, w
+
+
+def test_dcn_oracle_zero_offsets_is_a_plain_grouped_convolution():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    x, w = _dcn_inputs(rng)
+    for stride, pad, dil in ((1, 1, 1), (2, 1, 1), (1, 2, 2)):
+        want = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, stride, pad, dil, 4).numpy()
+        Ho, Wo = want.shape[2:]
+        got = OC.deform_conv(x, np.zeros((2, 18, Ho, Wo), np.float32), w, stride, pad, dil, groups=4)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_dcn_oracle_offset_channel_order_is_dy_then_dx_per_tap():
+    """One tap of a 3x3 kernel with weight 1, offset (dy, dx) = (+1, 0) on channel pair (2*t, 2*t + 1): the output is the
+    input shifted UP by one more row for that tap (reads y + 1), not shifted along x."""
+    x = np.arange(5 * 6, dtype=np.float32).reshape(1, 1, 5, 6)
+    w = np.zeros((1, 1, 3, 3), np.float32)
+    w[0, 0, 1, 1] = 1.0                                        # centre tap t = 4 reads x[y, x] when undeformed
+    off = np.zeros((1, 18, 5, 6), np.float32)
+    off[0, 2 * 4] = 1.0                                        # dy of the centre tap
+    got = OC.deform_conv(x, off, w, 1, 1, 1)
+    want = np.zeros_like(x)
+    want[0, 0, :4] = x[0, 0, 1:]                               # row y + 1; the last row reads y = 5 = H: outside, 0
+    assert np.array_equal(got, want)
+    off[:] = 0
+    off[0, 2 * 4 + 1] = -2.0                                   # dx of the centre tap
+    got = OC.deform_conv(x, off, w, 1, 1, 1)
+    want = np.zeros_like(x)
+    want[0, 0, :, 2:] = x[0, 0, :, :-2]
+    assert np.array_equal(got, want)
+
+
+def test_dcn_oracle_border_rule_gt_minus_one_lt_size():
+    """h in (-1, 0): only the in-range corner row contributes, with its bilinear weight; h <= -1 and h >= H: zero; h in
+    (H-1, H): the row H-1 with weight H - h (mmcv: `h_im > -1 && ... && h_im < height`, corners outside contribute 0)."""
+    x = np.full((1, 1, 4, 4), 2.0, np.float32)
+    w = np.zeros((1, 1, 3, 3), np.float32)
+    w[0, 0, 1, 1] = 1.0
+    def at(dy, dx=0.0):
+        off = np.zeros((1, 18, 4, 4), np.float32)
+        off[0, 8], off[0, 9] = dy, dx
+        return OC.deform_conv(x, off, w, 1, 1, 1)[0, 0]
+    np.testing.assert_allclose(at(-0.25)[0], 2.0 * 0.75)       # h = -0.25: corner rows -1 (out) and 0 (weight 0.75)
+    np.testing.assert_allclose(at(-1.0)[0], 0.0)
+    np.testing.assert_allclose(at(-1.5)[0], 0.0)
+    np.testing.assert_allclose(at(0.75)[3], 2.0 * 0.25)        # h = 3.75 on the last row: row 3 (weight 0.25), row 4 out
+    np.testing.assert_allclose(at(1.0)[3], 0.0)                # h = 4 = H
+    np.testing.assert_allclose(at(-0.5, -0.5)[0, 0], 2.0 * 0.25)   # one valid corner of four
+
+
+def test_dcn_oracle_backward_is_the_gradient_of_its_forward():
+    rng = np.random.default_rng(3)
+    x, w = _dcn_inputs(rng, B=1, C=4, H=5, W=6, N=4, G=2)
+    off = (rng.standard_normal((1, 18, 5, 6)) * 0.7).astype(np.float32)
+    off += 0.013                                               # keep sampling positions off the integer grid
+    g = rng.standard_normal((1, 4, 5, 6)).astype(np.float32)
+    out, gx, go, gw = OC.deform_conv(x, off, w, 1, 1, 1, groups=2, grad_out=g)
+    f = lambda x_, o_, w_: float((OC.deform_conv(x_, o_, w_, 1, 1, 1, groups=2).astype(np.float64) * g).sum())
+    eps = 1e-2
+    for arr, grad, name in ((x, gx, "x"), (off, go, "offset"), (w, gw, "weight")):
+        for _ in range(12):
+            idx = tuple(int(rng.integers(0, s)) for s in arr.shape)
+            a, b = arr.copy(), arr.copy()
+            a[idx] += eps; b[idx] -= eps
+            args = {"x": (a, off, w), "offset": (x, a, w), "weight": (x, off, a)}[name], {"x": (b, off, w), "offset": (x, b, w), "weight": (x, off, b)}[name]
+            num = (f(*args[0]) - f(*args[1])) / (2 * eps)
+            assert abs(num - grad[idx]) <= 2e-2 * max(1.0, abs(num)), (name, idx, num, grad[idx])

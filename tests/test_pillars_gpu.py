@@ -70,9 +70,6 @@ def test_stream_only_tiny_step_hip_ops_match_oracle_ops(cuda, stream):
         assert _close(sa.sort()[0], sb.sort()[0])
 
 
-@pytest.mark.skipif(os.environ.get("OMNIHD_TEST_PENDING", "0") != "1",
-                    reason="packed HardVFE: CPU-verified (tests/test_pillars_cpu.py), first GPU run pending (round 2); "
-                           "OMNIHD_TEST_PENDING=1 runs it")
 def test_packed_hard_vfe_on_the_gpu_matches_the_dense_form_at_lidar_sizes(cuda):
     import copy
     from omnihd_amd import ops

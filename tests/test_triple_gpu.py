@@ -44,14 +44,15 @@ def test_tiny_queue_hip_ops_match_oracle_ops(cuda):
     for n in ("temporal_conv.conv.weight", "reduc_conv.conv.weight", "lidar_stream.pts_voxel_encoder.vfe_layers.0.linear.weight",
               "lidar_stream.pts_backbone.blocks.0.0.weight", "pts_voxel_encoder.pfn_layers.0.linear.weight",
               "lift_splat_shot_vis.bevencode.0.weight"):
-        assert _close(got["grads"][n], want["grads"][n], 2e-3), n
+        # (5e-3 as in tests/test_detector_gpu.py: the dense convolutions of the fp32 path run on the fp32-grade split kernels or on
+        # MIOpen by a per-geometry measurement, 1e-5 apart; behind ReLUs that moves single gradient entries)
+        assert _close(got["grads"][n], want["grads"][n], 5e-3), n
 
 
-@pytest.mark.skipif(os.environ.get("OMNIHD_TRIPLE_FULL", "0") != "1",
-                    reason="full-size 4-frame step: opt-in (OMNIHD_TRIPLE_FULL=1).  Not yet measured: its first step "
-                           "(three new batch sizes of every convolution geometry) did not finish inside the 155 s that "
-                           "were left of round 1's GPU budget; see DESIGN.md section 1, row (f) rank 4")
 def test_full_size_bs2_four_frame_bf16_step(cuda):
+    """BASELINE.json configs[4] at full size: camera + radar + LiDAR, 4-frame queue, bs = 2 per GPU, bf16.  In the verified set
+    since round 3: with MIOpen's records for its batch sizes in omnihd-scenes_amd/miopen_db (seeded by the ``cuda`` fixture)
+    the first step takes ~5 s instead of 7.7 min (profiles/round3/configs4_*)."""
     from omnihd_amd.harness import FusionTrainStep
     st = FusionTrainStep(res="r1", batch=2, radar_dims=7, device=cuda, dtype="bf16", sets=1, task="triple", frames=4)
     b = st.batches[0]
