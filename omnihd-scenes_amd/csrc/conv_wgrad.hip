@@ -460,14 +460,14 @@ constexpr int kBKS = 16;
 
 __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* __restrict__ Gt, const unsigned short* __restrict__ Gt2,
                                                          const unsigned short* __restrict__ Xt, const unsigned short* __restrict__ Xt2,
-                                                         const unsigned short* __restrict__ zero_page, float* __restrict__ slab,
-                                                         int Cout, int Cin, int Coutp, int Cinp, int M, int Mp, int H, int W,
-                                                         int n_split, int k_per_split, int dil) {
+                                                         const unsigned short* __restrict__ ws_base, unsigned ws_bytes,
+                                                         float* __restrict__ slab, int Cout, int Cin, int Coutp, int Cinp, int M,
+                                                         int Mp, int H, int W, int n_split, int k_per_split, int dil) {
   // tiles: 0 = G_hi, 1 = G_lo, 2..4 = X_hi copies, 5..7 = X_lo copies
   __shared__ __attribute__((aligned(16))) unsigned short sm[kStages3][8][kTile][kBKS];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_c = Cinp / kTile, tiles_n = Coutp / kTile;
   int bid = blockIdx.x;
   const int ct = bid % tiles_c; bid /= tiles_c;
@@ -477,31 +477,56 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
   const int dy = (ky - 1) * dil;
   const int k0 = split * k_per_split;
   const int k1 = min(k0 + k_per_split, Mp);
+  const int k_last = k1 - kBKS;
 
-  // loader: one DMA call = 32 rows of 32 B; wave w owns rows [32w, 32w+32) of every tile: one call per tile
+  // loader: one DMA call = 32 rows of 32 B; wave w owns rows [32w, 32w+32) of every tile: one call per tile.  The calls
+  // are `buffer_load_dwordx4 ... offen lds` through ONE range-checked descriptor over the staging workspace (all four
+  // planes live in it): the lane's offset is static, the K-step position travels in the scalar offset, and an X row outside
+  // the image is an offset beyond the buffer (the hardware writes zeros) — no zero page, no 64-bit address arithmetic.
+  constexpr unsigned kOOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws_base, 0, (int)ws_bytes, 0x00020000);
   const int lr = lane >> 1;                          // row inside the call
   const int gch = (lane & 1) ^ ((lr >> 3) & 1);      // global 16-byte chunk this lane fetches (LDS slot lane & 1)
-  const size_t a_off = (size_t)(nt * kTile + wave * 32 + lr) * Mp;
-  const ptrdiff_t b_off = (ptrdiff_t)(((size_t)ct * kTile + wave * 32 + lr) * Mp) + (ptrdiff_t)dy * W;
-  const size_t copy_pitch = (size_t)Cinp * Mp;
+  const size_t a_row = (size_t)(nt * kTile + wave * 32 + lr) * Mp;
+  const ptrdiff_t b_row = (ptrdiff_t)(((size_t)ct * kTile + wave * 32 + lr) * Mp) + (ptrdiff_t)dy * W;   // may reach into the guard
+  const unsigned g_off0 = (unsigned)((const char*)(Gt + a_row) - (const char*)ws_base) + gch * 16;
+  const unsigned g_off1 = (unsigned)((const char*)(Gt2 + a_row) - (const char*)ws_base) + gch * 16;
+  const unsigned x_off0 = (unsigned)((const char*)(Xt + b_row) - (const char*)ws_base) + gch * 16;
+  const unsigned x_off1 = (unsigned)((const char*)(Xt2 + b_row) - (const char*)ws_base) + gch * 16;
+  const unsigned copy_pitch = (unsigned)((size_t)Cinp * Mp * 2);
   int px = (k0 + gch * 8) % W, py = ((k0 + gch * 8) / W) % H;
+  int k_issue = k0;
 
-  auto issue = [&](int k, int stage) {
-    const bool real = k < k1;
-    const bool ok = real && (k + gch * 8 < M) && (py + dy >= 0) && (py + dy < H);
-    const size_t ka = (size_t)k + gch * 8;
-    const unsigned short* g0 = real ? Gt + a_off + ka : zero_page;
-    const unsigned short* g1 = real ? Gt2 + a_off + ka : zero_page;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g0, (lds_ptr_t*)&sm[stage][0][wave * 32][0], 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g1, (lds_ptr_t*)&sm[stage][1][wave * 32][0], 16, 0, 0);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const unsigned short* x0 = ok ? Xt + b_off + c * copy_pitch + ka : zero_page;
-      const unsigned short* x1 = ok ? Xt2 + b_off + c * copy_pitch + ka : zero_page;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)x0, (lds_ptr_t*)&sm[stage][2 + c][wave * 32][0], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)x1, (lds_ptr_t*)&sm[stage][5 + c][wave * 32][0], 16, 0, 0);
+  // call c (0..7) of the fill of the next K-step in issue order; the dummy fills behind the last K-step re-read it (their
+  // ring slot is never read again; the wait counts stay uniform)
+  unsigned xm0 = 0, xm1 = 0;
+  auto fill_begin = [&]() {
+    const int kk = min(k_issue, k_last);
+    const bool ok = (kk + gch * 8 < M) && (py + dy >= 0) && (py + dy < H);
+    xm0 = ok ? x_off0 : kOOB;
+    xm1 = ok ? x_off1 : kOOB;
+  };
+  auto fill_call = [&](int stage, int c) {
+    const unsigned so = (unsigned)min(k_issue, k_last) * 2;                 // scalar offset: the K-step position
+    if (c == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][0][wave * 32][0], 16, g_off0, so, 0, 0);
+    else if (c == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][1][wave * 32][0], 16, g_off1, so, 0, 0);
+    else if (c < 5) {
+      const unsigned v = xm0 + (unsigned)(c - 2) * copy_pitch;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][c][wave * 32][0], 16, v, so, 0, 0);
+    } else {
+      const unsigned v = xm1 + (unsigned)(c - 5) * copy_pitch;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][c][wave * 32][0], 16, v, so, 0, 0);
     }
+  };
+  auto fill_end = [&]() {
+    k_issue += kBKS;
     px += kBKS; while (px >= W) { px -= W; py = (py + 1 == H) ? 0 : py + 1; }
+  };
+  auto issue = [&](int stage) {
+    fill_begin();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fill_call(stage, c);
+    fill_end();
   };
 
   f32x16 acc[3][2][2];
@@ -518,14 +543,14 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
 
-  issue(k0, 0);
-  issue(k0 + kBKS, 1);
-  issue(k0 + 2 * kBKS, 2);
+  issue(0);
+  issue(1);
+  issue(2);
   int stage = 0;
   for (int k = k0; k < k1; k += kBKS) {
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(k + 3 * kBKS, (stage + 3) % kStages3);
+    const int fill = (stage + 3) % kStages3;          // its buffer was last read before this barrier
     bf16x8 ah[2], al[2], bh[3][2], bl[3][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -540,9 +565,10 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
         bl[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][5 + t][rb][sb]);
       }
     }
-    // all 16 fragment reads are requested before the first MFMA (hipcc otherwise interleaves them with four lgkmcnt(0) waits
-    // per K-step: one wavefront per SIMD has nobody to cover an exposed LDS round trip)
+    // all 16 fragment reads are requested before the first MFMA; ONE wavefront per SIMD has nobody to cover its fills, so the
+    // 8 fill calls of the K-step three ahead are issued between the three MFMA groups, in the shadow of the matrix pipe
     __builtin_amdgcn_sched_barrier(0);
+    fill_begin();
     // term-major: consecutive MFMAs go to different accumulators
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -550,18 +576,25 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[t][j], acc[t][i][j], 0, 0, 0);
+    fill_call(fill, 0); fill_call(fill, 1); fill_call(fill, 2);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[t][j], acc[t][i][j], 0, 0, 0);
+    fill_call(fill, 3); fill_call(fill, 4); fill_call(fill, 5);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[t][j], acc[t][i][j], 0, 0, 0);
+    fill_call(fill, 6); fill_call(fill, 7);
+    fill_end();
+    __builtin_amdgcn_sched_barrier(0);
     stage = (stage + 1) % kStages3;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -760,9 +793,11 @@ int wgrad_impl(const void* x_nhwc, const void* x_lo, const void* gout_nhwc, cons
     const int k_per_split3 = ((p.mp / kBK + n_split - 1) / n_split) * kBK;
     const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * 3 * n_split;
     static const bool fused8 = [] { const char* e = getenv("OMNIHD_WGRAD_SPLIT8"); return !(e && e[0] == '0'); }();
-    if (split && fused8)
-      hipLaunchKernelGGL(k_wgrad_split3, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2, zero_page, n_split > 1 ? slab : dw, cout,
-                         cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil);
+    // (the 8-tile kernel reaches all four staged planes through one 32-bit buffer descriptor over the workspace)
+    if (split && fused8 && (size_t)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)) < (1ull << 31))
+      hipLaunchKernelGGL(k_wgrad_split3, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2,
+                         reinterpret_cast<const unsigned short*>(workspace), (unsigned)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)),
+                         n_split > 1 ? slab : dw, cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil);
     else
       hipLaunchKernelGGL(k_wgrad_mfma_glds3, dim3(blocks), dim3(kBlock), 0, st, Gt, Xt, zero_page, n_split > 1 ? slab : dw, cout,
                          cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil, Gt2, Xt2, n_terms);

@@ -713,11 +713,12 @@ def conv_fwd(x, w_cl, bias=None, dilation=1, tile=0):
     return y
 
 
-def conv_dgrad_weights(w_cl):
+def conv_dgrad_weights(w_cl, out=None):
     """(Cout,Cin,k,k) channels_last bf16 -> (Cin,Cout,k,k) channels_last bf16 with mirrored taps: the weights with which
     the data gradient is ``conv_fwd(grad_out, wt)``."""
     cout, cin, k, _ = w_cl.shape
-    wt = torch.empty((cin, cout, k, k), dtype=torch.bfloat16, device=w_cl.device, memory_format=torch.channels_last)
+    wt = out if out is not None else torch.empty((cin, cout, k, k), dtype=torch.bfloat16, device=w_cl.device,
+                                                 memory_format=torch.channels_last)
     with _on(w_cl.device):
         check(lib().omnihd_conv_dgrad_weights(w_cl.data_ptr(), wt.data_ptr(), cout, cin, k, _raw_stream()),
               "omnihd_conv_dgrad_weights")
@@ -944,14 +945,26 @@ def split_f32(t):
         raise TypeError("split_f32 takes an fp32 CUDA(HIP) tensor")
     if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
         t = t.contiguous()
-    hi = torch.empty_like(t, dtype=torch.bfloat16)          # preserve_format: same strides
-    lo = torch.empty_like(t, dtype=torch.bfloat16)
+    # both planes in ONE allocation, back to back (the row-shift kernels reach them through one buffer descriptor)
+    n = t.numel()
+    pitch = (n + 7) // 8 * 8                                  # 16-byte aligned planes
+    planes = torch.empty(2 * pitch, dtype=torch.bfloat16, device=t.device)
+    hi, lo = (planes[i * pitch:i * pitch + n].as_strided(t.shape, t.stride()) for i in (0, 1))
     with _on(t.device):
         check(lib().omnihd_split_f32(t.data_ptr(), t.numel(), hi.data_ptr(), lo.data_ptr(), _raw_stream()), "omnihd_split_f32")
     return hi, lo
 
 
 _SPLIT_SHADOW = {}
+
+
+def split_dgrad_weights(ws):
+    """(w_hi, w_lo) (Cout,Cin,k,k) channels_last -> the two planes re-laid for the data gradient ((Cin,Cout,k,k) channels_last,
+    taps mirrored), in one allocation back to back (the kernels reach both planes through one buffer descriptor)."""
+    hi, lo = ws
+    cout, cin, k, _ = hi.shape
+    both = torch.empty((2, cin, k, k, cout), dtype=torch.bfloat16, device=hi.device)
+    return tuple(conv_dgrad_weights(p_, both[i].permute(0, 3, 1, 2)) for i, p_ in enumerate((hi, lo)))
 
 
 def split_weight(weight, dgrad=False):
@@ -962,8 +975,7 @@ def split_weight(weight, dgrad=False):
     if e is not None and e[0]() is weight and e[1] == weight._version and e[2][0].device == weight.device:
         return e[2]
     if dgrad:
-        hi, lo = split_weight(weight)
-        planes = (conv_dgrad_weights(hi), conv_dgrad_weights(lo))
+        planes = split_dgrad_weights(split_weight(weight))
     else:
         planes = split_f32(weight.detach().float().contiguous(memory_format=torch.channels_last))
     if len(_SPLIT_SHADOW) > 4096:
@@ -1059,37 +1071,53 @@ class _ConvSplit(torch.autograd.Function):
         k = weight.shape[2]
         geo = (tuple(x.shape), weight.shape[0], k, stride[0], padding[0], dilation[0], dev.index)
         ok_f, ok_d, ok_w = conv_split_geometry(x.shape, weight.shape[0], k, stride, padding, dilation)
-        xs = split_f32(x)
-        ctx.save_for_backward(xs[0], xs[1], weight)
+        # what the backward needs of x: its two bf16 planes for the split weight-gradient chain, or x itself where MIOpen's
+        # fp32 weight gradient has measured faster for this geometry (no reconstruction of x from the planes then)
+        wg_miopen = (not ok_w) or (os.environ.get("OMNIHD_FP32_CONV", "tune") == "tune" and _SPLIT_CHOICE.get(("wgrad",) + geo) == "miopen")
+        use_split_fwd = ok_f and not (os.environ.get("OMNIHD_FP32_CONV", "tune") == "tune" and _SPLIT_CHOICE.get(("fwd",) + geo) == "miopen")
+        xs = split_f32(x) if (use_split_fwd or not wg_miopen) else None
+        if wg_miopen:
+            ctx.save_for_backward(x, weight)
+        else:
+            ctx.save_for_backward(xs[0], xs[1], weight)
+        ctx.x_is_full = wg_miopen
         ctx.conv = (list(stride), list(padding), list(dilation), geo, ok_d, ok_w)
         ctx.has_bias = bias is not None
         ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
         run_miopen = lambda: torch.nn.functional.conv2d(x, weight.detach(), None if bias is None else bias.detach(), stride,
                                                          padding, dilation)
-        if not ok_f:
+        if not use_split_fwd:
             return run_miopen()
         run_split = lambda: conv_fwd_split(xs, split_weight(weight), None if bias is None else bias.detach(), dilation[0])
         return _split_pick(("fwd",) + geo, run_split, run_miopen, dev)
 
     @staticmethod
     def backward(ctx, g):
-        x_hi, x_lo, weight = ctx.saved_tensors
+        if ctx.x_is_full:
+            x_saved, weight = ctx.saved_tensors
+            x_hi = x_lo = None
+            x_shape = x_saved.shape
+        else:
+            x_hi, x_lo, weight = ctx.saved_tensors
+            x_saved, x_shape = None, x_hi.shape
         stride, padding, dilation, geo, ok_d, ok_w = ctx.conv
         dev = g.device
         g = g.float().contiguous(memory_format=torch.channels_last)
-        gs = split_f32(g) if ((ok_d and ctx.needs_input_grad[0]) or (ok_w and ctx.needs_input_grad[1])) else None
+        want_w_split = ok_w and ctx.needs_input_grad[1] and not ctx.x_is_full
+        gs = split_f32(g) if ((ok_d and ctx.needs_input_grad[0]) or want_w_split) else None
         gx = gw = gb = None
         x_f32 = []
 
         def x_full():                      # only for MIOpen's weight gradient: hi + lo reproduces x to 2^-17
+            if x_saved is not None:
+                return x_saved
             if not x_f32:
                 x_f32.append(x_hi.float().add_(x_lo))
             return x_f32[0]
 
         if ctx.needs_input_grad[0]:
-            # (an uninitialised fp32 stand-in for the input: only its shape / layout matter to the data gradient; with
-            # torch.nn.grad.conv2d_input's stride-0 stand-in MIOpen took a kernel that was 2e-2 off on a strided 3x3 layer)
-            x_like = lambda: torch.empty(x_hi.shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+            # (an uninitialised fp32 stand-in for the input: only its shape / layout matter to the data gradient)
+            x_like = lambda: torch.empty(x_shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
             run_miopen = lambda: torch.ops.aten.convolution_backward(g, x_like(), weight.detach(), None, stride, padding, dilation,
                                                                      False, [0, 0], 1, [True, False, False])[0]
             if ok_d:
@@ -1102,9 +1130,8 @@ class _ConvSplit(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             run_miopen = lambda: torch.ops.aten.convolution_backward(g, x_full(), weight.detach(), None, stride, padding, dilation,
                                                                      False, [0, 0], 1, [False, True, False])[1]
-            if ok_w:
+            if want_w_split:
                 k = weight.shape[2]
-
                 run_split = lambda: conv_wgrad_split((x_hi, x_lo), gs, k, stride[0], padding[0], dilation[0])
                 gw = _split_pick(("wgrad",) + geo, run_split, run_miopen, dev)
             else:

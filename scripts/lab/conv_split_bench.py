@@ -41,7 +41,7 @@ for B, H, W, cin, cout, k, dil in GEOMS:
     g = torch.randn(B, cout, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
     flops = 2.0 * B * H * W * cin * cout * k * k
     xs, ws, gs = ops.split_f32(x), ops.split_f32(w), ops.split_f32(g)
-    wt = tuple(ops.conv_dgrad_weights(p) for p in ws)
+    wt = ops.split_dgrad_weights(ws)
     t_sp = clock(lambda: ops.split_f32(x))
     f_s = clock(lambda: ops.conv_fwd_split(xs, ws, None, dil))
     f_m = clock(lambda: F.conv2d(x, w, None, padding=pad, dilation=dil))

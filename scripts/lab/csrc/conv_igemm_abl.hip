@@ -1,3 +1,6 @@
+// LAB COPY of omnihd-scenes_amd/csrc/conv_igemm.hip (round 3) with timing-ablation switches for the row-shift kernel:
+// -DOMNIHD_CONV_ABL bits: 1 = no border masks, 2 = no LDS-DMA fills, 4 = no fragment reads, 8 = no MFMAs.  Results are garbage
+// for any non-zero value; built only by scripts/lab/conv_abl.sh.  Not part of the product library.
 // Forward and data gradient of the dense stride-1 convolutions on the gfx950 matrix cores: implicit GEMM over NHWC.
 //
 // Where it sits: the BEV encoder of the camera stream (3x3 convs 1024->1024->512->512->256 at 160x240, reference
@@ -33,6 +36,9 @@
 // per MFMA against 1.0 in the bf16 kernel, which is bound by the bytes streamed into LDS).  The result is written in fp32.
 #include "common.h"
 #include <type_traits>
+#ifndef OMNIHD_CONV_ABL
+#define OMNIHD_CONV_ABL 0
+#endif
 
 namespace omnihd {
 namespace {
@@ -73,54 +79,43 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: LDS destinations of the fills are SALU math
+  const int wave = tid >> 6;
   const int taps = ksize * ksize;
   const int half = ksize / 2;
   const int K = taps * Cin;
 
   // ---- loader state: this lane's rows of A (pixels) and of B (output channels) -------------------------------
-  // Fills are `buffer_load_dwordx4 ... offen lds` through one range-checked descriptor per operand (see k_conv_igemm_rs): a
-  // row that does not exist is an offset beyond the buffer and arrives as zeros.
-  constexpr unsigned kOOB = 0x80000000u;
-  const unsigned short* xbase = (SPLIT && X2 < X) ? X2 : X;
-  const unsigned short* wbase = (SPLIT && Wt2 < Wt) ? Wt2 : Wt;
-  const size_t x_plane = (size_t)M * Cin * 2, w_plane = (size_t)Cout * K * 2;
-  const unsigned x_hi_off = (unsigned)((const char*)X - (const char*)xbase), w_hi_off = (unsigned)((const char*)Wt - (const char*)wbase);
-  const unsigned x_lo_off = SPLIT ? (unsigned)((const char*)X2 - (const char*)xbase) : 0u;
-  const unsigned w_lo_off = SPLIT ? (unsigned)((const char*)Wt2 - (const char*)wbase) : 0u;
-  const unsigned x_bytes = (unsigned)((SPLIT ? (x_lo_off > x_hi_off ? x_lo_off : x_hi_off) : 0u) + x_plane);
-  const unsigned w_bytes = (unsigned)((SPLIT ? (w_lo_off > w_hi_off ? w_lo_off : w_hi_off) : 0u) + w_plane);
-  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, (int)x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)w_bytes, 0x00020000);
-
   const int lr = lane >> 3;                       // row inside an 8-row call
   const int pos = lane & 7;                       // 16-byte slot inside the 128-byte LDS row
   const int c_even = pos ^ ((lane >> 4) & 7);     // global chunk for even calls; odd calls use c_even ^ 4
-  // per call: the lane's byte offset at tap (0,0), channel slice 0 (SPLIT: slots 0-3 of a row come from the hi plane, slots
-  // 4-7 from the lo plane of the same 32 channels); a fill adds ONE wave-uniform offset to it
-  int a_y[A_CALLS], a_x[A_CALLS];                 // pixel coordinates (y = -huge: row beyond M)
-  unsigned a_off[A_CALLS];
+  // per call: the lane's source pointer at tap (0,0) offset, channel slice 0 (SPLIT: slots 0-3 of a row come from the hi
+  // plane, slots 4-7 from the lo plane of the same 32 channels); a fill adds ONE wave-uniform offset to it
+  int a_y[A_CALLS], a_x[A_CALLS];                 // pixel coordinates (y = -1: row beyond M)
+  const unsigned short* a_ptr[A_CALLS];
 #pragma unroll
   for (int i = 0; i < A_CALLS; ++i) {
     const int c = (i & 1) ? (c_even ^ 4) : c_even;
+    const unsigned short* plane = (SPLIT && c >= 4) ? X2 : X;
     const int cc = SPLIT ? (c & 3) : c;
     const int m = mt * TM + wave * (8 * A_CALLS) + 8 * i + lr;
     if (m < M) {
       const int xx = m % W, r = m / W;
-      a_x[i] = xx; a_y[i] = r % H;
-      a_off[i] = ((SPLIT && c >= 4) ? x_lo_off : x_hi_off) + (unsigned)((size_t)m * Cin * 2) + cc * 16;
+      a_x[i] = xx; a_y[i] = r % H; a_ptr[i] = plane + (size_t)m * Cin + cc * 8;
     } else {
-      a_x[i] = 0; a_y[i] = -(1 << 20); a_off[i] = kOOB;
+      a_x[i] = 0; a_y[i] = -(1 << 20); a_ptr[i] = zero_page;
     }
   }
-  unsigned b_off[B_CALLS];                        // kOOB + any tap / slice offset stays beyond the buffer
+  const unsigned short* b_ptr[B_CALLS];
+  bool b_ok[B_CALLS];
 #pragma unroll
   for (int i = 0; i < B_CALLS; ++i) {
     const int call = A_CALLS + i;                 // A_CALLS is even: the parity of a B call is that of its index
     const int c = (call & 1) ? (c_even ^ 4) : c_even;
+    const unsigned short* plane = (SPLIT && c >= 4) ? Wt2 : Wt;
     const int cc = SPLIT ? (c & 3) : c;
     const int n = nt * TN + wave * (8 * B_CALLS) + 8 * i + lr;
-    b_off[i] = n < Cout ? ((SPLIT && c >= 4) ? w_lo_off : w_hi_off) + (unsigned)((size_t)n * K * 2) + cc * 16 : kOOB;
+    b_ok[i] = n < Cout;
+    b_ptr[i] = b_ok[i] ? plane + (size_t)n * K + cc * 8 : zero_page;
   }
 
   int k_tap = 0, k_c = 0;                         // position of the NEXT K-step to issue
@@ -130,16 +125,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
       const int i = call;
       const int dy = (k_tap / ksize - half) * dil, dx = (k_tap % ksize - half) * dil;
       const bool ok = real && (unsigned)(a_y[i] + dy) < (unsigned)H && (unsigned)(a_x[i] + dx) < (unsigned)W;
-      const int goff = ((dy * W + dx) * Cin + k_c) * 2;                        // wave-uniform, may be negative
-      const unsigned voff = ok ? a_off[i] + (unsigned)goff : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t*)&sm[stage][wave * (8 * A_CALLS) + 8 * i][0], 16, voff, 0, 0, 0);
+      const ptrdiff_t goff = ((ptrdiff_t)dy * W + dx) * Cin + k_c;             // wave-uniform
+      const unsigned short* g = ok ? a_ptr[i] + goff : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][wave * (8 * A_CALLS) + 8 * i][0], 16, 0, 0);
     } else {
       const int i = call - A_CALLS;
-      const unsigned goff = real ? (unsigned)((k_tap * Cin + k_c) * 2) : kOOB;   // wave-uniform
-      // (the offset in a named variable: with the sum written in the argument list hipcc's host pass silently dropped the
-      // kernel's launch stub)
-      const unsigned voff = b_off[i] + goff;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t*)&sm[stage][TM + wave * (8 * B_CALLS) + 8 * i][0], 16, voff, 0, 0, 0);
+      const ptrdiff_t goff = (ptrdiff_t)k_tap * Cin + k_c;                     // wave-uniform
+      const unsigned short* g = (real && b_ok[i]) ? b_ptr[i] + goff : zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t*)g, (lds_ptr_t*)&sm[stage][TM + wave * (8 * B_CALLS) + 8 * i][0], 16, 0, 0);
     }
   };
   // channels OUTER, taps INNER: the nine taps of one 64-channel slice read the same pixels' 128-byte lines (shifted), so a
@@ -206,81 +199,51 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[2 + j], acc[i][j], 0, 0, 0);
     }
   };
-  auto wait_stage = [&]() {   // this wave's fills of the next K-step have landed: (STAGES-2) younger K-steps may be outstanding
-    __builtin_amdgcn_sched_barrier(0);
-    if (STAGES == 2) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (STAGES == 4) {
+
+  // prologue: STAGES-1 K-steps in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) issue(s, s < n_steps);
+  int stage = 0;
+  for (int step = 0; step < n_steps; ++step) {
+    // the oldest K-step has landed when at most (STAGES-2) younger ones (CALLS DMA calls each) are outstanding
+    if (STAGES == 4) {
       if (CALLS == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     } else {
       if (CALLS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto bar = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // prologue: STAGES-1 K-steps in flight
+    const int fill = (stage + STAGES - 1) % STAGES;             // its buffer was last read before this barrier
+    const bool fill_real = step + STAGES - 1 < n_steps;
+    // slices software-pipelined by hand (two fragment sets): the reads of slice s+1 are in flight while slice s multiplies;
+    // the DMA calls of the next fill are issued BEHIND each slice's MFMAs (their issue time, 60-185 cycles each, then
+    // overlaps the matrix pipe instead of preceding it): CALLS calls over the NS slices
+    bf16x8 fa[NF], fb[NF];
+    load_slice(stage, 0, fa);
+    if (!SPREAD) issue(fill, fill_real);
+    constexpr int PER = (CALLS + NS - 1) / NS;
+    auto spread = [&](int ks) {
+      if (!SPREAD) return;
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) issue(s, s < n_steps);
-  bf16x8 fr[NS][NF];
-  int stage = 0;
-  // staggered two-group schedule for the 8-wavefront shapes (see k_conv_igemm_rs): waves 0-3 read and fill while waves 4-7
-  // multiply, then the roles swap.  (The segment lambdas live at function scope: hipcc drops the host stub of the kernel
-  // when they are declared inside the `if constexpr` branch.)
-  auto seg_load = [&](int step) {
+      for (int q = 0; q < PER; ++q)
+        if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
+    };
 #pragma unroll
-    for (int ks = 0; ks < NS; ++ks) load_slice(stage, ks, fr[ks]);
-    __builtin_amdgcn_sched_barrier(0);
-    issue((stage + STAGES - 1) % STAGES, step + STAGES - 1 < n_steps);
-    stage = (stage + 1) % STAGES;
-  };
-  auto seg_compute = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < NS; ++ks) mma_slice(fr[ks]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  if (NW == 8) {
-    wait_stage();
-    __builtin_amdgcn_s_barrier();
-    if (wave < 4) {
-      for (int step = 0; step < n_steps; ++step) { seg_load(step); bar(); seg_compute(); wait_stage(); bar(); }
-    } else {
-      bar();
-      for (int step = 0; step < n_steps; ++step) {
-        seg_load(step); wait_stage(); bar(); seg_compute();
-        if (step + 1 < n_steps) bar();
-      }
-    }
-  } else {
-    for (int step = 0; step < n_steps; ++step) {
-      wait_stage();
-      __builtin_amdgcn_s_barrier();
-      const int fill = (stage + STAGES - 1) % STAGES;             // its buffer was last read before this barrier
-      const bool fill_real = step + STAGES - 1 < n_steps;
-      // all fragment reads of the K-step first, then its MFMAs with the fills of the next K-steps spread behind them
-#pragma unroll
-      for (int ks = 0; ks < NS; ++ks) load_slice(stage, ks, fr[ks]);
+    for (int ks = 0; ks < NS; ks += 2) {
+      load_slice(stage, ks + 1, fb);
       __builtin_amdgcn_sched_barrier(0);
-      constexpr int PER = (CALLS + NS - 1) / NS;
-#pragma unroll
-      for (int ks = 0; ks < NS; ++ks) {
-        mma_slice(fr[ks]);
-#pragma unroll
-        for (int q = 0; q < PER; ++q)
-          if (ks * PER + q < CALLS) issue_call(fill, fill_real, ks * PER + q);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      advance();
-      stage = (stage + 1) % STAGES;
+      mma_slice(fa);
+      spread(ks);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < NS) load_slice(stage, ks + 2, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_slice(fb);
+      spread(ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (SPREAD) advance();
+    stage = (stage + 1) % STAGES;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail loads before the epilogue stores
 
@@ -345,53 +308,39 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: LDS destinations of the fills are SALU math
+  const int wave = tid >> 6;
   const int K = 9 * Cin;
   const int lr = lane >> 3;
   const int pos = lane & 7;
   const int chunk = pos ^ (((wave & 1) << 2) | ((lane >> 4) & 3));   // call index parity == wave parity for A and B calls
   // SPLIT: slots 0-3 of a row come from the hi plane, slots 4-7 from the lo plane
   const int cchunk = SPLIT ? (chunk & 3) : chunk;
-  const bool lo_plane = SPLIT && chunk >= 4;
-
-  // The fills are `buffer_load_dwordx4 ... offen lds` through ONE range-checked descriptor per operand (both planes of a
-  // split operand lie in it): a lane whose source row does not exist — image border, rows beyond M / Cout, the dummy fills
-  // behind the last K-step — asks for an offset beyond the buffer and the hardware writes ZEROS into its LDS slot (checked:
-  // scripts/micro/buffer_lds_oob.hip).  No zero page, no pointer select, no 64-bit address arithmetic: a fill call is one
-  // v_add_u32 (+ compare / select for the dy border) and the load.
-  constexpr unsigned kOOB = 0x80000000u;               // every buffer is smaller than 2 GiB
-  const unsigned short* xbase = (SPLIT && X2 < X) ? X2 : X;
-  const unsigned short* wbase = (SPLIT && Wt2 < Wt) ? Wt2 : Wt;
-  const size_t x_plane = (size_t)M * Cin * 2, w_plane = (size_t)Cout * K * 2;
-  const unsigned x_hi_off = (unsigned)((const char*)X - (const char*)xbase), w_hi_off = (unsigned)((const char*)Wt - (const char*)wbase);
-  const unsigned x_lo_off = SPLIT ? (unsigned)((const char*)X2 - (const char*)xbase) : 0u;
-  const unsigned w_lo_off = SPLIT ? (unsigned)((const char*)Wt2 - (const char*)wbase) : 0u;
-  const unsigned x_bytes = (unsigned)((SPLIT ? (x_lo_off > x_hi_off ? x_lo_off : x_hi_off) : 0u) + x_plane);
-  const unsigned w_bytes = (unsigned)((SPLIT ? (w_lo_off > w_hi_off ? w_lo_off : w_hi_off) : 0u) + w_plane);
-  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, (int)x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)w_bytes, 0x00020000);
+  const unsigned short* Xp = (SPLIT && chunk >= 4) ? X2 : X;
+  const unsigned short* Wp = (SPLIT && chunk >= 4) ? Wt2 : Wt;
 
   // A calls of this wavefront: call index ca = wave + 8*q (q = 0..4), rows 8*ca .. 8*ca+7 of the A buffer,
-  // row j <-> pixel m0 - kHalo + j.  a_off = byte offset of (pixel, channel chunk) at channel slice 0, dy = 0.
+  // row j <-> pixel m0 - kHalo + j.  a_ptr = address of (pixel, channel chunk) at channel slice 0, dy = 0.
   int a_y[5];
-  unsigned a_off[5];
+  const unsigned short* a_ptr[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const int ca = wave + 8 * q;
     const long long m = (long long)mt * TM - kHalo + 8 * ca + lr;
     if (ca < A_ROWS / 8 && m >= 0 && m < M) {
-      a_off[q] = (lo_plane ? x_lo_off : x_hi_off) + (unsigned)((size_t)m * Cin * 2) + cchunk * 16;
+      a_ptr[q] = Xp + (size_t)m * Cin + cchunk * 8;
       a_y[q] = (int)((m / W) % H);
     } else {
-      a_off[q] = kOOB;
+      a_ptr[q] = zero_page;
       a_y[q] = -(1 << 20);
     }
   }
-  unsigned b_off[2];                                   // kOOB + any tap / slice offset stays beyond the buffer
+  const unsigned short* b_ptr[2];
+  bool b_ok[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int n = nt * TN + 8 * (wave + 8 * q) + lr;
-    b_off[q] = n < Cout ? (lo_plane ? w_lo_off : w_hi_off) + (unsigned)((size_t)n * K * 2) + cchunk * 16 : kOOB;
+    b_ok[q] = n < Cout;
+    b_ptr[q] = b_ok[q] ? Wp + (size_t)n * K + cchunk * 8 : zero_page;
   }
 
   // fragment rows of this lane and the x coordinate of their pixels (for the border mask)
@@ -408,25 +357,29 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
   const int n_c = Cin / kCS;
   const int n_groups = n_c * 3;
   const int n_steps = n_groups * 3;
-  const int row_pitch = W * Cin * 2;                  // bytes per image row
+  const ptrdiff_t row_pitch = (ptrdiff_t)W * Cin;
 
   auto issue_a = [&](int g, int q) {                  // call q (0..4) of the A fill of group g = (c, ky)
+    const bool real = g < n_groups;
     const int c = g / 3, ky = g - 3 * c;
     const int dy = (ky - 1) * dil;
     const int ca = wave + 8 * q;
-    const int goff = dy * row_pitch + c * (kCS * 2);                        // wave-uniform, may be negative
-    const bool ok = (g < n_groups) && (unsigned)(a_y[q] + dy) < (unsigned)H;
-    const unsigned voff = ok ? a_off[q] + (unsigned)goff : kOOB;
+    const bool ok = real && (unsigned)(a_y[q] + dy) < (unsigned)H;
+    const ptrdiff_t goff = (ptrdiff_t)dy * row_pitch + c * kCS;            // wave-uniform
+    const unsigned short* src = ok ? a_ptr[q] + goff : zero_page;
     unsigned short(*dst)[kBK] = a_buf(g & 1) + (ca < A_ROWS / 8 ? 8 * ca : A_ROWS);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t*)&dst[0][0], 16, voff, 0, 0, 0);
+    if (!(OMNIHD_CONV_ABL & 2)) __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
+    else asm volatile("" :: "v"(src), "v"(dst));
   };
   auto issue_b = [&](int k, int q) {                  // call q (0..1) of the B fill of K-step k = (c, ky, kx)
+    const bool real = k < n_steps;
     const int g = k / 3, kx = k - 3 * g;
     const int c = g / 3, ky = g - 3 * c;
-    const unsigned goff = k < n_steps ? (unsigned)(((ky * 3 + kx) * Cin + c * kCS) * 2) : kOOB;   // wave-uniform
+    const ptrdiff_t goff = (ptrdiff_t)(ky * 3 + kx) * Cin + c * kCS;       // wave-uniform
+    const unsigned short* src = (real && b_ok[q]) ? b_ptr[q] + goff : zero_page;
     unsigned short(*dst)[kBK] = b_buf(k & 3) + 8 * (wave + 8 * q);
-    const unsigned voff = b_off[q] + goff;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t*)&dst[0][0], 16, voff, 0, 0, 0);
+    if (!(OMNIHD_CONV_ABL & 2)) __builtin_amdgcn_global_load_lds((gbl_ptr_t*)src, (lds_ptr_t*)&dst[0][0], 16, 0, 0);
+    else asm volatile("" :: "v"(src), "v"(dst));
   };
 
   f32x16 acc[2][2];
@@ -510,15 +463,33 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
   // Stage k is read by A in the half-step before BARa_k and by B in the one after it; its fills were waited for by every
   // wave before BARb_{k-1}; the fills issued in L(k) go to buffers whose last read (K-step k-1, group B) lies before
   // BARb_{k-1}.  Per wavefront the program order of fills and waits is unchanged, so are the literal vmcnt counts.
-  const bool grp_b = wave >= 4;
+#ifndef OMNIHD_CONV_GRP
+#define OMNIHD_CONV_GRP 0
+#endif
+  const bool grp_b = OMNIHD_CONV_GRP == 0 ? wave >= 4 : OMNIHD_CONV_GRP == 1 ? (wave & 1) : ((wave >> 1) & 1);
   bf16x8 fr[NS][NF];
+  if (OMNIHD_CONV_ABL & 4) {
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+      for (int q = 0; q < NF; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fr[ks][q][e] = (__bf16)1.0f;
+  }
   auto seg_load = [&](int k, int g, auto kx_tag) {
     constexpr int KX = decltype(kx_tag)::value;
     const int dx = (KX - 1) * dil;
     const unsigned short(*A)[kBK] = a_buf(g & 1);
     const unsigned short(*B)[kBK] = b_buf(k & 3);
+    if (!(OMNIHD_CONV_ABL & 4)) {
 #pragma unroll
-    for (int ks = 0; ks < NS; ++ks) load_slice(A, B, dx, ks, fr[ks]);
+      for (int ks = 0; ks < NS; ++ks) load_slice(A, B, dx, ks, fr[ks]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+        for (int q = 0; q < NF; ++q) asm volatile("" : "+v"(fr[ks][q]));
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (KX == 0) {
 #pragma unroll
@@ -527,17 +498,22 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     issue_b(k + 3, 0);
     issue_b(k + 3, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (KX != 1) {
+    if (KX != 1 && !(OMNIHD_CONV_ABL & 1)) {
       bool ok[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) ok[i] = (unsigned)(fx[i] + dx) < (unsigned)W;
-      if (__builtin_amdgcn_ballot_w64(!(ok[0] && ok[1])) != 0ull) {          // most wavefronts touch no image border column
 #pragma unroll
-        for (int ks = 0; ks < NS; ++ks) mask_slice(fr[ks], ok);
-      }
+      for (int ks = 0; ks < NS; ++ks) mask_slice(fr[ks], ok);
     }
   };
   auto seg_compute = [&]() {
+    if (OMNIHD_CONV_ABL & 8) {
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks)
+#pragma unroll
+        for (int q = 0; q < NF; ++q) asm volatile("" :: "v"(fr[ks][q]));
+      return;
+    }
     // the computing wavefront outranks its partner's LOAD segment at the SIMD's issue arbiter (the role split gives
     // s_setprio something to arbitrate: cdna_hip_programming.md T5)
     __builtin_amdgcn_s_setprio(1);
@@ -643,14 +619,6 @@ __global__ __launch_bounds__(256) void k_split_f32(const float* __restrict__ x, 
   }
 }
 
-// The row-shift kernel addresses each operand through ONE buffer descriptor with 32-bit offsets: both planes of a split operand
-// must lie within 2 GiB of each other (the wrappers allocate them back to back).
-bool rs_addressable(const void* hi, const void* lo, size_t plane_bytes) {
-  const uintptr_t a = reinterpret_cast<uintptr_t>(hi), b = lo ? reinterpret_cast<uintptr_t>(lo) : a;
-  const uintptr_t span = (a > b ? a - b : b - a) + plane_bytes;
-  return span < (1ull << 31);
-}
-
 const unsigned short* igemm_zero_page() {
   static void* pages[64] = {nullptr};
   int dev = 0;
@@ -690,23 +658,13 @@ extern "C" int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, cons
   // tile 0 = choose: 256x128 when that still fills the chip several times over, else 128x128
   const long long big_tiles = (long long)((M + 255) / 256) * ((cout + 127) / 128);
   const bool big = tile == 256 || (tile == 0 && big_tiles >= 2 * kCUs);
-  OMNIHD_REQUIRE(rs_addressable(X, nullptr, (size_t)M * cin * 2) && rs_addressable(Wt, nullptr, (size_t)cout * ksize * ksize * cin * 2),
-                 "operands of 2 GiB and more are not addressable (32-bit buffer offsets)");
-  const bool rs_ok = ksize == 3 && dil <= kHalo;
-  if (tile == 300 || (tile == 0 && rs_ok && big_tiles >= 2 * kCUs)) {
+  if (tile == 300 || (tile == 0 && ksize == 3 && dil <= kHalo && big_tiles >= 2 * kCUs)) {
     // 3x3 with row-shift reuse of the activation tile
-    OMNIHD_REQUIRE(rs_ok, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
+    OMNIHD_REQUIRE(ksize == 3 && dil <= kHalo, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
     const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
     hipLaunchKernelGGL((k_conv_igemm_rs<true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout, dil,
                        tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
-  } else if (tile == 129 || (tile == 0 && !big && (long long)((M + 127) / 128) * ((cout + 127) / 128) >= kCUs)) {
-    // 128x128 tile, 2-stage ring (64 KB): two workgroups per CU cover each other's fills — where there are enough tiles for
-    // two per CU (scripts/lab/conv_small_tiles.py: 1.4x on the 6 x 64 x 176 1x1 layers, a loss on deep small maps)
-    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
-    const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm<2, 2, 2, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout,
-                       ksize, dil, tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
   } else if (tile == 254) {   // 128x256 tile (2 x 4 wavefronts): half the A traffic per flop, twice the weights'
     const int tiles_m = (M + 127) / 128, tiles_n = (cout + 255) / 256;
     const int per = (tiles_m * tiles_n + 7) / 8;
@@ -760,20 +718,12 @@ extern "C" int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const v
   const unsigned short *Wt = static_cast<const unsigned short*>(w_hi), *Wt2 = static_cast<const unsigned short*>(w_lo);
   const long long big_tiles = (long long)((M + 255) / 256) * ((cout + 127) / 128);
   const bool big = tile == 256 || (tile == 0 && big_tiles >= 2 * kCUs);
-  OMNIHD_REQUIRE(rs_addressable(X, X2, (size_t)M * cin * 2) && rs_addressable(Wt, Wt2, (size_t)cout * ksize * ksize * cin * 2),
-                 "the two planes of a split operand must lie within 2 GiB of each other (32-bit buffer offsets)");
-  const bool rs_ok = ksize == 3 && dil <= kHalo;
-  if (tile == 300 || (tile == 0 && rs_ok && big_tiles >= 2 * kCUs)) {
-    OMNIHD_REQUIRE(rs_ok, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
+  if (tile == 300 || (tile == 0 && ksize == 3 && dil <= kHalo && big_tiles >= 2 * kCUs)) {
+    OMNIHD_REQUIRE(ksize == 3 && dil <= kHalo, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
     const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
     hipLaunchKernelGGL((k_conv_igemm_rs<true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc, M, h, w, cin,
                        cout, dil, tiles_m, tiles_n, per, X2, Wt2);
-  } else if (tile == 129 || (tile == 0 && !big && (long long)((M + 127) / 128) * ((cout + 127) / 128) >= kCUs)) {
-    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
-    const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm<2, 2, 2, true, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc,
-                       M, h, w, cin, cout, ksize, dil, tiles_m, tiles_n, per, X2, Wt2);
   } else if (tile == 254) {
     const int tiles_m = (M + 127) / 128, tiles_n = (cout + 255) / 256;
     const int per = (tiles_m * tiles_n + 7) / 8;

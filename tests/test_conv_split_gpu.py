@@ -57,7 +57,7 @@ def test_split_forward_and_data_gradient_match_fp32_convolution(cuda, B, H, W, c
     if cout % 64 == 0:
         g = torch.randn_like(want)
         want_gx = torch.nn.grad.conv2d_input(x.shape, w, g, padding=pad, dilation=dil)
-        wt = tuple(ops.conv_dgrad_weights(p) for p in ops.split_f32(w))
+        wt = ops.split_dgrad_weights(ops.split_f32(w))
         got_gx = ops.conv_fwd_split(ops.split_f32(g), wt, None, dil, tile)
         assert _rel(got_gx, want_gx) <= 1e-4, _rel(got_gx, want_gx)
 
