@@ -486,8 +486,11 @@ def main():
     # sets, before the training loop heats the chip (the same kernel inside the step runs ~15 % slower: DVFS
     # after MFMA-heavy convolutions and a polluted L2 — see profiles/ for the in-step rocprofv3 average).
     kernel_times = kernel_cold = other_ops = None
+    kept_bytes = 0
     if rank == 0:
         ops_wl = BevOps(a.res, a.batch, dev, seed=1234)
+        if ops_wl.keep_empty:      # same switch (OMNIHD_POOL_KEEP_ZEROS) in the detector's view transformer
+            kept_bytes = 4 * ops_wl.C * (ops_wl.plan.n_rows - ops_wl.plan.n_intervals)
         kernel_cold = time_kernel_cold(ops_wl.pool_fwd, len(ops_wl.sets))
         kernel_times = (time_kernel(ops_wl.pool_fwd, len(ops_wl.sets), a.kernel_launches),
                         time_kernel(ops_wl.pool_bwd, len(ops_wl.sets), a.kernel_launches),
@@ -561,14 +564,18 @@ def main():
         # calibrated on a 128 MiB read of the same width (2.0 on gfx950, as the microarch guide says) + WRITE_SIZE
         # (a pointer to a committed measurement of THIS kernel, not a counter read in this run: PMC passes need rocprofv3)
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "round2", "pmc_pool_r1.json")
+        pmc = os.path.join(ROOT, "profiles", "round3", "pmc_pool_r1.json")
         if os.path.exists(pmc) and a.res == "r1" and a.batch == 1:
             rec = json.load(open(pmc))
             k = rec.get("fwd_lean", {})
             if fwd_kernel.startswith(rec.get("fwd_kernel", "?")) and "read_bytes_corrected" in k and "write_bytes" in k:
                 traffic = round(k["read_bytes_corrected"] + k["write_bytes"])
-                traffic_src = "profiles/round2/pmc_pool_r1.json (rocprofv3 --pmc passes of scripts/lab/pmc_bwd.sh on %s, commit %s)" % (
+                traffic_src = "profiles/round3/pmc_pool_r1.json (rocprofv3 --pmc passes of scripts/lab/pmc_bwd.sh on %s, commit %s)" % (
                     rec.get("fwd_kernel"), rec.get("commit", "?"))
+        # BEV rows no frustum point reaches keep the zeros of the previous launch (plan.py::_kept_output): the kernel skips
+        # their zero fill, so it MOVES fewer bytes than the SURVEY 8(d) formula counts — both rates are reported
+        kept = kept_bytes
+        ach_moved = (fwd_bytes - kept) / t_main / 1e9
         line = {
             "metric": "frames/sec (6-cam+6-radar BEV fwd+bwd)", "value": round(a.batch * world * a.steps / el, 3),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -586,10 +593,12 @@ def main():
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
                                        "overlapped with backward) + naiveSyncBN stat exchange" if a.workload == "fusion"
                                        else f"dp{world} (independent frames, no data-path collective)")},
-            "roofline": {"kernel": fwd_kernel + " (bev_pool_v2 forward, dense, balanced tiles, azimuth XCD schedule)", "bound": "hbm",
+            "roofline": {"kernel": fwd_kernel + " (bev_pool_v2 forward, dense, balanced tiles, azimuth XCD schedule, rows without points keep their zeros)", "bound": "hbm",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": fwd_bytes, "mean_launch_us": round(t_main * 1e6, 2),
+                         "zero_rows_not_rewritten_bytes": kept, "achieved_on_moved_bytes": round(ach_moved, 1),
+                         "frac_on_moved_bytes": round(ach_moved / HBM_PEAK_GBS, 4),
                          "measured": ("launches inside the %d timed steps (HIP events on the launching stream)" % a.steps
                                       if t_step else "isolated back-to-back launches"),
                          "isolated_cache_warm_us": round(t_fwd * 1e6, 2), "isolated_cold_us": round(cold_fwd * 1e6, 2),

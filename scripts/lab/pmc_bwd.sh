@@ -20,6 +20,9 @@ for k, d in res.items():
     if "TCC_HIT_sum" in d: d["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
     if "TCP_TCC_READ_REQ_sum" in d: d["l1_miss_share"] = d["TCP_TCC_READ_REQ_sum"] / max(d["TCP_TOTAL_CACHE_ACCESSES_sum"], 1)
 res["fetch_calibration_factor"] = cal
+res["fwd_kernel"], res["bwd_kernel"] = "k_pool_fwd_lean2", "k_pool_bwd_patch"
+res["how"] = ("scripts/lab/pmc_bwd.sh: three separate rocprofv3 --pmc passes over scripts/lab/pmc_bwd.py (cold launches: a 128 MiB copy "
+              "between them, rotating buffer sets; rows without points keep their zeros); FETCH_SIZE x 1024 x the factor calibrated on the copy")
 print(json.dumps(res, indent=1))
 json.dump(res, open("$OUT/pmc_pool_$RES.json", "w"), indent=1)
 PY

@@ -156,4 +156,6 @@ def test_bevf_faster_rcnn_tiny_step_hip_ops_match_oracle_ops(cuda):
     assert set(got["grads"]) == set(want["grads"])
     for n in ("lift_splat_shot_vis.camencode.depthnet.weight", "lift_splat_shot_vis.bevencode.0.weight",
               "reduc_conv.conv.weight", "pts_voxel_encoder.pfn_layers.0.linear.weight", "pts_bbox_head.conv_cls.weight"):
-        assert _close(got["grads"][n], want["grads"][n], 2e-3), n
+        # (5e-3 as in tests/test_detector_gpu.py: the fp32 dense convolutions run on the fp32-grade split kernels or on MIOpen by a
+        # per-geometry measurement, ~1e-5 apart per layer; behind ReLUs that moves single gradient entries)
+        assert _close(got["grads"][n], want["grads"][n], 5e-3), n
