@@ -469,11 +469,13 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_c = Cinp / kTile, tiles_n = Coutp / kTile;
+  // (integer division runs on the vector ALU: without readfirstlane the tile indices, and every K-step counter derived from
+  // them, live in VGPRs and each LDS-DMA call below turns into a waterfall loop over its "divergent" scalar offset)
   int bid = blockIdx.x;
-  const int ct = bid % tiles_c; bid /= tiles_c;
-  const int nt = bid % tiles_n; bid /= tiles_n;
-  const int ky = bid % 3;
-  const int split = bid / 3;
+  const int ct = __builtin_amdgcn_readfirstlane(bid % tiles_c); bid /= tiles_c;
+  const int nt = __builtin_amdgcn_readfirstlane(bid % tiles_n); bid /= tiles_n;
+  const int ky = __builtin_amdgcn_readfirstlane(bid % 3);
+  const int split = __builtin_amdgcn_readfirstlane(bid / 3);
   const int dy = (ky - 1) * dil;
   const int k0 = split * k_per_split;
   const int k1 = min(k0 + k_per_split, Mp);
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
     xm1 = ok ? x_off1 : kOOB;
   };
   auto fill_call = [&](int stage, int c) {
-    const unsigned so = (unsigned)min(k_issue, k_last) * 2;                 // scalar offset: the K-step position
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(min(k_issue, k_last) * 2);   // scalar offset: the K-step position
     if (c == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][0][wave * 32][0], 16, g_off0, so, 0, 0);
     else if (c == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][1][wave * 32][0], 16, g_off1, so, 0, 0);
     else if (c < 5) {
@@ -543,58 +545,273 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
 
+  // Software pipeline over the K-steps (one wavefront per SIMD has nobody to hide its LDS latency behind).  A step is three
+  // groups of 12 MFMAs:  A = G_hi*X_hi,  B = G_lo*X_hi,  C = G_hi*X_lo.  The fragment reads run ONE GROUP ahead of their use:
+  //     during A(k): G_lo(k)          during B(k): X_lo(k)          during C(k): G_hi(k+1), X_hi(k+1)
+  // so that only G_hi needs a second register set (72 fragment registers instead of 128 for whole-step double buffering, which
+  // spilled).  Ring: in front of C(k) one wait + barrier makes stage k+1 visible (vmcnt(16): the two younger stages may be in
+  // flight) and proves that every wave has read stage k (lgkmcnt(0)), whose slot then takes the 8 fill calls of stage k+4.
+  bf16x8 ah0[2], ah1[2], al[2], bh[3][2], bl[3][2];
+  int stage = 0;                                      // ring slot of step k
+  const int ra0 = wm * 64 + frow, rb0 = wn * 64 + frow;
+  auto slot_of = [&](int r) { return (fhalf ^ ((r >> 3) & 1)) * 8; };
+  auto read_g = [&](bf16x8 (&g)[2], int st, int tile) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) g[i] = *reinterpret_cast<const bf16x8*>(&sm[st][tile][ra0 + i * 32][slot_of(ra0 + i * 32)]);
+  };
+  auto read_x = [&](bf16x8 (&x)[3][2], int st, int tile0) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) x[t][i] = *reinterpret_cast<const bf16x8*>(&sm[st][tile0 + t][rb0 + i * 32][slot_of(rb0 + i * 32)]);
+  };
+  auto mma12 = [&](const bf16x8 (&g)[2], const bf16x8 (&x)[3][2]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[i], x[t][j], acc[t][i][j], 0, 0, 0);
+  };
+  auto step = [&](const bf16x8 (&ah_cur)[2], bf16x8 (&ah_nxt)[2]) {
+    __builtin_amdgcn_sched_barrier(0);
+    read_g(al, stage, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma12(ah_cur, bh);                                // A
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(bl, stage, 5);
+    __builtin_amdgcn_sched_barrier(0);
+    mma12(al, bh);                                    // B
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = (stage + 1) % kStages3;
+    read_g(ah_nxt, nxt, 0);
+    read_x(bh, nxt, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    fill_begin();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fill_call(stage, c);   // stage k+4 into the slot every wave has just finished reading
+    fill_end();
+    __builtin_amdgcn_sched_barrier(0);
+    mma12(ah_cur, bl);                                // C
+    __builtin_amdgcn_sched_barrier(0);
+    stage = nxt;
+  };
   issue(0);
   issue(1);
   issue(2);
-  int stage = 0;
-  for (int k = k0; k < k1; k += kBKS) {
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int fill = (stage + 3) % kStages3;          // its buffer was last read before this barrier
-    bf16x8 ah[2], al[2], bh[3][2], bl[3][2];
+  issue(3);
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_g(ah0, 0, 0);
+  read_x(bh, 0, 2);
+  for (int k = k0; k < k1; k += 2 * kBKS) {
+    step(ah0, ah1);
+    if (k + kBKS < k1) step(ah1, ah0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* dst = slab + (size_t)split * Cout * 9 * Cin;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = ky * 3 + t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nt * kTile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int cc = ct * kTile + wn * 64 + j * 32 + (lane & 31);
+          if (n < Cout && cc < Cin) dst[((size_t)n * 9 + tap) * Cin + cc] = acc[t][i][j][r];
+        }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Three taps per workgroup on SPLIT operands, the dx shifts made IN REGISTERS (dilation 1; round 3).
+// Counters of k_wgrad_split3 on 1024->1024 at 160x240 (profiles/round3/wgrad_split3_pmc.txt): matrix pipes busy 40 %, 64 % of the
+// wave time waiting for fills, 475 M L2 requests per launch = 12.7 TB/s of 32-byte requests — its 32-byte LDS rows (K-step 16, the
+// only way 8 operand tiles x 4 stages fit) turn every row of every tile into one half-used L2 request, and three of the eight
+// tiles per plane are dx-shifted copies of the same X.  Here ONE copy of X is staged, on a raster whose image rows are padded
+// with at least one zero column (Wp = roundup(W + 1, 8)), so the element next to a row's end is a zero and
+//     dW[ky][0] = sum_q G[q+1] X[q]      dW[ky][1] = sum_q G[q] X[q]      dW[ky][2] = sum_q G[q] X[q+1]
+// (q = padded pixel index + the row offset of ky): the outer taps use a fragment SHIFTED BY ONE ELEMENT — four v_alignbit over
+// the fragment's dwords and the first dword of the following 16-byte chunk, read from LDS as one extra ds_read_b32 (for the last
+// chunk of a K-step it lies in the NEXT stage of the ring, which is resident by then).  Per K-step of 32 pixels a stage holds
+// G_hi, G_lo, X_hi, X_lo = 4 tiles of 128 rows x 64 B (ring of 4 stages = 128 KB): 4x fewer L2 requests per MFMA than
+// k_wgrad_split3, half the LDS fragment reads, one staged copy of X instead of three.
+// Pipeline (one wavefront per SIMD): a K-step is two 16-pixel slices of 36 MFMAs; the fragments of the next slice are requested
+// while the current slice multiplies (two register sets), the 8 fill calls of stage k+3 are spread over the step, one barrier
+// per step: behind it stage k+2 has landed (vmcnt(8)) and every wave is done with stage k (lgkmcnt(0)).
+// The step after a split's last one is fetched for real (k_lim): its first elements are the "next elements" of the last step.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBKH = 32;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 shift_in_next(bf16x8 f, unsigned next_dword) {
+  const u32x4v d = __builtin_bit_cast(u32x4v, f);
+  u32x4v o;
+  o.x = __builtin_amdgcn_alignbit(d.y, d.x, 16);
+  o.y = __builtin_amdgcn_alignbit(d.z, d.y, 16);
+  o.z = __builtin_amdgcn_alignbit(d.w, d.z, 16);
+  o.w = __builtin_amdgcn_alignbit(next_dword, d.w, 16);
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+__global__ __launch_bounds__(kBlock) void k_wgrad_split_sh(const unsigned short* __restrict__ Gt, const unsigned short* __restrict__ Gt2,
+                                                           const unsigned short* __restrict__ Xt, const unsigned short* __restrict__ Xt2,
+                                                           const unsigned short* __restrict__ ws_base, unsigned ws_bytes,
+                                                           float* __restrict__ slab, int Cout, int Cin, int Coutp, int Cinp, int M,
+                                                           int Mp, int H, int Wp, int n_split, int k_per_split) {
+  // tiles: 0 = G_hi, 1 = G_lo, 2 = X_hi, 3 = X_lo
+  __shared__ __attribute__((aligned(16))) unsigned short sm[kStages3][4][kTile][kBKH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_c = Cinp / kTile, tiles_n = Coutp / kTile;
+  int bid = blockIdx.x;
+  const int ct = __builtin_amdgcn_readfirstlane(bid % tiles_c); bid /= tiles_c;
+  const int nt = __builtin_amdgcn_readfirstlane(bid % tiles_n); bid /= tiles_n;
+  const int ky = __builtin_amdgcn_readfirstlane(bid % 3);
+  const int split = __builtin_amdgcn_readfirstlane(bid / 3);
+  const int dy = ky - 1;
+  const int k0 = split * k_per_split;
+  const int k1 = min(k0 + k_per_split, Mp);
+  const int k_lim = min(k1, Mp - kBKH);
+
+  // loader: one DMA call = 16 rows of 64 B; wave w owns rows [32w, 32w+32) of every tile: two calls per tile, 8 per stage.
+  // Chunks are XOR-swizzled by ((row >> 2) & 3) on the global source and again on the fragment read (conflict-free b128).
+  constexpr unsigned kOOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws_base, 0, (int)ws_bytes, 0x00020000);
+  const int lr = lane >> 2;
+  const int gch = (lane & 3) ^ ((lane >> 4) & 3);
+  const size_t a_row = (size_t)(nt * kTile + wave * 32 + lr) * Mp;
+  const ptrdiff_t b_row = (ptrdiff_t)(((size_t)ct * kTile + wave * 32 + lr) * Mp) + (ptrdiff_t)dy * Wp;   // may reach into the guard
+  const unsigned g_off0 = (unsigned)((const char*)(Gt + a_row) - (const char*)ws_base) + gch * 16;
+  const unsigned g_off1 = (unsigned)((const char*)(Gt2 + a_row) - (const char*)ws_base) + gch * 16;
+  const unsigned x_off0 = (unsigned)((const char*)(Xt + b_row) - (const char*)ws_base) + gch * 16;
+  const unsigned x_off1 = (unsigned)((const char*)(Xt2 + b_row) - (const char*)ws_base) + gch * 16;
+  const unsigned row16 = (unsigned)Mp * 32u;            // bytes between the two calls of a tile (16 rows)
+  int px = (k0 + gch * 8) % Wp, py = ((k0 + gch * 8) / Wp) % H;
+  int k_issue = k0;
+  unsigned xm0 = kOOB, xm1 = kOOB;
+  auto fill_begin = [&]() {
+    const int kk = min(k_issue, k_lim);
+    const bool ok = (kk + gch * 8 < M) && (py + dy >= 0) && (py + dy < H);
+    xm0 = ok ? x_off0 : kOOB;
+    xm1 = ok ? x_off1 : kOOB;
+  };
+  auto fill_call = [&](int stage, int c) {              // c = 2 * tile + half
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(min(k_issue, k_lim) * 2);
+    const int tile = c >> 1, i = c & 1;
+    const unsigned base = tile == 0 ? g_off0 : tile == 1 ? g_off1 : tile == 2 ? xm0 : xm1;
+    const unsigned v = base + (i ? row16 : 0u);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][tile][wave * 32 + 16 * i][0], 16, v, so, 0, 0);
+  };
+  auto fill_end = [&]() {
+    k_issue += kBKH;
+    px += kBKH; while (px >= Wp) { px -= Wp; py = (py + 1 == H) ? 0 : py + 1; }
+  };
+
+  f32x16 acc[3][2][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  const int ra0 = wm * 64 + frow, rb0 = wn * 64 + frow;
+
+  struct Slice { bf16x8 gh[2], gl[2], xh[2], xl[2]; unsigned ngh[2], ngl[2], nxh[2], nxl[2]; };
+  // fragments of slice s of the step in ring slot st, and the first dword of the chunk behind each of them
+  auto read_slice = [&](Slice& f, int st, int s) {
+    const int c = 2 * s + fhalf;
+    const bool wrap = c == 3;                           // the following chunk is chunk 0 of the next stage
+    const int st_n = wrap ? (st + 1) % kStages3 : st;
+    const int c_n = wrap ? 0 : c + 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ra = wm * 64 + i * 32 + frow;
-      const int rb = wn * 64 + i * 32 + frow;
-      const int sa = (fhalf ^ ((ra >> 3) & 1)) * 8, sb = (fhalf ^ ((rb >> 3) & 1)) * 8;
-      ah[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][0][ra][sa]);
-      al[i] = *reinterpret_cast<const bf16x8*>(&sm[stage][1][ra][sa]);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        bh[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][2 + t][rb][sb]);
-        bl[t][i] = *reinterpret_cast<const bf16x8*>(&sm[stage][5 + t][rb][sb]);
-      }
+      const int ra = ra0 + i * 32, rb = rb0 + i * 32;
+      const int sa = (c ^ ((ra >> 2) & 3)) * 8, sb = (c ^ ((rb >> 2) & 3)) * 8;
+      const int na = (c_n ^ ((ra >> 2) & 3)) * 8, nb = (c_n ^ ((rb >> 2) & 3)) * 8;
+      f.gh[i] = *reinterpret_cast<const bf16x8*>(&sm[st][0][ra][sa]);
+      f.gl[i] = *reinterpret_cast<const bf16x8*>(&sm[st][1][ra][sa]);
+      f.xh[i] = *reinterpret_cast<const bf16x8*>(&sm[st][2][rb][sb]);
+      f.xl[i] = *reinterpret_cast<const bf16x8*>(&sm[st][3][rb][sb]);
+      f.ngh[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][0][ra][na]);
+      f.ngl[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][1][ra][na]);
+      f.nxh[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][2][rb][nb]);
+      f.nxl[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][3][rb][nb]);
     }
-    // all 16 fragment reads are requested before the first MFMA; ONE wavefront per SIMD has nobody to cover its fills, so the
-    // 8 fill calls of the K-step three ahead are issued between the three MFMA groups, in the shadow of the matrix pipe
+  };
+  auto mma4 = [&](int t, const bf16x8 (&g)[2], const bf16x8 (&x)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[i], x[j], acc[t][i][j], 0, 0, 0);
+  };
+  // the 36 MFMAs of one slice; `fill_lo .. fill_hi` of the stage's 8 fill calls are issued between its MFMA groups
+  auto slice_mma = [&](const Slice& f, int fill_stage, int fill_lo) {
+    mma4(1, f.gh, f.xh); mma4(1, f.gl, f.xh);
+    fill_call(fill_stage, fill_lo);
+    mma4(1, f.gh, f.xl);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 sgh[2], sgl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { sgh[i] = shift_in_next(f.gh[i], f.ngh[i]); sgl[i] = shift_in_next(f.gl[i], f.ngl[i]); }
+    mma4(0, sgh, f.xh);
+    fill_call(fill_stage, fill_lo + 1);
+    mma4(0, sgl, f.xh);
+    fill_call(fill_stage, fill_lo + 2);
+    mma4(0, sgh, f.xl);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 sxh[2], sxl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { sxh[i] = shift_in_next(f.xh[i], f.nxh[i]); sxl[i] = shift_in_next(f.xl[i], f.nxl[i]); }
+    mma4(2, f.gh, sxh);
+    fill_call(fill_stage, fill_lo + 3);
+    mma4(2, f.gl, sxh); mma4(2, f.gh, sxl);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto issue = [&](int stage) {
+    fill_begin();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fill_call(stage, c);
+    fill_end();
+  };
+  issue(0);
+  issue(1);
+  issue(2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // stages 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  Slice fa, fb;
+  read_slice(fa, 0, 0);
+  int stage = 0;
+  for (int k = k0; k < k1; k += kBKH) {
+    const int fill = (stage + 3) % kStages3;            // slot of step k-1: every wave left it before the last barrier
+    __builtin_amdgcn_sched_barrier(0);
+    read_slice(fb, stage, 1);
     __builtin_amdgcn_sched_barrier(0);
     fill_begin();
-    // term-major: consecutive MFMAs go to different accumulators
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[t][j], acc[t][i][j], 0, 0, 0);
-    fill_call(fill, 0); fill_call(fill, 1); fill_call(fill, 2);
+    slice_mma(fa, fill, 0);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[t][j], acc[t][i][j], 0, 0, 0);
-    fill_call(fill, 3); fill_call(fill, 4); fill_call(fill, 5);
+    read_slice(fa, (stage + 1) % kStages3, 0);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[t][j], acc[t][i][j], 0, 0, 0);
-    fill_call(fill, 6); fill_call(fill, 7);
+    slice_mma(fb, fill, 4);
     fill_end();
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     stage = (stage + 1) % kStages3;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -688,8 +905,15 @@ struct WgradPlan {
   size_t gt_bytes, xt_bytes, slab_bytes, guard;
 };
 
+// shift_form: one staged copy of X on a raster with >= 1 zero column per image row (k_wgrad_split_sh makes the dx shifts in
+// registers); only for split operands, 3x3, stride 1, pad == dil == 1.
+bool shift_form_enabled() {
+  static const bool on = [] { const char* e = getenv("OMNIHD_WGRAD_SHIFT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 bool make_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad,
-               int dil, WgradPlan* p) {
+               int dil, WgradPlan* p, bool shift_form = false) {
   if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ho <= 0 || wo <= 0) return false;
   if (kh != kw || (kh != 1 && kh != 3) || stride < 1 || dil < 1 || pad < 0) return false;
   if (cin % 8 || cout % 8) return false;
@@ -699,6 +923,7 @@ bool make_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int k
   p->cinp = round_up(cin, kTile);
   if (kh == 3 && stride == 1 && pad == dil && dil <= kMaxDil) {
     p->mode = 0; p->copies = 3; p->wp = round_up(w, 8); p->rows_h = h;
+    if (shift_form && dil == 1) { p->copies = 1; p->wp = round_up(w + 1, 8); }
     p->mpix = batch * h * p->wp;
   } else if (kh == 1 && stride == 1 && pad == 0) {
     p->mode = 0; p->copies = 1; p->wp = 64; p->rows_h = 1 << 30;
@@ -715,6 +940,20 @@ bool make_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int k
   p->slab_bytes = align_up((size_t)(p->split3 > p->split ? p->split3 : p->split) * cout * p->taps * cin * 4, 256);
   p->guard = align_up((size_t)dil * p->wp * 2 + 256, 256);
   return true;
+}
+
+// The plan of one call: the shift form where it applies (split operands, 3x3, stride 1, pad == dil == 1, and the geometry fills
+// the chip with three-tap workgroups), the three-copy form otherwise.
+bool plan_for(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad, int dil,
+              bool split, WgradPlan* p, bool* shift_form) {
+  static const bool three_taps = [] { const char* e = getenv("OMNIHD_WGRAD_3TAPS"); return !(e && e[0] == '0'); }();
+  *shift_form = false;
+  if (split && three_taps && shift_form_enabled() && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 &&
+      make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, p, true) && p->split3 > 0) {
+    *shift_form = true;
+    return true;
+  }
+  return make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, p, false);
 }
 
 }  // namespace
@@ -738,7 +977,8 @@ int wgrad_impl(const void* x_nhwc, const void* x_lo, const void* gout_nhwc, cons
   hipStream_t st = (hipStream_t)stream;
   const bool split = x_lo != nullptr;
   WgradPlan p;
-  if (!make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, &p)) {
+  bool shift_form = false;
+  if (!plan_for(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, split, &p, &shift_form)) {
     set_error("conv_wgrad: unsupported geometry (square 1x1/3x3 kernels, channels multiples of 8, consistent output size)");
     return OMNIHD_ERR_ARG;
   }
@@ -774,7 +1014,7 @@ int wgrad_impl(const void* x_nhwc, const void* x_lo, const void* gout_nhwc, cons
     const StageArgs aG{gs, gt, cout, p.coutp, 1};
     if (p.mode == 0 && p.taps == 9) {
       // G and X share the padded raster (b, y, x) with row pitch wp
-      const StageArgs aX{xs, xt, cin, p.cinp, 3};
+      const StageArgs aX{xs, xt, cin, p.cinp, p.copies};
       hipLaunchKernelGGL(k_to_kmajor, dim3(p.mp / 64, cmax / 64, 2), dim3(kBlock), 0, st, aG, aX, batch * h * w, w, p.wp, p.mp, dil);
     } else if (p.mode == 0) {
       // 1x1: the raster is the plain pixel index (one "row" of mp pixels, nothing to shift)
@@ -794,7 +1034,13 @@ int wgrad_impl(const void* x_nhwc, const void* x_lo, const void* gout_nhwc, cons
     const int blocks = (p.cinp / kTile) * (p.coutp / kTile) * 3 * n_split;
     static const bool fused8 = [] { const char* e = getenv("OMNIHD_WGRAD_SPLIT8"); return !(e && e[0] == '0'); }();
     // (the 8-tile kernel reaches all four staged planes through one 32-bit buffer descriptor over the workspace)
-    if (split && fused8 && (size_t)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)) < (1ull << 31))
+    const bool one_desc = (size_t)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)) < (1ull << 31);
+    if (shift_form) {
+      OMNIHD_REQUIRE(one_desc && p.copies == 1, "conv_wgrad_split: staged operands beyond 2 GiB");
+      hipLaunchKernelGGL(k_wgrad_split_sh, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2,
+                         reinterpret_cast<const unsigned short*>(workspace), (unsigned)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)),
+                         n_split > 1 ? slab : dw, cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3);
+    } else if (split && fused8 && one_desc)
       hipLaunchKernelGGL(k_wgrad_split3, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2,
                          reinterpret_cast<const unsigned short*>(workspace), (unsigned)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)),
                          n_split > 1 ? slab : dw, cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3, dil);
@@ -825,7 +1071,8 @@ extern "C" int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc,
 extern "C" size_t omnihd_conv_wgrad_split_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh,
                                                           int kw, int stride, int pad, int dil) {
   WgradPlan p;
-  if (!make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, &p)) return 0;
+  bool shift_form = false;
+  if (!plan_for(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, true, &p, &shift_form)) return 0;
   return 256 + 2 * (p.gt_bytes + p.xt_bytes + 2 * p.guard) + p.slab_bytes + 2 * p.guard;
 }
 

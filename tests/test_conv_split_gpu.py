@@ -118,3 +118,25 @@ def test_split_weight_gradient_of_a_bev_sized_layer(cuda, monkeypatch):
     x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
     wx, ww = torch.autograd.grad(F.conv2d(x2, w2, None, padding=1), [x2, w2], g)
     assert _rel(gx, wx) <= 1e-4 and _rel(gw, ww) <= 1e-4, (_rel(gx, wx), _rel(gw, ww))
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [
+    (2, 48, 47, 512, 256),      # W + 1 a multiple of 8: exactly one zero column per padded image row; two images (row offsets cross them)
+    (1, 40, 60, 520, 264),      # channel counts that are not multiples of the 128-wide tiles
+    (3, 33, 50, 384, 384),      # odd image height, three images
+    (1, 160, 240, 640, 384),    # the fusion convolution of the detector
+])
+def test_split_weight_gradient_with_register_shifted_taps(cuda, B, H, W, cin, cout):
+    """3x3 / dilation 1 weight gradient on split operands: the kernel stages ONE copy of x and shifts fragments by one element
+    for the outer taps (csrc/conv_wgrad.hip::k_wgrad_split_sh); every tap against the fp32 library gradient, 1e-4."""
+    from omnihd_amd import ops
+    torch.manual_seed(B * 1000 + W)
+    x = torch.randn(B, cin, H, W, device=cuda).contiguous(memory_format=torch.channels_last)
+    g = (torch.randn(B, cout, H, W, device=cuda) * 0.05).contiguous(memory_format=torch.channels_last)
+    dw = ops.conv_wgrad_split(ops.split_f32(x), ops.split_f32(g), 3, 1, 1, 1)
+    w0 = torch.zeros(cout, cin, 3, 3, device=cuda)
+    ref = torch.ops.aten.convolution_backward(g, x, w0, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    dw = dw.reshape(ref.shape) if dw.shape != ref.shape else dw
+    for ky in range(3):
+        for kx in range(3):
+            assert _rel(dw[:, :, ky, kx], ref[:, :, ky, kx]) <= 1e-4, (ky, kx, _rel(dw[:, :, ky, kx], ref[:, :, ky, kx]))
