@@ -648,7 +648,6 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split3(const unsigned short* _
 // per step: behind it stage k+2 has landed (vmcnt(8)) and every wave is done with stage k (lgkmcnt(0)).
 // The step after a split's last one is fetched for real (k_lim): its first elements are the "next elements" of the last step.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBKH = 32;
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 shift_in_next(bf16x8 f, unsigned next_dword) {
@@ -661,13 +660,23 @@ __device__ __forceinline__ bf16x8 shift_in_next(bf16x8 f, unsigned next_dword) {
   return __builtin_bit_cast(bf16x8, o);
 }
 
-__global__ __launch_bounds__(kBlock) void k_wgrad_split_sh(const unsigned short* __restrict__ Gt, const unsigned short* __restrict__ Gt2,
-                                                           const unsigned short* __restrict__ Xt, const unsigned short* __restrict__ Xt2,
-                                                           const unsigned short* __restrict__ ws_base, unsigned ws_bytes,
-                                                           float* __restrict__ slab, int Cout, int Cin, int Coutp, int Cinp, int M,
-                                                           int Mp, int H, int Wp, int n_split, int k_per_split) {
-  // tiles: 0 = G_hi, 1 = G_lo, 2 = X_hi, 3 = X_lo
-  __shared__ __attribute__((aligned(16))) unsigned short sm[kStages3][4][kTile][kBKH];
+// SPLIT = true : fp32-grade split operands, K-step 32 (64-byte LDS rows), tiles G_hi, G_lo, X_hi, X_lo, 36 MFMAs per 16-pixel slice.
+// SPLIT = false: plain bf16 operands, K-step 64 (128-byte rows = whole cache lines), tiles G, X, 12 MFMAs per slice.
+// Either way a stage is 32 KB (ring of 4 = 128 KB) and a wave issues 8 fill calls per stage.
+template <bool SPLIT>
+__global__ __launch_bounds__(kBlock) void k_wgrad_shift(const unsigned short* __restrict__ Gt, const unsigned short* __restrict__ Gt2,
+                                                        const unsigned short* __restrict__ Xt, const unsigned short* __restrict__ Xt2,
+                                                        const unsigned short* __restrict__ ws_base, unsigned ws_bytes,
+                                                        float* __restrict__ slab, int Cout, int Cin, int Coutp, int Cinp, int M,
+                                                        int Mp, int H, int Wp, int n_split, int k_per_split) {
+  constexpr int kStep = SPLIT ? 32 : 64;               // pixels per K-step = elements per LDS row
+  constexpr int kTiles = SPLIT ? 4 : 2;                // SPLIT: 0 = G_hi, 1 = G_lo, 2 = X_hi, 3 = X_lo ; else 0 = G, 1 = X
+  constexpr int kX = SPLIT ? 2 : 1;                    // first X tile
+  constexpr int kChunks = kStep / 8;                   // 16-byte chunks per row
+  constexpr int kSlices = kStep / 16;
+  constexpr int kRowsPerCall = 64 / kChunks;           // 16 or 8
+  constexpr int kCallsPerTile = 32 / kRowsPerCall;     // 2 or 4
+  __shared__ __attribute__((aligned(16))) unsigned short sm[kStages3][kTiles][kTile][kStep];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -680,40 +689,52 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split_sh(const unsigned short*
   const int dy = ky - 1;
   const int k0 = split * k_per_split;
   const int k1 = min(k0 + k_per_split, Mp);
-  const int k_lim = min(k1, Mp - kBKH);
+  const int k_lim = min(k1, Mp - kStep);
 
-  // loader: one DMA call = 16 rows of 64 B; wave w owns rows [32w, 32w+32) of every tile: two calls per tile, 8 per stage.
-  // Chunks are XOR-swizzled by ((row >> 2) & 3) on the global source and again on the fragment read (conflict-free b128).
+  // loader: one DMA call = kRowsPerCall rows of one tile; wave w owns rows [32w, 32w+32) of every tile.  Chunks are XOR-swizzled
+  // (64-byte rows: by (row >> 2) & 3, 128-byte rows: by (row >> 1) & 7) on the global source and again on the fragment read.
+  auto swz = [](int row) { return SPLIT ? ((row >> 2) & 3) : ((row >> 1) & 7); };
   constexpr unsigned kOOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws_base, 0, (int)ws_bytes, 0x00020000);
-  const int lr = lane >> 2;
-  const int gch = (lane & 3) ^ ((lane >> 4) & 3);
+  // (128-byte rows: the swizzle of a row depends on bit 2 of the call's first row, i.e. on the parity of the call — two chunk
+  //  positions per lane, `[part & 1]`; 64-byte rows: one)
+  const int lr = lane / kChunks;
+  const int gch = (lane % kChunks) ^ swz(lr);
+  const int gch2[2] = {gch, SPLIT ? gch : (gch ^ 4)};
   const size_t a_row = (size_t)(nt * kTile + wave * 32 + lr) * Mp;
   const ptrdiff_t b_row = (ptrdiff_t)(((size_t)ct * kTile + wave * 32 + lr) * Mp) + (ptrdiff_t)dy * Wp;   // may reach into the guard
-  const unsigned g_off0 = (unsigned)((const char*)(Gt + a_row) - (const char*)ws_base) + gch * 16;
-  const unsigned g_off1 = (unsigned)((const char*)(Gt2 + a_row) - (const char*)ws_base) + gch * 16;
-  const unsigned x_off0 = (unsigned)((const char*)(Xt + b_row) - (const char*)ws_base) + gch * 16;
-  const unsigned x_off1 = (unsigned)((const char*)(Xt2 + b_row) - (const char*)ws_base) + gch * 16;
-  const unsigned row16 = (unsigned)Mp * 32u;            // bytes between the two calls of a tile (16 rows)
-  int px = (k0 + gch * 8) % Wp, py = ((k0 + gch * 8) / Wp) % H;
+  const unsigned g_off0 = (unsigned)((const char*)(Gt + a_row) - (const char*)ws_base);       // row starts: multiples of 128 B
+  const unsigned g_off1 = SPLIT ? (unsigned)((const char*)(Gt2 + a_row) - (const char*)ws_base) : 0u;
+  const unsigned x_off0 = (unsigned)((const char*)(Xt + b_row) - (const char*)ws_base);
+  const unsigned x_off1 = SPLIT ? (unsigned)((const char*)(Xt2 + b_row) - (const char*)ws_base) : 0u;
+  const unsigned call_pitch = (unsigned)Mp * 2u * kRowsPerCall;   // bytes between two calls of a tile
+  constexpr int kPos = SPLIT ? 1 : 2;
+  int px[kPos], py[kPos];
+#pragma unroll
+  for (int e = 0; e < kPos; ++e) { px[e] = (k0 + gch2[e] * 8) % Wp; py[e] = ((k0 + gch2[e] * 8) / Wp) % H; }
   int k_issue = k0;
-  unsigned xm0 = kOOB, xm1 = kOOB;
+  bool x_ok[kPos];
   auto fill_begin = [&]() {
     const int kk = min(k_issue, k_lim);
-    const bool ok = (kk + gch * 8 < M) && (py + dy >= 0) && (py + dy < H);
-    xm0 = ok ? x_off0 : kOOB;
-    xm1 = ok ? x_off1 : kOOB;
+#pragma unroll
+    for (int e = 0; e < kPos; ++e) x_ok[e] = (kk + gch2[e] * 8 < M) && (py[e] + dy >= 0) && (py[e] + dy < H);
   };
-  auto fill_call = [&](int stage, int c) {              // c = 2 * tile + half
+  auto fill_call = [&](int stage, int c) {              // c = tile * kCallsPerTile + part
     const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(min(k_issue, k_lim) * 2);
-    const int tile = c >> 1, i = c & 1;
-    const unsigned base = tile == 0 ? g_off0 : tile == 1 ? g_off1 : tile == 2 ? xm0 : xm1;
-    const unsigned v = base + (i ? row16 : 0u);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][tile][wave * 32 + 16 * i][0], 16, v, so, 0, 0);
+    const int tile = c / kCallsPerTile, part = c % kCallsPerTile;
+    const int e = SPLIT ? 0 : (part & 1);
+    const bool is_x = tile >= kX;
+    const unsigned base = SPLIT ? (tile == 0 ? g_off0 : tile == 1 ? g_off1 : tile == 2 ? x_off0 : x_off1) : (tile == 0 ? g_off0 : x_off0);
+    const unsigned v = (is_x && !x_ok[e]) ? kOOB : base + (unsigned)gch2[e] * 16u + (unsigned)part * call_pitch;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)&sm[stage][tile][wave * 32 + kRowsPerCall * part][0], 16, v, so, 0, 0);
   };
   auto fill_end = [&]() {
-    k_issue += kBKH;
-    px += kBKH; while (px >= Wp) { px -= Wp; py = (py + 1 == H) ? 0 : py + 1; }
+    k_issue += kStep;
+#pragma unroll
+    for (int e = 0; e < kPos; ++e) {
+      px[e] += kStep;
+      while (px[e] >= Wp) { px[e] -= Wp; py[e] = (py[e] + 1 == H) ? 0 : py[e] + 1; }
+    }
   };
 
   f32x16 acc[3][2][2];
@@ -735,22 +756,24 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split_sh(const unsigned short*
   // fragments of slice s of the step in ring slot st, and the first dword of the chunk behind each of them
   auto read_slice = [&](Slice& f, int st, int s) {
     const int c = 2 * s + fhalf;
-    const bool wrap = c == 3;                           // the following chunk is chunk 0 of the next stage
+    const bool wrap = c == kChunks - 1;                 // the following chunk is chunk 0 of the next stage
     const int st_n = wrap ? (st + 1) % kStages3 : st;
     const int c_n = wrap ? 0 : c + 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ra = ra0 + i * 32, rb = rb0 + i * 32;
-      const int sa = (c ^ ((ra >> 2) & 3)) * 8, sb = (c ^ ((rb >> 2) & 3)) * 8;
-      const int na = (c_n ^ ((ra >> 2) & 3)) * 8, nb = (c_n ^ ((rb >> 2) & 3)) * 8;
+      const int sa = (c ^ swz(ra)) * 8, sb = (c ^ swz(rb)) * 8;
+      const int na = (c_n ^ swz(ra)) * 8, nb = (c_n ^ swz(rb)) * 8;
       f.gh[i] = *reinterpret_cast<const bf16x8*>(&sm[st][0][ra][sa]);
-      f.gl[i] = *reinterpret_cast<const bf16x8*>(&sm[st][1][ra][sa]);
-      f.xh[i] = *reinterpret_cast<const bf16x8*>(&sm[st][2][rb][sb]);
-      f.xl[i] = *reinterpret_cast<const bf16x8*>(&sm[st][3][rb][sb]);
+      f.xh[i] = *reinterpret_cast<const bf16x8*>(&sm[st][kX][rb][sb]);
       f.ngh[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][0][ra][na]);
-      f.ngl[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][1][ra][na]);
-      f.nxh[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][2][rb][nb]);
-      f.nxl[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][3][rb][nb]);
+      f.nxh[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][kX][rb][nb]);
+      if (SPLIT) {
+        f.gl[i] = *reinterpret_cast<const bf16x8*>(&sm[st][kTiles - 3][ra][sa]);
+        f.xl[i] = *reinterpret_cast<const bf16x8*>(&sm[st][kTiles - 1][rb][sb]);
+        f.ngl[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][kTiles - 3][ra][na]);
+        f.nxl[i] = *reinterpret_cast<const unsigned*>(&sm[st_n][kTiles - 1][rb][nb]);
+      }
     }
   };
   auto mma4 = [&](int t, const bf16x8 (&g)[2], const bf16x8 (&x)[2]) {
@@ -759,27 +782,33 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split_sh(const unsigned short*
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g[i], x[j], acc[t][i][j], 0, 0, 0);
   };
-  // the 36 MFMAs of one slice; `fill_lo .. fill_hi` of the stage's 8 fill calls are issued between its MFMA groups
+  // the MFMAs of one slice; kFillsPerSlice of the stage's 8 fill calls are issued between its MFMA groups
+  constexpr int kFillsPerSlice = 8 / kSlices;           // 4 or 2
   auto slice_mma = [&](const Slice& f, int fill_stage, int fill_lo) {
-    mma4(1, f.gh, f.xh); mma4(1, f.gl, f.xh);
+    mma4(1, f.gh, f.xh);
+    if (SPLIT) mma4(1, f.gl, f.xh);
     fill_call(fill_stage, fill_lo);
-    mma4(1, f.gh, f.xl);
+    if (SPLIT) mma4(1, f.gh, f.xl);
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 sgh[2], sgl[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { sgh[i] = shift_in_next(f.gh[i], f.ngh[i]); sgl[i] = shift_in_next(f.gl[i], f.ngl[i]); }
+    for (int i = 0; i < 2; ++i) { sgh[i] = shift_in_next(f.gh[i], f.ngh[i]); if (SPLIT) sgl[i] = shift_in_next(f.gl[i], f.ngl[i]); }
     mma4(0, sgh, f.xh);
     fill_call(fill_stage, fill_lo + 1);
-    mma4(0, sgl, f.xh);
-    fill_call(fill_stage, fill_lo + 2);
-    mma4(0, sgh, f.xl);
+    if (SPLIT) {
+      mma4(0, sgl, f.xh);
+      fill_call(fill_stage, fill_lo + 2);
+      mma4(0, sgh, f.xl);
+    }
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 sxh[2], sxl[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { sxh[i] = shift_in_next(f.xh[i], f.nxh[i]); sxl[i] = shift_in_next(f.xl[i], f.nxl[i]); }
+    for (int i = 0; i < 2; ++i) { sxh[i] = shift_in_next(f.xh[i], f.nxh[i]); if (SPLIT) sxl[i] = shift_in_next(f.xl[i], f.nxl[i]); }
     mma4(2, f.gh, sxh);
-    fill_call(fill_stage, fill_lo + 3);
-    mma4(2, f.gl, sxh); mma4(2, f.gh, sxl);
+    if (SPLIT) {
+      fill_call(fill_stage, fill_lo + 3);
+      mma4(2, f.gl, sxh); mma4(2, f.gh, sxl);
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -797,22 +826,26 @@ __global__ __launch_bounds__(kBlock) void k_wgrad_split_sh(const unsigned short*
   Slice fa, fb;
   read_slice(fa, 0, 0);
   int stage = 0;
-  for (int k = k0; k < k1; k += kBKH) {
+  for (int k = k0; k < k1; k += kStep) {
     const int fill = (stage + 3) % kStages3;            // slot of step k-1: every wave left it before the last barrier
-    __builtin_amdgcn_sched_barrier(0);
-    read_slice(fb, stage, 1);
-    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = (stage + 1) % kStages3;
     fill_begin();
-    slice_mma(fa, fill, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_slice(fa, (stage + 1) % kStages3, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    slice_mma(fb, fill, 4);
+#pragma unroll
+    for (int s = 0; s < kSlices; s += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      read_slice(fb, stage, s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      slice_mma(fa, fill, s * kFillsPerSlice);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < kSlices) read_slice(fa, stage, s + 2); else read_slice(fa, nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      slice_mma(fb, fill, (s + 1) * kFillsPerSlice);
+    }
     fill_end();
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    stage = (stage + 1) % kStages3;
+    stage = nxt;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -905,7 +938,7 @@ struct WgradPlan {
   size_t gt_bytes, xt_bytes, slab_bytes, guard;
 };
 
-// shift_form: one staged copy of X on a raster with >= 1 zero column per image row (k_wgrad_split_sh makes the dx shifts in
+// shift_form: one staged copy of X on a raster with >= 1 zero column per image row (k_wgrad_shift makes the dx shifts in
 // registers); only for split operands, 3x3, stride 1, pad == dil == 1.
 bool shift_form_enabled() {
   static const bool on = [] { const char* e = getenv("OMNIHD_WGRAD_SHIFT"); return !(e && e[0] == '0'); }();
@@ -948,7 +981,8 @@ bool plan_for(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh
               bool split, WgradPlan* p, bool* shift_form) {
   static const bool three_taps = [] { const char* e = getenv("OMNIHD_WGRAD_3TAPS"); return !(e && e[0] == '0'); }();
   *shift_form = false;
-  if (split && three_taps && shift_form_enabled() && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 &&
+  (void)split;
+  if (three_taps && shift_form_enabled() && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 &&
       make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, p, true) && p->split3 > 0) {
     *shift_form = true;
     return true;
@@ -964,7 +998,8 @@ using namespace omnihd;
 extern "C" size_t omnihd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout,
                                                     int kh, int kw, int stride, int pad, int dil) {
   WgradPlan p;
-  if (!make_plan(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, &p)) return 0;
+  bool shift_form = false;
+  if (!plan_for(batch, h, w, cin, ho, wo, cout, kh, kw, stride, pad, dil, false, &p, &shift_form)) return 0;
   return 256 + p.gt_bytes + p.xt_bytes + p.slab_bytes + 4 * p.guard;
 }
 
@@ -1037,9 +1072,14 @@ int wgrad_impl(const void* x_nhwc, const void* x_lo, const void* gout_nhwc, cons
     const bool one_desc = (size_t)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)) < (1ull << 31);
     if (shift_form) {
       OMNIHD_REQUIRE(one_desc && p.copies == 1, "conv_wgrad_split: staged operands beyond 2 GiB");
-      hipLaunchKernelGGL(k_wgrad_split_sh, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2,
-                         reinterpret_cast<const unsigned short*>(workspace), (unsigned)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)),
-                         n_split > 1 ? slab : dw, cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3);
+      if (split)
+        hipLaunchKernelGGL(k_wgrad_shift<true>, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2,
+                           reinterpret_cast<const unsigned short*>(workspace), (unsigned)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)),
+                           n_split > 1 ? slab : dw, cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3);
+      else
+        hipLaunchKernelGGL(k_wgrad_shift<false>, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt, Xt, Xt,
+                           reinterpret_cast<const unsigned short*>(workspace), (unsigned)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)),
+                           n_split > 1 ? slab : dw, cout, cin, p.coutp, p.cinp, p.mpix, p.mp, p.rows_h, p.wp, n_split, k_per_split3);
     } else if (split && fused8 && one_desc)
       hipLaunchKernelGGL(k_wgrad_split3, dim3(blocks), dim3(kBlock), 0, st, Gt, Gt2, Xt, Xt2,
                          reinterpret_cast<const unsigned short*>(workspace), (unsigned)(reinterpret_cast<char*>(slab) - static_cast<char*>(workspace)),

@@ -14,7 +14,8 @@ def ref_wgrad(x, g):
     return torch.autograd.grad(y, w, g.float())[0]
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 16, 24, 128, 128), (2, 9, 40, 256, 128), (1, 160, 240, 128, 256), (1, 7, 8, 384, 640)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 16, 24, 128, 128), (2, 9, 40, 256, 128), (1, 160, 240, 128, 256), (1, 7, 8, 384, 640),
+                                             (2, 48, 47, 512, 256), (1, 160, 240, 640, 384), (3, 33, 50, 392, 264)])   # the last three: register-shifted taps (k_wgrad_shift)
 def test_wgrad_matches_fp32_reference(cuda, B, H, W, cin, cout):
     from omnihd_amd import ops
     torch.manual_seed(B * H + cin)
