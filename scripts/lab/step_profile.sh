@@ -40,6 +40,17 @@ if probe:
         for j in range(max(0, i - 5), min(len(ss), i + 4)):
             r = ss[j]
             print(("  >> " if j == i else "     ") + f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp']))/1e3:8.1f} us  grid {r.get('Grid_Size', '?')}  {short(r['Kernel_Name'])}")
+pairs = os.environ.get("STEP_PROFILE_PAIRS")           # histogram of (previous kernel, next kernel) around every launch matching this
+if pairs:
+    short2 = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
+    hist = collections.defaultdict(lambda: [0, 0])
+    for i, r in enumerate(ss):
+        if pairs in r["Kernel_Name"] and 0 < i < len(ss) - 1:
+            key = (short2(ss[i - 1]["Kernel_Name"]), r.get("Grid_Size", "?"), short2(ss[i + 1]["Kernel_Name"]))
+            hist[key][0] += 1; hist[key][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    print("--- (previous, grid, next) around", pairs)
+    for k, (c, t) in sorted(hist.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"{c/$N:6.1f} x {t/1e3/max(c,1):7.1f} us  prev {k[0]} | grid {k[1]} | next {k[2]}")
 print("--- by launch count")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:22]:
     print(f"{c/$N:7.1f} calls/step {t/1e6/$N:7.3f} ms/step  {k}")
