@@ -157,6 +157,8 @@ class BevOps:
         rots, trans = rig(res, batch, dev)
         geom = geometry(frustum, rots, trans).contiguous()
         self.plan = omnihd_amd.build_plan(geom, dx, bx, nx, layout="byxz")
+        from omnihd_amd.plan import _row_bin
+        self.row_bin = _row_bin(self.plan)
         del geom
         g = torch.Generator(device=dev).manual_seed(seed)
         self.sets = []
@@ -170,6 +172,7 @@ class BevOps:
                                         self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
                                         self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_desc, self.plan.ranks_row,
                                         self.plan.pix_desc, self.plan.pix_ptr, self.plan.patch_order)]
+            tabs.append(None if self.row_bin is None else self.row_bin.clone())
             self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
         rng = np.random.default_rng(seed)
         self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
@@ -187,7 +190,10 @@ class BevOps:
     def pool_bwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
         if self.patch_bwd:
-            self.ops.bev_pool_v2_backward_patch(og, depth, feat, tb[3], tb[5], tb[11], tb[12], dg, fg)
+            if tb[13] is not None:       # one packed table (row | depth bin << 24), as the plan's autograd function does
+                self.ops.bev_pool_v2_backward_patch(og, depth, feat, None, tb[13], tb[11], tb[12], dg, fg)
+            else:
+                self.ops.bev_pool_v2_backward_patch(og, depth, feat, tb[3], tb[5], tb[11], tb[12], dg, fg)
             return
         dg.zero_()
         if self.sched_bwd:

@@ -125,7 +125,9 @@ int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const int* tile_or
  * of that order: points [pix_ptr[f], pix_ptr[f+1]) belong to pixel f.  patch_order (n_slots = 8*k ints): entry
  * [x*k + i] = the i-th patch handled on XCD x, patch p = 16 consecutive pixels [16*(p % ppi), ...) of image p / ppi with
  * ppi = ceil(fhw/16); -1 = idle slot; every patch exactly once.  BOTH outputs are written densely (depth_grad zero where
- * no frustum point lies, feat_grad zero for pixels without points): the caller does not clear them.                    */
+ * no frustum point lies, feat_grad zero for pixels without points): the caller does not clear them.
+ * ranks_depth == NULL selects the one-table form: ranks_row[i] = output row | (depth bin << 24) of point i (rows < 2^24 - 1,
+ * d_bins <= 127) — one table word per point instead of two.                                                              */
 int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* depth, const float* feat,
                                  const int* ranks_depth, const int* ranks_row, const int* pix_ptr,
                                  const int* patch_order, int n_slots, int n_img, int d_bins, int fhw,

@@ -199,7 +199,8 @@ def bev_pool_v2_backward_patch(out_grad, depth, feat, ranks_depth, ranks_row, pi
     for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad),
                  ("feat_grad", feat_grad)):
         _want(t, torch.float32, n)
-    for n, t in (("ranks_depth", ranks_depth), ("ranks_row", ranks_row), ("pix_ptr", pix_ptr), ("patch_order", patch_order)):
+    # ranks_depth None: ``ranks_row`` is the packed per-point table (output row | depth bin << 24), plan.bp_row_bin
+    for n, t in (("ranks_row", ranks_row), ("pix_ptr", pix_ptr), ("patch_order", patch_order)) + ((("ranks_depth", ranks_depth),) if ranks_depth is not None else ()):
         _want(t, torch.int32, n)
     if depth.dim() != 5 or feat.dim() != 5 or feat.size(-1) != 64:
         raise ValueError("depth must be (B,N,D,H,W) and feat (B,N,H,W,64)")
@@ -207,9 +208,11 @@ def bev_pool_v2_backward_patch(out_grad, depth, feat, ranks_depth, ranks_row, pi
     n_img, fhw = B * N, H * W
     if pix_ptr.numel() != n_img * fhw + 1 or patch_order.numel() % 8:
         raise ValueError("pix_ptr must have B*N*H*W + 1 entries and patch_order 8*k")
-    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, ranks_depth, ranks_row, pix_ptr, patch_order)
+    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, ranks_row, pix_ptr, patch_order)
+    if ranks_depth is None and D > 127:
+        raise ValueError("the packed table holds at most 127 depth bins")
     with _on(dev):
-        check(lib().omnihd_bev_pool_v2_bwd_patch(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_row),
+        check(lib().omnihd_bev_pool_v2_bwd_patch(_ptr(out_grad), _ptr(depth), _ptr(feat), None if ranks_depth is None else _ptr(ranks_depth), _ptr(ranks_row),
                                                  _ptr(pix_ptr), _ptr(patch_order), patch_order.numel(), n_img, D, fhw,
                                                  out_grad.numel() // 64, _ptr(depth_grad), _ptr(feat_grad), 64, _stream()),
               "omnihd_bev_pool_v2_bwd_patch")

@@ -45,6 +45,7 @@ class BevPoolPlan:
     pix_desc: torch.Tensor = None   # int32 [8*k, 4] schedule of the scheduled backward (every pixel once)
     pix_ptr: torch.Tensor = None    # int32 [n_feat_rows+1] CSR of the backward tables over image-feature pixels
     patch_order: torch.Tensor = None  # int32 [8*k] schedule of the patch backward (16-pixel patches, -1 idle)
+    bp_row_bin: torch.Tensor = None   # int32 [Npts] (output row | depth bin << 24) in backward order: the patch backward's one table
     depth_bins: int = 0             # D and fH*fW of the frustum the plan was built from (0: unknown, e.g. foreign
     feat_hw: int = 0                # tables): with them the forward derives ranks_feat from ranks_depth in-kernel
 
@@ -340,6 +341,17 @@ def _kept_output(plan, c, device):
     return keeper
 
 
+def _row_bin(plan):
+    """(output row | depth bin << 24) per point in backward order, built once per plan on the device: the patch backward then
+    reads ONE table word per point (the bin was ``(ranks_depth // (fH*fW)) % D``).  None when the fields do not fit or
+    OMNIHD_POOL_BWD_PACKED=0."""
+    if plan.bp_row_bin is None and os.environ.get("OMNIHD_POOL_BWD_PACKED", "1") != "0":
+        if 0 < plan.depth_bins <= 127 and plan.n_rows < 0xffffff and plan.feat_hw > 0:
+            d = torch.div(plan.bp_ranks_depth, plan.feat_hw, rounding_mode="floor") % plan.depth_bins
+            plan.bp_row_bin = (plan.bp_ranks_row | (d << 24)).to(torch.int32).contiguous()
+    return plan.bp_row_bin if os.environ.get("OMNIHD_POOL_BWD_PACKED", "1") != "0" else None
+
+
 class _PlannedPool(torch.autograd.Function):
     """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order."""
 
@@ -380,12 +392,15 @@ class _PlannedPool(torch.autograd.Function):
         if patch and out_grad.dtype != torch.float32 and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0":
             # the forward's tensors and the backward tables have long left the Infinity Cache: read them ahead on the side
             # stream while the cast of the incoming gradient runs (bf16 step; in the fp32 step nothing precedes the kernel)
-            ops.prefetch([plan.bp_ranks_depth, plan.bp_ranks_row, depth, feat])
+            packed = _row_bin(plan)
+            ops.prefetch([packed, depth, feat] if packed is not None else [plan.bp_ranks_depth, plan.bp_ranks_row, depth, feat])
         out_grad = out_grad.contiguous().float()
         if patch:
             depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)   # both written densely
+            packed = _row_bin(plan)
             _timed("bwd", lambda: ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat,
-                                                                 plan.bp_ranks_depth, plan.bp_ranks_row, plan.pix_ptr,
+                                                                 None if packed is not None else plan.bp_ranks_depth,
+                                                                 packed if packed is not None else plan.bp_ranks_row, plan.pix_ptr,
                                                                  plan.patch_order, depth_grad, feat_grad))
             return depth_grad, feat_grad, None, None
         depth_grad = torch.zeros_like(depth)
