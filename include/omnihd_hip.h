@@ -354,6 +354,17 @@ int omnihd_conv_fwd_supported(int batch, int h, int w, int cin, int cout, int ks
  *         300 = 3x3 row-shift kernel (256x128 tile, dilation <= 8).                                                 */
 int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, const float* bias, void* y_nhwc, int batch, int h,
                          int w, int cin, int cout, int ksize, int dil, int tile, void* stream);
+/* Weight images of many convolution layers in one launch (fp32 master weights -> what the kernels above read): `table` is a
+ * DEVICE array of n_entries records
+ *   { const float* src; long long so, si, sy, sx;            fp32 weight and its element strides (cout, cin, ky, kx)
+ *     uint16* f_hi, *f_lo;                                    (Cout,k,k,Cin) bf16 image: hi plane (= the plain bf16 rounding) and,
+ *                                                             unless NULL, lo = bf16(w - hi) for the split kernels
+ *     uint16* d_hi, *d_lo;                                    (Cin,k,k,Cout) images with mirrored taps for the data gradient, or NULL
+ *     int cout, cin, k, first_block; }                        first_block = sum over the earlier records of ceil(cout/32)*ceil(cin/32)
+ * in increasing first_block order; total_blocks = that sum over all records.  Replaces, per layer and step, a layout copy +
+ * omnihd_split_f32 + two omnihd_conv_dgrad_weights launches.                                                              */
+int omnihd_weight_images(const void* table, int n_entries, int total_blocks, void* stream);
+
 /* wt[c,k-1-ky,k-1-kx,n] = w[n,ky,kx,c]: the weights with which the DATA GRADIENT of the convolution above is the same
  * convolution applied to the output gradient:  omnihd_conv_fwd_bf16(gout, wt, NULL, gx, batch, h, w, cout, cin, ...).  */
 int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream);

@@ -726,6 +726,84 @@ extern "C" int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, cons
   return check_launch("conv_fwd_bf16");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight images of MANY convolution layers in ONE launch (round 3).  Per layer and step the fp32 master weight (any strides:
+// OIHW or channels_last parameters) has to become: its bf16 plane(s) in (Cout,k,k,Cin) memory for the forward kernel and the
+// mirrored / transposed plane(s) in (Cin,k,k,Cout) memory for the data gradient — done layer by layer that was a layout copy,
+// a split pass and two transposes (4 launches x 76 layers per fp32 step).  One workgroup = a 32 x 32 (cout, cin) tile of one
+// layer, all taps; the layer of a workgroup is found in the table by its first-block prefix.
+// ---------------------------------------------------------------------------------------------
+struct WeightImageEntry {
+  const float* src;                 // fp32 master weight
+  long long so, si, sy, sx;         // its element strides (cout, cin, ky, kx)
+  unsigned short* f_hi;             // (Cout,k,k,Cin) bf16: hi plane (or the plain bf16 image)
+  unsigned short* f_lo;             // lo plane, or null
+  unsigned short* d_hi;             // (Cin,k,k,Cout) bf16, taps mirrored: data-gradient image, or null
+  unsigned short* d_lo;             // its lo plane, or null
+  int cout, cin, k, first_block;
+};
+
+__global__ __launch_bounds__(256) void k_weight_images(const WeightImageEntry* __restrict__ table, int n_entries) {
+  __shared__ float s[32][9][33];
+  // binary search for the layer of this workgroup (first_block is increasing; the table has a closing sentinel entry)
+  int lo_e = 0, hi_e = n_entries - 1;
+  while (lo_e < hi_e) {
+    const int mid = (lo_e + hi_e + 1) >> 1;
+    if (table[mid].first_block <= (int)blockIdx.x) lo_e = mid; else hi_e = mid - 1;
+  }
+  const WeightImageEntry e = table[lo_e];
+  const int taps = e.k * e.k;
+  const int tiles_i = (e.cin + 31) / 32;
+  const int b = (int)blockIdx.x - e.first_block;
+  const int o0 = (b / tiles_i) * 32, i0 = (b % tiles_i) * 32;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 32 * 32 * taps; idx += 256) {
+    const int t = idx % taps, i = (idx / taps) % 32, o = idx / (taps * 32);
+    float v = 0.f;
+    if (o0 + o < e.cout && i0 + i < e.cin)
+      v = e.src[(long long)(o0 + o) * e.so + (long long)(i0 + i) * e.si + (long long)(t / e.k) * e.sy + (long long)(t % e.k) * e.sx];
+    s[o][t][i] = v;
+  }
+  __syncthreads();
+  auto split = [](float v, unsigned short& h, unsigned short& l) {
+    h = f2bf_rn(v);
+    const float hv = __uint_as_float((unsigned)h << 16);
+    l = ((h & 0x7f80) != 0x7f80) ? f2bf_rn(v - hv) : (unsigned short)0;
+  };
+  // forward image: (o, tap, i), i fastest
+  for (int idx = tid; idx < 32 * 32 * taps; idx += 256) {
+    const int i = idx % 32, t = (idx / 32) % taps, o = idx / (32 * taps);
+    if (o0 + o < e.cout && i0 + i < e.cin) {
+      unsigned short h, l;
+      split(s[o][t][i], h, l);
+      const size_t at = ((size_t)(o0 + o) * taps + t) * e.cin + i0 + i;
+      e.f_hi[at] = h;
+      if (e.f_lo) e.f_lo[at] = l;
+    }
+  }
+  // data-gradient image: (i, mirrored tap, o), o fastest
+  if (e.d_hi) {
+    for (int idx = tid; idx < 32 * 32 * taps; idx += 256) {
+      const int o = idx % 32, t = (idx / 32) % taps, i = idx / (32 * taps);
+      if (o0 + o < e.cout && i0 + i < e.cin) {
+        unsigned short h, l;
+        split(s[o][t][i], h, l);
+        const size_t at = ((size_t)(i0 + i) * taps + (taps - 1 - t)) * e.cout + o0 + o;
+        e.d_hi[at] = h;
+        if (e.d_lo) e.d_lo[at] = l;
+      }
+    }
+  }
+}
+
+extern "C" int omnihd_weight_images(const void* table_dev, int n_entries, int total_blocks, void* stream) {
+  OMNIHD_REQUIRE(n_entries >= 0 && total_blocks >= 0 && (n_entries == 0 || table_dev), "arguments");
+  if (n_entries == 0 || total_blocks == 0) return OMNIHD_OK;
+  hipLaunchKernelGGL(k_weight_images, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const WeightImageEntry*>(table_dev), n_entries);
+  return check_launch("weight_images");
+}
+
 extern "C" int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream) {
   OMNIHD_REQUIRE(w_ohwi && wt_ihwo && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "arguments");
   hipLaunchKernelGGL(k_dgrad_weights, dim3((cout + 63) / 64, (cin + 63) / 64, ksize * ksize), dim3(256), 0,

@@ -400,5 +400,6 @@ class FusionTrainStep:
         if self.device.type == "cuda":
             from . import ops
             ops.refresh_bf16_shadows()            # one fused fp32 -> bf16 copy of all convolution weights
+            ops.refresh_split_shadows()           # fp32 step: forward + data-gradient planes of every split convolution, one launch
         self.last_losses = losses
         return total

@@ -816,9 +816,40 @@ def bf16_of(weight):
     e = _BF16_SHADOW.get(id(weight))
     if e is not None and e[0]() is weight and e[1] == weight._version and e[2].device == weight.device:
         return e[2]
-    shadow = weight.detach().to(torch.bfloat16)
+    # convolution weights: the image lives in channels_last memory ((Cout,k,k,Cin), what the implicit-GEMM kernels and the
+    # NHWC library kernels read), so no layer pays a layout copy per step
+    if weight.dim() == 4 and e is not None and e[0]() is weight and e[2].shape == weight.shape and e[2].device == weight.device:
+        shadow = e[2]
+        shadow.copy_(weight.detach())
+    elif weight.dim() == 4:
+        shadow = weight.detach().to(torch.bfloat16, memory_format=torch.channels_last)
+    else:
+        shadow = weight.detach().to(torch.bfloat16)
     _BF16_SHADOW[id(weight)] = (weakref.ref(weight), weight._version, shadow)
     return shadow
+
+
+_BF16_DGRAD = {}
+
+
+def bf16_dgrad_image(param, wb):
+    """The bf16 weights re-laid for the data gradient ((Cin,k,k,Cout) memory, taps mirrored), cached per parameter version and
+    refreshed together with the bf16 image by ``refresh_bf16_shadows``.  ``param`` None: not cached."""
+    w_cl = wb if wb.is_contiguous(memory_format=torch.channels_last) else wb.contiguous(memory_format=torch.channels_last)
+    if param is None:
+        return conv_dgrad_weights(w_cl)
+    e = _BF16_DGRAD.get(id(param))
+    if e is not None and e[0]() is param and e[2].device == wb.device and e[2].shape[:2] == (wb.shape[1], wb.shape[0]):
+        if e[1] == param._version:
+            return e[2]
+        img = conv_dgrad_weights(w_cl, out=e[2])
+    else:
+        img = conv_dgrad_weights(w_cl)
+    if len(_BF16_DGRAD) > 4096:
+        for k in [k for k, v in _BF16_DGRAD.items() if v[0]() is None]:
+            del _BF16_DGRAD[k]
+    _BF16_DGRAD[id(param)] = (weakref.ref(param), param._version, img)
+    return img
 
 
 class _Bf16Weight(torch.autograd.Function):
@@ -841,19 +872,35 @@ def bf16_weight(weight):
 
 
 def refresh_bf16_shadows():
-    """Bring every stale bf16 image up to date with one fused copy; returns how many were refreshed."""
+    """Bring every stale bf16 image up to date: convolution weights (and their data-gradient images, where a layer has one) with
+    ONE launch of omnihd_weight_images, everything else with one fused copy; returns how many were refreshed."""
     src, dst, keys = [], [], []
+    per_dev = {}
     for k, (ref, ver, shadow) in list(_BF16_SHADOW.items()):
         w = ref()
         if w is None:
             del _BF16_SHADOW[k]
+            _BF16_DGRAD.pop(k, None)
         elif ver != w._version and w.device == shadow.device and w.shape == shadow.shape:
-            src.append(w.detach()); dst.append(shadow); keys.append((k, ref, w))
+            if (w.dim() == 4 and w.dtype == torch.float32 and w.is_cuda and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)
+                    and shadow.is_contiguous(memory_format=torch.channels_last)):
+                d = _BF16_DGRAD.get(k)
+                d = d[2] if d is not None and d[0]() is w and d[2].device == w.device else None
+                cout, cin, kk, _ = w.shape
+                per_dev.setdefault(w.device, []).append((w.data_ptr(),) + tuple(w.stride()) + (shadow.data_ptr(), 0, 0 if d is None else d.data_ptr(),
+                                                                                               0, cout, cin, kk))
+                keys.append((k, ref, w, shadow, d))
+            else:
+                src.append(w.detach()); dst.append(shadow); keys.append((k, ref, w, shadow, None))
+    for dev, recs in per_dev.items():
+        weight_images(recs, dev)
     if src:
         torch._foreach_copy_(dst, src)
-        for (k, ref, w), shadow in zip(keys, dst):
-            _BF16_SHADOW[k] = (ref, w._version, shadow)
-    return len(src)
+    for k, ref, w, shadow, d in keys:
+        _BF16_SHADOW[k] = (ref, w._version, shadow)
+        if d is not None:
+            _BF16_DGRAD[k] = (ref, w._version, d)
+    return len(keys)
 
 
 # Forward and data gradient of the stride-1 "same" convolutions: the implicit-GEMM MFMA kernel of this library
@@ -988,6 +1035,72 @@ def split_weight(weight, dgrad=False):
     return planes
 
 
+_WIMG_DTYPE = None
+_WIMG_TABLES = {}
+
+
+def _weight_image_table(records, dev):
+    """Device table of omnihd_weight_images records (cached while the same buffers are asked for)."""
+    global _WIMG_DTYPE
+    import numpy as np
+    if _WIMG_DTYPE is None:
+        _WIMG_DTYPE = np.dtype([("src", "<u8"), ("so", "<i8"), ("si", "<i8"), ("sy", "<i8"), ("sx", "<i8"), ("f_hi", "<u8"), ("f_lo", "<u8"),
+                                ("d_hi", "<u8"), ("d_lo", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("k", "<i4"), ("first_block", "<i4")])
+    key = (dev.index, tuple(records))
+    hit = _WIMG_TABLES.get(key)
+    if hit is None:
+        arr = np.zeros(len(records), dtype=_WIMG_DTYPE)
+        first = 0
+        for n, r in enumerate(records):
+            arr[n] = r + (first,)
+            first += ((r[9] + 31) // 32) * ((r[10] + 31) // 32)
+        if len(_WIMG_TABLES) > 8:
+            _WIMG_TABLES.clear()
+        hit = _WIMG_TABLES[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(dev), first)
+    return hit
+
+
+def weight_images(records, dev):
+    """One launch of omnihd_weight_images over ``records`` = tuples (src_ptr, so, si, sy, sx, f_hi, f_lo, d_hi, d_lo, cout, cin, k)."""
+    if not records:
+        return
+    table, blocks = _weight_image_table(records, dev)
+    with _on(dev):
+        check(lib().omnihd_weight_images(table.data_ptr(), len(records), blocks, _raw_stream()), "omnihd_weight_images")
+
+
+def refresh_split_shadows():
+    """Bring every stale split image of an fp32 convolution weight (forward planes and, where a layer has asked for them, the
+    data-gradient planes) up to date with ONE launch; a training loop calls it right after the optimiser step, like
+    ``refresh_bf16_shadows``.  Returns how many layers were refreshed.  (Without it ``split_weight`` refreshes layer by layer.)"""
+    per_dev = {}
+    touched = []
+    layers = {}
+    for (wid, dgrad), (ref, ver, planes) in list(_SPLIT_SHADOW.items()):
+        w = ref()
+        if w is None:
+            del _SPLIT_SHADOW[(wid, dgrad)]
+            continue
+        if ver == w._version or planes[0].device != w.device or w.dtype != torch.float32:
+            continue
+        layers.setdefault(wid, [w, None, None])[2 if dgrad else 1] = planes
+        touched.append((wid, dgrad, ref, w, planes))
+    for wid, (w, fwd, dg) in layers.items():
+        if fwd is None:                      # the data-gradient image alone is stale (cannot happen in a training loop): lazy path
+            touched = [t for t in touched if t[0] != wid]
+            continue
+        cout, cin, k, _ = w.shape
+        so, si, sy, sx = w.stride()
+        rec = (w.data_ptr(), so, si, sy, sx, fwd[0].data_ptr(), fwd[1].data_ptr(), 0 if dg is None else dg[0].data_ptr(),
+               0 if dg is None else dg[1].data_ptr(), cout, cin, k)
+        per_dev.setdefault(w.device, []).append(rec)
+    for dev, recs in per_dev.items():
+        weight_images(recs, dev)
+    for wid, dgrad, ref, w, planes in touched:
+        _SPLIT_SHADOW[(wid, dgrad)] = (ref, w._version, planes)
+    return len(layers)
+
+
 def conv_fwd_split(xs, ws, bias=None, dilation=1, tile=0):
     """fp32-grade y = conv2d(x, w, bias, stride 1, padding = dilation*(k//2)) from split operands: xs = (x_hi, x_lo)
     (B,Cin,H,W) bf16 channels-last, ws = (w_hi, w_lo) (Cout,Cin,k,k) bf16 channels_last -> (B,Cout,H,W) fp32 channels-last."""
@@ -1063,7 +1176,7 @@ def conv_split_all_miopen(x_shape, cout, k, stride, padding, dilation, device_in
 
 class _ConvSplit(torch.autograd.Function):
     """fp32 convolution of the reference-precision step on the split kernels: forward and data gradient on
-    omnihd_conv_fwd_split, weight gradient as three launches of the bf16 k-major chain (hi*hi + hi*lo + lo*hi, fp32 slabs);
+    omnihd_conv_fwd_split, weight gradient on omnihd_conv_wgrad_split (one launch, hi*hi + hi*lo + lo*hi into fp32 tiles);
     per geometry and direction the measured faster of that and MIOpen's fp32 kernel runs.  The input is saved as its two
     bf16 planes (the same bytes as the fp32 tensor)."""
 
@@ -1222,6 +1335,7 @@ class _ConvHipWgrad(torch.autograd.Function):
         # and their gradients are returned in THEIR dtype, so autograd adds no cast kernels of its own.
         wb = bf16_of(weight) if x.dtype == torch.bfloat16 else weight.detach().to(x.dtype)
         ctx.save_for_backward(x, wb)
+        ctx.wparam = weakref.ref(weight) if (weight.dtype == torch.float32 and x.dtype == torch.bfloat16) else None
         ctx.has_bias = bias is not None
         ctx.conv = (list(stride), list(padding), list(dilation))
         ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
@@ -1245,7 +1359,7 @@ class _ConvHipWgrad(torch.autograd.Function):
             if (g.dtype == torch.bfloat16 and stride[0] == 1 and weight.shape[0] % 64 == 0 and weight.shape[1] % 8 == 0
                     and k in (1, 3) and padding[0] == dilation[0] * (k // 2)
                     and os.environ.get("OMNIHD_CONV_POLICY", "tune") != "miopen"):
-                wt = lambda: conv_dgrad_weights(weight.contiguous(memory_format=torch.channels_last))
+                wt = lambda: bf16_dgrad_image(None if ctx.wparam is None else ctx.wparam(), weight)
                 gx = _conv_impl("dgrad", g, wt, stride, padding, dilation, run_miopen, n_out=weight.shape[1], k=k)
             else:
                 gx = run_miopen()

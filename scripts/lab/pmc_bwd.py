@@ -14,8 +14,7 @@ n = 128 * 1024 * 1024 // 4
 bufs = [(torch.randn(n, device="cuda"), torch.empty(n, device="cuda")) for _ in range(4)]
 for k in range(8):
     torch.mul(bufs[k % 4][0], 1.5, out=bufs[k % 4][1])
-    depth, feat, og, out, dg, fg, tb = wl.sets[k % len(wl.sets)]
-    ops.bev_pool_v2_backward_patch(og, depth, feat, tb[3], tb[5], plan.pix_ptr, plan.patch_order, dg, fg)
+    wl.pool_bwd(k % len(wl.sets))           # the product path: one packed table (row | depth bin << 24)
     wl.pool_fwd(k % len(wl.sets))
 torch.cuda.synchronize()
 print("done")

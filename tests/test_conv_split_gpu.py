@@ -140,3 +140,30 @@ def test_split_weight_gradient_with_register_shifted_taps(cuda, B, H, W, cin, co
     for ky in range(3):
         for kx in range(3):
             assert _rel(dw[:, :, ky, kx], ref[:, :, ky, kx]) <= 1e-4, (ky, kx, _rel(dw[:, :, ky, kx], ref[:, :, ky, kx]))
+
+
+def test_batched_weight_images_equal_the_layer_by_layer_path(cuda):
+    """ops.refresh_split_shadows(): ONE launch refreshes the forward and data-gradient planes of every registered layer; bit for bit
+    what split_weight builds layer by layer (layout copy + split + two transposes), for OIHW and channels_last parameters."""
+    from omnihd_amd import ops
+    torch.manual_seed(11)
+    ws = [torch.nn.Parameter(torch.randn(s, device=cuda) * 0.1) for s in [(64, 128, 3, 3), (40, 64, 1, 1), (256, 192, 3, 3), (8, 64, 3, 3)]]
+    ws.append(torch.nn.Parameter((torch.randn(96, 64, 3, 3, device=cuda) * 0.1).contiguous(memory_format=torch.channels_last)))
+    for i, w in enumerate(ws):
+        ops.split_weight(w)
+        if i != 1:
+            ops.split_weight(w, dgrad=True)           # layer 1 never asked for its data-gradient image
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5).add_(0.01)                    # the optimiser step: versions move on
+    assert ops.refresh_split_shadows() == len(ws)
+    got = [(ops.split_weight(w), ops.split_weight(w, dgrad=True) if i != 1 else None) for i, w in enumerate(ws)]
+    got = [tuple(None if p is None else tuple(t.clone() for t in p) for p in g) for g in got]
+    assert ops.refresh_split_shadows() == 0           # nothing stale any more
+    ops._SPLIT_SHADOW.clear()
+    for i, w in enumerate(ws):
+        f = ops.split_weight(w)
+        assert all(torch.equal(a, b) for a, b in zip(got[i][0], f)), i
+        if i != 1:
+            d = ops.split_weight(w, dgrad=True)
+            assert all(torch.equal(a, b) for a, b in zip(got[i][1], d)), i

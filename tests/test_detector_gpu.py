@@ -54,7 +54,27 @@ def _close(a, b, tol=1e-3):
     return float((a - b).abs().max()) / scale <= tol
 
 
-def test_tiny_detector_hip_ops_match_oracle_ops(cuda):
+CONV_POLICIES = ["miopen", "split"]
+
+
+def _grads_agree(gpu, cpu, names, policy):
+    """Gradients of the named parameters.  With the dense convolutions on MIOpen's fp32 kernels (whose outputs agree with the CPU's
+    to ~1e-6) every entry is held to 5e-3 of the largest.  On the fp32-grade split kernels (5e-6 per convolution) a handful of
+    near-zero pre-activations land on the other side of a ReLU than on the CPU; in these tiny maps ONE flipped mask moves single
+    weight-gradient entries by percent (scripts/lab/diag_rcfusion_grads.py: forward outputs 4e-5, individual gradient entries up to
+    3e-2, the same entries 1e-6 with MIOpen) — there the gradients are compared as whole tensors (relative L2 <= 3e-2); the split
+    kernels' own gradient parity (1e-4, smooth activations, BEV-sized layers) is tests/test_conv_split_gpu.py."""
+    for n in names:
+        a, b = gpu["grads"][n].double(), cpu["grads"][n].double()
+        if policy == "miopen":
+            assert _close(a, b, 5e-3), n
+        else:
+            assert float((a - b).norm() / b.norm().clamp_min(1e-30)) <= 3e-2, n
+
+
+@pytest.mark.parametrize("policy", CONV_POLICIES)
+def test_tiny_detector_hip_ops_match_oracle_ops(cuda, policy, monkeypatch):
+    monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
     gpu = _run("cuda:0", use_oracle=False)
     cpu = _run("cpu", use_oracle=True)
     assert _close(gpu["depth"], cpu["depth"]), "depth distribution"
@@ -64,16 +84,17 @@ def test_tiny_detector_hip_ops_match_oracle_ops(cuda):
         assert abs(gpu["losses"][k] - cpu["losses"][k]) <= 1e-3 * max(abs(cpu["losses"][k]), 1e-3), k
     assert abs(gpu["depth_loss"] - cpu["depth_loss"]) <= 1e-3 * abs(cpu["depth_loss"])
     # gradients through the HIP backward kernels (pooling, pillar gather) reach the same values
-    for n in ["lift_splat_shot_vis.camencode.depthnet.context_conv.weight", "lift_splat_shot_vis.camencode.depthnet.depth_conv.5.weight",
-              "pts_voxel_encoder.pfn_layers.0.linear.weight", "img_neck.reduc_conv.conv.weight", "reduc_conv.conv.weight"]:
-        assert _close(gpu["grads"][n], cpu["grads"][n], 5e-3), n
+    _grads_agree(gpu, cpu, ["lift_splat_shot_vis.camencode.depthnet.context_conv.weight", "lift_splat_shot_vis.camencode.depthnet.depth_conv.5.weight",
+                            "pts_voxel_encoder.pfn_layers.0.linear.weight", "img_neck.reduc_conv.conv.weight", "reduc_conv.conv.weight"], policy)
 
 
-def test_tiny_detector_fp32_backward_with_allow_tf32_switched_off(cuda):
+@pytest.mark.parametrize("policy", CONV_POLICIES)
+def test_tiny_detector_fp32_backward_with_allow_tf32_switched_off(cuda, policy, monkeypatch):
     """the reference's `close_tf32` switch (tools/train.py:148-153) sets torch.backends.cudnn.allow_tf32 =
     False.  Round 1 suspected MIOpen's fp32 backward kernels under that setting (1e-2 off); the error was traced to torch's
     channels-last BatchNorm backward instead, which the product no longer runs.  The same parity bounds as the
     default setting must hold with the switch off."""
+    monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
     torch.backends.cudnn.allow_tf32 = False
     try:
         gpu = _run("cuda:0", use_oracle=False)
@@ -81,14 +102,15 @@ def test_tiny_detector_fp32_backward_with_allow_tf32_switched_off(cuda):
         torch.backends.cudnn.allow_tf32 = True
     cpu = _run("cpu", use_oracle=True)
     assert _close(gpu["bev"], cpu["bev"]) and _close(gpu["reg"], cpu["reg"]) and _close(gpu["depth"], cpu["depth"])
-    for n in ["lift_splat_shot_vis.camencode.depthnet.context_conv.weight", "lift_splat_shot_vis.camencode.depthnet.depth_conv.5.weight",
-              "img_neck.reduc_conv.conv.weight", "reduc_conv.conv.weight", "lift_splat_shot_vis.bevencode.0.weight"]:
-        assert _close(gpu["grads"][n], cpu["grads"][n], 5e-3), n
+    _grads_agree(gpu, cpu, ["lift_splat_shot_vis.camencode.depthnet.context_conv.weight", "lift_splat_shot_vis.camencode.depthnet.depth_conv.5.weight",
+                            "img_neck.reduc_conv.conv.weight", "reduc_conv.conv.weight", "lift_splat_shot_vis.bevencode.0.weight"], policy)
 
 
-def test_tiny_rcfusion_detector_hip_ops_match_oracle_ops(cuda):
+@pytest.mark.parametrize("policy", CONV_POLICIES)
+def test_tiny_rcfusion_detector_hip_ops_match_oracle_ops(cuda, policy, monkeypatch):
     """RCFusion_FasterRCNN (RadarPillarFeatureNet + Cross_Modal_Fusion) on the GPU for the first time:
     HIP operators vs the same weights on the CPU over the oracle operators, fp32, 1e-3."""
+    monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
     gpu = _run("cuda:0", use_oracle=False, variant="rcfusion")
     cpu = _run("cpu", use_oracle=True, variant="rcfusion")
     assert _close(gpu["depth"], cpu["depth"]) and _close(gpu["bev"], cpu["bev"]), "distribution / cross-modal BEV feature"
@@ -96,9 +118,8 @@ def test_tiny_rcfusion_detector_hip_ops_match_oracle_ops(cuda):
     for k in cpu["losses"]:
         assert abs(gpu["losses"][k] - cpu["losses"][k]) <= 1e-3 * max(abs(cpu["losses"][k]), 1e-3), k
     assert abs(gpu["depth_loss"] - cpu["depth_loss"]) <= 1e-3 * abs(cpu["depth_loss"])
-    for n in ["cross_attention.att_img.0.weight", "cross_attention.att_radar.0.weight", "cross_attention.reduce_mixBEV.conv.weight",
-              "pts_voxel_encoder.pfn_layers.0.linear1.weight", "lift_splat_shot_vis.camencode.depthnet.context_conv.weight"]:
-        assert _close(gpu["grads"][n], cpu["grads"][n], 5e-3), n
+    _grads_agree(gpu, cpu, ["cross_attention.att_img.0.weight", "cross_attention.att_radar.0.weight", "cross_attention.reduce_mixBEV.conv.weight",
+                            "pts_voxel_encoder.pfn_layers.0.linear1.weight", "lift_splat_shot_vis.camencode.depthnet.context_conv.weight"], policy)
 
 
 @pytest.mark.parametrize("policy", ["split", "miopen"])

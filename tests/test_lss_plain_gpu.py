@@ -148,7 +148,10 @@ def _detector_run(device, use_oracle):
                             for k, v in losses.items()}, grads=grads)
 
 
-def test_bevf_faster_rcnn_tiny_step_hip_ops_match_oracle_ops(cuda):
+def test_bevf_faster_rcnn_tiny_step_hip_ops_match_oracle_ops(cuda, monkeypatch):
+    # an OPERATOR parity test: the dense fp32 convolutions are pinned to the library kernels here (with the fp32-grade split kernels
+    # single ReLU masks of these tiny maps flip and move gradient entries by percent — tests/test_detector_gpu.py::_grads_agree)
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "miopen")
     got, want = _detector_run(cuda, False), _detector_run("cpu", True)
     assert set(got["losses"]) == set(want["losses"]) >= {"loss_cls", "loss_bbox", "loss_dir", "img_depth_loss"}
     for k, v in want["losses"].items():

@@ -52,7 +52,8 @@ def _run(device, use_oracle, stream):
 
 
 @pytest.mark.parametrize("stream", ["radar", "rcfusion", "lidar"])
-def test_stream_only_tiny_step_hip_ops_match_oracle_ops(cuda, stream):
+def test_stream_only_tiny_step_hip_ops_match_oracle_ops(cuda, stream, monkeypatch):
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "miopen")     # operator parity: library fp32 convolutions (see test_detector_gpu._grads_agree)
     got, want = _run(cuda, False, stream), _run("cpu", True, stream)
     assert got["feat"].shape == want["feat"].shape and _close(got["feat"], want["feat"])
     for k, v in want["losses"].items():

@@ -35,7 +35,10 @@ def _run(device, use_oracle):
                     grads={n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None})
 
 
-def test_tiny_queue_hip_ops_match_oracle_ops(cuda):
+def test_tiny_queue_hip_ops_match_oracle_ops(cuda, monkeypatch):
+    # an OPERATOR parity test: the dense fp32 convolutions are pinned to the library kernels here (with the fp32-grade split kernels
+    # single ReLU masks of these tiny maps flip and move gradient entries by percent — tests/test_detector_gpu.py::_grads_agree)
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "miopen")
     got, want = _run(cuda, False), _run("cpu", True)
     assert got["hist"].shape == want["hist"].shape and _close(got["hist"], want["hist"])
     for k, v in want["losses"].items():
