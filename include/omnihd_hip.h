@@ -435,6 +435,10 @@ int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, voi
 /* The same two passes on fp32 rows (the reference-precision step: the reference trains in fp32).       */
 int omnihd_affine_act_fwd_f32(const float* x, const float* scale, const float* shift, const float* res, float* y,
                               long long n_rows, int c, int relu, void* stream);
+/* The same pass, y additionally written as its two bf16 planes (hi = bf16(y), lo = bf16(y - hi): what omnihd_split_f32 produces)
+ * for the fp32-grade convolution that reads y next — saves that split pass over y.                                          */
+int omnihd_affine_act_fwd_f32_planes(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                                     void* y_hi, void* y_lo, long long n_rows, int c, int relu, void* stream);
 int omnihd_affine_act_bwd_f32(const float* gy, const float* y, const float* scale, float* gx, float* gres,
                               long long n_rows, int c, int relu, void* stream);
 
@@ -497,6 +501,14 @@ int omnihd_bn_train_fwd_f32(const float* x, const float* res, const float* gamma
 int omnihd_bn_train_bwd_f32(const float* gy, const float* y_mask, int relu_from_x, const float* x, const float* gamma,
                             const float* consts4c, float* gx, float* gres, float* sums2c, float* out5c, long long rows,
                             int c, void* workspace, size_t workspace_bytes, void* stream);
+/* One-call forms that also write the bf16 planes of their output (y resp. gx) for the adjacent fp32-grade convolution. */
+int omnihd_bn_train_fwd_f32_planes(const float* x, const float* res, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float var_correction, int relu, float* y,
+                                   void* y_hi, void* y_lo, float* stats2c, float* consts4c, long long rows, int c, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+int omnihd_bn_train_bwd_f32_planes(const float* gy, const float* y_mask, int relu_from_x, const float* x, const float* gamma,
+                                   const float* consts4c, float* gx, void* gx_hi, void* gx_lo, float* gres, float* sums2c,
+                                   float* out5c, long long rows, int c, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Column sums of a row-major [rows][c] bf16 (is_f32 = 0) or fp32 matrix for ANY c, in fp32, two stages in a fixed order:
  * the bias gradient of a convolution whose channel count is not a multiple of 8 (sum over N, H, W of the NHWC output

@@ -21,7 +21,8 @@ namespace {
 template <typename T, bool RELU, bool RES>
 __global__ __launch_bounds__(256) void k_affine_fwd(const T* __restrict__ x, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const T* __restrict__ res,
-                                                    T* __restrict__ y, int64_t n_vec, int c8) {
+                                                    T* __restrict__ y, int64_t n_vec, int c8, bf16_t* __restrict__ y_hi = nullptr,
+                                                    bf16_t* __restrict__ y_lo = nullptr) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
     float xv[8], rv[8], out[8];
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void k_affine_fwd(const T* __restrict__ x, con
       out[k] = v;
     }
     store8(y, i, out);
+    if (y_hi) store_planes8(y_hi, y_lo, i, out);     // the next fp32-grade convolution reads these instead of a split pass over y
   }
 }
 
@@ -67,15 +69,15 @@ __global__ __launch_bounds__(256) void k_affine_bwd(const T* __restrict__ gy, co
 
 template <typename T>
 int affine_fwd_t(const void* x, const float* scale, const float* shift, const void* res, void* y, long long n_rows, int c,
-                 int relu, void* stream) {
+                 int relu, void* stream, bf16_t* y_hi = nullptr, bf16_t* y_lo = nullptr) {
   const int64_t n_vec = (int64_t)n_rows * (c / 8);
   const dim3 grid(grid_for(n_vec, 256 * 2)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const T *xv = (const T*)x, *rv = (const T*)res;
-  if (relu && res) hipLaunchKernelGGL((k_affine_fwd<T, true, true>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
-  else if (relu) hipLaunchKernelGGL((k_affine_fwd<T, true, false>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
-  else if (res) hipLaunchKernelGGL((k_affine_fwd<T, false, true>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
-  else hipLaunchKernelGGL((k_affine_fwd<T, false, false>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8);
+  if (relu && res) hipLaunchKernelGGL((k_affine_fwd<T, true, true>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8, y_hi, y_lo);
+  else if (relu) hipLaunchKernelGGL((k_affine_fwd<T, true, false>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8, y_hi, y_lo);
+  else if (res) hipLaunchKernelGGL((k_affine_fwd<T, false, true>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8, y_hi, y_lo);
+  else hipLaunchKernelGGL((k_affine_fwd<T, false, false>), grid, block, 0, st, xv, scale, shift, rv, (T*)y, n_vec, c / 8, y_hi, y_lo);
   return check_launch("affine_act_fwd");
 }
 
@@ -112,6 +114,16 @@ extern "C" int omnihd_affine_act_fwd_f32(const float* x, const float* scale, con
   if (n_rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(x && scale && shift && y, "null pointer");
   return affine_fwd_t<float>(x, scale, shift, res, y, n_rows, c, relu, stream);
+}
+
+/* omnihd_affine_act_fwd_f32 that ALSO writes the two bf16 planes of y (omnihd_split_f32's output) for the next split convolution */
+extern "C" int omnihd_affine_act_fwd_f32_planes(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                                                void* y_hi, void* y_lo, long long n_rows, int c, int relu, void* stream) {
+  OMNIHD_REQUIRE(n_rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
+  if (n_rows == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(x && scale && shift && y && y_hi && y_lo, "null pointer");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15u) == 0, "16-byte alignment");
+  return affine_fwd_t<float>(x, scale, shift, res, y, n_rows, c, relu, stream, static_cast<bf16_t*>(y_hi), static_cast<bf16_t*>(y_lo));
 }
 
 extern "C" int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gres,

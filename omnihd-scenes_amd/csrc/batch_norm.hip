@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ gy, 
                                                       const T* __restrict__ x, const float* __restrict__ coefA,
                                                       const float* __restrict__ coefB, const float* __restrict__ coefC,
                                                       const float* __restrict__ fss, T* __restrict__ gx,
-                                                      T* __restrict__ gres, int64_t n_vec, int c8) {
+                                                      T* __restrict__ gres, int64_t n_vec, int c8, bf16_t* __restrict__ gx_hi = nullptr,
+                                                      bf16_t* __restrict__ gx_lo = nullptr) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
     float gv[8], xv[8], mv[8], out[8], masked[8];
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ gy, 
       out[k] = fmaf(g, coefA[c + k], fmaf(xv[k], coefB[c + k], coefC[c + k]));
     }
     store8(gx, i, out);
+    if (gx_hi) store_planes8(gx_hi, gx_lo, i, out);  // the convolution behind this layer reads these instead of a split pass over gx
     if (gres) store8(gres, i, masked);             // gradient of a residual added before the ReLU
   }
 }
@@ -361,13 +363,15 @@ int channel_sums_t(const void* a, const void* b, const void* mask, const float* 
 
 template <typename T>
 int bwd_apply_t(const void* gy, const void* y_mask, const float* fwd_scale_shift, const void* x, const float* coef_a,
-                const float* coef_b, const float* coef_c, void* gx, void* gres, long long rows, int c, void* stream) {
+                const float* coef_b, const float* coef_c, void* gx, void* gres, long long rows, int c, void* stream,
+                bf16_t* gx_hi = nullptr, bf16_t* gx_lo = nullptr) {
   OMNIHD_REQUIRE(rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
   if (rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && gx, "null pointer");
   const int64_t n_vec = (int64_t)rows * (c / 8);
   hipLaunchKernelGGL((k_bn_bwd_apply<T>), dim3(grid_for(n_vec, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const T*)gy,
-                     (const T*)y_mask, (const T*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (T*)gx, (T*)gres, n_vec, c / 8);
+                     (const T*)y_mask, (const T*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (T*)gx, (T*)gres, n_vec, c / 8,
+                     gx_hi, gx_lo);
   return check_launch("bn_bwd_apply");
 }
 }  // namespace
@@ -424,7 +428,8 @@ namespace {
 template <typename T>
 int train_fwd_t(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, float momentum, float eps, float var_correction, int relu, void* y, float* stats2c,
-                float* consts4c, long long rows, int c, void* workspace, size_t workspace_bytes, void* stream) {
+                float* consts4c, long long rows, int c, void* workspace, size_t workspace_bytes, void* stream,
+                void* y_hi = nullptr, void* y_lo = nullptr) {
   int blocks = 0;
   int rc = channel_sums_t<T>(x, nullptr, nullptr, nullptr, stats2c, rows, c, 0, 1.0f, workspace, workspace_bytes, stream,
                              &blocks);
@@ -436,13 +441,16 @@ int train_fwd_t(const void* x, const void* res, const float* gamma, const float*
   rc = check_launch("bn_fwd_consts");
   if (rc) return rc;
   if (sizeof(T) == 2) return omnihd_affine_act_fwd(x, consts4c, consts4c + c, res, y, rows, c, relu, stream);
+  if (y_hi)
+    return omnihd_affine_act_fwd_f32_planes((const float*)x, consts4c, consts4c + c, (const float*)res, (float*)y, y_hi, y_lo, rows, c,
+                                            relu, stream);
   return omnihd_affine_act_fwd_f32((const float*)x, consts4c, consts4c + c, (const float*)res, (float*)y, rows, c, relu, stream);
 }
 
 template <typename T>
 int train_bwd_t(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma, const float* consts4c,
                 void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
-                size_t workspace_bytes, void* stream) {
+                size_t workspace_bytes, void* stream, void* gx_hi = nullptr, void* gx_lo = nullptr) {
   const float* fss = (relu_from_x && !y_mask) ? consts4c : nullptr;    // consts4c starts with scale, shift
   int blocks = 0;
   int rc = channel_sums_t<T>(gy, x, y_mask, fss, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream, &blocks);
@@ -453,7 +461,8 @@ int train_bwd_t(const void* gy, const void* y_mask, int relu_from_x, const void*
                      out5c + 4 * c);
   rc = check_launch("bn_bwd_consts");
   if (rc) return rc;
-  return bwd_apply_t<T>(gy, y_mask, fss, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream);
+  return bwd_apply_t<T>(gy, y_mask, fss, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream,
+                        static_cast<bf16_t*>(gx_hi), static_cast<bf16_t*>(gx_lo));
 }
 }  // namespace
 
@@ -476,6 +485,18 @@ extern "C" int omnihd_bn_train_fwd_f32(const float* x, const float* res, const f
                             consts4c, rows, c, workspace, workspace_bytes, stream);
 }
 
+/* ..._f32_planes: the same call, y additionally written as its two bf16 planes (omnihd_split_f32's output) for the next
+ * fp32-grade convolution.                                                                                 */
+extern "C" int omnihd_bn_train_fwd_f32_planes(const float* x, const float* res, const float* gamma, const float* beta,
+                                              float* running_mean, float* running_var, float momentum, float eps,
+                                              float var_correction, int relu, float* y, void* y_hi, void* y_lo, float* stats2c,
+                                              float* consts4c, long long rows, int c, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+  OMNIHD_REQUIRE(y_hi && y_lo && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15u) == 0, "plane pointers");
+  return train_fwd_t<float>(x, res, gamma, beta, running_mean, running_var, momentum, eps, var_correction, relu, y, stats2c,
+                            consts4c, rows, c, workspace, workspace_bytes, stream, y_hi, y_lo);
+}
+
 /* backward = masked channel sums -> dgamma/dbeta + coefficients -> gx (and gres).  out5c [5, c] receives
  * dgamma, dbeta and the three coefficient vectors; sums2c is scratch.                                     */
 extern "C" int omnihd_bn_train_bwd(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma,
@@ -491,4 +512,14 @@ extern "C" int omnihd_bn_train_bwd_f32(const float* gy, const float* y_mask, int
                                        void* stream) {
   return train_bwd_t<float>(gy, y_mask, relu_from_x, x, gamma, consts4c, gx, gres, sums2c, out5c, rows, c, workspace,
                             workspace_bytes, stream);
+}
+
+/* ..._f32_planes: gx additionally written as its two bf16 planes for the convolution in front of this layer. */
+extern "C" int omnihd_bn_train_bwd_f32_planes(const float* gy, const float* y_mask, int relu_from_x, const float* x,
+                                              const float* gamma, const float* consts4c, float* gx, void* gx_hi, void* gx_lo,
+                                              float* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  OMNIHD_REQUIRE(gx_hi && gx_lo && ((reinterpret_cast<uintptr_t>(gx_hi) | reinterpret_cast<uintptr_t>(gx_lo)) & 15u) == 0, "plane pointers");
+  return train_bwd_t<float>(gy, y_mask, relu_from_x, x, gamma, consts4c, gx, gres, sums2c, out5c, rows, c, workspace,
+                            workspace_bytes, stream, gx_hi, gx_lo);
 }

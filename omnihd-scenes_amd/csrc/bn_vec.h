@@ -41,4 +41,20 @@ __device__ __forceinline__ void store8(float* __restrict__ p, int64_t i, const f
   reinterpret_cast<f32x4*>(p)[2 * i + 1] = f32x4{v[4], v[5], v[6], v[7]};
 }
 
+// the two bf16 planes of 8 fp32 values (hi = bf16(v), lo = bf16(v - hi); inf / nan stay in the hi plane alone): what
+// omnihd_split_f32 writes, here from the registers of the kernel that produced v
+__device__ __forceinline__ void store_planes8(bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t i, const float (&v)[8]) {
+  u32x4 rh, rl;
+  unsigned short* eh = reinterpret_cast<unsigned short*>(&rh);
+  unsigned short* el = reinterpret_cast<unsigned short*>(&rl);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    eh[k] = f2bf(v[k]);
+    const bool finite = (eh[k] & 0x7f80) != 0x7f80;
+    el[k] = finite ? f2bf(v[k] - bf2f(eh[k])) : (unsigned short)0;
+  }
+  reinterpret_cast<u32x4*>(hi)[i] = rh;
+  reinterpret_cast<u32x4*>(lo)[i] = rl;
+}
+
 }  // namespace omnihd

@@ -807,6 +807,34 @@ def wgrad_choices():
 # the parameter, and reused while the parameter's version counter is unchanged; a training loop may refresh all
 # of them with ONE multi-tensor copy right after the optimiser step (``refresh_bf16_shadows``).
 
+# When is a cached image of a master weight stale?  The parameter's autograd version counter moves on every in-place write that
+# goes through torch's dispatcher (copy_, load_state_dict, foreach optimisers) — but NOT on the fused optimisers
+# (torch.optim.AdamW(fused=True) updates the parameters inside one kernel and leaves ``_version`` alone; found in round 3: the
+# caches below then served step-0 images for ever).  So every optimiser step of ANY optimiser also moves a global generation
+# counter (torch's global step post-hook), and an image is current only if both match.
+_WEIGHT_GEN = [0]
+
+
+def _bump_weight_generation(*_a, **_k):
+    _WEIGHT_GEN[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook
+    _WEIGHT_GEN_HOOK = _reg_step_hook(_bump_weight_generation)
+except Exception:            # pragma: no cover - very old torch: callers must use weights_changed()
+    _WEIGHT_GEN_HOOK = None
+
+
+def weights_changed():
+    """Tell the weight-image caches that parameters were written outside torch's dispatcher and outside an optimiser step."""
+    _bump_weight_generation()
+
+
+def _wver(w):
+    return (w._version, _WEIGHT_GEN[0])
+
+
 _BF16_SHADOW = {}
 
 
@@ -814,7 +842,7 @@ def bf16_of(weight):
     if weight.dtype == torch.bfloat16:
         return weight.detach()
     e = _BF16_SHADOW.get(id(weight))
-    if e is not None and e[0]() is weight and e[1] == weight._version and e[2].device == weight.device:
+    if e is not None and e[0]() is weight and e[1] == _wver(weight) and e[2].device == weight.device:
         return e[2]
     # convolution weights: the image lives in channels_last memory ((Cout,k,k,Cin), what the implicit-GEMM kernels and the
     # NHWC library kernels read), so no layer pays a layout copy per step
@@ -825,7 +853,7 @@ def bf16_of(weight):
         shadow = weight.detach().to(torch.bfloat16, memory_format=torch.channels_last)
     else:
         shadow = weight.detach().to(torch.bfloat16)
-    _BF16_SHADOW[id(weight)] = (weakref.ref(weight), weight._version, shadow)
+    _BF16_SHADOW[id(weight)] = (weakref.ref(weight), _wver(weight), shadow)
     return shadow
 
 
@@ -840,7 +868,7 @@ def bf16_dgrad_image(param, wb):
         return conv_dgrad_weights(w_cl)
     e = _BF16_DGRAD.get(id(param))
     if e is not None and e[0]() is param and e[2].device == wb.device and e[2].shape[:2] == (wb.shape[1], wb.shape[0]):
-        if e[1] == param._version:
+        if e[1] == _wver(param):
             return e[2]
         img = conv_dgrad_weights(w_cl, out=e[2])
     else:
@@ -848,7 +876,7 @@ def bf16_dgrad_image(param, wb):
     if len(_BF16_DGRAD) > 4096:
         for k in [k for k, v in _BF16_DGRAD.items() if v[0]() is None]:
             del _BF16_DGRAD[k]
-    _BF16_DGRAD[id(param)] = (weakref.ref(param), param._version, img)
+    _BF16_DGRAD[id(param)] = (weakref.ref(param), _wver(param), img)
     return img
 
 
@@ -881,7 +909,7 @@ def refresh_bf16_shadows():
         if w is None:
             del _BF16_SHADOW[k]
             _BF16_DGRAD.pop(k, None)
-        elif ver != w._version and w.device == shadow.device and w.shape == shadow.shape:
+        elif ver != _wver(w) and w.device == shadow.device and w.shape == shadow.shape:
             if (w.dim() == 4 and w.dtype == torch.float32 and w.is_cuda and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)
                     and shadow.is_contiguous(memory_format=torch.channels_last)):
                 d = _BF16_DGRAD.get(k)
@@ -897,9 +925,9 @@ def refresh_bf16_shadows():
     if src:
         torch._foreach_copy_(dst, src)
     for k, ref, w, shadow, d in keys:
-        _BF16_SHADOW[k] = (ref, w._version, shadow)
+        _BF16_SHADOW[k] = (ref, _wver(w), shadow)
         if d is not None:
-            _BF16_DGRAD[k] = (ref, w._version, d)
+            _BF16_DGRAD[k] = (ref, _wver(w), d)
     return len(keys)
 
 
@@ -1005,6 +1033,63 @@ def split_f32(t):
     return hi, lo
 
 
+def _alloc_planes(t):
+    """Uninitialised (hi, lo) planes for ``t`` in split_f32's layout (one allocation, lo at a 16-byte-aligned pitch behind hi)."""
+    n = t.numel()
+    pitch = (n + 7) // 8 * 8
+    planes = torch.empty(2 * pitch, dtype=torch.bfloat16, device=t.device)
+    return tuple(planes[i * pitch:i * pitch + n].as_strided(t.shape, t.stride()) for i in (0, 1))
+
+
+# Planes handed from a producer kernel to the split convolution that reads the tensor next (round 3): the fused BatchNorm kernels
+# can write the two bf16 planes of their fp32 output in the same pass (omnihd_bn_train_fwd_f32_planes / ..._bwd_f32_planes), which
+# saves the convolution's own split pass (a read + write of the whole tensor and a launch).  Protocol: the producer tags its
+# output tensor OBJECT with (planes, version counter, producer key); the convolution uses the planes if the tag is there and the
+# tensor has not been written since; on a miss it notes the producer key, and from the next step on that producer writes planes.
+# A producer whose planes nobody picked up stops writing them.  OMNIHD_SPLIT_HANDOVER=0 turns the whole thing off.
+_PLANES_WANTED = set()
+_PLANES_UNUSED = {}
+HANDOVER_STATS = {"taken": 0, "stale": 0, "asked": 0, "untagged": 0}
+
+
+def planes_wanted(key):
+    return key in _PLANES_WANTED and os.environ.get("OMNIHD_SPLIT_HANDOVER", "1") != "0"
+
+
+def tag_planes(t, planes, key):
+    t._omnihd_planes = (planes, t._version, key)
+    n = _PLANES_UNUSED.get(key, 0) + 1
+    _PLANES_UNUSED[key] = n
+    if n > 8:                                      # eight tensors in a row that no convolution took: stop producing
+        _PLANES_WANTED.discard(key)
+        _PLANES_UNUSED[key] = 0
+
+
+def tag_producer(t, key):
+    t._omnihd_planes = (None, t._version, key)
+
+
+def take_planes(t):
+    """The planes a producer attached to ``t`` (fp32, channels_last-dense, unmodified since), or None — in which case the
+    producer, if there is one, is asked to write them from now on."""
+    tag = getattr(t, "_omnihd_planes", None)
+    if tag is None:
+        HANDOVER_STATS["untagged"] += 1
+        return None
+    planes, version, key = tag
+    if planes is None:
+        if os.environ.get("OMNIHD_SPLIT_HANDOVER", "1") != "0":
+            _PLANES_WANTED.add(key)
+        HANDOVER_STATS["asked"] += 1
+        return None
+    if version != t._version or planes[0].shape != t.shape or planes[0].stride() != t.stride():
+        HANDOVER_STATS["stale"] += 1
+        return None
+    _PLANES_UNUSED[key] = 0
+    HANDOVER_STATS["taken"] += 1
+    return planes
+
+
 _SPLIT_SHADOW = {}
 
 
@@ -1022,7 +1107,7 @@ def split_weight(weight, dgrad=False):
     parameter's version is unchanged; ``dgrad=True``: the planes re-laid for the data gradient ((Cin,k,k,Cout), taps mirrored)."""
     key = (id(weight), dgrad)
     e = _SPLIT_SHADOW.get(key)
-    if e is not None and e[0]() is weight and e[1] == weight._version and e[2][0].device == weight.device:
+    if e is not None and e[0]() is weight and e[1] == _wver(weight) and e[2][0].device == weight.device:
         return e[2]
     if dgrad:
         planes = split_dgrad_weights(split_weight(weight))
@@ -1031,7 +1116,7 @@ def split_weight(weight, dgrad=False):
     if len(_SPLIT_SHADOW) > 4096:
         for k in [k for k, v in _SPLIT_SHADOW.items() if v[0]() is None]:
             del _SPLIT_SHADOW[k]
-    _SPLIT_SHADOW[key] = (weakref.ref(weight), weight._version, planes)
+    _SPLIT_SHADOW[key] = (weakref.ref(weight), _wver(weight), planes)
     return planes
 
 
@@ -1081,7 +1166,7 @@ def refresh_split_shadows():
         if w is None:
             del _SPLIT_SHADOW[(wid, dgrad)]
             continue
-        if ver == w._version or planes[0].device != w.device or w.dtype != torch.float32:
+        if ver == _wver(w) or planes[0].device != w.device or w.dtype != torch.float32:
             continue
         layers.setdefault(wid, [w, None, None])[2 if dgrad else 1] = planes
         touched.append((wid, dgrad, ref, w, planes))
@@ -1097,7 +1182,7 @@ def refresh_split_shadows():
     for dev, recs in per_dev.items():
         weight_images(recs, dev)
     for wid, dgrad, ref, w, planes in touched:
-        _SPLIT_SHADOW[(wid, dgrad)] = (ref, w._version, planes)
+        _SPLIT_SHADOW[(wid, dgrad)] = (ref, _wver(w), planes)
     return len(layers)
 
 
@@ -1191,7 +1276,11 @@ class _ConvSplit(torch.autograd.Function):
         # fp32 weight gradient has measured faster for this geometry (no reconstruction of x from the planes then)
         wg_miopen = (not ok_w) or (os.environ.get("OMNIHD_FP32_CONV", "tune") == "tune" and _SPLIT_CHOICE.get(("wgrad",) + geo) == "miopen")
         use_split_fwd = ok_f and not (os.environ.get("OMNIHD_FP32_CONV", "tune") == "tune" and _SPLIT_CHOICE.get(("fwd",) + geo) == "miopen")
-        xs = split_f32(x) if (use_split_fwd or not wg_miopen) else None
+        xs = None
+        if use_split_fwd or not wg_miopen:
+            xs = take_planes(x)
+            if xs is None:
+                xs = split_f32(x)
         if wg_miopen:
             ctx.save_for_backward(x, weight)
         else:
@@ -1218,9 +1307,14 @@ class _ConvSplit(torch.autograd.Function):
             x_saved, x_shape = None, x_hi.shape
         stride, padding, dilation, geo, ok_d, ok_w = ctx.conv
         dev = g.device
+        g_in = g
         g = g.float().contiguous(memory_format=torch.channels_last)
         want_w_split = ok_w and ctx.needs_input_grad[1] and not ctx.x_is_full
-        gs = split_f32(g) if ((ok_d and ctx.needs_input_grad[0]) or want_w_split) else None
+        gs = None
+        if (ok_d and ctx.needs_input_grad[0]) or want_w_split:
+            gs = take_planes(g_in) if g is g_in else None
+            if gs is None:
+                gs = split_f32(g)
         gx = gw = gb = None
         x_f32 = []
 
@@ -1588,6 +1682,9 @@ class _BnTrainAct(torch.autograd.Function):
         gamma, beta = _f32c(weight), _f32c(bias)
         L = lib()
         st = _raw_stream()
+        # fp32 4-D outputs can be handed to the next split convolution as planes (see take_planes)
+        pkey = ("bn_y", id(weight)) if (x.dtype == torch.float32 and x.dim() == 4 and ranks == 1) else None
+        y_planes = _alloc_planes(y) if (pkey is not None and planes_wanted(pkey)) else None
         rm = None if running_mean is None else running_mean.data_ptr()
         rv = None if running_var is None else running_var.data_ptr()
         resp = None if res is None else res.data_ptr()
@@ -1599,9 +1696,15 @@ class _BnTrainAct(torch.autograd.Function):
             if ranks == 1:
                 # torch's BatchNorm keeps the unbiased variance in running_var
                 corr = rows / (rows - 1.0) if rows > 1 else 1.0
-                check(getattr(L, "omnihd_bn_train_fwd" + sfx)(
-                    x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr, 1 if relu else 0,
-                    y.data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd")
+                if y_planes is not None:
+                    check(L.omnihd_bn_train_fwd_f32_planes(
+                        x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr, 1 if relu else 0,
+                        y.data_ptr(), y_planes[0].data_ptr(), y_planes[1].data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c,
+                        ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd_f32_planes")
+                else:
+                    check(getattr(L, "omnihd_bn_train_fwd" + sfx)(
+                        x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr, 1 if relu else 0,
+                        y.data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd")
             else:
                 check(getattr(L, "omnihd_bn_channel_sums" + sfx)(x.data_ptr(), None, None, None, stats.data_ptr(), rows, c, 0,
                                                                  1.0 / rows, ws.data_ptr(), ws.numel(), st), "omnihd_bn_channel_sums")
@@ -1623,6 +1726,12 @@ class _BnTrainAct(torch.autograd.Function):
         ctx.save_for_backward(x, y if keep_y else None, gamma, consts)
         ctx.relu, ctx.group, ctx.ranks, ctx.param_dtypes = relu, group, ranks, (weight.dtype, bias.dtype)
         ctx.has_res = res is not None
+        ctx.gkey = ("bn_gx", id(weight)) if pkey is not None else None
+        if pkey is not None:
+            if y_planes is not None:
+                tag_planes(y, y_planes, pkey)
+            else:
+                tag_producer(y, pkey)
         return y
 
     @staticmethod
@@ -1646,7 +1755,16 @@ class _BnTrainAct(torch.autograd.Function):
         st = _raw_stream()
         with _on(dev):
             ws = _wgrad_workspace(_SIZE_CACHE[("bn", rows, c)], dev)
-            if ctx.ranks == 1:
+            gx_planes = _alloc_planes(gx) if (ctx.gkey is not None and ctx.ranks == 1 and planes_wanted(ctx.gkey)) else None
+            if gx_planes is not None:
+                check(L.omnihd_bn_train_bwd_f32_planes(
+                    gy.data_ptr(), yp, 1 if ctx.relu else 0, x.data_ptr(), gamma.data_ptr(), consts.data_ptr(), gx.data_ptr(),
+                    gx_planes[0].data_ptr(), gx_planes[1].data_ptr(), gresp, local.data_ptr(), out.data_ptr(), rows, c,
+                    ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_bwd_f32_planes")
+                tag_planes(gx, gx_planes, ctx.gkey)
+            elif ctx.ranks == 1:
+                if ctx.gkey is not None:
+                    tag_producer(gx, ctx.gkey)
                 check(getattr(L, "omnihd_bn_train_bwd" + sfx)(
                     gy.data_ptr(), yp, 1 if ctx.relu else 0, x.data_ptr(), gamma.data_ptr(), consts.data_ptr(), gx.data_ptr(),
                     gresp, local.data_ptr(), out.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_bwd")

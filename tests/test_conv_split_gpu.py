@@ -167,3 +167,77 @@ def test_batched_weight_images_equal_the_layer_by_layer_path(cuda):
         if i != 1:
             d = ops.split_weight(w, dgrad=True)
             assert all(torch.equal(a, b) for a, b in zip(got[i][1], d)), i
+
+
+def test_batchnorm_hands_its_planes_to_the_next_split_convolution(cuda, monkeypatch):
+    """conv -> BatchNorm(train)+ReLU -> conv in fp32: from the second step on the fused BatchNorm kernels write the bf16 planes of
+    their output (forward) and of their input gradient (backward) and the convolutions skip their own split pass; results are
+    bit-identical to the run without the hand-over."""
+    from omnihd_amd import ops
+    from omnihd_amd.mm.bricks import run_fused, use_bev_conv
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "split")
+
+    def run(handover, steps=3):
+        monkeypatch.setenv("OMNIHD_SPLIT_HANDOVER", "1" if handover else "0")
+        ops._PLANES_WANTED.clear(); ops._PLANES_UNUSED.clear()
+        for k in ops.HANDOVER_STATS:
+            ops.HANDOVER_STATS[k] = 0
+        torch.manual_seed(4)
+        net = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 3, padding=1, bias=False), torch.nn.BatchNorm2d(128), torch.nn.ReLU(),
+                                  torch.nn.Conv2d(128, 64, 3, padding=1, bias=False), torch.nn.BatchNorm2d(64), torch.nn.ReLU(),
+                                  torch.nn.Conv2d(64, 64, 1, bias=False)).to(cuda).to(memory_format=torch.channels_last)
+        use_bev_conv(net)
+        x = torch.randn(2, 64, 24, 40, device=cuda).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for _ in range(steps):
+            net.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_()
+            y = run_fused(net, xi)
+            y.square().mean().backward()
+            outs.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in net.parameters()])
+        return outs, dict(ops.HANDOVER_STATS)
+
+    base, _ = run(False)
+    got, stats = run(True)
+    for a, b in zip(base, got):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    assert stats["taken"] >= 4, stats           # steps 2 and 3: at least the two forward hand-overs each
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_weight_images_follow_the_fused_optimiser_in_the_step_loop(cuda, dtype):
+    """Regression (round 3): torch.optim.AdamW(fused=True) does not move the parameters' version counters, so version-keyed weight
+    images went stale after the first step.  In the step loop of the harness every convolution weight image (bf16 shadow / split
+    planes / data-gradient image) must equal an image rebuilt from the CURRENT master weight after each optimiser step."""
+    from omnihd_amd import ops
+    from omnihd_amd.harness import FusionTrainStep
+    st = FusionTrainStep(res="tiny", batch=1, radar_dims=7, dtype=dtype)
+    for _ in range(3):
+        st.step()
+    torch.cuda.synchronize()
+    checked = 0
+    if dtype == "bf16":
+        for k, (ref, ver, shadow) in list(ops._BF16_SHADOW.items()):
+            w = ref()
+            if w is None or not w.requires_grad:
+                continue
+            assert ver == ops._wver(w)
+            assert torch.equal(shadow, w.detach().to(torch.bfloat16)), "stale bf16 image"
+            d = ops._BF16_DGRAD.get(k)
+            if d is not None and d[0]() is w:
+                want = ops.conv_dgrad_weights(w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+                assert torch.equal(d[2], want), "stale data-gradient image"
+            checked += 1
+    else:
+        for (wid, dgrad), (ref, ver, planes) in list(ops._SPLIT_SHADOW.items()):
+            w = ref()
+            if w is None or not w.requires_grad:
+                continue
+            assert ver == ops._wver(w)
+            fresh = ops.split_f32(w.detach().float().contiguous(memory_format=torch.channels_last))
+            if dgrad:
+                fresh = ops.split_dgrad_weights(fresh)
+            assert all(torch.equal(a, b) for a, b in zip(planes, fresh)), "stale split planes"
+            checked += 1
+    assert checked > 10

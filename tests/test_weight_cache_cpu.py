@@ -1,0 +1,47 @@
+"""The cached kernel images of master weights (bf16 shadows, split planes) must notice EVERY optimiser step.
+Round 3 found that torch.optim.AdamW(fused=True) updates parameters without moving their autograd version counter, which the
+caches were keyed on: after the first step the convolutions kept reading step-0 weights.  The caches are now also keyed on a
+generation counter moved by torch's global optimiser-step hook (omnihd_amd/ops.py::_WEIGHT_GEN)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "omnihd-scenes_amd")]
+
+
+@pytest.mark.parametrize("kw", [dict(fused=True), dict(foreach=True), dict()])
+def test_bf16_image_follows_the_optimiser(kw):
+    from omnihd_amd import ops
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(16, 8, 3, 3))
+    try:
+        opt = torch.optim.AdamW([w], lr=0.1, **kw)
+    except (RuntimeError, TypeError):
+        pytest.skip("this optimiser variant does not exist for CPU tensors here")
+    first = ops.bf16_of(w).clone()
+    assert torch.equal(first, w.detach().to(torch.bfloat16))
+    for _ in range(2):
+        w.grad = torch.randn_like(w)
+        opt.step()
+        img = ops.bf16_of(w)
+        assert torch.equal(img, w.detach().to(torch.bfloat16)), "stale bf16 image after an optimiser step"
+    assert not torch.equal(first, ops.bf16_of(w))
+
+
+def test_generation_counter_moves_with_every_optimiser_step_and_on_request():
+    from omnihd_amd import ops
+    w = torch.nn.Parameter(torch.zeros(4))
+    g0 = ops._WEIGHT_GEN[0]
+    opt = torch.optim.SGD([w], lr=0.1)
+    w.grad = torch.ones(4)
+    opt.step()
+    assert ops._WEIGHT_GEN[0] == g0 + 1
+    ops.weights_changed()
+    assert ops._WEIGHT_GEN[0] == g0 + 2
+    v = ops._wver(w)
+    with torch.no_grad():
+        w.add_(1.0)                       # writes through the dispatcher move the version counter
+    assert ops._wver(w) != v
