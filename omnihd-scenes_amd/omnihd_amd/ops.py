@@ -1046,14 +1046,16 @@ def _alloc_planes(t):
 # saves the convolution's own split pass (a read + write of the whole tensor and a launch).  Protocol: the producer tags its
 # output tensor OBJECT with (planes, version counter, producer key); the convolution uses the planes if the tag is there and the
 # tensor has not been written since; on a miss it notes the producer key, and from the next step on that producer writes planes.
-# A producer whose planes nobody picked up stops writing them.  OMNIHD_SPLIT_HANDOVER=0 turns the whole thing off.
+# A producer whose planes nobody picked up stops writing them.  Measured in the R1 fp32 step (alternating runs of
+# scripts/lab/step_times.py): 50.9 ms with, 50.6 ms without — the BatchNorm kernels' extra 4 B/element of stores cost what the
+# convolutions' split passes saved, so it is OFF by default (OMNIHD_SPLIT_HANDOVER=1 turns it on; results are bit-identical).
 _PLANES_WANTED = set()
 _PLANES_UNUSED = {}
 HANDOVER_STATS = {"taken": 0, "stale": 0, "asked": 0, "untagged": 0}
 
 
 def planes_wanted(key):
-    return key in _PLANES_WANTED and os.environ.get("OMNIHD_SPLIT_HANDOVER", "1") != "0"
+    return key in _PLANES_WANTED and os.environ.get("OMNIHD_SPLIT_HANDOVER", "0") == "1"
 
 
 def tag_planes(t, planes, key):
@@ -1078,7 +1080,7 @@ def take_planes(t):
         return None
     planes, version, key = tag
     if planes is None:
-        if os.environ.get("OMNIHD_SPLIT_HANDOVER", "1") != "0":
+        if os.environ.get("OMNIHD_SPLIT_HANDOVER", "0") == "1":
             _PLANES_WANTED.add(key)
         HANDOVER_STATS["asked"] += 1
         return None
