@@ -1002,10 +1002,10 @@ def sync_tuned_choices(group=None, src=0):
         return 0
     me = _current_device() if torch.cuda.is_available() else None
     strip = lambda table: {k[:-1]: v for k, v in table.items()}
-    payload = [(strip(_CONV_CHOICE), strip(_WGRAD_CHOICE))] if dist.get_rank(group) == src else [None]
+    payload = [(strip(_CONV_CHOICE), strip(_WGRAD_CHOICE), strip(_SPLIT_CHOICE))] if dist.get_rank(group) == src else [None]
     dist.broadcast_object_list(payload, src=src, group=group)
     changed = 0
-    for table, theirs in ((_CONV_CHOICE, payload[0][0]), (_WGRAD_CHOICE, payload[0][1])):
+    for table, theirs in ((_CONV_CHOICE, payload[0][0]), (_WGRAD_CHOICE, payload[0][1]), (_SPLIT_CHOICE, payload[0][2])):
         for k, v in theirs.items():
             if table.get(k + (me,)) != v:
                 table[k + (me,)] = v

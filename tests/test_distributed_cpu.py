@@ -180,3 +180,38 @@ def test_packed_hard_vfe_exchanges_statistics_like_the_dense_one_on_two_ranks():
     for r in (0, 1):
         assert res[r][0] < 1e-6 and res[r][1] < 1e-5 and res[r][2] < 1e-6, res[r]      # the layer's exchange branch computes in float32
     assert abs(res[0][3] - res[1][3]) < 1e-6                 # both ranks hold the same running statistics
+
+
+def _choice_worker(rank, world, port, out):
+    import sys
+    sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                    os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omnihd-scenes_amd")]
+    from omnihd_amd import ops
+    _init(rank, world, port)
+    geo = ((1, 64, 8, 8), 64, 3, 1, 1, 1)
+    # every rank has measured something else (rank 1 also knows a geometry rank 0 has not seen)
+    ops._CONV_CHOICE[("fwd", (1, 64, 8, 8), 64, 3, 1, None)] = "hip" if rank == 0 else "miopen"
+    ops._WGRAD_CHOICE[((1, 64, 8, 8), 64, 3, 1, 1, 1, None)] = "miopen" if rank == 0 else "hip"
+    for d in ("fwd", "dgrad", "wgrad"):
+        ops._SPLIT_CHOICE[(d,) + geo + (None,)] = "split" if rank == 0 else "miopen"
+    if rank == 1:
+        ops._SPLIT_CHOICE[("fwd", (1, 8, 4, 4), 8, 1, 1, 0, 1, None)] = "split"
+    changed = ops.sync_tuned_choices()
+    torch.save(dict(changed=changed, conv=dict(ops._CONV_CHOICE), wgrad=dict(ops._WGRAD_CHOICE), split=dict(ops._SPLIT_CHOICE)),
+               os.path.join(out, f"choices{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_agree_on_rank_zeros_kernel_choices_including_the_split_convolutions():
+    """per-geometry kernel choices are measured per rank; after ops.sync_tuned_choices() every rank runs
+    rank 0's choices — the bf16 forward / data-gradient table, the weight-gradient table and (round 3) the fp32 split table."""
+    import tempfile
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_choice_worker, args=(2, port, out), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(out, f"choices{r}.pt")) for r in range(2))
+    assert r0["changed"] == 0 and r1["changed"] == 5
+    for table in ("conv", "wgrad", "split"):
+        for k, v in r0[table].items():
+            assert r1[table][k] == v, (table, k)
+    assert len(r1["split"]) == len(r0["split"]) + 1          # what only rank 1 had measured stays
