@@ -832,10 +832,12 @@ def weights_changed():
 
 
 def _wver(w):
-    return (w._version, _WEIGHT_GEN[0])
+    # (frozen weights are not touched by an optimiser: only the version counter applies to them)
+    return (w._version, _WEIGHT_GEN[0] if w.requires_grad else -1)
 
 
 _BF16_SHADOW = {}
+_SHADOW_EPOCH = [0]          # moves whenever an image BUFFER is created or replaced (the cached refresh plan holds raw pointers)
 
 
 def bf16_of(weight):
@@ -851,8 +853,10 @@ def bf16_of(weight):
         shadow.copy_(weight.detach())
     elif weight.dim() == 4:
         shadow = weight.detach().to(torch.bfloat16, memory_format=torch.channels_last)
+        _SHADOW_EPOCH[0] += 1
     else:
         shadow = weight.detach().to(torch.bfloat16)
+        _SHADOW_EPOCH[0] += 1
     _BF16_SHADOW[id(weight)] = (weakref.ref(weight), _wver(weight), shadow)
     return shadow
 
@@ -873,6 +877,7 @@ def bf16_dgrad_image(param, wb):
         img = conv_dgrad_weights(w_cl, out=e[2])
     else:
         img = conv_dgrad_weights(w_cl)
+        _SHADOW_EPOCH[0] += 1
     if len(_BF16_DGRAD) > 4096:
         for k in [k for k, v in _BF16_DGRAD.items() if v[0]() is None]:
             del _BF16_DGRAD[k]
@@ -899,17 +904,26 @@ def bf16_weight(weight):
     return _Bf16Weight.apply(weight) if weight.requires_grad and torch.is_grad_enabled() else bf16_of(weight)
 
 
+_BF16_PLAN = {}
+
+
 def refresh_bf16_shadows():
-    """Bring every stale bf16 image up to date: convolution weights (and their data-gradient images, where a layer has one) with
-    ONE launch of omnihd_weight_images, everything else with one fused copy; returns how many were refreshed."""
-    src, dst, keys = [], [], []
-    per_dev = {}
-    for k, (ref, ver, shadow) in list(_BF16_SHADOW.items()):
-        w = ref()
-        if w is None:
-            del _BF16_SHADOW[k]
-            _BF16_DGRAD.pop(k, None)
-        elif ver != _wver(w) and w.device == shadow.device and w.shape == shadow.shape:
+    """Bring the bf16 images of all TRAINABLE weights up to date: convolution weights (and their data-gradient images, where a layer
+    has one) with ONE launch of omnihd_weight_images, everything else with one fused copy; returns how many were refreshed.  The
+    launch plan (device table, copy lists) is kept while the set of registered images is unchanged, so a steady-state call is a
+    table lookup, two launches and one pass over the entries to stamp them current."""
+    sig = (len(_BF16_SHADOW), len(_BF16_DGRAD), _SHADOW_EPOCH[0])
+    plan = _BF16_PLAN.get("plan")
+    if plan is None or plan[0] != sig or any(ref() is None for _k, ref, _s, _d in plan[1]):
+        entries, per_dev, src, dst = [], {}, [], []
+        for k, (ref, ver, shadow) in list(_BF16_SHADOW.items()):
+            w = ref()
+            if w is None:
+                del _BF16_SHADOW[k]
+                _BF16_DGRAD.pop(k, None)
+                continue
+            if not w.requires_grad or w.device != shadow.device or w.shape != shadow.shape:
+                continue                          # frozen weights change only through torch (version counter): bf16_of sees that
             if (w.dim() == 4 and w.dtype == torch.float32 and w.is_cuda and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)
                     and shadow.is_contiguous(memory_format=torch.channels_last)):
                 d = _BF16_DGRAD.get(k)
@@ -917,18 +931,21 @@ def refresh_bf16_shadows():
                 cout, cin, kk, _ = w.shape
                 per_dev.setdefault(w.device, []).append((w.data_ptr(),) + tuple(w.stride()) + (shadow.data_ptr(), 0, 0 if d is None else d.data_ptr(),
                                                                                                0, cout, cin, kk))
-                keys.append((k, ref, w, shadow, d))
+                entries.append((k, ref, shadow, d))
             else:
-                src.append(w.detach()); dst.append(shadow); keys.append((k, ref, w, shadow, None))
+                src.append(w.detach()); dst.append(shadow); entries.append((k, ref, shadow, None))
+        plan = _BF16_PLAN["plan"] = ((len(_BF16_SHADOW), len(_BF16_DGRAD), _SHADOW_EPOCH[0]), entries, per_dev, src, dst)
+    _sig, entries, per_dev, src, dst = plan
     for dev, recs in per_dev.items():
         weight_images(recs, dev)
     if src:
         torch._foreach_copy_(dst, src)
-    for k, ref, w, shadow, d in keys:
-        _BF16_SHADOW[k] = (ref, _wver(w), shadow)
+    for k, ref, shadow, d in entries:
+        ver = _wver(ref())
+        _BF16_SHADOW[k] = (ref, ver, shadow)
         if d is not None:
-            _BF16_DGRAD[k] = (ref, _wver(w), d)
-    return len(keys)
+            _BF16_DGRAD[k] = (ref, ver, d)
+    return len(entries)
 
 
 # Forward and data gradient of the stride-1 "same" convolutions: the implicit-GEMM MFMA kernel of this library
