@@ -589,7 +589,7 @@ def main():
             "step_ms": spread, "vs_baseline": None, "dtype": ("bf16" if main_dt == "bf16" else "f32"),
             "data": "synthetic",
             "config": {"workload": (f"fusion@{a.res}: BEVFUSION_depth (reference config bevfusion_NewScenes/bevfusion.py) training step "
-                                    f"fwd+bwd+clip+AdamW; 6 cams {RES[a.res][0]}x{RES[a.res][1]}, R50+FPNC, LSS D=59 C=64, BEV 240x160x16, "
+                                    f"fwd+bwd+clip+AdamW+refresh of the kernels' weight images; 6 cams {RES[a.res][0]}x{RES[a.res][1]}, R50+FPNC, LSS D=59 C=64, BEV 240x160x16, "
                                     f"radar N~U(8k,20k)x{radar_dims}, 30 GT boxes; random-init weights"
                                     if a.workload == "fusion" else
                                     f"bev_ops@{a.res}: LSS bev_pool_v2 fwd(dense)+bwd, radar hard-voxelize + pillar scatter; "
