@@ -827,7 +827,8 @@ except Exception:            # pragma: no cover - very old torch: callers must u
 
 
 def weights_changed():
-    """Tell the weight-image caches that parameters were written outside torch's dispatcher and outside an optimiser step."""
+    """Tell the weight-image caches that parameters were changed in a way that moves neither their version counter nor an
+    optimiser step (writes through ``param.data``, custom kernels on the raw pointer)."""
     _bump_weight_generation()
 
 

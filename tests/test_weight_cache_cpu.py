@@ -45,3 +45,15 @@ def test_generation_counter_moves_with_every_optimiser_step_and_on_request():
     with torch.no_grad():
         w.add_(1.0)                       # writes through the dispatcher move the version counter
     assert ops._wver(w) != v
+
+
+def test_writes_through_data_need_the_explicit_notice():
+    """``param.data.add_()`` moves neither the version counter nor an optimiser step: the documented contract is to call
+    ops.weights_changed() afterwards (INTEGRATION.md)."""
+    from omnihd_amd import ops
+    w = torch.nn.Parameter(torch.randn(8, 8, 1, 1))
+    a = ops.bf16_of(w).clone()
+    w.data.add_(1.0)
+    ops.weights_changed()
+    b = ops.bf16_of(w)
+    assert torch.equal(b, w.detach().to(torch.bfloat16)) and not torch.equal(a, b)
