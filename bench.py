@@ -595,6 +595,11 @@ def main():
                                     f"bev_ops@{a.res}: LSS bev_pool_v2 fwd(dense)+bwd, radar hard-voxelize + pillar scatter; "
                                     f"6 cams {RES[a.res][0]}x{RES[a.res][1]} -> fmap {fH}x{fW}, D=59, C=64, BEV 240x160x16; "
                                     "conv backbone/BEV encoder NOT in this workload"),
+                       "precision": ("fp32 activations and master weights; dense convolutions on the fp32-grade split-bf16 MFMA kernels of this "
+                                     "library (x*w = hi*hi + hi*lo + lo*hi with fp32 accumulation, 5e-6 of an fp32 convolution: parity 1e-4 in "
+                                     "tests/test_conv_split_gpu.py) or on MIOpen's fp32 kernels, measured per geometry (OMNIHD_FP32_CONV)"
+                                     if (main_dt != "bf16" and a.workload == "fusion") else
+                                     "bf16 autocast for the dense convolutions, everything else fp32" if a.workload == "fusion" else "fp32 operators"),
                        "frames_per_gpu": a.batch, "n_points": n_points, "n_intervals": n_intervals,
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
                                        "overlapped with backward) + naiveSyncBN stat exchange" if a.workload == "fusion"
