@@ -140,3 +140,25 @@ def test_cost_balanced_patch_schedule_is_a_permutation_with_equal_cost_runs():
     per0 = flat.numel() // 8
     c0 = [float(cost[flat[k * per0:(k + 1) * per0][flat[k * per0:(k + 1) * per0] >= 0].long()].sum()) for k in range(8)]
     assert max(c0) / min(c0) > max(run_cost) / min(run_cost)
+
+
+def test_packed_row_and_depth_bin_table_of_the_patch_backward(monkeypatch):
+    """plan._row_bin: one int32 per frustum point = output row | depth bin << 24 (what omnihd_bev_pool_v2_bwd_patch reads when
+    ranks_depth is NULL); the bin is recovered from the depth rank as (rank // (fH*fW)) % D; limits fall back to two tables."""
+    from types import SimpleNamespace
+    from omnihd_amd.plan import _row_bin
+    rng = np.random.default_rng(3)
+    n_img, D, fhw, n_rows = 5, 59, 7 * 11, 4000
+    img, d, hw = rng.integers(0, n_img, 900), rng.integers(0, D, 900), rng.integers(0, fhw, 900)
+    rd = torch.from_numpy(((img * D + d) * fhw + hw).astype(np.int32))
+    rr = torch.from_numpy(rng.integers(0, n_rows, 900).astype(np.int32))
+    plan = SimpleNamespace(bp_row_bin=None, depth_bins=D, n_rows=n_rows, feat_hw=fhw, bp_ranks_depth=rd, bp_ranks_row=rr)
+    packed = _row_bin(plan)
+    assert packed.dtype == torch.int32 and packed is plan.bp_row_bin
+    assert torch.equal(packed & 0x00ffffff, rr) and torch.equal((packed >> 24) & 0xff, torch.from_numpy(d.astype(np.int32)))
+    assert _row_bin(plan) is packed                                     # built once per plan
+    for bad in (dict(depth_bins=128), dict(n_rows=0x00ffffff), dict(depth_bins=0)):
+        p2 = SimpleNamespace(**{**vars(plan), "bp_row_bin": None, **bad})
+        assert _row_bin(p2) is None
+    monkeypatch.setenv("OMNIHD_POOL_BWD_PACKED", "0")
+    assert _row_bin(plan) is None
