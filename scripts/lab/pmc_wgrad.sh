@@ -9,7 +9,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/p[12]/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_wgrad_split3" in r["Kernel_Name"]:
+        if "k_wgrad_split3" in r["Kernel_Name"] or "k_wgrad_shift" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:34s} {sum(v[-5:])/len(v[-5:]):16.0f}")
