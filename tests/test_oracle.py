@@ -315,3 +315,26 @@ def test_dcn_oracle_backward_is_the_gradient_of_its_forward():
             args = {"x": (a, off, w), "offset": (x, a, w), "weight": (x, off, a)}[name], {"x": (b, off, w), "offset": (x, b, w), "weight": (x, off, b)}[name]
             num = (f(*args[0]) - f(*args[1])) / (2 * eps)
             assert abs(num - grad[idx]) <= 2e-2 * max(1.0, abs(num)), (name, idx, num, grad[idx])
+
+
+@pytest.mark.parametrize("dg", [1, 2])
+def test_dcn_oracle_agrees_with_the_two_torch_formulations_of_the_product(dg):
+    """Three independent restatements of mmcv's deformable convolution — the C oracle (plain loops), the product's row-gather +
+    GEMM formulation and its grid_sample formulation (omnihd_amd/mm/dcn.py, the CPU / reference paths of DeformConv2dPack) — on
+    random fractional offsets that reach across the border (|offset| up to 2.5), groups = 4; 1e-5 of the largest output."""
+    import torch
+    from omnihd_amd.mm.dcn import DeformConv2dPack
+    rng = np.random.default_rng(31 + dg)
+    B, C, H, W, N = 2, 16, 7, 9, 16
+    m = DeformConv2dPack(C, N, 3, stride=1, padding=1, dilation=1, groups=4, deform_groups=dg)
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(rng.normal(size=m.weight.shape).astype(np.float32)))
+    x = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    off = rng.uniform(-2.5, 2.5, size=(B, dg * 18, H, W)).astype(np.float32)
+    want = OC.deform_conv(x, off, m.weight.detach().numpy(), 1, 1, 1, groups=4, deform_groups=dg)
+    with torch.no_grad():
+        got = [m._sample_and_contract(torch.from_numpy(x), torch.from_numpy(off)).numpy()]
+        if dg == 1:
+            got.append(m._gather_and_gemm(torch.from_numpy(x), torch.from_numpy(off), torch.float32).numpy())
+    for g in got:
+        assert g.shape == want.shape and np.abs(g - want).max() <= 1e-5 * np.abs(want).max()
