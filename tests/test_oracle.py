@@ -147,6 +147,43 @@ def test_hard_voxelize_refused_voxel_does_not_block_existing():
     assert c.tolist() == [[0, 0, 0], [0, 0, 1]] and n.tolist() == [2, 1]
 
 
+def test_hard_voxelize_against_an_independent_dictionary_restatement():
+    """A second, independent statement of upstream's sequential algorithm (a dict from cell to voxel id, point by point) on random
+    clouds that hit both caps and contain NaNs / out-of-range points; every output identical."""
+    rng = np.random.default_rng(12)
+    vs, cr = np.float32([0.5, 0.5, 4.0]), np.float32([-4.0, -3.0, -2.0, 4.0, 3.0, 2.0])
+    grid = [int(round(float((cr[3 + a] - cr[a]) / vs[a]))) for a in range(3)]
+    for trial, (n, mp, mv) in enumerate([(3000, 4, 150), (500, 10, 400), (2000, 1, 50)]):
+        pts = rng.uniform(-4.6, 4.6, size=(n, 5)).astype(np.float32)
+        pts[:, 2] = rng.uniform(-2.4, 2.4, size=n)
+        pts[rng.integers(0, n, 5), 0] = np.nan
+        ids, vox, coors, num = {}, [], [], []
+        for p in pts:
+            c = []
+            for a in range(3):
+                v = np.floor((np.float32(p[a]) - cr[a]) / vs[a])
+                if not (v >= 0 and v < grid[a]):           # NaN fails both comparisons
+                    c = None
+                    break
+                c.append(int(v))
+            if c is None:
+                continue
+            key = (c[2], c[1], c[0])
+            if key not in ids:
+                if len(vox) >= mv:
+                    continue
+                ids[key] = len(vox)
+                vox.append(np.zeros((mp, 5), np.float32)); coors.append(key); num.append(0)
+            k = ids[key]
+            if num[k] < mp:
+                vox[k][num[k]] = p
+                num[k] += 1
+        v, c, m = OC.hard_voxelize(pts, vs, cr, max_points=mp, max_voxels=mv)
+        assert c.tolist() == [list(k) for k in coors] and m.tolist() == num, trial
+        assert np.array_equal(v, np.stack(vox), equal_nan=True), trial
+        assert len(vox) == mv or trial == 1                 # trials 0 and 2 hit the voxel cap
+
+
 def test_pillar_scatter_index():
     feats = np.arange(2 * 3, dtype=np.float32).reshape(2, 3) + 1
     coors = np.array([[0, 0, 1, 2], [1, 0, 0, 3]], dtype=np.int32)
