@@ -113,6 +113,21 @@ int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int
                                 const int* tile_desc, int n_tiles, float* out, int c, int n_rows, int n_points,
                                 int d_bins, int fhw, int n_feat_rows, int empty_rows_kept, void* stream);
 
+/* The same dense forward for C = 64 without LDS staging of the point records (round 4): every group of 16 lanes walks its
+ * own piece of the tile's point list straight from global memory (csrc/bev_pool_v2.hip, k_pool_fwd_direct).
+ *   pt        (n_points ints)   ranks_depth | closing << 31, closing = the point is the last one of its output row;
+ *   ivl_rel   (n_intervals ints) output row of the k-th non-empty row of the launch, relative to the first row of its tile;
+ *   desc32    (n_slots x 32 ints, n_slots = 8*k, 16-byte aligned) launch schedule as in omnihd_bev_pool_v2_fwd_csr:
+ *             {first row, #rows, first point, #points, 0, 0, 0, 0, g[16], 0 x 8} with g[j] = number of non-empty rows of the
+ *             launch that close before point first_point + min(j*w, #points), w = ceil(#points/16), | 1<<31 when that
+ *             point continues the row of the point in front of it inside the same tile;
+ *   row_ptr   CSR over all rows (only read to zero-fill empty rows: may be NULL when empty_rows_kept != 0).
+ * Same tiles, same result contract as omnihd_bev_pool_v2_fwd_lean (rows cut by the in-tile split are combined in a fixed
+ * order; run-to-run identical; no atomics).  ref: replaces ops/bev_pool_v2/src/bev_pool_cuda.cu:21-48 + bev_pool.py:27,91. */
+int omnihd_bev_pool_v2_fwd_direct(const float* depth, const float* feat, const int* pt, const int* ivl_rel, int n_intervals,
+                                  const int* desc32, int n_slots, const int* row_ptr, float* out, int c, int n_rows,
+                                  int n_points, int d_bins, int fhw, int n_feat_rows, int empty_rows_kept, void* stream);
+
 /* Schedule descriptors for the call above from a tile table (omnihd_csr_tiles) and an optional
  * tile order (8*ceil(n_tiles/8) ints, -1 = idle slot, NULL = tiles in index order).          */
 int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const int* tile_order,

@@ -1191,6 +1191,198 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_pool_fwd_direct (round 4, C = 64): the tiled dense forward WITHOUT the LDS staging of the point records.
+//
+// Why: at the repo's own resolution (544x960: 4.5 M points, 6 552 tiles) k_pool_fwd_lean2 takes 93 us with every input
+// resident in the Infinity Cache, 86 us with ALL feature gathers compiled out and 98 us with all stores compiled out
+// (profiles/round4/pool_fwd_r2_ablation.txt): neither bytes nor gathers bound it.  Its per-workgroup timeline (same
+// file) is a chain of dependent phases — descriptor 1.8-5 us -> rank table + row_ptr loads 4.8 -> depth gather -> LDS
+// records -> barrier 3.3 -> closing flags -> barrier 1.3 -> 11 point steps of four gathers each 10 -> tail 2 = 27 us per
+// tile, 3.4 rounds of 2 048 resident workgroups: the launch is the latency of that chain times the rounds.
+//
+// Here a group of 16 lanes (one output row at a time, as before) reads ITS OWN piece of the tile's point list straight from
+// global memory, 16 points at a time, one per lane: the lane gathers the depth value of its point, derives the pixel row,
+// and hands {pixel offset, depth, closing flag, output row} to the row's lanes with DPP row broadcasts — the scheme of
+// k_pool_bwd_patch.  No record staging, no barrier in front of the point loop, 8 feature-row gathers in flight per group
+// instead of 4, tables of chunk k+2 / depth values of chunk k+1 requested while chunk k is being accumulated.
+//   * per-point table: ONE int32 `pt` = ranks_depth | closing << 31 (closing = last point of its output row);
+//   * the output row of the k-th non-empty row of the launch is `ivl_rel[k]`, relative to its tile's first row; a group finds
+//     its first k in the tile descriptor (number of rows closed before its piece), later ones by counting closing flags;
+//   * pad lanes hold a sentinel whose depth offset and pixel offset lie beyond their buffers: range-checked buffer loads
+//     return 0 * 0, the point loop has no bounds test (as in k_pool_fwd_lean2);
+//   * rows cut by a piece boundary are combined after ONE barrier in piece order (same rule as k_pool_fwd_lean2); pieces
+//     are ceil(n/16) points, so such rows may differ from k_pool_fwd_lean2 in the last bit; no atomics, run-to-run identical.
+// Tile descriptor: 32 ints {first row, #rows, first point, #points, 0,0,0,0, g[16], 0 x 8}, g[j] = number of non-empty rows
+// of the launch closed before group j's piece | (piece starts inside a row) << 31.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPtSentinel = 0x3fffffff;
+
+struct DirectChunk {       // what a lane holds about ITS point of a 16-point chunk
+  float dval;              // depth value (0 for a pad lane)
+  int px;                  // byte offset of the pixel's feature row (beyond the buffer for a pad lane)
+  int flag;                // < 0: the point closes its output row
+  int row;                 // output row of a closing point, relative to the tile's first row
+  unsigned long long cm;   // wave ballot of `flag < 0`
+};
+
+template <int J>
+__device__ __forceinline__ void direct_point(const u32x4t a, const DirectChunk& ck, const __amdgpu_buffer_rsrc_t out_rsrc,
+                                             unsigned lane_off, float4& acc, bool& pend, float4* s_head, int* s_head_row,
+                                             int tid, int grp, int sub) {
+  const float d = dpp_row_bcast_f<J>(ck.dval);
+  acc = fma4(d, make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)), acc);
+  if (ck.cm & (0x0001000100010001ull << J)) {          // wave-uniform: one of the wave's four groups closes a row at its point J
+    const int cj = dpp_row_bcast_i<J>(ck.flag);        // every lane is active here (DPP reads other lanes)
+    const int rj = dpp_row_bcast_i<J>(ck.row);
+    if (cj < 0) {
+      if (pend) {                                      // head partial of a row that an earlier piece started
+        s_head[tid] = acc;
+        if (sub == 0) s_head_row[grp] = rj;
+        pend = false;
+      } else {
+        const u32x4t o = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)rj << 8) | lane_off, 0, 2 /* nt */);
+      }
+      acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+template <int J0>
+__device__ __forceinline__ void direct_batch8(const __amdgpu_buffer_rsrc_t feat_rsrc, const __amdgpu_buffer_rsrc_t out_rsrc,
+                                              unsigned lane_off, const DirectChunk& ck, float4& acc, bool& pend, float4* s_head,
+                                              int* s_head_row, int tid, int grp, int sub) {
+#define OMNIHD_G(K) const u32x4t a##K = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)dpp_row_bcast_i<J0 + K>(ck.px) | lane_off, 0, 0);
+  OMNIHD_G(0) OMNIHD_G(1) OMNIHD_G(2) OMNIHD_G(3) OMNIHD_G(4) OMNIHD_G(5) OMNIHD_G(6) OMNIHD_G(7)
+#undef OMNIHD_G
+  direct_point<J0 + 0>(a0, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+  direct_point<J0 + 1>(a1, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+  direct_point<J0 + 2>(a2, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+  direct_point<J0 + 3>(a3, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+  direct_point<J0 + 4>(a4, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+  direct_point<J0 + 5>(a5, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+  direct_point<J0 + 6>(a6, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+  direct_point<J0 + 7>(a7, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pool_fwd_direct(
+    const float* __restrict__ depth, unsigned depth_bytes, const float* __restrict__ feat, unsigned feat_bytes,
+    const int* __restrict__ pt, const int* __restrict__ ivl_rel, unsigned ivl_bytes, const int* __restrict__ desc32,
+    const int* __restrict__ row_ptr, float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw,
+    float inv_dfhw, int empty_rows_kept) {
+  constexpr int C4 = 16, G = kBlock / C4, GPW = 64 / C4;
+  __shared__ float4 s_tail[kBlock];
+  __shared__ float4 s_head[kBlock];
+  __shared__ int s_head_row[G];
+  __shared__ int s_tail_flags[G];
+
+  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
+  const int* dsc = desc32 + ((size_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)) * 32;
+  const int Ra = dsc[0], nrows = dsc[1], Pa = dsc[2], npts = dsc[3];
+  if (nrows <= 0) return;
+  const int tid = threadIdx.x;
+  const int sub = tid % C4;
+  const int grp = tid / C4;
+  const int lane = tid & 63;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4* out4 = reinterpret_cast<float4*>(out);
+
+  // ---- my piece of the point list; its first table words are requested before anything else --------------------
+  const int Wp = (npts + G - 1) / G;
+  const int q0 = Pa + min(grp * Wp, npts);
+  const int q1 = Pa + min(grp * Wp + Wp, npts);
+  const int nchunks = (Wp + kPatch - 1) / kPatch;            // the same for every group (scalar trip count)
+  int pt_a = kPtSentinel, pt_b = kPtSentinel, pt_last = -1, gi = 0;
+  if (npts > 0) {
+    if (q0 + sub < q1) pt_a = pt[q0 + sub];
+    if (q0 + kPatch + sub < q1) pt_b = pt[q0 + kPatch + sub];
+    if (q1 > q0) pt_last = pt[q1 - 1];
+    gi = dsc[8 + grp];
+  }
+
+  // ---- zero-fill the rows no point falls into (unless the caller's buffer holds those zeros already) -----------
+  if (!empty_rows_kept && !(nrows == 1 && npts > 0)) {
+    const int gw = lane / C4;
+    for (int base = 0; base < nrows; base += kBlock) {
+      const int i = base + tid;
+      bool empty = false;
+      if (i < nrows) empty = row_ptr[Ra + i + 1] == row_ptr[Ra + i];
+      const unsigned long long m = __ballot(empty);
+      if (m == 0ull) continue;
+      const int wave_row0 = Ra + base + (tid & ~63);
+      for (int k = 0; k < 64; k += GPW) {
+        if (((m >> k) & ((1ull << GPW) - 1ull)) == 0ull) continue;
+        if ((m >> (k + gw)) & 1ull) store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
+      }
+    }
+  }
+  if (npts == 0) return;
+
+  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t depth_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)depth, 0, (int)depth_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ivl_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ivl_rel, 0, (int)ivl_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)Ra * (C4 * 4)), 0, nrows << 8, 0x00020000);
+  const unsigned lane_off = (unsigned)sub << 4;
+  int ivl = gi & 0x7fffffff;                                 // non-empty rows of the launch closed before my piece
+  const bool was_pending = (gi < 0) && (q0 < q1);            // my first point continues a row an earlier piece started
+  bool pend = was_pending;
+  const unsigned below = (1u << sub) - 1u;
+  const int gsh = lane & 48;
+
+  // lane's own point of a chunk: depth gather + pixel offset + output row of a closing point (all requests, no waits)
+  auto stage = [&](int p) {
+    DirectChunk ck;
+    const int rd = p & 0x7fffffff;
+    ck.flag = p;
+    ck.dval = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(depth_rsrc, (unsigned)rd << 2, 0, 0));   // pad: beyond -> 0
+    const int n = div_const(rd, dfhw, inv_dfhw);
+    const int q = div_const(rd, fhw, inv_fhw);
+    const int pixel = n * fhw + (rd - q * fhw);
+    ck.px = (p == kPtSentinel) ? (int)0x80000000 : (pixel << 8);
+    ck.cm = __builtin_amdgcn_ballot_w64(p < 0);
+    const unsigned m16 = (unsigned)(ck.cm >> gsh) & 0xffffu;
+    const int k = ivl + __builtin_popcount(m16 & below);
+    ck.row = (int)__builtin_amdgcn_raw_buffer_load_b32(ivl_rsrc, (p < 0) ? ((unsigned)k << 2) : 0xfffffffcu, 0, 0);
+    ivl += __builtin_popcount(m16);
+    return ck;
+  };
+
+  float4 acc = zero4;
+  DirectChunk nxt = stage(pt_a);
+  for (int c = 0; c < nchunks; ++c) {
+    const DirectChunk ck = nxt;
+    pt_a = pt_b;
+    pt_b = kPtSentinel;
+    if (q0 + (c + 2) * kPatch + sub < q1) pt_b = pt[q0 + (c + 2) * kPatch + sub];
+    if (c + 1 < nchunks) nxt = stage(pt_a);
+    direct_batch8<0>(feat_rsrc, out_rsrc, lane_off, ck, acc, pend, s_head, s_head_row, tid, grp, sub);
+    direct_batch8<8>(feat_rsrc, out_rsrc, lane_off, ck, acc, pend, s_head, s_head_row, tid, grp, sub);
+  }
+
+  // ---- rows cut by a piece boundary: tails of earlier pieces + my head partial, in piece order ------------------
+  const bool pending = pend;                                 // started inside a row and never closed it
+  const bool open_end = (q1 <= q0) || (pt_last >= 0);        // the piece ends inside a row (an empty piece lies inside one)
+  s_tail[tid] = acc;
+  if (sub == 0) s_tail_flags[grp] = (open_end ? 1 : 0) | ((pending || q1 <= q0) ? 2 : 0);
+  __syncthreads();
+  if (was_pending && !pending) {
+    int g0 = grp;
+    while (g0 > 0) {
+      const int f = s_tail_flags[g0 - 1];
+      if (!(f & 1)) break;
+      --g0;
+      if (!(f & 2)) break;
+    }
+    float4 tsum = zero4;
+    for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
+    tsum = add4(tsum, s_head[tid]);
+    const u32x4t o = {__float_as_uint(tsum.x), __float_as_uint(tsum.y), __float_as_uint(tsum.z), __float_as_uint(tsum.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)s_head_row[grp] << 8) | lane_off, 0, 2);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_pool_bwd_generic(
     const float* __restrict__ og, const float* __restrict__ depth, const float* __restrict__ feat,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
@@ -1365,6 +1557,30 @@ extern "C" int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat
   }
 #undef OMNIHD_LEAN_CASE
   return check_launch("bev_pool_v2_fwd_lean");
+}
+
+extern "C" int omnihd_bev_pool_v2_fwd_direct(const float* depth, const float* feat, const int* pt, const int* ivl_rel,
+                                             int n_intervals, const int* desc32, int n_slots, const int* row_ptr, float* out,
+                                             int c, int n_rows, int n_points, int d_bins, int fhw, int n_feat_rows,
+                                             int empty_rows_kept, void* stream) {
+  OMNIHD_REQUIRE(c == 64, "the direct forward is written for C = 64 (use omnihd_bev_pool_v2_fwd_lean otherwise)");
+  OMNIHD_REQUIRE(n_rows >= 0 && n_slots > 0 && n_slots % 8 == 0 && n_points >= 0 && n_intervals >= 0 && d_bins > 0 && fhw > 0 &&
+                     n_feat_rows > 0, "sizes");
+  if (n_rows == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(depth && feat && out && desc32 && (n_points == 0 || (pt && ivl_rel)), "null pointer");
+  OMNIHD_REQUIRE(empty_rows_kept || row_ptr, "row_ptr is needed to zero-fill the empty rows");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(desc32)) & 15u) == 0,
+                 "16-byte aligned feat / out / desc32");
+  const long long feat_bytes = (long long)n_feat_rows * c * 4;
+  const long long depth_bytes = (long long)n_feat_rows * d_bins * 4;
+  OMNIHD_REQUIRE(feat_bytes < (1ll << 31) && depth_bytes < (1ll << 32) - 8 && (long long)n_feat_rows * d_bins < kPtSentinel,
+                 "feature table below 2 GiB and depth tensor below 4 GiB (32-bit gather offsets)");
+  OMNIHD_REQUIRE((long long)d_bins * fhw < (1ll << 30), "D * fH * fW too large");
+  const int dfhw = d_bins * fhw;
+  hipLaunchKernelGGL(k_pool_fwd_direct, dim3(n_slots), dim3(kBlock), 0, (hipStream_t)stream, depth, (unsigned)depth_bytes, feat,
+                     (unsigned)feat_bytes, pt, ivl_rel, (unsigned)((long long)n_intervals * 4), desc32, row_ptr, out, n_slots / 8, fhw,
+                     dfhw, 1.0f / (float)fhw, 1.0f / (float)dfhw, empty_rows_kept);
+  return check_launch("bev_pool_v2_fwd_direct");
 }
 
 extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,

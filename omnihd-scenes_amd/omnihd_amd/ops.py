@@ -176,6 +176,29 @@ def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, 
                                                 _stream()), "omnihd_bev_pool_v2_fwd_lean")
 
 
+def bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, row_ptr, out, depth_bins, feat_hw, empty_rows_kept=False):
+    """Dense tiled forward for C = 64 whose lane groups walk their piece of the point list straight from global memory
+    (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_direct; tables from ``plan.direct_tables``)."""
+    _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
+    _want(pt, torch.int32, "pt"); _want(ivl_rel, torch.int32, "ivl_rel"); _want(desc32, torch.int32, "desc32")
+    _want(row_ptr, torch.int32, "row_ptr")
+    c = feat.size(-1)
+    n_rows = row_ptr.numel() - 1
+    if c != 64 or out.numel() != n_rows * c:
+        raise ValueError(f"C must be 64 and out must hold {n_rows}*{c} elements")
+    if desc32.dim() != 2 or desc32.size(1) != 32 or desc32.size(0) % 8:
+        raise ValueError("desc32 must be (8*k, 32) int32")
+    if depth.numel() != (feat.numel() // c) * int(depth_bins) or (feat.numel() // c) % int(feat_hw):
+        raise ValueError(f"depth ({depth.numel()} values) must hold depth_bins={depth_bins} values per pixel row of feat "
+                         f"({feat.numel() // c} rows, feat_hw={feat_hw})")
+    dev = _same_device(depth, feat, out, pt, ivl_rel, desc32, row_ptr)
+    with _on(dev):
+        check(lib().omnihd_bev_pool_v2_fwd_direct(_ptr(depth), _ptr(feat), _ptr(pt), _ptr(ivl_rel), ivl_rel.numel(), _ptr(desc32),
+                                                  desc32.size(0), _ptr(row_ptr), _ptr(out), c, n_rows, pt.numel(), int(depth_bins),
+                                                  int(feat_hw), feat.numel() // c, 1 if empty_rows_kept else 0, _stream()),
+              "omnihd_bev_pool_v2_fwd_direct")
+
+
 def bev_pool_v2_backward_sched(out_grad, depth, feat, ranks_depth, ranks_row, pix_desc, depth_grad, feat_grad):
     """Scheduled backward (see include/omnihd_hip.h): ``pix_desc`` (8*k, 4) int32 lists every pixel once."""
     for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad),

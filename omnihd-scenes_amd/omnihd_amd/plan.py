@@ -205,6 +205,57 @@ def patch_schedule(n_img, feat_hw, n_xcd=8, pix_ptr=None):
     return flat.contiguous()
 
 
+DIRECT_GROUPS = 16   # lane groups per workgroup of k_pool_fwd_direct (C = 64: 16 lanes per output row)
+
+
+def direct_tables_from(ranks_row, ranks_depth, tile_row, tile_desc):
+    """Tables of the direct forward kernel (include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_direct) from the plan's forward
+    tables; pure torch (host-side planning, once per calibration; works on CPU tensors for the tests).
+
+    pt[p]      = ranks_depth[p] | closing[p] << 31, closing = p is the last point of its output row;
+    ivl_rel[k] = output row of the k-th non-empty row, relative to the first row of the tile that holds it;
+    desc32[s]  = {first row, #rows, first point, #points, 0,0,0,0, g[16], 0 x 8}: group j of the workgroup walks points
+                 [first + min(j*w, n), first + min((j+1)*w, n)), w = ceil(n/16); g[j] = number of non-empty rows closed before
+                 its first point | 1 << 31 when that point continues the row of the point in front of it (same tile)."""
+    dev = ranks_row.device
+    rows = ranks_row.long()
+    n = rows.numel()
+    S = tile_desc.size(0)
+    desc32 = torch.zeros((S, 32), dtype=torch.int64, device=dev)
+    desc32[:, :4] = tile_desc.long()
+    if n == 0:
+        return (torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev),
+                desc32.int().contiguous())
+    closing = torch.ones(n, dtype=torch.bool, device=dev)
+    closing[:-1] = rows[1:] != rows[:-1]
+    rd = ranks_depth.long()
+    pt = torch.where(closing, rd - (1 << 31), rd).to(torch.int32).contiguous()          # rd | 1 << 31 as a signed word
+    closed_before = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    closed_before[1:] = closing.long().cumsum(0)
+    crow = rows[closing]
+    tr = tile_row.long()
+    ivl_rel = (crow - tr[torch.searchsorted(tr, crow, right=True) - 1]).to(torch.int32).contiguous()
+    Pa, npts = desc32[:, 2], desc32[:, 3]
+    w = (npts + DIRECT_GROUPS - 1) // DIRECT_GROUPS
+    g = torch.arange(DIRECT_GROUPS, device=dev)
+    off = torch.minimum(g[None, :] * w[:, None], npts[:, None])
+    q = Pa[:, None] + off                                                               # first point of every group's piece
+    inside = off < npts[:, None]
+    head = inside & (off > 0) & ~closing[(q - 1).clamp(min=0, max=n - 1)]
+    gi = closed_before[q.clamp(max=n)] + head.long() * (1 << 31)
+    gi = torch.where(gi >= (1 << 31), gi - (1 << 32), gi)
+    desc32[:, 8:8 + DIRECT_GROUPS] = torch.where(inside, gi, torch.zeros_like(gi))
+    return pt, ivl_rel, desc32.to(torch.int32).contiguous()
+
+
+def direct_tables(plan):
+    """(pt, ivl_rel, desc32) of ``plan`` for the direct forward kernel, built on first use and kept with the plan."""
+    got = getattr(plan, "_direct", None)
+    if got is None:
+        got = plan._direct = direct_tables_from(plan.ranks_row, plan.ranks_depth, plan.tile_row, plan.tile_desc)
+    return got
+
+
 def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=None, origin_cell=None):
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X

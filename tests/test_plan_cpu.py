@@ -162,3 +162,82 @@ def test_packed_row_and_depth_bin_table_of_the_patch_backward(monkeypatch):
         assert _row_bin(p2) is None
     monkeypatch.setenv("OMNIHD_POOL_BWD_PACKED", "0")
     assert _row_bin(plan) is None
+
+
+def _walk_direct_tables(depth, feat, pt, ivl_rel, desc32, n_rows, d_bins, fhw):
+    """Host emulation of k_pool_fwd_direct's walk (csrc/bev_pool_v2.hip): 16 groups per tile, pieces of ceil(n/16) points,
+    closing flags in bit 31 of the point word, output rows from ivl_rel, partials of cut rows combined in piece order."""
+    C = feat.shape[-1]
+    out = np.zeros((n_rows, C), dtype=np.float64)
+    written = np.zeros(n_rows, dtype=np.int64)
+    dflat, frows = depth.reshape(-1).astype(np.float64), feat.reshape(-1, C).astype(np.float64)
+    for s in range(desc32.shape[0]):
+        Ra, nrows, Pa, npts = (int(v) for v in desc32[s, :4])
+        if nrows <= 0 or npts == 0:
+            continue
+        w = (npts + 15) // 16
+        tails, flags, heads, closed_own = [], [], {}, []
+        for g in range(16):
+            q0, q1 = Pa + min(g * w, npts), Pa + min(g * w + w, npts)
+            gi = int(desc32[s, 8 + g])
+            ivl, pend = gi & 0x7fffffff, gi < 0 and q0 < q1
+            was = pend
+            acc = np.zeros(C)
+            for q in range(q0, q1):
+                p = int(pt[q])
+                rd = p & 0x7fffffff
+                pix = (rd // (d_bins * fhw)) * fhw + rd % fhw
+                acc = acc + dflat[rd] * frows[pix]
+                if p < 0:
+                    row = Ra + int(ivl_rel[ivl]); ivl += 1
+                    assert Ra <= row < Ra + nrows
+                    if pend:
+                        heads[g] = (acc, row); pend = False
+                    else:
+                        out[row] = acc; written[row] += 1
+                    acc = np.zeros(C)
+            open_end = q1 <= q0 or int(pt[q1 - 1]) >= 0
+            tails.append(acc); flags.append((1 if open_end else 0) | (2 if (pend or q1 <= q0) else 0)); closed_own.append(was and not pend)
+        for g in range(16):
+            if closed_own[g]:
+                g0 = g
+                while g0 > 0:
+                    f = flags[g0 - 1]
+                    if not f & 1:
+                        break
+                    g0 -= 1
+                    if not f & 2:
+                        break
+                acc, row = heads[g]
+                out[row] = sum(tails[g0:g], np.zeros(C)) + acc; written[row] += 1
+    return out, written
+
+
+@pytest.mark.parametrize("tile_rows", [3, 17, 64])
+def test_direct_forward_tables_walk_every_point_once_and_close_every_row(tile_rows):
+    """plan.direct_tables_from: the per-point word, the row table and the 32-int tile descriptors drive a walk that equals the
+    pooling oracle on every row (tiny rig; tiles so small that most rows are cut by a piece boundary, and single-row tiles)."""
+    from omnihd_amd.plan import direct_tables_from
+    from oracle import cpu as OC
+    rb, rd, rf, st, ln, (X, Y, Z), rng = _tables()
+    n_rows = Z * Y * X
+    row_ptr = _csr(rb, n_rows)
+    tile_row = np.unique(np.concatenate([np.arange(0, n_rows, tile_rows), [n_rows]])).astype(np.int32)
+    n_tiles = len(tile_row) - 1
+    S = 8 * ((n_tiles + 7) // 8)
+    order = rng.permutation(S)                                   # any schedule order: results must not depend on it
+    desc = np.zeros((S, 4), dtype=np.int32)
+    for t in range(n_tiles):
+        ra, rb_ = tile_row[t], tile_row[t + 1]
+        desc[order[t]] = (ra, rb_ - ra, row_ptr[ra], row_ptr[rb_] - row_ptr[ra])
+    pt, ivl_rel, desc32 = direct_tables_from(torch.from_numpy(rb.astype(np.int32)), torch.from_numpy(rd), torch.from_numpy(tile_row),
+                                             torch.from_numpy(desc))
+    assert pt.dtype == torch.int32 and desc32.shape == (S, 32) and ivl_rel.numel() == len(st)
+    N, D, H, W, C = 4, 8, 8, 12, 8
+    depth = rng.random((1, N, D, H, W), dtype=np.float32)
+    feat = rng.standard_normal((1, N, H, W, C), dtype=np.float32)
+    got, written = _walk_direct_tables(depth, feat, pt.numpy(), ivl_rel.numpy(), desc32.numpy(), n_rows, D, H * W)
+    want = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, (1, Z, Y, X, C), st, ln).reshape(n_rows, C)
+    nonempty = np.diff(row_ptr) > 0
+    assert np.array_equal(written > 0, nonempty) and written.max() == 1      # every non-empty row written exactly once
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
