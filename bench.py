@@ -150,6 +150,7 @@ class BevOps:
         self.patch_bwd = os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"   # k_pool_bwd_patch (C = 64), the default
         self.scheduled = True
         self.keep_empty = os.environ.get("OMNIHD_POOL_KEEP_ZEROS", "1") != "0"
+        self.direct = os.environ.get("OMNIHD_POOL_DIRECT", "1") != "0"      # k_pool_fwd_direct (C = 64), the default
         H, W, _ = RES[res]
         self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
         dx, bx, nx, frustum = lss_constants(res)
@@ -157,8 +158,9 @@ class BevOps:
         rots, trans = rig(res, batch, dev)
         geom = geometry(frustum, rots, trans).contiguous()
         self.plan = omnihd_amd.build_plan(geom, dx, bx, nx, layout="byxz")
-        from omnihd_amd.plan import _row_bin
+        from omnihd_amd.plan import _row_bin, direct_tables
         self.row_bin = _row_bin(self.plan)
+        self.direct_tabs = direct_tables(self.plan) if self.direct else None
         del geom
         g = torch.Generator(device=dev).manual_seed(seed)
         self.sets = []
@@ -173,6 +175,7 @@ class BevOps:
                                         self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_desc, self.plan.ranks_row,
                                         self.plan.pix_desc, self.plan.pix_ptr, self.plan.patch_order)]
             tabs.append(None if self.row_bin is None else self.row_bin.clone())
+            tabs.append([t.clone() for t in self.direct_tabs] if self.direct else None)       # tb[14]: pt, ivl_rel, desc32
             self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
         rng = np.random.default_rng(seed)
         self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
@@ -180,8 +183,12 @@ class BevOps:
 
     def pool_fwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
-        if self.tiled and self.lean:
+        if self.tiled and self.lean and self.direct:
             # as the product launches it: the empty rows of `out` are zero already (same plan, nobody wrote to it) and are kept
+            pt, ivl_rel, desc32 = tb[14]
+            self.ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, tb[2], out, self.D, self.fH * self.fW,
+                                                empty_rows_kept=self.keep_empty)
+        elif self.tiled and self.lean:
             self.ops.bev_pool_v2_forward_lean(depth, feat, tb[0], tb[2], tb[8], out, self.D, self.fH * self.fW,
                                               empty_rows_kept=self.keep_empty)
         else:
@@ -273,6 +280,8 @@ class BevOps:
         self.radar()
 
     def fwd_kernel_name(self):
+        if self.tiled and self.lean and self.direct:
+            return "k_pool_fwd_direct"
         if self.tiled and self.lean:
             return "k_pool_fwd_lean2<16,4>" if os.environ.get("OMNIHD_POOL_LEAN2", "1") != "0" else "k_pool_fwd_lean<16,4>"
         return "k_pool_fwd_tiles<16,4>" if self.tiled else "k_pool_fwd<16,true>"

@@ -1226,15 +1226,26 @@ struct DirectChunk {       // what a lane holds about ITS point of a 16-point ch
   unsigned long long cm;   // wave ballot of `flag < 0`
 };
 
+// row broadcasts whose `old` operand is never read (bound_ctrl: a disabled source lane would yield 0; every lane is active where
+// these are used): ONE v_mov_b32_dpp, without the zero-initialising move the plain form needs in front of it
+template <int J>
+__device__ __forceinline__ int dpp_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, true);
+}
+template <int J>
+__device__ __forceinline__ float dpp_bcast_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, true));
+}
+
 template <int J>
 __device__ __forceinline__ void direct_point(const u32x4t a, const DirectChunk& ck, const __amdgpu_buffer_rsrc_t out_rsrc,
                                              unsigned lane_off, float4& acc, bool& pend, float4* s_head, int* s_head_row,
                                              int tid, int grp, int sub) {
-  const float d = dpp_row_bcast_f<J>(ck.dval);
+  const float d = dpp_bcast_f<J>(ck.dval);
   acc = fma4(d, make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)), acc);
   if (ck.cm & (0x0001000100010001ull << J)) {          // wave-uniform: one of the wave's four groups closes a row at its point J
-    const int cj = dpp_row_bcast_i<J>(ck.flag);        // every lane is active here (DPP reads other lanes)
-    const int rj = dpp_row_bcast_i<J>(ck.row);
+    const int cj = dpp_bcast_i<J>(ck.flag);        // every lane is active here (DPP reads other lanes)
+    const int rj = dpp_bcast_i<J>(ck.row);
     if (cj < 0) {
       if (pend) {                                      // head partial of a row that an earlier piece started
         s_head[tid] = acc;
@@ -1253,7 +1264,7 @@ template <int J0>
 __device__ __forceinline__ void direct_batch8(const __amdgpu_buffer_rsrc_t feat_rsrc, const __amdgpu_buffer_rsrc_t out_rsrc,
                                               unsigned lane_off, const DirectChunk& ck, float4& acc, bool& pend, float4* s_head,
                                               int* s_head_row, int tid, int grp, int sub) {
-#define OMNIHD_G(K) const u32x4t a##K = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)dpp_row_bcast_i<J0 + K>(ck.px) | lane_off, 0, 0);
+#define OMNIHD_G(K) const u32x4t a##K = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, (unsigned)dpp_bcast_i<J0 + K>(ck.px) | lane_off, 0, 0);
   OMNIHD_G(0) OMNIHD_G(1) OMNIHD_G(2) OMNIHD_G(3) OMNIHD_G(4) OMNIHD_G(5) OMNIHD_G(6) OMNIHD_G(7)
 #undef OMNIHD_G
   direct_point<J0 + 0>(a0, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);

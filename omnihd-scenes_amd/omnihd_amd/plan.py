@@ -318,6 +318,13 @@ def _lean_forward():
     return os.environ.get("OMNIHD_POOL_LEAN", "1") != "0"
 
 
+def _direct_forward():
+    """The direct forward (k_pool_fwd_direct, C = 64: lane groups walk their piece of the point list from global memory, no LDS
+    record staging) is the default where it applies; OMNIHD_POOL_DIRECT=0 selects k_pool_fwd_lean2 (same tiles; rows cut by
+    the in-tile split may differ in the last bit)."""
+    return os.environ.get("OMNIHD_POOL_DIRECT", "1") != "0"
+
+
 def _patch_backward():
     """The patch backward (k_pool_bwd_patch, C = 64) is the default; OMNIHD_POOL_BWD_PATCH=0 selects the scheduled kernel."""
     import os
@@ -419,7 +426,14 @@ class _PlannedPool(torch.autograd.Function):
                                                                               keeper.stride())
         else:
             out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
-        if lean:
+        # the limits of omnihd_bev_pool_v2_fwd_direct (csrc/bev_pool_v2.hip): C = 64, 32-bit gather offsets into feat / depth
+        direct = (lean and feat.size(-1) == 64 and feat.numel() * 4 < 2 ** 31 and depth.numel() * 4 < 2 ** 32 - 8
+                  and depth.numel() < 0x3fffffff and feat.data_ptr() % 16 == 0 and _direct_forward())
+        if direct:
+            pt, ivl_rel, desc32 = direct_tables(plan)
+            _timed("fwd", lambda: ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, plan.row_ptr, out, plan.depth_bins,
+                                                                 plan.feat_hw, empty_rows_kept=keeper is not None))
+        elif lean:
             _timed("fwd", lambda: ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, out,
                                                                plan.depth_bins, plan.feat_hw, empty_rows_kept=keeper is not None))
         else:

@@ -355,31 +355,97 @@ def test_one_table_forward_full_size_plan(cuda):
     assert torch.equal((a == 0).all(1), (b2 == 0).all(1))                 # the same rows are empty
 
 
-def test_default_dense_forward_full_size_against_the_oracle(cuda, golden):
-    """The headline kernel (k_pool_fwd_lean2, what ``planned_pool`` launches) at the BASELINE frame size R1 against the
-    CPU restatement of the reference kernel on the reference-format tables of the same geometry: every output row,
-    1e-5 relative (summation order of rows cut inside a tile differs; north_star allows 1e-3), empty rows exactly zero,
-    and rows with a single point bit-exact."""
+FULL = {"r1": (64, 176, 2025022), "r2": (136, 240, 4503872)}      # fH, fW, points the reference keeps
+
+
+@pytest.mark.parametrize("res", ["r1", "r2"])
+def test_default_dense_forward_full_size_against_the_oracle(cuda, golden, res, monkeypatch):
+    """The headline kernel (what ``planned_pool`` launches: k_pool_fwd_direct, and k_pool_fwd_lean2 behind
+    OMNIHD_POOL_DIRECT=0) at the BASELINE frame size R1 and at the repo's own resolution R2 (544x960) against the CPU
+    restatement of the reference kernel on the reference-format tables of the same geometry: every output row, 1e-5 relative
+    (summation order of rows cut inside a tile differs; north_star allows 1e-3), empty rows exactly zero, rows with a single
+    point bit-exact; the kept-buffer path (rows without points keep their zeros) gives the same bits on its second use."""
     from omnihd_amd import build_plan
     from omnihd_amd.plan import planned_pool
-    geom, dx, bx, nx = full_size_geometry("r1")
+    fH, fW, n_ref = FULL[res]
+    geom, dx, bx, nx = full_size_geometry(res)
     plan = build_plan(t(geom, cuda), dx, bx, nx, layout="bzyx")              # the reference's (B,Z,Y,X,C) row order
     rng = np.random.default_rng(5)
-    depth = rng.random((1, 6, 59, 64, 176), dtype=np.float32)
+    depth = rng.random((1, 6, 59, fH, fW), dtype=np.float32)
     depth /= depth.sum(2, keepdims=True)
-    feat = rng.standard_normal((1, 6, 64, 176, 64), dtype=np.float32)
-    got = planned_pool(t(depth, cuda), t(feat, cuda), plan)                   # logical (B,C,Z,Y,X)
+    feat = rng.standard_normal((1, 6, fH, fW, 64), dtype=np.float32)
     rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(geom, dx, bx, nx)
-    assert len(rb) == int(golden["full_r1_checksums"][0]) == 2025022        # the point count the reference produced (SURVEY 8d)
+    assert len(rb) == int(golden[f"full_{res}_checksums"][0]) == n_ref     # the point count the reference produced
     want = OC.bev_pool_v2_fwd(depth, feat, rd, rf, rb, (1, 16, 160, 240, 64), st, ln, threads=True)   # (B,Z,Y,X,C)
-    got = got.permute(0, 2, 3, 4, 1).contiguous().cpu().numpy()
-    assert got.shape == want.shape
     scale = float(np.abs(want).max())
-    assert float(np.abs(got - want).max()) <= 1e-5 * scale
-    assert np.array_equal((got == 0).all(-1), (want == 0).all(-1))
     single = np.zeros(16 * 160 * 240, dtype=bool)
     single[rb[st[ln == 1]]] = True
-    assert np.array_equal(got.reshape(-1, 64)[single], want.reshape(-1, 64)[single])
+    results = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("OMNIHD_POOL_DIRECT", direct)
+        got = planned_pool(t(depth, cuda), t(feat, cuda), plan)               # logical (B,C,Z,Y,X)
+        got = got.permute(0, 2, 3, 4, 1).contiguous().cpu().numpy()
+        assert got.shape == want.shape
+        assert float(np.abs(got - want).max()) <= 1e-5 * scale
+        assert np.array_equal((got == 0).all(-1), (want == 0).all(-1))
+        assert np.array_equal(got.reshape(-1, 64)[single], want.reshape(-1, 64)[single])
+        results[direct] = got
+    monkeypatch.setenv("OMNIHD_POOL_DIRECT", "1")
+    for _ in range(3):                                                        # kept buffers: fresh, reused, reused
+        again = planned_pool(t(depth, cuda), t(feat, cuda), plan, keep_empty_rows=True)
+        again = again.permute(0, 2, 3, 4, 1).contiguous().cpu().numpy()
+        assert np.array_equal(again, results["1"])
+        del again
+
+
+@pytest.mark.parametrize("tile_items,long_len", [(64, 64), (200, 256), (768, 512), (3000, 4000)])
+@pytest.mark.parametrize("B", [1, 2])
+def test_direct_forward_on_heavy_tailed_rows(cuda, tile_items, long_len, B):
+    """k_pool_fwd_direct (C = 64) on rows longer than a tile, single-row tiles, empty runs, tiles with fewer than 16 points and
+    rows cut at every piece boundary, written into NaN-filled buffers: equals the oracle to 1e-5 (rows of one point bit-exact),
+    agrees with k_pool_fwd_lean2 to the last-bit association difference, is run-to-run identical, does not depend on the
+    schedule order, and with ``empty_rows_kept`` leaves exactly the empty rows untouched."""
+    from omnihd_amd import ops
+    from omnihd_amd.plan import direct_tables_from, tile_schedule
+    rng = np.random.default_rng(tile_items + B)
+    N, D, fH, fW, c = 2, 7, 5, 12, 64
+    fhw, n_rows = fH * fW, 2500
+    rows = np.concatenate([np.full(4000, 3), np.full(1300, 4), np.full(2600, 1200), np.full(600, n_rows - 1), np.full(9, 2000),
+                           rng.choice(n_rows, 500, replace=False).repeat(rng.integers(1, 12, 500))])
+    rows = np.sort(rows).astype(np.int32)
+    rd = rng.integers(0, B * N * D * fhw, rows.size).astype(np.int32)
+    rf = ((rd // (D * fhw)) * fhw + rd % fhw).astype(np.int32)
+    depth = t(rng.random((B, N, D, fH, fW), dtype=np.float32), cuda)
+    feat = t(rng.standard_normal((B, N, fH, fW, c), dtype=np.float32), cuda)
+    row_ptr = ops.csr_from_sorted_keys(t(rows, cuda), n_rows)
+    tiles = ops.csr_tiles(row_ptr, tile_items, long_len)
+    st, ln = O.run_length(rows)
+    want = OC.bev_pool_v2_fwd(depth.cpu().numpy(), feat.cpu().numpy(), rd, rf, rows, (1, 1, 1, n_rows, c), st, ln).reshape(n_rows, c)
+    one = np.bincount(rows, minlength=n_rows) == 1
+    empty = np.bincount(rows, minlength=n_rows) == 0
+    first = None
+    for order in (None, tile_schedule(row_ptr, tiles, t(rf, cuda), (fH, fW))):
+        desc = ops.tile_descriptors(row_ptr, tiles, order)
+        pt, ivl_rel, desc32 = direct_tables_from(t(rows, cuda), t(rd, cuda), tiles, desc)
+        a = torch.full((n_rows, c), float("nan"), device=cuda)
+        ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, row_ptr, a, D, fhw)
+        assert not torch.isnan(a).any()
+        np.testing.assert_allclose(a.cpu().numpy(), want, rtol=1e-5, atol=2e-4)
+        assert np.array_equal(a.cpu().numpy()[one], want[one])
+        assert not a.cpu().numpy()[empty].any()
+        a2 = torch.full((n_rows, c), float("nan"), device=cuda)
+        ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, row_ptr, a2, D, fhw)
+        assert torch.equal(a, a2)                                              # run-to-run identical
+        first = a if first is None else first
+        assert torch.equal(a, first)                                           # the schedule order changes speed only
+        k = torch.full((n_rows, c), float("nan"), device=cuda)
+        ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, row_ptr, k, D, fhw, empty_rows_kept=True)
+        kk = k.cpu().numpy()
+        assert np.isnan(kk[empty]).all() and np.array_equal(kk[~empty], a.cpu().numpy()[~empty])
+        if tile_items <= 768:                                                  # the LDS record window of k_pool_fwd_lean2
+            b = torch.full((n_rows, c), float("nan"), device=cuda)
+            ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b, D, fhw)
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
 @pytest.mark.parametrize("fH,fW,B", [(5, 12, 1), (8, 12, 2), (4, 44, 1), (3, 7, 2)])
@@ -428,17 +494,20 @@ def test_patch_backward_matches_oracle(cuda, fH, fW, B):
     assert torch.equal(dg, dg3) and torch.equal(fg, fg3)
 
 
-def test_patch_backward_full_size_against_the_reference_api_kernel(cuda):
-    """R1 frame geometry through the autograd path of ``planned_pool`` (patch backward) against the reference-API
-    backward kernel (itself bit-identical to the reference's own kernel compiled by hipcc) on the plan's backward tables."""
+@pytest.mark.parametrize("res", ["r1", "r2"])
+def test_patch_backward_full_size_against_the_reference_api_kernel(cuda, res):
+    """R1 and R2 (the repo's own 544x960) frame geometry through the autograd path of ``planned_pool`` (patch backward) against
+    the reference-API backward kernel (itself bit-identical to the reference's own kernel compiled by hipcc) on the plan's
+    backward tables."""
     from omnihd_amd import build_plan, ops
     from omnihd_amd.plan import planned_pool
-    geom, dx, bx, nx = full_size_geometry("r1")
+    fH, fW, _ = FULL[res]
+    geom, dx, bx, nx = full_size_geometry(res)
     plan = build_plan(t(geom, cuda), dx, bx, nx, layout="byxz")
-    assert plan.patch_order is not None and plan.pix_ptr.numel() == 6 * 64 * 176 + 1
+    assert plan.patch_order is not None and plan.pix_ptr.numel() == 6 * fH * fW + 1
     g = torch.Generator(device="cpu").manual_seed(3)
-    depth = torch.rand(1, 6, 59, 64, 176, generator=g).softmax(2).to(cuda).requires_grad_()
-    feat = torch.randn(1, 6, 64, 176, 64, generator=g).to(cuda).requires_grad_()
+    depth = torch.rand(1, 6, 59, fH, fW, generator=g).softmax(2).to(cuda).requires_grad_()
+    feat = torch.randn(1, 6, fH, fW, 64, generator=g).to(cuda).requires_grad_()
     og = torch.randn(plan.n_rows, 64, generator=g).to(cuda)
     out = planned_pool(depth, feat, plan)                                               # (B,C,Z,Y,X) view of (B,Y,X,Z,C)
     out.backward(og.view(1, 160, 240, 16, 64).permute(0, 4, 3, 1, 2))
