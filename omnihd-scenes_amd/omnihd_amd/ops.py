@@ -938,7 +938,14 @@ def refresh_bf16_shadows():
     table lookup, two launches and one pass over the entries to stamp them current."""
     sig = (len(_BF16_SHADOW), len(_BF16_DGRAD), _SHADOW_EPOCH[0])
     plan = _BF16_PLAN.get("plan")
-    if plan is None or plan[0] != sig or any(ref() is None for _k, ref, _s, _d in plan[1]):
+
+    def moved(ref, where):
+        # a Parameter may keep its identity and get NEW storage (module.to(memory_format=...), ``param.data = ema``,
+        # vector_to_parameters, sharded optimisers): neither its version counter nor the signature above moves, while the plan
+        # holds the old storage's raw pointer and strides (or a detached alias of it)
+        w = ref()
+        return w is None or (w.data_ptr(), w.stride()) != where
+    if plan is None or plan[0] != sig or any(moved(ref, where) for _k, ref, _s, _d, where in plan[1]):
         entries, per_dev, src, dst = [], {}, [], []
         for k, (ref, ver, shadow) in list(_BF16_SHADOW.items()):
             w = ref()
@@ -955,16 +962,16 @@ def refresh_bf16_shadows():
                 cout, cin, kk, _ = w.shape
                 per_dev.setdefault(w.device, []).append((w.data_ptr(),) + tuple(w.stride()) + (shadow.data_ptr(), 0, 0 if d is None else d.data_ptr(),
                                                                                                0, cout, cin, kk))
-                entries.append((k, ref, shadow, d))
+                entries.append((k, ref, shadow, d, (w.data_ptr(), w.stride())))
             else:
-                src.append(w.detach()); dst.append(shadow); entries.append((k, ref, shadow, None))
+                src.append(w.detach()); dst.append(shadow); entries.append((k, ref, shadow, None, (w.data_ptr(), w.stride())))
         plan = _BF16_PLAN["plan"] = ((len(_BF16_SHADOW), len(_BF16_DGRAD), _SHADOW_EPOCH[0]), entries, per_dev, src, dst)
     _sig, entries, per_dev, src, dst = plan
     for dev, recs in per_dev.items():
         weight_images(recs, dev)
     if src:
         torch._foreach_copy_(dst, src)
-    for k, ref, shadow, d in entries:
+    for k, ref, shadow, d, _where in entries:
         ver = _wver(ref())
         _BF16_SHADOW[k] = (ref, ver, shadow)
         if d is not None:

@@ -57,3 +57,24 @@ def test_writes_through_data_need_the_explicit_notice():
     ops.weights_changed()
     b = ops.bf16_of(w)
     assert torch.equal(b, w.detach().to(torch.bfloat16)) and not torch.equal(a, b)
+
+
+def test_one_launch_refresh_follows_a_parameter_that_gets_new_storage():
+    """``refresh_bf16_shadows`` keeps a launch plan with the master weights' raw pointers / detached aliases.  A
+    Parameter that keeps its identity but gets NEW storage (``param.data = ...``, ``module.to(memory_format=...)``) moves neither
+    its version counter nor the set of registered images: the plan must notice (pointer + strides are re-checked every call)
+    and copy from the live tensor, not from the freed one."""
+    from omnihd_amd import ops
+    torch.manual_seed(1)
+    w = torch.nn.Parameter(torch.randn(16, 8, 3, 3))
+    v = torch.nn.Parameter(torch.randn(32))
+    ops.bf16_of(w); ops.bf16_of(v)
+    assert ops.refresh_bf16_shadows() >= 2
+    old_w, old_v = w.data, v.data                             # keep the old storages alive: a stale plan would copy from them
+    w.data = torch.randn(16, 8, 3, 3).contiguous(memory_format=torch.channels_last)       # new storage AND new strides
+    v.data = torch.randn(32)
+    ops.weights_changed()                                     # the documented notice for writes outside torch's optimisers
+    ops.refresh_bf16_shadows()
+    assert torch.equal(ops.bf16_of(w), w.detach().to(torch.bfloat16)), "bf16 image copied from the parameter's OLD storage"
+    assert torch.equal(ops.bf16_of(v), v.detach().to(torch.bfloat16))
+    assert not torch.equal(ops.bf16_of(w), old_w.to(torch.bfloat16)) and not torch.equal(ops.bf16_of(v), old_v.to(torch.bfloat16))
