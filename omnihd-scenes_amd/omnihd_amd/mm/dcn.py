@@ -57,14 +57,15 @@ class DeformConv2dPack(nn.Module):
         col = ops.dcn3x3_sample(xb, ob, self.stride, self.padding, self.dilation)
         Ho, Wo = ob.shape[1:3]
         wmat = self._grouped_weight()                                            # (9*Cin, Cout) fp32, block-diagonal
-        if (gemm_dtype == torch.float32 and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen"
-                and col.shape[1] % 64 == 0 and self.out_channels % 8 == 0):
+        if gemm_dtype == torch.float32 and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen":
             # the fp32 step: the contraction is a 1x1 convolution over the column rows — on the fp32-grade split kernels
-            # (3-term bf16 MFMA, csrc/conv_igemm.hip) where they measure faster than the fp32 GEMM library
+            # (3-term bf16 MFMA, csrc/conv_igemm.hip) where they apply and measure faster than the fp32 GEMM library.  w4 is a
+            # temporary of this forward: ops.split_weight does not cache the planes of non-leaf weights.
             rows = col.view(1, B * Ho * Wo, 1, col.shape[1]).permute(0, 3, 1, 2)   # (1, 9*Cin, M, 1) over (M, 9*Cin) memory
             w4 = wmat.t().reshape(self.out_channels, col.shape[1], 1, 1)
-            out = ops.conv_split(rows, w4, None, (1, 1), (0, 0), (1, 1))            # (1, Cout, M, 1) channels-last
-            return out.permute(0, 2, 3, 1).reshape(B, Ho, Wo, self.out_channels).permute(0, 3, 1, 2).to(x.dtype)
+            if ops.conv_split_supported(rows, w4, (1, 1), (0, 0), (1, 1)):
+                out = ops.conv_split(rows, w4, None, (1, 1), (0, 0), (1, 1))        # (1, Cout, M, 1) channels-last
+                return out.permute(0, 2, 3, 1).reshape(B, Ho, Wo, self.out_channels).permute(0, 3, 1, 2).to(x.dtype)
         out = col @ wmat.to(gemm_dtype)
         return out.view(B, Ho, Wo, self.out_channels).permute(0, 3, 1, 2).to(x.dtype)
 

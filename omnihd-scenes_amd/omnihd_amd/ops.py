@@ -1155,6 +1155,11 @@ def split_dgrad_weights(ws):
 def split_weight(weight, dgrad=False):
     """(hi, lo) bf16 planes of an fp32 convolution weight in channels_last memory ((Cout,k,k,Cin)), cached while the
     parameter's version is unchanged; ``dgrad=True``: the planes re-laid for the data gradient ((Cin,k,k,Cout), taps mirrored)."""
+    if weight.grad_fn is not None:
+        # a temporary computed from a parameter (the block-diagonal matrix DCN rebuilds every forward): never seen again under
+        # this id, so caching it would only pin its planes until the 4096-entry sweep (ADVICE round 3)
+        planes = split_f32(weight.detach().float().contiguous(memory_format=torch.channels_last))
+        return split_dgrad_weights(planes) if dgrad else planes
     key = (id(weight), dgrad)
     e = _SPLIT_SHADOW.get(key)
     if e is not None and e[0]() is weight and e[1] == _wver(weight) and e[2][0].device == weight.device:

@@ -370,7 +370,57 @@ def _storage_users(t):
         return None
 
 
+_USE_COUNT_OK = None
+
+
+def _use_count_works():
+    """``torch._C._storage_Use_Count`` is a private hook: trust it only after it has counted a view coming and going on a
+    scratch tensor in THIS process (absent, or with another meaning in a later torch: the kept-buffer path is simply off)."""
+    global _USE_COUNT_OK
+    if _USE_COUNT_OK is None:
+        t = torch.zeros(4)
+        n0 = _storage_users(t)
+        v = t.view(2, 2)
+        n1 = _storage_users(t)
+        del v
+        n2 = _storage_users(t)
+        _USE_COUNT_OK = n0 is not None and n1 == n0 + 1 and n2 == n0
+    return _USE_COUNT_OK
+
+
 MAX_KEPT_OUTPUTS = 2      # output buffers kept per plan (one in flight between forward and backward + one spare)
+_KEPT_TOTAL = [0]         # bytes of all live kept buffers of this process (every plan), bounded by OMNIHD_POOL_KEEP_MAX_MB
+_WARNED = set()
+
+
+def _warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+class _Keeper:
+    """One kept output buffer of a plan: the tensor, the owner count of its storage when nobody else holds it, and the tensor's
+    version counter after our last launch (kernels write through raw pointers and do not move it; every in-place torch
+    operation on the buffer OR on a view of it does)."""
+    __slots__ = ("tensor", "base", "version", "__weakref__")
+
+    def __init__(self, tensor, base):
+        self.tensor, self.base, self.version = tensor, base, tensor._version
+
+    def __del__(self):
+        try:
+            _KEPT_TOTAL[0] -= self.tensor.numel() * 4
+        except Exception:
+            pass
+
+
+def _empty_row_index(plan):
+    idx = getattr(plan, "_empty_rows", None)
+    if idx is None:
+        idx = plan._empty_rows = torch.nonzero(plan.row_ptr[1:] == plan.row_ptr[:-1]).flatten()
+    return idx
 
 
 def _kept_output(plan, c, device):
@@ -380,23 +430,51 @@ def _kept_output(plan, c, device):
     of the plan, i.e. of the calibration.  The dense forward has to leave zeros there; the reference zero-fills the whole
     tensor every forward (ops/bev_pool_v2/bev_pool.py:27).  A buffer that a previous forward of the SAME plan produced
     still holds those zeros as long as nobody wrote to it, so the kernel stores only the rows that collect points (94 MB
-    instead of 157 MB per launch at R1).  A buffer is handed out again only when every other owner of its storage is gone
-    (the result tensor, its views, the copy the next layer saved for its backward): while a result is alive its memory is
-    never touched, whatever the caller does with it.  Callers that WRITE into the result in place must not opt in."""
+    instead of 157 MB per launch at R1).  Guards:
+      * a buffer is handed out again only when every other owner of its storage is gone (the result tensor, its views, the
+        copy the next layer saved for its backward): while a result is alive its memory is never touched;
+      * the result is handed out as a VIEW of the kept tensor, so (i) under autograd torch itself refuses in-place writes into
+        it ("a view created inside a custom Function ... is being modified inplace"), and (ii) without autograd an in-place
+        write moves the kept tensor's version counter: the buffer is then zero-filled again before its next use (one extra
+        fill, result still right) and a warning names the cause;
+      * OMNIHD_POOL_VERIFY_ZEROS=1 additionally sums the empty rows before every reuse (a host synchronisation: debugging
+        aid against writers that bypass torch, e.g. foreign kernels on raw pointers);
+      * the private use-count hook is probed once per process (``_use_count_works``), and the bytes kept by all plans are
+        bounded (OMNIHD_POOL_KEEP_MAX_MB, default 2048): beyond that, or with the hook missing, the plain path runs."""
+    if not _use_count_works():
+        return None
     kept = getattr(plan, "_kept_outputs", None)
     if kept is None:
         kept = plan._kept_outputs = []
-    for keeper, base in kept:
-        if keeper.shape[1] == c and keeper.device == device and _storage_users(keeper) == base:
-            return keeper
+    for k in kept:
+        t = k.tensor
+        if t.shape[1] == c and t.device == device and _storage_users(t) == k.base:
+            if t._version != k.version:
+                _warn_once(("inplace", id(plan)), "omnihd_amd: a pooled BEV tensor obtained with keep_empty_rows=True was written in "
+                           "place; its buffer is zero-filled again (results stay right, the saving of the kept rows is lost for "
+                           "this step).  Callers that write into the result must not pass keep_empty_rows.")
+                t.zero_()
+            elif os.environ.get("OMNIHD_POOL_VERIFY_ZEROS", "0") == "1":
+                idx = _empty_row_index(plan)
+                if idx.numel() and float(t.index_select(0, idx).abs().sum()) != 0.0:
+                    _warn_once(("dirty", id(plan)), "omnihd_amd: OMNIHD_POOL_VERIFY_ZEROS found non-zero values in rows no frustum "
+                               "point reaches (somebody wrote into a kept pooling buffer behind torch's back); zero-filled again")
+                    t.zero_()
+            k.version = t._version
+            return k
     if len(kept) >= MAX_KEPT_OUTPUTS:
+        return None
+    nbytes = plan.n_rows * c * 4
+    if _KEPT_TOTAL[0] + nbytes > int(os.environ.get("OMNIHD_POOL_KEEP_MAX_MB", "2048")) * (1 << 20):
         return None
     keeper = torch.zeros((plan.n_rows, c), dtype=torch.float32, device=device)          # zero-filled once
     base = _storage_users(keeper)
     if base is None:
         return None
-    kept.append((keeper, base))
-    return keeper
+    _KEPT_TOTAL[0] += nbytes
+    k = _Keeper(keeper, base)
+    kept.append(k)
+    return k
 
 
 def _row_bin(plan):
@@ -419,16 +497,16 @@ class _PlannedPool(torch.autograd.Function):
         feat = feat.contiguous().float()
         _check_plan_matches(plan, depth, feat)
         lean = plan.depth_bins > 0 and plan.tile_desc is not None and plan.n_points > 0 and _lean_forward()
-        keeper = _kept_output(plan, feat.size(-1), feat.device) if (keep_empty_rows and lean) else None
-        if keeper is not None:
-            # a fresh tensor object over the kept storage (not a view: nothing ties it to the keeper in autograd)
-            out = torch.empty(0, dtype=torch.float32, device=feat.device).set_(keeper.untyped_storage(), 0, keeper.shape,
-                                                                              keeper.stride())
-        else:
-            out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
         # the limits of omnihd_bev_pool_v2_fwd_direct (csrc/bev_pool_v2.hip): C = 64, 32-bit gather offsets into feat / depth
         direct = (lean and feat.size(-1) == 64 and feat.numel() * 4 < 2 ** 31 and depth.numel() * 4 < 2 ** 32 - 8
                   and depth.numel() < 0x3fffffff and feat.data_ptr() % 16 == 0 and _direct_forward())
+        # only the direct and the second-generation lean kernel know how to leave the empty rows alone
+        can_keep = direct or (lean and os.environ.get("OMNIHD_POOL_LEAN2", "1") != "0" and feat.numel() * 4 < 2 ** 31)
+        keeper = _kept_output(plan, feat.size(-1), feat.device) if (keep_empty_rows and can_keep) else None
+        if keeper is not None:
+            out = keeper.tensor.view(plan.n_rows, feat.size(-1))    # a VIEW: see the guards listed in _kept_output
+        else:
+            out = torch.empty((plan.n_rows, feat.size(-1)), dtype=torch.float32, device=feat.device)
         if direct:
             pt, ivl_rel, desc32 = direct_tables(plan)
             _timed("fwd", lambda: ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, plan.row_ptr, out, plan.depth_bins,

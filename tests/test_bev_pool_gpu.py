@@ -517,3 +517,69 @@ def test_patch_backward_full_size_against_the_reference_api_kernel(cuda, res):
     assert torch.equal(feat.grad, fg)
     assert float((depth.grad - dg).abs().max()) <= 1e-5 * float(dg.abs().max())
     assert torch.equal(depth.grad == 0, dg == 0)
+
+
+def test_kept_output_buffers_survive_consumers_that_write_in_place(cuda, monkeypatch):
+    """``planned_pool(keep_empty_rows=True)`` reuses an output buffer whose empty rows are zero already.
+    A consumer that writes into the result in place must never make a later forward silently wrong:
+      * without autograd the write moves the kept tensor's version counter -> the buffer is zero-filled again before reuse
+        (warning, correct result);
+      * under autograd torch refuses the write (the result is a view created inside the autograd function);
+      * a writer that bypasses torch (an alias with its own version counter stands in for a foreign kernel) is caught by
+        OMNIHD_POOL_VERIFY_ZEROS=1;
+      * the bytes kept by all plans are bounded (OMNIHD_POOL_KEEP_MAX_MB): beyond the bound the plain path runs."""
+    import warnings
+    from omnihd_amd import build_plan
+    from omnihd_amd import plan as P
+    rng = np.random.default_rng(11)
+    fr = O.create_frustum((32, 48), 4, [1.0, 9.0, 1.0])
+    l2i = O.synthetic_rig(32, 48, 30.0, yaws_deg=(0, 120, -120), radius=0.5, height=0.3)
+    inv = [np.linalg.inv(m).astype(np.float32) for m in l2i]
+    geom = O.get_geometry(fr, np.stack([m[:3, :3] for m in inv])[None], np.stack([m[:3, 3] for m in inv])[None])
+    dx, bx, nx = O.gen_dx_bx([-8.0, 8.0, 1.0], [-6.0, 6.0, 1.0], [-1.0, 1.0, 1.0])
+    plan = build_plan(t(geom, cuda), dx, bx, nx, layout="byxz")
+    B, N, D, H, W = geom.shape[:5]
+    depth = t(rng.random((B, N, D, H, W), dtype=np.float32), cuda)
+    feat = t(rng.standard_normal((B, N, H, W, 64), dtype=np.float32), cuda)
+    want = P.planned_pool(depth, feat, plan).clone()                       # plain path: every row written
+    empty = (plan.row_ptr[1:] == plan.row_ptr[:-1])
+    assert int(empty.sum()) > 0
+    with torch.no_grad():
+        a = P.planned_pool(depth, feat, plan, keep_empty_rows=True)
+        assert torch.equal(a, want) and len(plan._kept_outputs) == 1
+        a.add_(1.0)                                                        # in-place write into the result (and the kept buffer)
+        del a
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            P._WARNED.clear()
+            b = P.planned_pool(depth, feat, plan, keep_empty_rows=True)
+        assert torch.equal(b, want), "a kept buffer that was written in place must be zero-filled again, not reused as is"
+        assert any("written in place" in str(x.message) for x in w)
+        del b
+        c = P.planned_pool(depth, feat, plan, keep_empty_rows=True)        # clean reuse afterwards, same buffer
+        assert torch.equal(c, want) and len(plan._kept_outputs) == 1
+        del c
+    d = depth.clone().requires_grad_()
+    out = P.planned_pool(d, feat, plan, keep_empty_rows=True)
+    with pytest.raises(RuntimeError, match="modified inplace|in-place"):
+        out.relu_()
+    del out, d
+    # a writer behind torch's back: same storage, separate version counter
+    keeper = plan._kept_outputs[0].tensor
+    alias = torch.empty(0, dtype=torch.float32, device=keeper.device).set_(keeper.untyped_storage(), 0, keeper.shape, keeper.stride())
+    alias[torch.nonzero(empty).flatten()[:3]] = 7.0
+    del alias
+    monkeypatch.setenv("OMNIHD_POOL_VERIFY_ZEROS", "1")
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        P._WARNED.clear()
+        e = P.planned_pool(depth, feat, plan, keep_empty_rows=True)
+    assert torch.equal(e, want) and any("VERIFY_ZEROS" in str(x.message) for x in w)
+    del e
+    monkeypatch.delenv("OMNIHD_POOL_VERIFY_ZEROS")
+    # bound on the kept bytes: a second plan is refused a buffer, its result is still right
+    monkeypatch.setenv("OMNIHD_POOL_KEEP_MAX_MB", "0")
+    plan2 = build_plan(t(geom, cuda), dx, bx, nx, layout="byxz")
+    with torch.no_grad():
+        f = P.planned_pool(depth, feat, plan2, keep_empty_rows=True)
+    assert torch.equal(f, want) and not getattr(plan2, "_kept_outputs", [])
