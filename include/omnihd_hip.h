@@ -274,10 +274,55 @@ int omnihd_pillar_scatter(const float* feats, const int* coors, int m, int c,
                           int batch, int ny, int nx, int channels_last, float* canvas,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same scatter in two calls around a CALLER-OWNED cell map (batch*ny*nx ints, all -1 = "clean"): omnihd_pillar_cell_map
+ * enters the pillars (last pillar of a cell wins), omnihd_pillar_canvas writes the dense canvas and — reset_map != 0 — leaves
+ * the map clean again, so a steady-state scatter is two launches without a memset (channels-last canvases with c % 4 == 0: one
+ * 16-byte non-temporal store per lane).                                                                                       */
+int omnihd_pillar_cell_map(const int* coors, int m, int batch, int ny, int nx, int* cell_map, void* stream);
+int omnihd_pillar_canvas(const float* feats, int* cell_map, int c, int batch, int ny, int nx, int channels_last, int reset_map,
+                         float* canvas, void* stream);
+
 /* Backward of the scatter: feats_grad[v, ch] = canvas_grad[b, ch, y, x] (gather).          */
 int omnihd_pillar_gather(const float* canvas_grad, const int* coors, int m, int c,
                          int batch, int ny, int nx, int channels_last, float* feats_grad,
                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused pillar feature net (decorate -> Linear -> BatchNorm -> ReLU -> max over the points of a pillar), C = 64 channels
+ * ref: PillarFeatureNetV1.forward (projects/mmdet3d_plugin/rcfusion/voxel_encoders/pillar_encoder.py:378-432) +
+ *      PFNLayer.forward (rcfusion/voxel_encoders/utils.py:144-181); radar variant RadarPillarFeatureNet.forward
+ *      (pillar_encoder.py:91-153) + PFNLayer_Radar.forward (utils.py:229-280: its three Linear / BatchNorm branches are one
+ *      Linear with a block-sparse (64 x K) weight and a per-channel BatchNorm).
+ * voxels (m, p, f) fp32 zero padded, num_points (m) int32, coors (m, 4) int32 = (b, z, y, x) — the hard voxeliser's output.
+ * flags: 1 cluster offset (xyz - mean), 2 pillar-centre offset, 4 distance, 8 legacy (centre offset also REPLACES raw x, y:
+ * pillar_encoder.py:410-416), 16 radar offsets (v_x v_y power snr - mean).  Decorated channels K = omnihd_pfn_channels(f, flags)
+ * <= 16, in the reference's concatenation order; padded slots are all-zero rows that DO take part in the statistics and in
+ * the maximum, as in the reference.  weight (64, K) row-major fp32.
+ *   omnihd_pfn_moments  moments (K + K*K DOUBLES): [0..K) = E[x_j], [K + i*K + j] = E[x_i x_j] over the m*p rows of this call (two launches,
+ *                       fixed-order reduction); a multi-GPU caller averages them over the ranks (naiveSyncBN: mean of rank means);
+ *   omnihd_pfn_consts   consts[0..64) mean, [64..128) 1/sqrt(var + eps), [128..192) scale, [192..256) shift per channel from
+ *                       the moments (use_running == 0; running statistics updated when given: `unbiased` selects torch's
+ *                       n/(n-1) variance for them) or from the running statistics (use_running != 0: inference);
+ *   omnihd_pfn_apply    out (m, 64) = max over slots of relu(scale * (W x) + shift);
+ *   omnihd_pfn_bwd_sums sums = [A (64) | B (64) | G (64 x K)]: A = sum g, B = sum g * yhat, G = sum g * x over the arg-max slot
+ *                       (first maximum) of every (pillar, channel) with a positive output, g = grad_out (m, 64);
+ *   omnihd_pfn_bwd_final dweight (64, K), dgamma, dbeta from this rank's sums, [A | B] summed over all ranks (= sums on one
+ *                       rank), this rank's moments and the constants of the forward.  No gradient flows to the points.      */
+int omnihd_pfn_channels(int f, int flags);
+size_t omnihd_pfn_workspace_bytes(int m, int p, int k);
+int omnihd_pfn_moments(const float* voxels, const int* num_points, const int* coors, int m, int p, int f, float vx, float vy,
+                       float x_off, float y_off, int flags, double* moments, void* workspace, size_t workspace_bytes, void* stream);
+int omnihd_pfn_consts(const float* weight, const float* gamma, const float* beta, const double* moments, int k, long long n_rows,
+                      float eps, float momentum, int unbiased, int use_running, float* running_mean, float* running_var,
+                      float* consts, void* stream);
+int omnihd_pfn_apply(const float* voxels, const int* num_points, const int* coors, int m, int p, int f, float vx, float vy,
+                     float x_off, float y_off, int flags, const float* weight, const float* consts, float* out, void* stream);
+int omnihd_pfn_bwd_sums(const float* voxels, const int* num_points, const int* coors, int m, int p, int f, float vx, float vy,
+                        float x_off, float y_off, int flags, const float* weight, const float* consts, const float* grad_out,
+                        float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int omnihd_pfn_bwd_final(const float* sums, const float* ab_all_ranks, const double* moments, const float* weight,
+                         const float* gamma, const float* consts, int k, long long n_rows, int n_ranks, float* dweight,
+                         float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense BEV convolutions (matrix cores)

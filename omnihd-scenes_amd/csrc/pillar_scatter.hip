@@ -78,6 +78,24 @@ __global__ __launch_bounds__(kBlock) void k_canvas_nhwc(const float* __restrict_
   }
 }
 
+// canvas [batch, ny, nx, c] with c % 4 == 0: one lane per float4 (a pillar row of 64 channels = 16 lanes = one 256-byte
+// coalesced, non-temporal store).  RESET: the map entry goes back to -1 once its row is out, so a caller-owned map that was
+// clean before the cell-map kernel is clean again after this one (no memset launch per call).
+template <bool RESET>
+__global__ __launch_bounds__(kBlock) void k_canvas_nhwc4(const float4* __restrict__ feats4, int* cell_map, int c4,
+                                                         unsigned total, float4* __restrict__ canvas4) {
+  for (unsigned t = blockIdx.x * kBlock + threadIdx.x; t < total; t += gridDim.x * kBlock) {
+    const unsigned cell = t / (unsigned)c4, sub = t - cell * (unsigned)c4;
+    const int id = cell_map[cell];
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (id >= 0) o = feats4[(size_t)id * c4 + sub];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(canvas4 + t));
+    if (RESET && id >= 0 && sub == 0) cell_map[cell] = -1;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_gather(const float* __restrict__ cg,
                                                    const int* __restrict__ coors, int m, int c,
                                                    int batch, int ny, int nx, int channels_last,
@@ -136,6 +154,45 @@ extern "C" int omnihd_pillar_scatter(const float* feats, const int* coors, int m
                        dim3(kBlock), 0, st, feats, cell_map, c, batch, plane, canvas);
   }
   return check_launch("pillar_scatter");
+}
+
+extern "C" int omnihd_pillar_cell_map(const int* coors, int m, int batch, int ny, int nx, int* cell_map, void* stream) {
+  OMNIHD_REQUIRE(m >= 0 && batch > 0 && ny > 0 && nx > 0 && cell_map && (m == 0 || coors), "arguments");
+  if (m == 0) return OMNIHD_OK;
+  hipLaunchKernelGGL(k_cell_map, dim3(grid_for(m, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, coors, m, batch, ny, nx, cell_map);
+  return check_launch("pillar_cell_map");
+}
+
+extern "C" int omnihd_pillar_canvas(const float* feats, int* cell_map, int c, int batch, int ny, int nx, int channels_last,
+                                    int reset_map, float* canvas, void* stream) {
+  OMNIHD_REQUIRE(c > 0 && batch > 0 && ny > 0 && nx > 0 && cell_map && canvas, "arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t cells = (size_t)batch * ny * nx;
+  const int plane = ny * nx;
+  if (channels_last && c % 4 == 0 && cells * (c / 4) < (1ull << 32) && feats != nullptr &&
+      ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(canvas)) & 15u) == 0) {
+    const unsigned total = (unsigned)(cells * (c / 4));
+    const int grid = grid_for(total, kBlock * 2);
+    if (reset_map)
+      hipLaunchKernelGGL(k_canvas_nhwc4<true>, dim3(grid), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(feats), cell_map,
+                         c / 4, total, reinterpret_cast<float4*>(canvas));
+    else
+      hipLaunchKernelGGL(k_canvas_nhwc4<false>, dim3(grid), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(feats), cell_map,
+                         c / 4, total, reinterpret_cast<float4*>(canvas));
+    return check_launch("pillar_canvas(nhwc4)");
+  }
+  if (channels_last) {
+    hipLaunchKernelGGL(k_canvas_nhwc, dim3(grid_for((int64_t)cells * c, kBlock * 4)), dim3(kBlock), 0, st, feats, cell_map, c,
+                       (int64_t)cells, canvas);
+  } else if (plane % 4 == 0 && (reinterpret_cast<uintptr_t>(canvas) & 15u) == 0 && (reinterpret_cast<uintptr_t>(cell_map) & 15u) == 0) {
+    hipLaunchKernelGGL(k_canvas_nchw4, dim3(grid_for((int64_t)batch * c * (plane / 4), kBlock * 2)), dim3(kBlock), 0, st, feats,
+                       cell_map, c, batch, plane / 4, reinterpret_cast<float4*>(canvas));
+  } else {
+    hipLaunchKernelGGL(k_canvas_nchw1, dim3(grid_for((int64_t)batch * c * plane, kBlock * 4)), dim3(kBlock), 0, st, feats, cell_map,
+                       c, batch, plane, canvas);
+  }
+  if (reset_map) OMNIHD_HIP_TRY(hipMemsetAsync(cell_map, 0xFF, cells * sizeof(int), st));
+  return check_launch("pillar_canvas");
 }
 
 extern "C" int omnihd_pillar_gather(const float* canvas_grad, const int* coors, int m, int c,

@@ -42,6 +42,15 @@ PROTOTYPES = {
     "omnihd_pillar_scatter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "omnihd_pillar_scatter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "omnihd_pfn_channels": (c_int, [c_int, c_int]),
+    "omnihd_pfn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "omnihd_pfn_moments": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float] * 4 + [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "omnihd_pfn_consts": (c_int, [c_void_p] * 4 + [c_int, c_longlong, c_float, c_float, c_int, c_int] + [c_void_p] * 4),
+    "omnihd_pfn_apply": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float] * 4 + [c_int] + [c_void_p] * 4),
+    "omnihd_pfn_bwd_sums": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float] * 4 + [c_int] + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    "omnihd_pfn_bwd_final": (c_int, [c_void_p] * 6 + [c_int, c_longlong, c_int] + [c_void_p] * 4),
+    "omnihd_pillar_cell_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "omnihd_pillar_canvas": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "omnihd_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "omnihd_conv3x3_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "omnihd_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 12),

@@ -566,6 +566,9 @@ def hard_voxelize(points, voxel_size, point_cloud_range, max_points, max_voxels)
     return hard_voxelize_async(points, voxel_size, point_cloud_range, max_points, max_voxels).get()
 
 
+_SCATTER_MAPS = {}
+
+
 class _PillarScatter(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, coors, batch, ny, nx, channels_last):
@@ -576,10 +579,18 @@ class _PillarScatter(torch.autograd.Function):
         shape = (batch, ny, nx, c) if channels_last else (batch, c, ny, nx)
         canvas = torch.empty(shape, dtype=torch.float32, device=dev)
         with _on(dev):
-            ws = _workspace(lib().omnihd_pillar_scatter_workspace_bytes(batch, ny, nx), dev)
-            check(lib().omnihd_pillar_scatter(_ptr(feats), _ptr(coors), m, c, batch, ny, nx,
-                                              1 if channels_last else 0, _ptr(canvas), _ptr(ws), ws.numel(),
-                                              _stream()), "omnihd_pillar_scatter")
+            # a cell map per (device, stream, grid) that is all -1 between calls: the canvas kernel resets what the map kernel
+            # entered, so the steady state is two launches (no memset); `dirty` covers a call that failed in between
+            st = _raw_stream()
+            key = (dev.index, st, batch, ny, nx)
+            ent = _SCATTER_MAPS.get(key)
+            if ent is None or ent[1]:
+                ent = _SCATTER_MAPS[key] = [torch.full((batch * ny * nx,), -1, dtype=torch.int32, device=dev), False]
+            ent[1] = True
+            check(lib().omnihd_pillar_cell_map(_ptr(coors), m, batch, ny, nx, _ptr(ent[0]), st), "omnihd_pillar_cell_map")
+            check(lib().omnihd_pillar_canvas(_ptr(feats), _ptr(ent[0]), c, batch, ny, nx, 1 if channels_last else 0, 1,
+                                             _ptr(canvas), st), "omnihd_pillar_canvas")
+            ent[1] = False
         ctx.save_for_backward(coors)
         ctx.meta = (m, c, batch, ny, nx, channels_last)
         if channels_last:
@@ -609,6 +620,109 @@ def pillar_scatter(feats, coors, batch, ny, nx, channels_last=False):
     if not feats.is_cuda:
         raise RuntimeError("pillar_scatter: CUDA(HIP) tensors only; no CPU path")
     return _PillarScatter.apply(feats.float(), coors, int(batch), int(ny), int(nx), bool(channels_last))
+
+
+# ---------------------------------------------------------------------------------------------
+# fused pillar feature net (csrc/pillar_pfn.hip)
+# ---------------------------------------------------------------------------------------------
+PFN_CLUSTER, PFN_CENTER, PFN_DISTANCE, PFN_LEGACY, PFN_RADAR = 1, 2, 4, 8, 16
+
+
+def pfn_channels(raw_channels, flags):
+    """Decorated channels K of a pillar point for ``flags`` (what the fused kernels support: K <= 16)."""
+    return int(lib().omnihd_pfn_channels(int(raw_channels), int(flags)))
+
+
+class _FusedPFN(torch.autograd.Function):
+    """out (M, 64) = max over the slots of a pillar of relu(BatchNorm(W x)), x = the decorated point (see csrc/pillar_pfn.hip).
+    Training statistics come from the moments of x; with a process group they are averaged over the ranks (mean of rank means,
+    the reference's naiveSyncBN semantics, ops/norm.py:65-72) by ONE all-reduce of K + K*K doubles forward and one of 128 floats
+    backward.  Gradients flow to weight / gamma / beta (the points carry none in the reference either)."""
+
+    @staticmethod
+    def forward(ctx, voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, geom, flags, eps, momentum,
+                training, group):
+        voxels = voxels.contiguous().float()
+        num_points = num_points.contiguous().int()
+        coors = coors.contiguous().int()
+        w = weight.detach().contiguous().float()
+        ga, be = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
+        m, p, f = voxels.shape
+        vx, vy, x_off, y_off = (float(v) for v in geom)
+        k = w.shape[1]
+        dev = voxels.device
+        L = lib()
+        out = torch.empty((m, 64), dtype=torch.float32, device=dev)
+        consts = torch.empty(256, dtype=torch.float32, device=dev)
+        world = 1
+        if training and group is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size(group)
+        moments = None
+        with _on(dev):
+            st = _raw_stream()
+            if training:
+                if m == 0:
+                    raise RuntimeError("fused pillar feature net: BatchNorm in training mode needs at least one pillar")
+                moments = torch.empty(k + k * k, dtype=torch.float64, device=dev)
+                ws = _workspace(L.omnihd_pfn_workspace_bytes(m, p, k), dev)
+                check(L.omnihd_pfn_moments(_ptr(voxels), _ptr(num_points), _ptr(coors), m, p, f, vx, vy, x_off, y_off, flags,
+                                           _ptr(moments), _ptr(ws), ws.numel(), st), "omnihd_pfn_moments")
+                stats = moments
+                if world > 1:                      # mean of the ranks' means / mean squares: every rank weighs 1 / world
+                    stats = moments.clone()
+                    torch.distributed.all_reduce(stats, group=group)
+                    stats.mul_(1.0 / world)
+                check(L.omnihd_pfn_consts(_ptr(w), _ptr(ga), _ptr(be), _ptr(stats), k, m * p, float(eps), float(momentum),
+                                          1 if world == 1 else 0, 0, _ptr(running_mean), _ptr(running_var), _ptr(consts), st),
+                      "omnihd_pfn_consts")
+            else:
+                check(L.omnihd_pfn_consts(_ptr(w), _ptr(ga), _ptr(be), None, k, max(m * p, 1), float(eps), 0.0, 0, 1,
+                                          _ptr(running_mean), _ptr(running_var), _ptr(consts), st), "omnihd_pfn_consts")
+            if m:
+                check(L.omnihd_pfn_apply(_ptr(voxels), _ptr(num_points), _ptr(coors), m, p, f, vx, vy, x_off, y_off, flags,
+                                         _ptr(w), _ptr(consts), _ptr(out), st), "omnihd_pfn_apply")
+        if training:
+            ctx.save_for_backward(voxels, num_points, coors, w, ga, consts, moments)
+            ctx.meta = (vx, vy, x_off, y_off, flags, world, group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        voxels, num_points, coors, w, ga, consts, moments = ctx.saved_tensors
+        vx, vy, x_off, y_off, flags, world, group = ctx.meta
+        m, p, f = voxels.shape
+        k = w.shape[1]
+        dev = voxels.device
+        g = g.contiguous().float()
+        L = lib()
+        sums = torch.empty(128 + 64 * k, dtype=torch.float32, device=dev)
+        dw = torch.empty((64, k), dtype=torch.float32, device=dev)
+        dg, db = torch.empty(64, dtype=torch.float32, device=dev), torch.empty(64, dtype=torch.float32, device=dev)
+        with _on(dev):
+            st = _raw_stream()
+            ws = _workspace(L.omnihd_pfn_workspace_bytes(m, p, k), dev)
+            check(L.omnihd_pfn_bwd_sums(_ptr(voxels), _ptr(num_points), _ptr(coors), m, p, f, vx, vy, x_off, y_off, flags, _ptr(w),
+                                        _ptr(consts), _ptr(g), _ptr(sums), _ptr(ws), ws.numel(), st), "omnihd_pfn_bwd_sums")
+            ab = sums
+            if world > 1:
+                ab = sums[:128].clone()
+                torch.distributed.all_reduce(ab, group=group)
+            check(L.omnihd_pfn_bwd_final(_ptr(sums), _ptr(ab), _ptr(moments), _ptr(w), _ptr(ga), _ptr(consts), k, m * p, world,
+                                         _ptr(dw), _ptr(dg), _ptr(db), st), "omnihd_pfn_bwd_final")
+        return (None, None, None, dw, dg, db) + (None,) * 8
+
+
+def pfn_fused(voxels, num_points, coors, weight, norm, geom, flags, group=None):
+    """Fused PillarFeatureNet layer: ``weight`` (64, K) fp32, ``norm`` a BatchNorm-type module with 64 channels (its affine
+    parameters, running statistics, eps, momentum and train / eval state are used), ``geom`` = (vx, vy, x_offset, y_offset)."""
+    if not voxels.is_cuda:
+        raise RuntimeError("pfn_fused: CUDA(HIP) tensors only; no CPU path")
+    training = bool(norm.training or not norm.track_running_stats)
+    if training and norm.track_running_stats and norm.num_batches_tracked is not None:
+        norm.num_batches_tracked.add_(1)
+    momentum = 0.0 if norm.momentum is None else norm.momentum
+    return _FusedPFN.apply(voxels, num_points, coors, weight, norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                           tuple(geom), int(flags), norm.eps, momentum, training, group)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -759,7 +873,82 @@ def conv_dgrad_weights(w_cl, out=None):
 # OMNIHD_WGRAD_POLICY = tune (default) | hip | miopen.  Measured in the full R1 step with MIOpen in find mode
 # (torch.backends.cudnn.benchmark = True): tune 35.8 ms (our chain on the 8 BEV-sized geometries, MIOpen on 37), hip 38.5 ms,
 # miopen 41.6 ms.  With MIOpen's immediate-mode kernels (benchmark off) our chain wins nearly everywhere: 45.4 vs 46.3 ms.
-_WGRAD_CHOICE = {}
+class _ChoiceTable(dict):
+    """{geometry + (device index,): implementation}.  A lookup that misses falls back to the PERSISTED table of this name
+    (omnihd-scenes_amd/kernel_choices/gfx950.json: the choices measured once on an MI355X and committed, keyed without the
+    device index) before anything is measured, so a run's kernels — hence its numerics, launch count and speed — do not
+    depend on the timing noise of its first steps.  A geometry the file does not know is measured as before and counted as
+    a miss (``choice_table_info()``); ``save_choice_table`` writes the merged table back."""
+
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+    def get(self, key, default=None):
+        if key in self:
+            return self[key]
+        hit = _persisted_choices().get(self.name, {}).get(tuple(key[:-1]))
+        if hit is not None:
+            self[key] = hit
+            return hit
+        return default
+
+    def measured(self, key, value):
+        """Record a choice that had to be measured in this process (a miss of the persisted table)."""
+        self[key] = value
+        _CHOICE_INFO["misses"] += 1
+        return value
+
+
+_CHOICE_INFO = {"path": None, "sha256": None, "entries": 0, "misses": 0, "loaded": False}
+_PERSISTED = {}
+
+
+def _tuplify(x):
+    return tuple(_tuplify(v) for v in x) if isinstance(x, list) else x
+
+
+def _persisted_choices():
+    if not _CHOICE_INFO["loaded"]:
+        _CHOICE_INFO["loaded"] = True
+        path = os.environ.get("OMNIHD_CHOICE_TABLE")
+        if path is None:
+            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kernel_choices", "gfx950.json")
+        if path and path != "off" and os.path.exists(path):
+            import hashlib
+            import json
+            raw = open(path, "rb").read()
+            doc = json.loads(raw)
+            for name in ("conv", "wgrad", "split"):
+                _PERSISTED[name] = {_tuplify(json.loads(k)): v for k, v in doc.get(name, {}).items()}
+            _CHOICE_INFO.update(path=path, sha256=hashlib.sha256(raw).hexdigest(), entries=sum(len(v) for v in _PERSISTED.values()))
+    return _PERSISTED
+
+
+def choice_table_info():
+    """{'path', 'sha256', 'entries', 'misses'} of the persisted kernel-choice table as this process sees it (``misses`` =
+    geometries that had to be measured here because the table did not hold them)."""
+    _persisted_choices()
+    return {k: _CHOICE_INFO[k] for k in ("path", "sha256", "entries", "misses")}
+
+
+def save_choice_table(path, note=""):
+    """Write every choice known to this process (persisted + measured) as the table ``_ChoiceTable`` reads; returns the count."""
+    import json
+    doc = {"note": note or "kernel choices per convolution geometry, measured on MI355X (gfx950); keys = geometry tuples without the device index"}
+    n = 0
+    for name, table in (("conv", _CONV_CHOICE), ("wgrad", _WGRAD_CHOICE), ("split", _SPLIT_CHOICE)):
+        merged = dict(_persisted_choices().get(name, {}))
+        merged.update({tuple(k[:-1]): v for k, v in table.items()})
+        doc[name] = {json.dumps(list(k)): v for k, v in sorted(merged.items(), key=lambda kv: json.dumps(list(kv[0])))}
+        n += len(merged)
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=0, sort_keys=True)
+        f.write("\n")
+    return n
+
+
+_WGRAD_CHOICE = _ChoiceTable("wgrad")
 
 
 def _miopen_wgrad(x, g, weight, stride, padding, dilation):
@@ -780,17 +969,8 @@ def _tuned_wgrad(x, g, weight, stride, padding, dilation):
     choice = _WGRAD_CHOICE.get(key)
     if choice is None:
         def clock(fn):
-            fn(); fn()
-            torch.cuda.synchronize(x.device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                fn()
-            e1.record()
-            torch.cuda.synchronize(x.device)
-            return e0.elapsed_time(e1)
-        choice = "hip" if clock(run_hip) <= clock(run_mi) else "miopen"
-        _WGRAD_CHOICE[key] = choice
+            return _clock(fn, x.device, n=5, warm=2)
+        choice = _WGRAD_CHOICE.measured(key, "hip" if clock(run_hip) <= clock(run_mi) else "miopen")
     return run_hip() if choice == "hip" else run_mi()
 
 
@@ -984,7 +1164,7 @@ def refresh_bf16_shadows():
 # (OMNIHD_CONV_POLICY = tune (default) | hip | miopen).  Measured at the BEV sizes (scripts/lab/conv_bench.py): the data
 # gradient is ours on every 3x3 geometry (854 vs 700 TFLOP/s on 1024->1024 at 160x240), the forward is a close race
 # (861 vs 875-966), 1x1 convolutions stay on MIOpen.
-_CONV_CHOICE = {}
+_CONV_CHOICE = _ChoiceTable("conv")
 _CONV_IMPLS = ("hip", "hip128x256", "miopen")
 
 
@@ -1015,20 +1195,11 @@ def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=N
     choice = _CONV_CHOICE.get(key)
     if choice is None:
         def clock(fn):
-            fn(); fn()
-            torch.cuda.synchronize(x.device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                fn()
-            e1.record()
-            torch.cuda.synchronize(x.device)
-            return e0.elapsed_time(e1)
+            return _clock(fn, x.device, n=5, warm=2)
         # "hip": the library's own pick (3x3 with dilation <= 8 at BEV sizes: the row-shift kernel, else the 256x128 tile,
         # 128x128 for small problems); "hip128x256": the wide-N tile
         times = {"hip": clock(lambda: run_hip(0, True)), "hip128x256": clock(lambda: run_hip(254, True)), "miopen": clock(run_miopen)}
-        choice = min(times, key=times.get)
-        _CONV_CHOICE[key] = choice
+        choice = _CONV_CHOICE.measured(key, min(times, key=times.get))
     if choice == "miopen":
         return run_miopen()
     return run_hip(0 if choice == "hip" else 254)
@@ -1273,19 +1444,26 @@ def conv_split_geometry(x_shape, cout, k, stride, padding, dilation, groups=1):
 
 
 # per-geometry measured choice between the split kernels and MIOpen's fp32 kernels (OMNIHD_FP32_CONV = tune | split | miopen)
-_SPLIT_CHOICE = {}
+_SPLIT_CHOICE = _ChoiceTable("split")
 
 
-def _clock(fn, dev, n=3):
-    fn()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1)
+def _clock(fn, dev, n=3, warm=1):
+    """Milliseconds of ``n`` back-to-back calls after ``warm`` untimed ones; OMNIHD_TUNE_REPEATS > 1 (used when the persisted
+    choice table is captured) repeats the measurement and keeps the minimum."""
+    best = None
+    for _ in range(max(1, int(os.environ.get("OMNIHD_TUNE_REPEATS", "1")))):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        t = e0.elapsed_time(e1)
+        best = t if best is None else min(best, t)
+    return best
 
 
 def _split_pick(key, run_split, run_miopen, dev):
@@ -1296,7 +1474,7 @@ def _split_pick(key, run_split, run_miopen, dev):
         return run_miopen()
     choice = _SPLIT_CHOICE.get(key)
     if choice is None:
-        choice = _SPLIT_CHOICE[key] = "split" if _clock(run_split, dev) <= _clock(run_miopen, dev) else "miopen"
+        choice = _SPLIT_CHOICE.measured(key, "split" if _clock(run_split, dev) <= _clock(run_miopen, dev) else "miopen")
     return run_split() if choice == "split" else run_miopen()
 
 

@@ -7,6 +7,8 @@ cluster offset (xyz - mean), pillar-centre offset and — radar variant — velo
 pillar-centre offset OVERWRITES the raw x,y channels as well (pillar_encoder.py:410-416), so the
 decorated tensor starts with (x-cx, y-cy, z, ...).  The caller's ``features`` tensor is not modified
 here (the reference mutates it; nothing reads it afterwards)."""
+import os
+
 import torch
 from torch import nn
 
@@ -57,6 +59,77 @@ class _PillarNetBase(nn.Module):
         parts[0] = base
         return parts, cnt, base
 
+    def _fused_weight(self):
+        """(64, K) weight of the single layer for the fused kernel, or None when the layer has another form."""
+        layer = self.pfn_layers[0]
+        if isinstance(layer, PFNLayer_Radar):
+            # three Linear + BatchNorm branches on channel subsets = one Linear with a block-sparse weight + per-channel BatchNorm
+            w = layer.linear1.weight.new_zeros(layer.units1 + layer.units2 + layer.units3, self.in_channels)
+            rows = 0
+            for idx, lin in ((layer.SPATIAL, layer.linear1), (layer.VELOCITY, layer.linear2), (layer.SNR, layer.linear3)):
+                w = w.index_put((torch.arange(rows, rows + lin.out_features, device=w.device).unsqueeze(1),
+                                 torch.tensor(idx, device=w.device).unsqueeze(0)), lin.weight)
+                rows += lin.out_features
+            return w
+        return layer.linear.weight
+
+    def _fused(self, features, num_points, coors, radar=False):
+        """The whole net as the fused HIP kernels of csrc/pillar_pfn.hip (decorate + Linear + BatchNorm + ReLU + max: 4 launches
+        forward, 3 backward, instead of ~25 + their autograd mirrors), or None where they do not apply: device tensors, one
+        layer of 64 units in 'max' mode, <= 16 decorated channels, <= 64 slots, BatchNorm1d / naiveSyncBN1d with running
+        statistics and a fixed momentum.  OMNIHD_PFN_FUSED=0 keeps the torch formulation (the CPU path and test oracle)."""
+        from omnihd_amd import ops
+        from omnihd_amd.mm.sync_bn import _NaiveSyncBN
+        if not features.is_cuda or len(self.pfn_layers) != 1 or os.environ.get("OMNIHD_PFN_FUSED", "1") == "0":
+            return None
+        layer = self.pfn_layers[0]
+        norms = [layer.norm1, layer.norm2, layer.norm3] if isinstance(layer, PFNLayer_Radar) else [layer.norm]
+        flags = (ops.PFN_CLUSTER * bool(self._with_cluster_center) | ops.PFN_CENTER * bool(self._with_voxel_center)
+                 | ops.PFN_DISTANCE * bool(self._with_distance) | ops.PFN_LEGACY * bool(self.legacy) | ops.PFN_RADAR * bool(radar))
+        ok = (layer.mode == "max" and features.dim() == 3 and features.shape[1] <= 64 and features.shape[2] >= (7 if radar else 3)
+              and sum(n.num_features for n in norms) == 64 and ops.pfn_channels(features.shape[2], flags) == self.in_channels <= 16
+              and all(type(n) is nn.BatchNorm1d or isinstance(n, _NaiveSyncBN) for n in norms)
+              and all(n.affine and n.track_running_stats and n.momentum is not None for n in norms)
+              and len({(n.eps, n.momentum, n.training, type(n)) for n in norms}) == 1)
+        if not ok:
+            return None
+        norm = norms[0]
+        if len(norms) > 1:
+            norm = self._joint_norm(norms)
+        sync = isinstance(norms[0], _NaiveSyncBN) and torch.distributed.is_available() and torch.distributed.is_initialized()
+        out = ops.pfn_fused(features, num_points, coors, self._fused_weight(), norm, (self.vx, self.vy, self.x_offset, self.y_offset),
+                            flags, group=torch.distributed.group.WORLD if sync else None)
+        if len(norms) > 1:
+            self._split_norm(norm, norms)
+        return out
+
+    @staticmethod
+    def _joint_norm(norms):
+        """A 64-channel BatchNorm view of the radar layer's three norms for one call: affine parameters concatenated
+        (differentiably), running statistics concatenated and written back afterwards by ``_split_norm``."""
+        joint = nn.BatchNorm1d(1, eps=norms[0].eps, momentum=norms[0].momentum)
+        joint.train(norms[0].training)
+        del joint._parameters["weight"], joint._parameters["bias"]
+        joint.weight = torch.cat([n.weight for n in norms])
+        joint.bias = torch.cat([n.bias for n in norms])
+        joint._buffers["running_mean"] = torch.cat([n.running_mean for n in norms])
+        joint._buffers["running_var"] = torch.cat([n.running_var for n in norms])
+        joint._buffers["num_batches_tracked"] = None
+        return joint
+
+    @staticmethod
+    def _split_norm(joint, norms):
+        if not joint.training:
+            return
+        o = 0
+        with torch.no_grad():
+            for n in norms:
+                n.running_mean.copy_(joint.running_mean[o:o + n.num_features])
+                n.running_var.copy_(joint.running_var[o:o + n.num_features])
+                if n.num_batches_tracked is not None:
+                    n.num_batches_tracked.add_(1)
+                o += n.num_features
+
     def _run(self, parts, num_points):
         features = torch.cat(parts, dim=-1)
         mask = get_paddings_indicator(num_points, features.shape[1], axis=0).unsqueeze(-1).type_as(features)
@@ -76,6 +149,9 @@ class PillarFeatureNetV1(_PillarNetBase):
                     point_cloud_range, norm_cfg, mode, legacy)
 
     def forward(self, features, num_points, coors, img_feats=None, img_metas=None):
+        fused = self._fused(features, num_points, coors)
+        if fused is not None:
+            return fused
         parts, _, _ = self._decorate(features, num_points, coors)
         return self._run(parts, num_points)
 
@@ -94,6 +170,9 @@ class RadarPillarFeatureNet(_PillarNetBase):
                     point_cloud_range, norm_cfg, mode, legacy, extra=4 * bool(with_velocity_snr_center))
 
     def forward(self, features, num_points, coors, img_feats=None, img_metas=None):
+        fused = self._fused(features, num_points, coors, radar=self._with_velocity_snr_center)
+        if fused is not None:
+            return fused
         parts, cnt, base = self._decorate(features, num_points, coors)
         if self._with_velocity_snr_center:
             parts.append(base[:, :, 3:7] - base[:, :, 3:7].sum(dim=1, keepdim=True) / cnt)

@@ -375,3 +375,25 @@ def test_dcn_oracle_agrees_with_the_two_torch_formulations_of_the_product(dg):
             got.append(m._gather_and_gemm(torch.from_numpy(x), torch.from_numpy(off), torch.float32).numpy())
     for g in got:
         assert g.shape == want.shape and np.abs(g - want).max() <= 1e-5 * np.abs(want).max()
+
+
+def test_pillar_feature_net_oracle_is_pinned_by_the_reference_outputs(golden):
+    """oracle/pfn_oracle.py against what the reference's PillarFeatureNetV1 / RadarPillarFeatureNet classes produced on fixed
+    inputs with fixed weights (BatchNorm in inference mode; tests/golden/make_golden.py keys g6_*)."""
+    from oracle import pfn_oracle as P
+    vsz, pcr = [0.25, 0.25, 8], [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
+    vox, npts, coors = golden["g6_voxels"], golden["g6_num_points"], golden["g6_coors"]
+    x = P.decorate(vox, npts, coors, vsz, pcr)
+    assert x.shape[-1] == 13
+    w, b, rm, rv = golden["g6_pfn_bn"]
+    out, _, _ = P.pfn_forward(x, golden["g6_pfn_linear_w"], w, b, rm, rv, eps=1e-3)
+    np.testing.assert_allclose(out, golden["g6_pfn_out"], rtol=2e-6, atol=2e-6)
+    sd = {k[len("g6_radar_sd__"):].replace("__", "."): golden[k] for k in golden.files if k.startswith("g6_radar_sd__")}
+    xr = P.decorate(vox[:, :, :7], npts, coors, vsz, pcr, radar=True)
+    assert xr.shape[-1] == 16
+    wr = P.radar_weight(sd["pfn_layers.0.linear1.weight"], sd["pfn_layers.0.linear2.weight"], sd["pfn_layers.0.linear3.weight"])
+    cat = lambda n: np.concatenate([sd[f"pfn_layers.0.norm{i}.{n}"] for i in (1, 2, 3)])
+    out, _, _ = P.pfn_forward(xr, wr, cat("weight"), cat("bias"), cat("running_mean"), cat("running_var"), eps=1e-3)
+    np.testing.assert_allclose(out, golden["g6_radar_out"], rtol=2e-6, atol=2e-6)
+    # padded slots are rows of zeros that take part in the maximum (a pillar with one point still sees relu(shift))
+    assert (npts < vox.shape[1]).any()
