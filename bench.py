@@ -50,6 +50,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; measured 2495 with 32x32x16)
+CONV_GEOMETRY = (1024, 1024, 3, 160, 240)     # (cin, cout, k, H, W) of the BEV encoder's first convolution: the largest dense layer
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured here: copy 5.2 TB/s, fill 6.5 TB/s (scripts/write_bw.py)
 RES = {"r1": (256, 704, 410.0), "r2": (544, 960, 560.0)}
 PC_RANGE = [-60.0, -40.0, -3.0, 60.0, 40.0, 5.0]
@@ -461,11 +463,106 @@ def selftest_launch(a, world, rank):
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
+        comm = {"world_size": dist.get_world_size(), "backend": dist.get_backend()} if world > 1 else None
         print(json.dumps({"selftest": "launch", "n_gpus": world, "max_over_ranks": float(t.item()), "steps": a.steps,
-                          "warmup": a.warmup}), flush=True)
+                          "warmup": a.warmup, "comm": comm}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pool_source_hash():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "omnihd-scenes_amd", "csrc", "bev_pool_v2.hip"), "rb").read()).hexdigest()
+
+
+def pmc_traffic(res, fwd_kernel):
+    """HBM-side bytes per launch of the pooling forward from the committed rocprofv3 PMC passes (profiles/round4/pmc_pool_<res>.json:
+    FETCH_SIZE x the factor calibrated on a 128 MiB copy + WRITE_SIZE, separate --pmc passes, scripts/lab/pmc_bwd.sh) — a pointer to
+    a measurement of THIS kernel, not a counter read in this run: null unless the file names the kernel that ran AND was taken from
+    the same csrc/bev_pool_v2.hip (sha256 recorded in the file)."""
+    pmc = os.path.join(ROOT, "profiles", "round4", f"pmc_pool_{res}.json")
+    if not os.path.exists(pmc):
+        return None, None
+    rec = json.load(open(pmc))
+    k = rec.get("fwd_lean", {})
+    if not (fwd_kernel.startswith(rec.get("fwd_kernel", "?")) and "read_bytes_corrected" in k and "write_bytes" in k):
+        return None, None
+    if rec.get("pool_source_sha256") != pool_source_hash():
+        return None, f"profiles/round4/pmc_pool_{res}.json is stale: csrc/bev_pool_v2.hip changed since the counters were taken"
+    return round(k["read_bytes_corrected"] + k["write_bytes"]), (
+        f"profiles/round4/pmc_pool_{res}.json (rocprofv3 --pmc passes of scripts/lab/pmc_bwd.sh on {rec.get('fwd_kernel')}, "
+        f"same csrc/bev_pool_v2.hip: sha256 {rec.get('pool_source_sha256', '?')[:12]})")
+
+
+def pooling_at_r2(dev, launches):
+    """The two pooling kernels at the repo's own resolution (configs[2]: 6 x 544 x 960 images, bevfusion.py:28), isolated
+    launches: back-to-back on one buffer set (inputs resident in the Infinity Cache, as behind the depth-head epilogue kernel in
+    the step) and after a 512 MiB sweep (cold)."""
+    wl = BevOps("r2", 1, dev, seed=1234, sets=2)
+    fb, bb = wl.fwd_algorithmic_bytes(), wl.bwd_algorithmic_bytes()
+    tf, tb = time_kernel(wl.pool_fwd, 1, launches), time_kernel(wl.pool_bwd, 1, launches)
+    cf, cb = time_kernel_cold(wl.pool_fwd, 2, 8), time_kernel_cold(wl.pool_bwd, 2, 8)
+    traffic, src = pmc_traffic("r2", wl.fwd_kernel_name())
+    out = {"workload": "bev_pool_v2 forward / backward at 544x960 (136x240 feature map, 4 503 872 points, 389 882 intervals)",
+           "fwd_kernel": wl.fwd_kernel_name(), "fwd_algorithmic_bytes": fb, "fwd_warm_us": round(tf * 1e6, 2),
+           "fwd_frac": round(fb / tf / 1e9 / HBM_PEAK_GBS, 4), "fwd_cold_us": round(cf * 1e6, 2),
+           "fwd_frac_cold": round(fb / cf / 1e9 / HBM_PEAK_GBS, 4), "fwd_traffic": traffic, "fwd_traffic_source": src,
+           "bwd_kernel": wl.bwd_kernel_name(), "bwd_algorithmic_bytes": bb, "bwd_warm_us": round(tb * 1e6, 2),
+           "bwd_frac": round(bb / tb / 1e9 / HBM_PEAK_GBS, 4), "bwd_cold_us": round(cb * 1e6, 2),
+           "bwd_frac_cold": round(bb / cb / 1e9 / HBM_PEAK_GBS, 4), "n_points": wl.plan.n_points}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def dense_rooflines(a, world, runs, flops, main_dt):
+    """`step_roofline`: dense-layer FLOPs of one step (module graph, harness.count_step_flops) / step time against the dense bf16
+    MFMA peak, per precision, with the MFMA work factor stated (the fp32-grade split kernels issue 3 bf16 products per fp32
+    product); `conv_roofline`: our implicit-GEMM kernel on the largest convolution from HIP events INSIDE the timed steps;
+    `fp32_library`: the fp32 step with every dense convolution on MIOpen's fp32 kernels."""
+    out = {}
+    cin, cout, k, H, W = CONV_GEOMETRY
+    conv_flops = 2.0 * a.batch * H * W * cin * cout * k * k
+    sr = {}
+    for dt, key in (("fp32", "f32_split_bf16"), ("bf16", "bf16_autocast"), ("fp32_library", "f32_library")):
+        if dt not in runs:
+            continue
+        el = runs[dt][0]
+        fl = flops.get("fp32" if dt == "fp32_library" else dt)
+        if not fl:
+            continue
+        tf = fl["total"] * world / (el / a.steps) / 1e12
+        factor = 3 if dt == "fp32" else 1
+        peak = MFMA_BF16_PEAK_TFLOPS if dt != "fp32_library" else 157.3
+        sr[key] = {"flops_per_step": fl["total"], "flops_forward": fl["forward"], "achieved_TFLOPs": round(tf, 1),
+                   "peak_TFLOPs": peak * world, "frac": round(tf / (peak * world), 4), "mfma_work_factor": factor,
+                   "frac_of_issued_mfma": round(tf * factor / (peak * world), 4)}
+    if sr:
+        sr["note"] = ("dense layers only (Conv2d / ConvTranspose2d / Linear / DCN contraction: forward + data gradient where the input "
+                      "carries one + weight gradient where the weight trains); peak = dense bf16 MFMA 2.5 PFLOP/s (fp32 matrix "
+                      "157.3 TFLOP/s for the library line); the split kernels issue 3 bf16 MFMA products per fp32 product "
+                      "(mfma_work_factor), so frac_of_issued_mfma is the share of the bf16 pipes' peak they keep busy")
+        out["step_roofline"] = sr
+    cr = {}
+    for dt, kind, key in (("fp32", "conv_split", "f32_split_bf16"), ("bf16", "conv_bf16", "bf16")):
+        if dt in runs and runs[dt][2].get(kind):
+            t = runs[dt][2][kind]
+            factor = 3 if dt == "fp32" else 1
+            cr[key] = {"mean_launch_us": round(t * 1e6, 1), "launches": runs[dt][2].get("n_" + kind),
+                       "effective_TFLOPs": round(conv_flops / t / 1e12, 1), "mfma_work_factor": factor,
+                       "frac_of_bf16_mfma_peak": round(conv_flops * factor / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+    if cr:
+        cr["kernel"] = "k_conv_igemm_rs (3x3 implicit GEMM with row-shift reuse of the activation tile, csrc/conv_igemm.hip)"
+        cr["geometry"] = f"{cin}->{cout} {k}x{k} @ {H}x{W}, batch {a.batch}: forward and data-gradient launches"
+        cr["measured"] = "HIP events on the launching stream around every launch inside the timed steps"
+        out["conv_roofline"] = cr
+    if "fp32_library" in runs:
+        e3, sp3, _ = runs["fp32_library"]
+        out["fp32_library"] = {"value": round(a.batch * world * a.steps / e3, 3), "unit": "frames/s", "ms_per_step": round(e3 / a.steps * 1e3, 4),
+                               "step_ms": sp3, "note": "OMNIHD_FP32_CONV=miopen: every dense convolution on MIOpen's fp32 kernels (fp32 MFMA, "
+                                                       "no bf16 products); everything else as in the headline step"}
+    return out
 
 
 def main():
@@ -500,7 +597,7 @@ def main():
     # Dominant north_star kernel (bev_pool_v2 forward): timed FIRST, on the same frame geometry with rotating buffer
     # sets, before the training loop heats the chip (the same kernel inside the step runs ~15 % slower: DVFS
     # after MFMA-heavy convolutions and a polluted L2 — see profiles/ for the in-step rocprofv3 average).
-    kernel_times = kernel_cold = other_ops = None
+    kernel_times = kernel_cold = other_ops = r2_block = None
     kept_bytes = 0
     if rank == 0:
         ops_wl = BevOps(a.res, a.batch, dev, seed=1234)
@@ -514,6 +611,8 @@ def main():
         other_ops = ops_wl.other_ops(a.res)
         del ops_wl
         torch.cuda.empty_cache()
+        if a.res == "r1" and a.batch == 1:
+            r2_block = pooling_at_r2(dev, a.kernel_launches)
 
     def barrier():
         if world > 1:
@@ -527,7 +626,9 @@ def main():
             wl.step()
         barrier()
         import omnihd_amd.plan as plan_mod
+        from omnihd_amd import ops as ops_mod
         plan_mod.TIMING = []                 # events around every pooling kernel launched inside the timed steps
+        ops_mod.CONV_TIMING, ops_mod.CONV_TIMING_GEOMETRY = [], CONV_GEOMETRY   # ... and around our kernel on the largest convolution
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
         t0 = time.perf_counter()
         marks[0].record()
@@ -544,10 +645,14 @@ def main():
         for kind, e0, e1 in plan_mod.TIMING:
             pool.setdefault(kind, []).append(e0.elapsed_time(e1) * 1e-3)
         plan_mod.TIMING = None
+        for kind, e0, e1 in ops_mod.CONV_TIMING:
+            pool.setdefault("conv_" + kind, []).append(e0.elapsed_time(e1) * 1e-3)
+        ops_mod.CONV_TIMING = None
         in_step = {k: sum(v) / len(v) for k, v in pool.items() if v}
+        in_step.update({"n_" + k: len(v) for k, v in pool.items()})
         return float(el.item()), {"median": round(q(0.5), 3), "p10": round(q(0.1), 3), "p90": round(q(0.9), 3)}, in_step
 
-    runs = {}
+    runs, flops, comm = {}, {}, None
     if a.workload == "fusion":
         from omnihd_amd.harness import FusionTrainStep
         for dt in (["fp32", "bf16"] if a.dtype == "both" else [a.dtype]):
@@ -559,7 +664,27 @@ def main():
                 wl.step()
             wl.sync_choices()                 # N > 1: every rank runs the kernels rank 0 measured best
             runs[dt] = timed(wl)
+            if rank == 0:
+                from omnihd_amd.harness import count_step_flops
+                flops[dt] = count_step_flops(wl)
+            if world > 1 and dt == ("fp32" if a.dtype == "both" else a.dtype):
+                from omnihd_amd.harness import comm_report
+                comm = comm_report(wl)        # after the timed region: its no_sync steps let the ranks' weights drift
             del wl
+            torch.cuda.empty_cache()
+        if a.dtype == "both" and world == 1:
+            # the same fp32 step with every dense convolution on MIOpen's fp32 kernels (strict fp32 MFMA, no bf16 products):
+            # the "library" line beside the split-bf16 headline
+            os.environ["OMNIHD_FP32_CONV"] = "miopen"
+            try:
+                wl = FusionTrainStep(res=a.res, batch=a.batch, radar_dims=radar_dims, device=f"cuda:{local}", seed=1234 + rank,
+                                     dtype="fp32", ddp=False, miopen_find=True)
+                for _ in range(3):
+                    wl.step()
+                runs["fp32_library"] = timed(wl)
+                del wl
+            finally:
+                os.environ.pop("OMNIHD_FP32_CONV", None)
             torch.cuda.empty_cache()
         main_dt = "fp32" if a.dtype == "both" else a.dtype
     else:
@@ -578,15 +703,7 @@ def main():
         # HBM-side bytes per launch from rocprofv3 PMC passes (scripts/pmc_traffic.sh): FETCH_SIZE x the factor
         # calibrated on a 128 MiB read of the same width (2.0 on gfx950, as the microarch guide says) + WRITE_SIZE
         # (a pointer to a committed measurement of THIS kernel, not a counter read in this run: PMC passes need rocprofv3)
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "round3", "pmc_pool_r1.json")
-        if os.path.exists(pmc) and a.res == "r1" and a.batch == 1:
-            rec = json.load(open(pmc))
-            k = rec.get("fwd_lean", {})
-            if fwd_kernel.startswith(rec.get("fwd_kernel", "?")) and "read_bytes_corrected" in k and "write_bytes" in k:
-                traffic = round(k["read_bytes_corrected"] + k["write_bytes"])
-                traffic_src = "profiles/round3/pmc_pool_r1.json (rocprofv3 --pmc passes of scripts/lab/pmc_bwd.sh on %s, commit %s)" % (
-                    rec.get("fwd_kernel"), rec.get("commit", "?"))
+        traffic, traffic_src = pmc_traffic(a.res, fwd_kernel) if a.batch == 1 else (None, None)
         # BEV rows no frustum point reaches keep the zeros of the previous launch (plan.py::_kept_output): the kernel skips
         # their zero fill, so it MOVES fewer bytes than the SURVEY 8(d) formula counts — both rates are reported
         kept = kept_bytes
@@ -628,6 +745,14 @@ def main():
                          "bwd_algorithmic_bytes": bwd_bytes},
         }
         line["ops_roofline"] = other_ops
+        if r2_block is not None:
+            line["r2"] = r2_block
+        from omnihd_amd import ops as ops_mod
+        line["kernel_choice_table"] = ops_mod.choice_table_info()
+        if a.workload == "fusion":
+            line.update(dense_rooflines(a, world, runs, flops, main_dt))
+        if comm is not None:
+            line["comm"] = comm
         if a.workload == "fusion" and a.dtype == "both":
             e2, sp2, _ = runs["bf16"]
             line["bf16_autocast"] = {"value": round(a.batch * world * a.steps / e2, 3), "unit": "frames/s",

@@ -403,3 +403,107 @@ class FusionTrainStep:
             ops.refresh_split_shadows()           # fp32 step: forward + data-gradient planes of every split convolution, one launch
         self.last_losses = losses
         return total
+
+
+def count_step_flops(step):
+    """Dense-layer FLOPs of ONE training step of ``step`` (a FusionTrainStep), read off the module graph with forward hooks on
+    one real forward: every Conv2d / ConvTranspose2d / Linear / deformable convolution contributes 2*MACs forward, the same again
+    for its data gradient where its input carries a gradient, and again for its weight gradient where the weight is trainable.
+    Pooling, voxelisation, BatchNorm, activations and the losses are bandwidth work and are not counted.
+    Returns {"forward", "backward", "total"} in FLOPs per step (all frames of the batch)."""
+    from .mm.dcn import DeformConv2dPack
+    fwd = [0.0]
+    bwd = [0.0]
+
+    def macs_of(mod, x, y):
+        if isinstance(mod, nn.Linear):
+            return y.numel() * mod.in_features
+        if isinstance(mod, DeformConv2dPack):
+            return y.numel() * (mod.in_channels // mod.groups) * mod.k * mod.k
+        kh, kw = mod.kernel_size
+        if isinstance(mod, nn.ConvTranspose2d):
+            return x.numel() * (mod.out_channels // mod.groups) * kh * kw
+        return y.numel() * (mod.in_channels // mod.groups) * kh * kw
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        if not torch.is_tensor(x) or not torch.is_tensor(out):
+            return
+        f = 2.0 * macs_of(mod, x, out)
+        fwd[0] += f
+        w = getattr(mod, "weight", None)
+        if torch.is_grad_enabled():
+            bwd[0] += f * (bool(x.requires_grad) + bool(w is not None and w.requires_grad))
+
+    handles = [m.register_forward_hook(hook) for m in step.raw_model.modules()
+               if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear, DeformConv2dPack))]
+    try:
+        b = step.batches[0]
+        with torch.autocast(step.device.type, dtype=torch.bfloat16, enabled=step.autocast):
+            losses = step.raw_model(return_loss=True, **b)
+        del losses
+    finally:
+        for h in handles:
+            h.remove()
+    return {"forward": fwd[0], "backward": bwd[0], "total": fwd[0] + bwd[0]}
+
+
+def comm_report(step, iters=3):
+    """What a multi-rank training step exchanges, measured / read where it happens (bench.py puts it into its JSON line as
+    ``comm`` at N > 1; tests/test_distributed_cpu.py runs it over gloo):
+      world_size / backend      as the process group reports them (backend "nccl" is RCCL on ROCm);
+      allreduce_bytes_per_step  gradient bytes DDP all-reduces per step (every trainable parameter once, fp32);
+      buckets                   DDP's gradient buckets (25 MB cap, reference: mmdet_train.py:76-80);
+      syncbn_exchanges_per_step all-reduces of the naiveSyncBN layers (one forward + one backward each, 2*C floats);
+      exposed_comm_ms           wall time of a step MINUS the same step under DDP.no_sync() (no gradient all-reduce): the part of
+                                the communication that backward does not hide.  Run after the timed region (no_sync steps let the
+                                ranks' weights drift apart)."""
+    import time
+    import torch.distributed as dist
+    from .mm.sync_bn import _NaiveSyncBN
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    params = [p for p in step.raw_model.parameters() if p.requires_grad]
+    nbytes = sum(p.numel() * p.element_size() for p in params)
+    rep = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes_per_step": int(nbytes),
+           "bucket_cap_mb": 25, "buckets": None, "exposed_comm_ms": None,
+           "syncbn_exchanges_per_step": 2 * sum(1 for m in step.raw_model.modules()
+                                                if (isinstance(m, _NaiveSyncBN) or isinstance(m, nn.SyncBatchNorm)) and m.training)}
+    ddp = step.model if isinstance(step.model, nn.parallel.DistributedDataParallel) else None
+    if ddp is None:
+        return rep
+
+    def sync():
+        if step.device.type == "cuda":
+            torch.cuda.synchronize(step.device)
+
+    def timed(no_sync):
+        ts = []
+        for _ in range(iters):
+            dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            if no_sync:
+                with ddp.no_sync():
+                    step.step()
+            else:
+                step.step()
+            sync()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    t_sync = timed(False)
+    try:
+        data = ddp._get_ddp_logging_data()
+        sizes = str(data.get("bucket_sizes", "")).strip()
+        if sizes:
+            rep["buckets"] = len([s for s in sizes.split(",") if s.strip()])
+    except Exception:
+        pass
+    if rep["buckets"] is None:
+        rep["buckets"] = max(1, -(-nbytes // (25 << 20)))
+    t_nosync = timed(True)
+    rep["step_ms"] = round(t_sync * 1e3, 3)
+    rep["step_no_allreduce_ms"] = round(t_nosync * 1e3, 3)
+    rep["exposed_comm_ms"] = round(max(t_sync - t_nosync, 0.0) * 1e3, 3)
+    return rep

@@ -835,6 +835,23 @@ def conv_fwd_supported(x_shape, cout, k, stride, padding, dilation):
             bool(lib().omnihd_conv_fwd_supported(B, H, W, cin, cout, k, dilation)))
 
 
+# bench.py sets CONV_TIMING to a list and CONV_TIMING_GEOMETRY to one (cin, cout, k, H, W): HIP events are then recorded around
+# every launch of our implicit-GEMM convolution kernels with that geometry inside the training step (forward and data gradient,
+# bf16 and split forms) -> the in-step duration the `conv_roofline` block of the bench line is computed from
+CONV_TIMING = None
+CONV_TIMING_GEOMETRY = None
+
+
+def _conv_timed(kind, geo, launch):
+    if CONV_TIMING is None or geo != CONV_TIMING_GEOMETRY:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    CONV_TIMING.append((kind, e0, e1))
+
+
 def conv_fwd(x, w_cl, bias=None, dilation=1, tile=0):
     """y = conv2d(x, w, bias, stride 1, padding = dilation*(k//2)) on the matrix cores (csrc/conv_igemm.hip).
     x (B,Cin,H,W) bf16 channels-last, w_cl (Cout,Cin,k,k) bf16 in channels_last memory format ((Cout,k,k,Cin) memory),
@@ -847,9 +864,10 @@ def conv_fwd(x, w_cl, bias=None, dilation=1, tile=0):
     # (B,Cout,H,W) with channels-last strides = NHWC memory; not a view of anything (a custom Function must not hand out views)
     y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     with _on(x.device):
-        check(lib().omnihd_conv_fwd_bf16(x.data_ptr(), w_cl.data_ptr(), None if bias is None else _f32c(bias).data_ptr(),
-                                         y.data_ptr(), B, H, W, cin, cout, k, int(dilation), int(tile), _raw_stream()),
-              "omnihd_conv_fwd_bf16")
+        _conv_timed("bf16", (cin, cout, k, H, W), lambda: check(
+            lib().omnihd_conv_fwd_bf16(x.data_ptr(), w_cl.data_ptr(), None if bias is None else _f32c(bias).data_ptr(),
+                                       y.data_ptr(), B, H, W, cin, cout, k, int(dilation), int(tile), _raw_stream()),
+            "omnihd_conv_fwd_bf16"))
     return y
 
 
@@ -1424,9 +1442,10 @@ def conv_fwd_split(xs, ws, bias=None, dilation=1, tile=0):
     cout, k = ws[0].shape[0], ws[0].shape[2]
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=xs[0].device, memory_format=torch.channels_last)
     with _on(y.device):
-        check(lib().omnihd_conv_fwd_split(xs[0].data_ptr(), xs[1].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
-                                          None if bias is None else _f32c(bias).data_ptr(), y.data_ptr(), B, H, W, cin, cout, k,
-                                          int(dilation), int(tile), _raw_stream()), "omnihd_conv_fwd_split")
+        _conv_timed("split", (cin, cout, k, H, W), lambda: check(
+            lib().omnihd_conv_fwd_split(xs[0].data_ptr(), xs[1].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                        None if bias is None else _f32c(bias).data_ptr(), y.data_ptr(), B, H, W, cin, cout, k,
+                                        int(dilation), int(tile), _raw_stream()), "omnihd_conv_fwd_split"))
     return y
 
 

@@ -325,6 +325,16 @@ def _direct_forward():
     return os.environ.get("OMNIHD_POOL_DIRECT", "1") != "0"
 
 
+def forward_tables(plan, channels=64):
+    """The static tables the forward kernel of ``plan`` will read for ``channels`` feature channels (what the LSS module streams
+    into the caches ahead of the launch, ``ops.prefetch``): the direct kernel's point words, row ids and 32-int descriptors, or
+    the lean kernels' tile descriptors, CSR and rank table."""
+    if channels == 64 and plan.depth_bins > 0 and _lean_forward() and _direct_forward():
+        pt, ivl_rel, desc32 = direct_tables(plan)
+        return [desc32, ivl_rel, pt]
+    return [plan.tile_desc, plan.row_ptr, plan.ranks_depth]
+
+
 def _patch_backward():
     """The patch backward (k_pool_bwd_patch, C = 64) is the default; OMNIHD_POOL_BWD_PATCH=0 selects the scheduled kernel."""
     import os

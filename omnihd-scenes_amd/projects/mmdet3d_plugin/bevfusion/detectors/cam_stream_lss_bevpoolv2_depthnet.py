@@ -29,7 +29,7 @@ from omnihd_amd import ops as _ops
 from omnihd_amd.mm import build_conv_layer, build_norm_layer
 from omnihd_amd.mm.bricks import bn_act, run_fused
 from omnihd_amd.mm.resnet import BasicBlock
-from omnihd_amd.plan import planned_pool
+from omnihd_amd.plan import forward_tables, planned_pool
 from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2  # noqa: F401  (API parity)
 from projects.mmdet3d_plugin.utils.gaussian import generate_guassian_depth_target
 
@@ -305,7 +305,7 @@ class LiftSplatShoot_Depth(nn.Module):
             # the plan's tables were last read a whole step ago: stream them into the caches on a side stream (the pooling
             # kernel is a chain of dependent reads per tile; 62 us with cold tables inside the step vs 45 us with resident
             # ones).  With the fused depth-head epilogue this has already happened in front of that kernel (get_voxels).
-            _ops.prefetch([plan.tile_desc, plan.row_ptr, plan.ranks_depth])
+            _ops.prefetch(forward_tables(plan, self.camC))
         self._tables_read_ahead = False
         feat = feat.permute(0, 1, 3, 4, 2).contiguous()      # a no-op behind the depth-head epilogue (pixel rows already)
         if plan is None:
@@ -327,7 +327,7 @@ class LiftSplatShoot_Depth(nn.Module):
             # and is finished when the pooling kernel starts (nothing else streams through the caches in between)
             if (x.is_cuda and getattr(plan, "tile_desc", None) is not None and plan.n_points > 0
                     and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0"):
-                _ops.prefetch([plan.tile_desc, plan.row_ptr, plan.ranks_depth])
+                _ops.prefetch(forward_tables(plan, self.camC))
                 self._tables_read_ahead = True
 
         self.camencode.before_epilogue = read_tables_ahead

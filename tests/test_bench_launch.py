@@ -31,6 +31,7 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_and_rank0_prints_one_line():
     assert out.returncode == 0, out.stderr[-2000:]
     line = _json_line(out)
     assert line["n_gpus"] == 2 and line["max_over_ranks"] == 2.0 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["comm"] == {"world_size": 2, "backend": "gloo"}       # the process group's own account of the job (not --gpus echoed)
 
 
 def test_world_size_must_match_gpus():

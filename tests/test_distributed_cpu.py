@@ -71,10 +71,14 @@ def _ddp_worker(rank, world, port, out, task="det"):
         st = FusionTrainStep(res="tiny", batch=1, radar_dims=7, device="cpu", seed=100 + rank, dtype="fp32", ddp=True,
                              channels_last=False, sets=1, task=task, frames=2)
         losses = [float(st.step().detach()) for _ in range(2)]
-    flat = torch.cat([p.detach().reshape(-1) for p in st.raw_model.parameters()])
-    gathered = [torch.zeros_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
-    out[rank] = (losses, bool(torch.equal(gathered[0], gathered[1])), float(flat.abs().sum()))
+        flat = torch.cat([p.detach().reshape(-1) for p in st.raw_model.parameters()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        comm = None
+        if task == "det":                                 # what bench.py reports as `comm` at N > 1 (runs no_sync steps: last)
+            from omnihd_amd.harness import comm_report
+            comm = comm_report(st, iters=1)
+    out[rank] = (losses, bool(torch.equal(gathered[0], gathered[1])), float(flat.abs().sum()), comm)
     dist.destroy_process_group()
 
 
@@ -87,6 +91,14 @@ def test_tiny_detector_two_rank_ddp_step_keeps_replicas_identical():
     assert res[0][1] and res[1][1]                       # parameters identical on both ranks after 2 steps
     assert res[0][0] != res[1][0]                        # ...although each rank saw different frames
     assert all(np.isfinite(res[r][0]).all() for r in (0, 1))
+    # the self-evidence block of a multi-rank bench line: what the process group reports, what DDP moves
+    for r in (0, 1):
+        comm = res[r][3]
+        assert comm["world_size"] == 2 and comm["backend"] == "gloo"
+        assert comm["allreduce_bytes_per_step"] > 1_000_000 and comm["allreduce_bytes_per_step"] % 4 == 0
+        assert comm["buckets"] >= 1 and comm["syncbn_exchanges_per_step"] >= 2
+        assert comm["exposed_comm_ms"] is not None and comm["exposed_comm_ms"] >= 0 and comm["step_ms"] > 0
+    assert res[0][3]["allreduce_bytes_per_step"] == res[1][3]["allreduce_bytes_per_step"]
 
 
 def test_triple_modal_temporal_two_rank_ddp_step_keeps_replicas_identical():

@@ -235,7 +235,7 @@ def test_scatter_with_the_persistent_cell_map(cuda):
     from oracle import cpu as OC
     rng = np.random.default_rng(4)
     for it in range(4):
-        m = int(rng.integers(500, 3000))
+        m = int(rng.integers(500, 2000))
         cells = rng.choice(40 * 56, m - 5, replace=False)
         cells = np.concatenate([cells, cells[:5]])                               # five duplicated cells
         coors = np.stack([rng.integers(0, 2, m), np.zeros(m, np.int64), cells // 56, cells % 56], 1).astype(np.int32)
