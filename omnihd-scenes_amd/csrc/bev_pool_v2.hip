@@ -1067,11 +1067,11 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd_sched(
 // ---------------------------------------------------------------------------------------------
 template <int J>
 __device__ __forceinline__ int dpp_row_bcast_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);       // row_newbcast:J (16-lane rows)
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, true);        // row_newbcast:J (16-lane rows); bound_ctrl: no `old` to initialise
 }
 template <int J>
 __device__ __forceinline__ float dpp_row_bcast_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xf, 0xf, true));
 }
 template <int N>
 __device__ __forceinline__ float dpp_ror_add(float v) {
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void patch_batch8(const __amdgpu_buffer_rsrc_t og_rsr
 // PACKED: `ranks_row` holds (output row | depth bin << 24) per point and `ranks_depth` is not read: one table word per point
 // instead of two (8.1 MB less traffic per launch at R1, one table load per chunk instead of two).
 template <bool PACKED>
-__global__ __launch_bounds__(kBlock) void k_pool_bwd_patch(
+__global__ __launch_bounds__(kBlock, 8) void k_pool_bwd_patch(
     const float* __restrict__ og, unsigned og_bytes, const float* __restrict__ depth, const float4* __restrict__ feat4,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_row, const int* __restrict__ pix_ptr,
     const int* __restrict__ patch_order, int patches_per_xcd, int patches_per_img, int fhw, int d_bins, float inv_fhw,
