@@ -94,11 +94,15 @@ class DeformConv2dPack(nn.Module):
         fy, fx = py - y0, px - x0
         y0, x0 = y0.long(), x0.long()
         base = (torch.arange(B, device=x.device) * (H * W)).view(B, 1, 1, 1)
+        # mmcv's sampling gate (deformable_im2col: `h_im > -1 && w_im > -1 && h_im < height && w_im < width`): a tap whose position
+        # lies ON or beyond that border contributes nothing — and, unlike a per-corner mask, has NO offset gradient either (at
+        # the zero-initialised offsets every border tap sits exactly on -1: the HIP kernels and oracle/dcn_oracle.c gate it)
+        gate = (py > -1) & (px > -1) & (py < H) & (px < W)
         idx, wts = [], []
         for dy_, wy in ((0, 1 - fy), (1, fy)):
             for dx_, wx in ((0, 1 - fx), (1, fx)):
                 yy, xx = y0 + dy_, x0 + dx_
-                ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)        # zero padding outside the image
+                ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W) & gate    # zero padding outside the image
                 idx.append(torch.where(ok, base + yy * W + xx, torch.zeros_like(yy)))
                 wts.append(wy * wx * ok)
         idx = torch.stack(idx, dim=-1).reshape(-1, 4)                   # one bag of 4 corner rows per (pixel, tap)

@@ -47,7 +47,7 @@ if tiny:
     ctx.__enter__()
     st = FusionTrainStep(res="tiny", batch=1, radar_dims=7, device="cpu", dtype="fp32", channels_last=False, sets=1)
 else:
-    st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16", miopen_find=True)
+    st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype=(sys.argv[1] if len(sys.argv) > 1 else "bf16"), miopen_find=True)
 for _ in range(2):
     st.step()
 with Spy():
