@@ -307,7 +307,9 @@ int omnihd_pillar_gather(const float* canvas_grad, const int* coors, int m, int 
  *   omnihd_pfn_bwd_sums sums = [A (64) | B (64) | G (64 x K)]: A = sum g, B = sum g * yhat, G = sum g * x over the arg-max slot
  *                       (first maximum) of every (pillar, channel) with a positive output, g = grad_out (m, 64);
  *   omnihd_pfn_bwd_final dweight (64, K), dgamma, dbeta from this rank's sums, [A | B] summed over all ranks (= sums on one
- *                       rank), this rank's moments and the constants of the forward.  No gradient flows to the points.      */
+ *                       rank), this rank's moments and the constants of the forward; n_ranks <= 0: the constants came from the
+ *                       running statistics (inference-mode BatchNorm inside a differentiated graph) — the batch-statistics
+ *                       terms vanish and `moments` is not read beyond being non-NULL.  No gradient flows to the points.      */
 int omnihd_pfn_channels(int f, int flags);
 size_t omnihd_pfn_workspace_bytes(int m, int p, int k);
 int omnihd_pfn_moments(const float* voxels, const int* num_points, const int* coors, int m, int p, int f, float vx, float vy,

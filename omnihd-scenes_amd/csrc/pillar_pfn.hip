@@ -305,7 +305,8 @@ __global__ __launch_bounds__(kC) void k_pfn_bwd_final(const float* __restrict__ 
     for (int i = 0; i < k; ++i) wy += (double)weight[c * k + i] * moments[k + i * k + j];
     const double s1j = moments[j] * n_rows;
     const double yhx = (wy * n_rows - mean * s1j) * invstd;
-    dweight[c * k + j] = (float)(gs * ((double)sums[2 * kC + c * k + j] - (A * s1j + B * yhx) / n_eff));
+    const double corr = n_eff > 0.0 ? (A * s1j + B * yhx) / n_eff : 0.0;     // n_eff <= 0: statistics that did not depend on the batch
+    dweight[c * k + j] = (float)(gs * ((double)sums[2 * kC + c * k + j] - corr));
   }
 }
 
@@ -399,7 +400,7 @@ extern "C" int omnihd_pfn_bwd_sums(const float* voxels, const int* num_points, c
 extern "C" int omnihd_pfn_bwd_final(const float* sums, const float* ab_all_ranks, const double* moments, const float* weight,
                                     const float* gamma, const float* consts, int k, long long n_rows, int n_ranks, float* dweight,
                                     float* dgamma, float* dbeta, void* stream) {
-  OMNIHD_REQUIRE(k > 0 && k <= kMaxK && n_rows > 0 && n_ranks > 0 && sums && ab_all_ranks && moments && weight && gamma && consts &&
+  OMNIHD_REQUIRE(k > 0 && k <= kMaxK && n_rows > 0 && sums && ab_all_ranks && moments && weight && gamma && consts &&
                      dweight && dgamma && dbeta, "arguments");
   hipLaunchKernelGGL(k_pfn_bwd_final, dim3(1), dim3(kC), 0, (hipStream_t)stream, sums, ab_all_ranks, moments, weight, gamma, consts, k,
                      (double)n_rows, (double)n_rows * n_ranks, dweight, dgamma, dbeta);

@@ -681,9 +681,10 @@ class _FusedPFN(torch.autograd.Function):
             if m:
                 check(L.omnihd_pfn_apply(_ptr(voxels), _ptr(num_points), _ptr(coors), m, p, f, vx, vy, x_off, y_off, flags,
                                          _ptr(w), _ptr(consts), _ptr(out), st), "omnihd_pfn_apply")
-        if training:
-            ctx.save_for_backward(voxels, num_points, coors, w, ga, consts, moments)
-            ctx.meta = (vx, vy, x_off, y_off, flags, world, group)
+        if moments is None:                        # inference statistics: the backward's batch terms vanish (world = 0 says so)
+            moments = torch.zeros(k + k * k, dtype=torch.float64, device=dev)
+        ctx.save_for_backward(voxels, num_points, coors, w, ga, consts, moments)
+        ctx.meta = (vx, vy, x_off, y_off, flags, world if training else 0, group)
         return out
 
     @staticmethod
@@ -695,6 +696,8 @@ class _FusedPFN(torch.autograd.Function):
         dev = voxels.device
         g = g.contiguous().float()
         L = lib()
+        if m == 0:
+            return (None, None, None, torch.zeros_like(w), torch.zeros_like(ga), torch.zeros_like(ga)) + (None,) * 8
         sums = torch.empty(128 + 64 * k, dtype=torch.float32, device=dev)
         dw = torch.empty((64, k), dtype=torch.float32, device=dev)
         dg, db = torch.empty(64, dtype=torch.float32, device=dev), torch.empty(64, dtype=torch.float32, device=dev)

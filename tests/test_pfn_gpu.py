@@ -147,6 +147,32 @@ def test_training_mode_forward_backward_and_running_statistics(cuda, variant, f,
     assert all(torch.equal(p_.grad.cpu().double(), got[n]) for n, p_ in net.named_parameters())
 
 
+def test_inference_statistics_inside_a_differentiated_graph(cuda, monkeypatch):
+    """BatchNorm in eval mode while gradients are taken (fine-tuning with frozen statistics; the tiny-detector parity tests): the
+    fused backward then has no batch-statistics terms.  Against the module's torch formulation in float64 on the CPU."""
+    PillarFeatureNetV1, _ = _nets()
+    rng = np.random.default_rng(3)
+    vox, num, coors = _pillars(rng, 5000, 8)
+    torch.manual_seed(2)
+    net = PillarFeatureNetV1(in_channels=8, feat_channels=[64], voxel_size=VSZ, point_cloud_range=PCR, norm_cfg=NCFG)
+    bn = net.pfn_layers[0].norm
+    bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+    W, gam, bet, rm, rv = (a.detach().clone().double() for a in (net.pfn_layers[0].linear.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    net = net.to(cuda).eval()
+    gy = torch.randn(len(vox), 64, generator=torch.Generator().manual_seed(1))
+    y = net(t(vox, cuda), t(num, cuda), t(coors, cuda))
+    y.backward(gy.to(cuda))
+    Wt, gt, bt = W.requires_grad_(), gam.requires_grad_(), bet.requires_grad_()
+    z = torch.from_numpy(PO.decorate(vox, num, coors, VSZ, PCR)) @ Wt.t()
+    out = torch.relu((z - rm) * torch.rsqrt(rv + 1e-3) * gt + bt).max(1)[0]
+    out.backward(gy.double())
+    rel = lambda a, b: float((a.cpu().double() - b).norm() / b.norm())
+    assert rel(y.detach(), out.detach()) <= 1e-5
+    assert rel(net.pfn_layers[0].linear.weight.grad, Wt.grad) <= 1e-4
+    assert rel(bn.weight.grad, gt.grad) <= 1e-4 and rel(bn.bias.grad, bt.grad) <= 1e-4
+    assert torch.equal(bn.running_mean.cpu().double(), rm) and torch.equal(bn.running_var.cpu().double(), rv)
+
+
 def test_unsupported_forms_keep_the_torch_formulation(cuda):
     """Two layers, 'avg' mode or more than 16 decorated channels are not what the fused kernels cover: the module falls back
     to its torch formulation instead of failing."""
