@@ -247,10 +247,13 @@ class BevOps:
         coors = torch.nn.functional.pad(c, (1, 0), value=0)
 
         def ev_time(fn):
+            """Mean GPU time per call: the calls are enqueued while a spin kernel keeps the device busy, so the events bracket
+            back-to-back execution and not the host's enqueue rate (these wrappers cost ~15 us of Python per call)."""
             for _ in range(5):
                 fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(8_000_000)
             e0.record()
             for _ in range(launches):
                 fn()
@@ -270,7 +273,7 @@ class BevOps:
                                       "host read-back; runs once per calibration (plan cache), not per step"},
                 "pillar_scatter": {"algorithmic_bytes": sc_bytes, "mean_us": round(t_sc * 1e6, 2), "achieved_GBps": gbs(sc_bytes, t_sc),
                                    "frac": round(sc_bytes / t_sc / 1e9 / HBM_PEAK_GBS, 4), "pillars": m,
-                                   "note": "cell map + one dense pass; incl. the canvas allocation of the wrapper"},
+                                   "note": "cell-map kernel + one dense pass that also resets the map (two launches); device time of back-to-back calls"},
                 "hard_voxelize": {"algorithmic_bytes": vx_bytes, "mean_us": round(t_vx * 1e6, 1), "launches": 8, "points": int(self.points[0].shape[0]),
                                   "voxels": m, "note": "latency-bound (<= 5 MB): 8 kernel launches + async count read-back per call"}}
 

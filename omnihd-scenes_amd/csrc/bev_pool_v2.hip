@@ -1369,7 +1369,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_direct(
     if (q0 + (c + 2) * kPatch + sub < q1) pt_b = pt[q0 + (c + 2) * kPatch + sub];
     if (c + 1 < nchunks) nxt = stage(pt_a);
     direct_batch8<0>(feat_rsrc, out_rsrc, lane_off, ck, acc, pend, s_head, s_head_row, tid, grp, sub);
-    direct_batch8<8>(feat_rsrc, out_rsrc, lane_off, ck, acc, pend, s_head, s_head_row, tid, grp, sub);
+    if (c * kPatch + 8 < Wp)                                 // (scalar) the last chunk of a piece may hold <= 8 points: no pad gathers
+      direct_batch8<8>(feat_rsrc, out_rsrc, lane_off, ck, acc, pend, s_head, s_head_row, tid, grp, sub);
   }
 
   // ---- rows cut by a piece boundary: tails of earlier pieces + my head partial, in piece order ------------------
