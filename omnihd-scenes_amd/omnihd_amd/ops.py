@@ -950,7 +950,12 @@ def choice_table_info():
     """{'path', 'sha256', 'entries', 'misses'} of the persisted kernel-choice table as this process sees it (``misses`` =
     geometries that had to be measured here because the table did not hold them)."""
     _persisted_choices()
-    return {k: _CHOICE_INFO[k] for k in ("path", "sha256", "entries", "misses")}
+    info = {k: _CHOICE_INFO[k] for k in ("path", "sha256", "entries", "misses")}
+    if info["path"]:
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        if os.path.abspath(info["path"]).startswith(root + os.sep):
+            info["path"] = os.path.relpath(info["path"], root)          # as committed, not where this checkout happens to live
+    return info
 
 
 def save_choice_table(path, note=""):
