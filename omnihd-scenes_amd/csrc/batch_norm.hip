@@ -201,25 +201,40 @@ __global__ __launch_bounds__(256) void k_bn_bwd_consts(const float* __restrict__
   coefC[i] = dmu * inv_count;
 }
 
-template <typename T>
+// MASK 0: no ReLU in front of the gradient; 1: mask from the saved output y; 2: mask recomputed from x with the forward's
+// scale / shift (fss).  The per-channel coefficients are read as two 16-byte vectors per array (round 3's form read them one
+// float at a time inside a three-way conditional: 24 dependent 4-byte loads per 8 elements, 2.4 TB/s; this form 4.8 TB/s on
+// a 157 MB tensor, scripts/micro/bn_apply_bw.hip).
+template <typename T, int MASK>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ gy, const T* __restrict__ y,
                                                       const T* __restrict__ x, const float* __restrict__ coefA,
                                                       const float* __restrict__ coefB, const float* __restrict__ coefC,
                                                       const float* __restrict__ fss, T* __restrict__ gx,
                                                       T* __restrict__ gres, int64_t n_vec, int c8, bf16_t* __restrict__ gx_hi = nullptr,
                                                       bf16_t* __restrict__ gx_lo = nullptr) {
+  auto vec8 = [](const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  };
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % c8) * 8;
-    float gv[8], xv[8], mv[8], out[8], masked[8];
+    const int c = (int)((uint64_t)i % (unsigned)c8) * 8;
+    float gv[8], xv[8], mv[8], out[8], masked[8], ca[8], cb[8], cc[8], fs[8], fh[8];
     load8(gy, i, gv);
     load8(x, i, xv);
-    if (y) load8(y, i, mv);
+    if (MASK == 1) load8(y, i, mv);
+    vec8(coefA + c, ca);
+    vec8(coefB + c, cb);
+    vec8(coefC + c, cc);
+    if (MASK == 2) {
+      vec8(fss + c, fs);
+      vec8(fss + c8 * 8 + c, fh);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const bool pass = y ? mv[k] > 0.f : (!fss || fmaf(xv[k], fss[c + k], fss[c8 * 8 + c + k]) > 0.f);
+      const bool pass = MASK == 0 ? true : MASK == 1 ? mv[k] > 0.f : fmaf(xv[k], fs[k], fh[k]) > 0.f;
       const float g = pass ? gv[k] : 0.f;
       masked[k] = g;
-      out[k] = fmaf(g, coefA[c + k], fmaf(xv[k], coefB[c + k], coefC[c + k]));
+      out[k] = fmaf(g, ca[k], fmaf(xv[k], cb[k], cc[k]));
     }
     store8(gx, i, out);
     if (gx_hi) store_planes8(gx_hi, gx_lo, i, out);  // the convolution behind this layer reads these instead of a split pass over gx
@@ -369,9 +384,14 @@ int bwd_apply_t(const void* gy, const void* y_mask, const float* fwd_scale_shift
   if (rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && gx, "null pointer");
   const int64_t n_vec = (int64_t)rows * (c / 8);
-  hipLaunchKernelGGL((k_bn_bwd_apply<T>), dim3(grid_for(n_vec, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const T*)gy,
-                     (const T*)y_mask, (const T*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (T*)gx, (T*)gres, n_vec, c / 8,
-                     gx_hi, gx_lo);
+  const dim3 grid(grid_for(n_vec, 256 * 2));
+#define OMNIHD_APPLY(M)                                                                                                     \
+  hipLaunchKernelGGL((k_bn_bwd_apply<T, M>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gy, (const T*)y_mask,       \
+                     (const T*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (T*)gx, (T*)gres, n_vec, c / 8, gx_hi, gx_lo)
+  if (y_mask) OMNIHD_APPLY(1);
+  else if (fwd_scale_shift) OMNIHD_APPLY(2);
+  else OMNIHD_APPLY(0);
+#undef OMNIHD_APPLY
   return check_launch("bn_bwd_apply");
 }
 }  // namespace
