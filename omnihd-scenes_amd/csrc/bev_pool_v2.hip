@@ -22,8 +22,8 @@
 #include "common.h"
 #include <stdlib.h>
 
-// (The traffic-attribution and phase-timeline builds of rounds 1-2 live in a lab copy of this file,
-// scripts/lab/csrc/bev_pool_v2_instrumented.hip; the product source carries no instrumentation.)
+// (The traffic-attribution, ablation and phase-timeline builds are PATCHES against this file, scripts/lab/patches/*.patch, applied
+// by scripts/build_abl.sh / scripts/lab/build_patched.sh; the product source carries no instrumentation.)
 
 namespace omnihd {
 namespace {
