@@ -21,4 +21,4 @@ def test_lab_patch_applies_to_the_product_source(patch, tmp_path):
     target = os.path.join(ROOT, "omnihd-scenes_amd", "csrc", m.group(2))
     out = subprocess.run(["patch", "-s", "-o", str(tmp_path / "patched.hip"), target, patch], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert os.path.getsize(tmp_path / "patched.hip") > os.path.getsize(target)        # hooks were added
+    assert "OMNIHD_" in open(tmp_path / "patched.hip").read()
