@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace omnihd
 
-extern "C" const char* omnihd_version(void) { return "omnihd_hip 0.1 (gfx950)"; }
+extern "C" const char* omnihd_version(void) { return "omnihd_hip 0.4 (gfx950)"; }
 
 extern "C" const char* omnihd_last_error(void) { return omnihd::error_buffer(); }
 
