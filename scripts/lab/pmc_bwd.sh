@@ -1,9 +1,9 @@
 #!/bin/bash
 # HBM bytes and L2 hit rate of the pooling kernels from PMC counters (separate passes; FETCH_SIZE calibrated on a copy).
 OUT=${1:-gpurun_out/pmc_bwd}; RES=${2:-r1}; export TMPDIR=/tmp; mkdir -p $OUT
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/p1 -o pmc -- python3 scripts/lab/pmc_bwd.py $RES > $OUT/p1.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/p2 -o pmc -- python3 scripts/lab/pmc_bwd.py $RES > $OUT/p2.log 2>&1
-rocprofv3 --output-format csv --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d $OUT/p3 -o pmc -- python3 scripts/lab/pmc_bwd.py $RES > $OUT/p3.log 2>&1
+timeout 240 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/p1 -o pmc -- python3 scripts/lab/pmc_bwd.py $RES > $OUT/p1.log 2>&1
+timeout 240 rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/p2 -o pmc -- python3 scripts/lab/pmc_bwd.py $RES > $OUT/p2.log 2>&1
+timeout 240 rocprofv3 --output-format csv --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d $OUT/p3 -o pmc -- python3 scripts/lab/pmc_bwd.py $RES > $OUT/p3.log 2>&1
 python3 - <<PY
 import csv, glob, json, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list)); names = set()
