@@ -1192,6 +1192,196 @@ __global__ __launch_bounds__(kBlock, 8) void k_pool_bwd_patch(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Shared-row backward (round 4, C = 64): k_pool_bwd_patch with every out_grad row of a patch fetched from global memory
+// ONCE and handed to the patch's pixels through LDS.
+//
+// Why: the patch backward is bound by the vector-L1 address path (TA busy 38.5 us of a 48 us launch at R1,
+// profiles/round4/pmc_units_r1.json): it issues one 256-byte row gather per frustum point, and neighbouring pixels ask for the
+// same rows (a voxel collects its points from adjacent rays).  Points per DISTINCT row inside a 16-pixel patch: 2.3 (16x1
+// run) / 2.9 (8x2) / 3.2 (4x4) at 256x704, 3.1 / 4.3 / 4.8 at 544x960 (profiles/round4/pool_bwd_row_reuse.txt): the cache
+// serves the repeats, but every repeat still costs the address unit a 16-byte-per-lane request.
+//
+// Here the plan lists, per patch, the distinct output rows its points touch (sorted: `uniq`) and cuts that list into STAGES
+// of R rows.  A pixel's points are sorted by output row (the backward tables are a stable sort of the row-sorted forward
+// tables by pixel), so the points of a pixel that fall into one stage are a contiguous piece of its list.  Per stage the
+// workgroup gathers the R rows once (16 lanes per row, M = R/16 rows per lane group, the NEXT stage's rows requested into
+// registers before the current one is consumed), stores them in LDS, and the 16 pixel groups walk their piece reading rows
+// with ds_read_b128.  Per point: one table word = LDS byte offset of its row inside the stage | depth bin << 24.
+// Same arithmetic in the same order as k_pool_bwd_patch: both gradients are bit-identical to that kernel's.
+//   sched[slot]   = {patch, first entry of the patch in uniq, #distinct rows, first row of the patch in px_stage_off} (-1: idle)
+//   px_stage_off  = per patch (S+1) x 16 ints: offset, inside pixel g's point list, of its first point of stage k
+//   patch         = (image, patch row, patch column) of a PW x (16/PW) pixel block, PW in {16, 8, 4}
+// ---------------------------------------------------------------------------------------------
+constexpr int kSharedMaxStages = 31;      // (S+1) x 16 offsets are kept in 2 KiB of LDS
+
+template <int JJ>
+__device__ __forceinline__ void shared_point(const float4 g, float d, const float4 x, float4& fg, float& mydot, int sub) {
+  fg = fma4(d, g, fg);
+  float p = fmaf(g.w, x.w, fmaf(g.z, x.z, fmaf(g.y, x.y, g.x * x.x)));
+  p = dpp_ror_add<8>(p); p = dpp_ror_add<4>(p); p = dpp_ror_add<2>(p); p = dpp_ror_add<1>(p);
+  mydot = (sub == JJ) ? p : mydot;
+}
+
+// points J0 .. J0+3 of the current chunk, rows read from the stage buffer
+template <int J0>
+__device__ __forceinline__ void shared_batch4(const char* s_lane, int off, float dval, const float4 x, float4& fg, float& mydot,
+                                              int sub) {
+  const float4 g0 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 0>(off));
+  const float4 g1 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 1>(off));
+  const float4 g2 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 2>(off));
+  const float4 g3 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 3>(off));
+  shared_point<J0 + 0>(g0, dpp_row_bcast_f<J0 + 0>(dval), x, fg, mydot, sub);
+  shared_point<J0 + 1>(g1, dpp_row_bcast_f<J0 + 1>(dval), x, fg, mydot, sub);
+  shared_point<J0 + 2>(g2, dpp_row_bcast_f<J0 + 2>(dval), x, fg, mydot, sub);
+  shared_point<J0 + 3>(g3, dpp_row_bcast_f<J0 + 3>(dval), x, fg, mydot, sub);
+}
+
+// rows grp*M + m (m = 0..M-1) of a stage: lane m of the group holds the row id, every lane of the group fetches 16 bytes
+template <int M, int m = 0>
+struct SharedStage {
+  static __device__ __forceinline__ void gather(const __amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int my_row, u32x4t (&pre)[M]) {
+    if constexpr (m < M) {
+      pre[m] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)dpp_row_bcast_i<m>(my_row) << 8) | lane_off, 0, 0);
+      SharedStage<M, m + 1>::gather(rsrc, lane_off, my_row, pre);
+    }
+  }
+};
+
+template <int M>
+__global__ __launch_bounds__(kBlock) void k_pool_bwd_shared(
+    const float* __restrict__ og, unsigned og_bytes, const float* __restrict__ depth, const float4* __restrict__ feat4,
+    const int* __restrict__ pt_word, const int* __restrict__ pix_ptr, const int4* __restrict__ sched, const int* __restrict__ uniq,
+    const int* __restrict__ px_stage_off, int slots_per_xcd, int fh, int fw, int pw_shift, int d_bins,
+    float* __restrict__ depth_grad, float4* __restrict__ feat_grad4) {
+  constexpr int C4 = 16;
+  constexpr int R = M * 16;                        // rows per stage
+  extern __shared__ float s_dyn[];                 // [(R+1) rows x 64][D*16 depth values][D*16 depth gradients][(S+1)*16 offsets]
+  const int slot = (int)(blockIdx.x >> 3);
+  if (slot >= slots_per_xcd) return;
+  const int4 sd = sched[(size_t)(blockIdx.x & 7) * slots_per_xcd + slot];
+  const int patch = sd.x;
+  if (patch < 0) return;
+  const int nu = sd.z;
+  const int n_stage = (nu + R - 1) / R;
+  const int tid = threadIdx.x;
+  const int sub = tid % C4;
+  const int grp = tid / C4;
+  float* s_rows = s_dyn;
+  float* s_dv = s_dyn + (R + 1) * 64;
+  float* s_dg = s_dv + d_bins * kPatch;
+  int* s_off = reinterpret_cast<int*>(s_dg + d_bins * kPatch);
+
+  const int fhw = fh * fw;
+  const int pw = 1 << pw_shift, ph = kPatch >> pw_shift;
+  const int pcols = (fw + pw - 1) >> pw_shift, prows = (fh + ph - 1) / ph;
+  const int img = patch / (pcols * prows);
+  const int pr = (patch - img * pcols * prows) / pcols, pc = patch - (img * prows + pr) * pcols;
+  const int h0 = pr * ph, w0 = pc << pw_shift;
+  const size_t img_base = (size_t)img * d_bins * fhw;
+
+  // ---- request the first stage's rows: nothing in front of them depends on LDS ---------------------------------
+  const __amdgpu_buffer_rsrc_t og_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)og_bytes, 0x00020000);
+  const unsigned lane_off = (unsigned)sub << 4;
+  u32x4t pre[M];
+  const int my_slot = grp * M + sub;               // lane `sub` (< M) of a group holds the id of the group's row `sub` of a stage
+  int row_next = 0x00ffffff;                       // a row beyond the buffer: the gather returns zeros
+  {
+    int my_row = 0x00ffffff;
+    if (sub < M && my_slot < nu) my_row = uniq[sd.y + my_slot];
+    if (sub < M && R + my_slot < nu) row_next = uniq[sd.y + R + my_slot];      // ids are read two stages ahead, rows one
+    SharedStage<M>::gather(og_rsrc, lane_off, my_row, pre);
+  }
+
+  // ---- depth values of the patch -> LDS, gradients start at zero, stage offsets of the 16 pixels -----------------
+  const int n_cell = d_bins * kPatch;
+  for (int i = tid; i < n_cell; i += kBlock) {
+    const int d = i / kPatch, px = i % kPatch;
+    const int hh = h0 + (px >> pw_shift), ww = w0 + (px & (pw - 1));
+    s_dv[i] = (hh < fh && ww < fw) ? depth[img_base + (size_t)d * fhw + hh * fw + ww] : 0.f;
+    s_dg[i] = 0.f;
+  }
+  for (int i = tid; i < (n_stage + 1) * kPatch; i += kBlock) s_off[i] = px_stage_off[(size_t)sd.w * kPatch + i];
+  if (grp == 0) reinterpret_cast<float4*>(s_rows)[R * C4 + sub] = make_float4(0.f, 0.f, 0.f, 0.f);     // the row of points past a list's end
+  const int hh = h0 + (grp >> pw_shift), ww = w0 + (grp & (pw - 1));
+  const bool valid = hh < fh && ww < fw;
+  const int f = img * fhw + hh * fw + ww;          // my pixel (feature row)
+  int s = 0, len = 0;
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) {
+    s = pix_ptr[f];
+    len = pix_ptr[f + 1] - s;
+    x = feat4[(size_t)f * C4 + sub];
+  }
+  const char* s_lane = reinterpret_cast<const char*>(s_rows) + lane_off;
+  constexpr int kZeroRow = R * 256;                // byte offset of the zero row
+  constexpr int kNoWord = kZeroRow;                // table word of "no point": zero row, depth bin 0
+  // Table words of my pixel's piece of a stage: chunk c, lane sub <-> point c*16 + sub of the piece (a pixel has at most
+  // d_bins <= 64 points).  The next stage's words are requested BEFORE its rows: memory returns in order, so nothing the point
+  // loop waits for may be queued behind the row gathers.  Two register sets (words, row ids) alternate between even and odd
+  // stages — rotating one set through copies would make the compiler wait for the loads at the copy.
+  int w_even[4], w_odd[4] = {kNoWord, kNoWord, kNoWord, kNoWord};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) w_even[c] = (c * kPatch + sub < len) ? pt_word[s + c * kPatch + sub] : kNoWord;   // cut to stage 0 by `cnt`
+  float4 fg = make_float4(0.f, 0.f, 0.f, 0.f);
+  int a = 0, b = 0;
+  int id_odd = row_next, id_even = 0x00ffffff;     // ids of the rows of stage 1 / of the next even stage
+  // one stage: `wq` its table words, `wn` <- the next stage's; `id_n` the next stage's row ids, `id_nn` <- the ids after those
+  auto stage = [&](const int k, int (&wq)[4], int (&wn)[4], const int id_n, int& id_nn) {
+#pragma unroll
+    for (int m = 0; m < M; ++m)                     // rows of stage k: registers -> LDS
+      reinterpret_cast<u32x4t*>(s_rows)[(grp * M + m) * C4 + sub] = pre[m];
+    __syncthreads();
+    if (k == 0) b = valid ? s_off[kPatch + grp] : 0;         // s_off is readable only now; stage 0 starts at the head of the list
+    const int cnt = b - a;
+    int b_next = b;
+    if (k + 1 < n_stage) {
+      b_next = valid ? s_off[(k + 2) * kPatch + grp] : b;
+      const int cnt_next = b_next - b;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wn[c] = (c * kPatch + sub < cnt_next) ? pt_word[s + b + c * kPatch + sub] : kNoWord;
+      const int i = (k + 2) * R + my_slot;
+      id_nn = (sub < M && i < nu) ? uniq[sd.y + i] : 0x00ffffff;
+      SharedStage<M>::gather(og_rsrc, lane_off, id_n, pre);
+    }
+    int ml = cnt;
+    ml = max(ml, __shfl_xor(ml, 16));
+    ml = max(ml, __shfl_xor(ml, 32));
+    const int wave_cnt = __builtin_amdgcn_readfirstlane(ml);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cb = c * kPatch;
+      if (cb < wave_cnt) {
+        const bool inb = cb + sub < cnt;
+        const int w = wq[c];
+        const int off = inb ? (w & 0x00ffffff) : kZeroRow;
+        const int dk = inb ? (int)((unsigned)w >> 24) : 0;
+        const float dval = inb ? s_dv[dk * kPatch + grp] : 0.f;
+        float mydot = 0.f;
+        shared_batch4<0>(s_lane, off, dval, x, fg, mydot, sub);
+        if (cb + 4 < wave_cnt) shared_batch4<4>(s_lane, off, dval, x, fg, mydot, sub);
+        if (cb + 8 < wave_cnt) shared_batch4<8>(s_lane, off, dval, x, fg, mydot, sub);
+        if (cb + 12 < wave_cnt) shared_batch4<12>(s_lane, off, dval, x, fg, mydot, sub);
+        if (inb) s_dg[dk * kPatch + grp] = mydot;
+      }
+    }
+    a = b;
+    b = b_next;
+    __syncthreads();                               // every group is done with the stage buffer
+  };
+  for (int k = 0; k < n_stage; k += 2) {
+    stage(k, w_even, w_odd, id_odd, id_even);
+    if (k + 1 < n_stage) stage(k + 1, w_odd, w_even, id_even, id_odd);
+  }
+  if (n_stage == 0) __syncthreads();
+  if (valid) feat_grad4[(size_t)f * C4 + sub] = fg;
+  for (int i = tid; i < n_cell; i += kBlock) {
+    const int d = i / kPatch, px = i % kPatch;
+    const int h2 = h0 + (px >> pw_shift), w2 = w0 + (px & (pw - 1));
+    if (h2 < fh && w2 < fw) depth_grad[img_base + (size_t)d * fhw + h2 * fw + w2] = s_dg[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_pool_fwd_direct (round 4, C = 64): the tiled dense forward WITHOUT the LDS staging of the point records.
 //
 // Why: at the repo's own resolution (544x960: 4.5 M points, 6 552 tiles) k_pool_fwd_lean2 takes 93 us with every input
@@ -1756,3 +1946,46 @@ extern "C" int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* 
   return check_launch("bev_pool_v2_bwd_patch");
 }
 
+extern "C" int omnihd_bev_pool_v2_bwd_shared_lds_bytes(int rows_per_stage, int d_bins) {
+  return (rows_per_stage + 1) * 256 + 2 * d_bins * kPatch * (int)sizeof(float) + (kSharedMaxStages + 1) * kPatch * (int)sizeof(int);
+}
+
+extern "C" int omnihd_bev_pool_v2_bwd_shared(const float* out_grad, const float* depth, const float* feat, const int* pt_word,
+                                             const int* pix_ptr, const int* sched, const int* uniq_rows,
+                                             const int* px_stage_off, int n_slots, int n_img, int d_bins, int fh, int fw,
+                                             int patch_w, int rows_per_stage, int max_stages, long long n_rows,
+                                             float* depth_grad, float* feat_grad, int c, void* stream) {
+  OMNIHD_REQUIRE(c == 64, "the shared-row backward is written for C = 64 (use omnihd_bev_pool_v2_bwd_sched otherwise)");
+  OMNIHD_REQUIRE(n_slots >= 0 && n_slots % 8 == 0 && n_img > 0 && d_bins > 0 && fh > 0 && fw > 0 && n_rows > 0, "sizes");
+  OMNIHD_REQUIRE(patch_w == 16 || patch_w == 8 || patch_w == 4, "patch width must be 16, 8 or 4 pixels");
+  OMNIHD_REQUIRE(rows_per_stage % 16 == 0 && rows_per_stage >= 32 && rows_per_stage <= 192, "rows per stage: 32, 48, ... 192");
+  OMNIHD_REQUIRE(max_stages >= 0 && max_stages <= kSharedMaxStages, "a patch has more stages than the kernel keeps offsets for");
+  if (n_slots == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(out_grad && depth && feat && pt_word && pix_ptr && sched && uniq_rows && px_stage_off && depth_grad && feat_grad,
+                 "null pointer");
+  OMNIHD_REQUIRE(d_bins <= 64, "a pixel's piece of a stage is held as 4 x 16 table words: at most 64 depth bins");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(out_grad) | reinterpret_cast<uintptr_t>(feat) |
+                   reinterpret_cast<uintptr_t>(feat_grad) | reinterpret_cast<uintptr_t>(sched)) & 15u) == 0, "16-byte alignment");
+  OMNIHD_REQUIRE(n_rows * 256 < (1ll << 32) && n_rows < 0x00ffffff, "out_grad must stay below 4 GiB (32-bit gather offsets)");
+  OMNIHD_REQUIRE((long long)d_bins * fh * fw * n_img < (1ll << 31), "depth tensor too large for int32 indices");
+  const size_t lds = (size_t)omnihd_bev_pool_v2_bwd_shared_lds_bytes(rows_per_stage, d_bins);
+  OMNIHD_REQUIRE(lds <= 64 * 1024, "stage buffer + depth blocks exceed 64 KiB of LDS");
+  hipStream_t st = (hipStream_t)stream;
+  int pw_shift = patch_w == 16 ? 4 : (patch_w == 8 ? 3 : 2);
+#define OMNIHD_SHARED_CASE(M)                                                                                              \
+  case M:                                                                                                                  \
+    hipLaunchKernelGGL(k_pool_bwd_shared<M>, dim3(n_slots), dim3(kBlock), lds, st, out_grad, (unsigned)(n_rows * 256), depth, \
+                       reinterpret_cast<const float4*>(feat), pt_word, pix_ptr, reinterpret_cast<const int4*>(sched),      \
+                       uniq_rows, px_stage_off, n_slots / 8, fh, fw, pw_shift, d_bins, depth_grad,                         \
+                       reinterpret_cast<float4*>(feat_grad));                                                              \
+    break;
+  switch (rows_per_stage / 16) {
+    OMNIHD_SHARED_CASE(2) OMNIHD_SHARED_CASE(3) OMNIHD_SHARED_CASE(4) OMNIHD_SHARED_CASE(5) OMNIHD_SHARED_CASE(6)
+    OMNIHD_SHARED_CASE(7) OMNIHD_SHARED_CASE(8) OMNIHD_SHARED_CASE(9) OMNIHD_SHARED_CASE(10) OMNIHD_SHARED_CASE(11)
+    OMNIHD_SHARED_CASE(12)
+    default:
+      return OMNIHD_ERR_ARG;
+  }
+#undef OMNIHD_SHARED_CASE
+  return check_launch("bev_pool_v2_bwd_shared");
+}

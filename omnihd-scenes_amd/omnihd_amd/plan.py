@@ -256,6 +256,135 @@ def direct_tables(plan):
     return got
 
 
+SHARED_MAX_STAGES = 31      # kSharedMaxStages of csrc/bev_pool_v2.hip: (S+1) x 16 stage offsets live in 2 KiB of LDS
+
+
+@dataclass
+class SharedBackwardTables:
+    """Tables of the shared-row backward (include/omnihd_hip.h: omnihd_bev_pool_v2_bwd_shared)."""
+    patch_w: int                # patches are patch_w x (16 / patch_w) pixel blocks
+    rows_per_stage: int         # R: distinct output rows staged in LDS at a time
+    pt_word: torch.Tensor       # int32 [Npts] backward order: (index of the point's row inside its stage) * 256 | depth bin << 24
+    uniq_rows: torch.Tensor     # int32: per patch, the sorted distinct output rows its points touch
+    px_stage_off: torch.Tensor  # int32: per patch (S+1) x 16: offset inside pixel g's point list of its first point of stage k
+    sched: torch.Tensor         # int32 [8*k, 4] launch schedule {patch, first uniq entry, #distinct rows, first px_stage_off row}
+    max_stages: int
+    reuse: float                # points per distinct (patch, row): how many row gathers one staged row replaces
+
+
+def _patch_geometry(n_img, feat_hw, patch_w):
+    fH, fW = feat_hw
+    pw, ph = patch_w, PATCH // patch_w
+    pcols, prows = (fW + pw - 1) // pw, (fH + ph - 1) // ph
+    return pw, ph, pcols, prows, n_img * pcols * prows
+
+
+def shared_schedule(n_img, feat_hw, patch_w, cost, n_xcd=8):
+    """Order of the patches of the shared-row backward: image by image in bands of 4 image rows, left to right inside a band
+    (vertically adjacent patches touch the same output rows: what one fetched is in L2 for the next), cut into ``n_xcd``
+    contiguous runs of equal COST (``cost`` per patch, points + a fixed cost), heaviest bands first inside a run (see
+    ``patch_schedule``).  Returns a list of ``n_xcd`` int64 tensors of patch ids; every patch appears exactly once."""
+    pw, ph, pcols, prows, n_patch = _patch_geometry(n_img, feat_hw, patch_w)
+    p = torch.arange(n_patch)
+    img, pr, pc = p // (pcols * prows), (p // pcols) % prows, p % pcols
+    band_rows = max(1, 4 // ph)
+    nb = (prows + band_rows - 1) // band_rows
+    band = img * nb + pr // band_rows
+    col_block = (pc * pw) // PATCH                                  # 16 image columns at a time
+    key = (band * ((pcols * pw + PATCH - 1) // PATCH + 1) + col_block) * (band_rows * (PATCH // pw)) + (pr % band_rows) * (PATCH // pw) + pc % (PATCH // pw)
+    order = p[torch.argsort(key, stable=True)]
+    c = cost[order].double()
+    cum = torch.cumsum(c, 0)
+    targets = cum[-1] * torch.arange(1, n_xcd, dtype=torch.float64) / n_xcd
+    cuts = [0] + torch.searchsorted(cum, targets).tolist() + [n_patch]
+    bands = band[order]
+    runs = []
+    for k_ in range(n_xcd):
+        run, rb, rc = order[cuts[k_]:cuts[k_ + 1]], bands[cuts[k_]:cuts[k_ + 1]], c[cuts[k_]:cuts[k_ + 1]]
+        if run.numel():
+            ids, inv = torch.unique(rb, return_inverse=True)
+            tot = torch.zeros(ids.numel(), dtype=torch.float64).index_add_(0, inv, rc)
+            cnt = torch.zeros(ids.numel(), dtype=torch.float64).index_add_(0, inv, torch.ones_like(rc))
+            rank = torch.argsort(torch.argsort(-(tot / cnt), stable=True), stable=True)       # heaviest band first
+            run = run[torch.argsort(rank[inv], stable=True)]
+        runs.append(run)
+    return runs
+
+
+def shared_tables_from(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w=8, rows_per_stage=128):
+    """Tables of the shared-row backward from the backward tables (points sorted by pixel, inside a pixel by output row) — pure
+    torch, host-side planning once per calibration (works on CPU tensors for the tests).  None when the tables do not fit the
+    kernel: a pixel list that is not sorted by row, more than 64 depth bins, a patch with more than SHARED_MAX_STAGES stages."""
+    if patch_w not in (16, 8, 4) or rows_per_stage % 16 or not 32 <= rows_per_stage <= 192 or not 0 < depth_bins <= 64:
+        return None
+    dev = bp_ranks_row.device
+    fH, fW = feat_hw
+    fhw = fH * fW
+    pw, ph, pcols, prows, n_patch = _patch_geometry(n_img, feat_hw, patch_w)
+    R = rows_per_stage
+    n = int(bp_ranks_row.numel())
+    pp = pix_ptr.long()
+    lens = pp[1:] - pp[:-1]
+    f = torch.repeat_interleave(torch.arange(n_img * fhw, device=dev), lens)            # pixel of every point
+    rows = bp_ranks_row.long()
+    if n > 1 and bool(((rows[1:] < rows[:-1]) & (f[1:] == f[:-1])).any()):
+        return None                                                                     # a pixel's points must be sorted by row
+    img, h, w = f // fhw, (f % fhw) // fW, f % fW
+    patch = (img * prows + h // ph) * pcols + w // pw
+    g = (h % ph) * pw + w % pw                                                          # the pixel's lane group inside its patch
+    key = patch * (1 << 24) + rows
+    uk, inv = torch.unique(key, return_inverse=True)                                    # sorted: by patch, then by row
+    u_patch = uk >> 24
+    nu = torch.bincount(u_patch, minlength=n_patch)
+    u_ptr = torch.zeros(n_patch + 1, dtype=torch.int64, device=dev)
+    u_ptr[1:] = nu.cumsum(0)
+    n_stage = (nu + R - 1) // R
+    max_stages = int(n_stage.max().item()) if n_patch else 0
+    if max_stages > SHARED_MAX_STAGES:
+        return None
+    idx = inv - u_ptr[patch]                                                            # index of the point's row among its patch's rows
+    stage = idx // R
+    dbin = torch.div(bp_ranks_depth.long(), fhw, rounding_mode="floor") % depth_bins
+    pt_word = (((idx % R) << 8) | (dbin << 24)).to(torch.int32).contiguous()
+    so_ptr = torch.zeros(n_patch + 1, dtype=torch.int64, device=dev)                    # first px_stage_off row of every patch
+    so_ptr[1:] = (n_stage + 1).cumsum(0)
+    total = int(so_ptr[-1].item())
+    cnt = torch.zeros(total * PATCH, dtype=torch.int64, device=dev)
+    if n:
+        cnt.index_add_(0, (so_ptr[patch] + stage + 1) * PATCH + g, torch.ones(n, dtype=torch.int64, device=dev))
+    cs = cnt.view(total, PATCH).cumsum(0)                                               # points of lane group g in all stages before this row
+    first = torch.repeat_interleave(so_ptr[:-1], n_stage + 1)
+    px_stage_off = (cs - cs[first]).to(torch.int32).contiguous().view(-1)
+    # launch schedule
+    pts = torch.bincount(patch, minlength=n_patch) if n else torch.zeros(n_patch, dtype=torch.int64, device=dev)
+    runs = shared_schedule(n_img, feat_hw, patch_w, (pts + PATCH_FIXED_COST).cpu())
+    per = max(1, max(r.numel() for r in runs))
+    order = torch.full((len(runs) * per,), -1, dtype=torch.int64)
+    for k_, r in enumerate(runs):
+        order[k_ * per:k_ * per + r.numel()] = r
+    order = order.to(dev)
+    safe = order.clamp(min=0)
+    sched = torch.stack([order, u_ptr[safe], nu[safe], so_ptr[safe]], dim=1)
+    sched[order < 0] = torch.tensor([-1, 0, 0, 0], device=dev)
+    reuse = float(n) / max(1, int(uk.numel()))
+    return SharedBackwardTables(patch_w, R, pt_word, (uk & 0xffffff).to(torch.int32).contiguous(), px_stage_off,
+                                sched.to(torch.int32).contiguous(), max_stages, reuse)
+
+
+SHARED_DEFAULT = (8, 128)       # (patch width, rows per stage) of the shared-row backward unless OMNIHD_POOL_BWD_SHARED_SHAPE="w,R"
+
+
+def shared_tables(plan, n_img, feat_hw2):
+    """The shared-row backward's tables of ``plan``, built on first use and kept with it (None: does not fit, see above)."""
+    shape = os.environ.get("OMNIHD_POOL_BWD_SHARED_SHAPE", "")
+    pw, R = (int(v) for v in shape.split(",")) if shape else SHARED_DEFAULT
+    cache = plan.__dict__.setdefault("_shared", {})
+    key = (pw, R, n_img, tuple(feat_hw2))
+    if key not in cache:
+        cache[key] = shared_tables_from(plan.bp_ranks_row, plan.bp_ranks_depth, plan.pix_ptr, n_img, plan.depth_bins, feat_hw2, pw, R)
+    return cache[key]
+
+
 def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=None, origin_cell=None):
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X

@@ -241,3 +241,96 @@ def test_direct_forward_tables_walk_every_point_once_and_close_every_row(tile_ro
     nonempty = np.diff(row_ptr) > 0
     assert np.array_equal(written > 0, nonempty) and written.max() == 1      # every non-empty row written exactly once
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def _walk_shared_tables(out_grad, depth, feat, pix_ptr, tb, d_bins, fh, fw):
+    """Host emulation of k_pool_bwd_shared's walk (csrc/bev_pool_v2.hip): per scheduled patch, stage by stage, the distinct rows
+    of the stage are 'staged' (a dict keyed by the word's row offset), every pixel group walks its piece of the stage."""
+    C = feat.shape[-1]
+    og = out_grad.reshape(-1, C).astype(np.float64)
+    dflat = depth.reshape(-1).astype(np.float64)
+    frows = feat.reshape(-1, C).astype(np.float64)
+    dg = np.full(dflat.shape, np.nan)
+    fg = np.full(frows.shape, np.nan)
+    pw, R = tb.patch_w, tb.rows_per_stage
+    ph = 16 // pw
+    pcols, prows = -(-fw // pw), -(-fh // ph)
+    fhw = fh * fw
+    sched, uniq, off, word = tb.sched.numpy(), tb.uniq_rows.numpy(), tb.px_stage_off.numpy(), tb.pt_word.numpy()
+    seen = []
+    for patch, ustart, nu, so in sched:
+        if patch < 0:
+            continue
+        seen.append(int(patch))
+        img, pr, pc = patch // (pcols * prows), (patch // pcols) % prows, patch % pcols
+        S = -(-nu // R)
+        assert S <= tb.max_stages
+        pix = []
+        for g in range(16):
+            hh, ww = pr * ph + g // pw, pc * pw + g % pw
+            pix.append(img * fhw + hh * fw + ww if (hh < fh and ww < fw) else None)
+        acc = {g: np.zeros(C) for g in range(16) if pix[g] is not None}
+        for g, f in enumerate(pix):                               # the dense D x 16 block of depth gradients starts at zero
+            if f is not None:
+                dg[(img * d_bins + np.arange(d_bins)) * fhw + f % fhw] = 0.0
+                assert off[so * 16 + g] == 0 and off[(so + S) * 16 + g] == pix_ptr[f + 1] - pix_ptr[f]
+        for k in range(S):
+            stage_rows = uniq[ustart + k * R:ustart + min(nu, (k + 1) * R)]
+            for g, f in enumerate(pix):
+                if f is None:
+                    continue
+                a, b = off[(so + k) * 16 + g], off[(so + k + 1) * 16 + g]
+                assert 0 <= b - a <= 64
+                for q in range(pix_ptr[f] + a, pix_ptr[f] + b):
+                    w = int(word[q])
+                    lid, dk = (w & 0xffffff) >> 8, (w >> 24) & 0xff
+                    assert (w & 0xff) == 0 and lid < len(stage_rows)
+                    row = og[stage_rows[lid]]
+                    rd = (img * d_bins + dk) * fhw + f % fhw
+                    acc[g] = acc[g] + dflat[rd] * row
+                    dg[rd] = float(row @ frows[f])
+        for g, f in enumerate(pix):
+            if f is not None:
+                fg[f] = acc[g]
+    return dg, fg, seen
+
+
+@pytest.mark.parametrize("patch_w,rows_per_stage", [(16, 32), (8, 32), (4, 48), (8, 192)])
+def test_shared_backward_tables_walk_every_point_once(patch_w, rows_per_stage):
+    """plan.shared_tables_from: distinct rows per patch, stage-relative point words, per-pixel stage offsets and the launch
+    schedule drive a walk that equals the pooling oracle's backward (tiny rig whose 8 x 12 feature image is cut by every patch
+    shape: partial patches on the right / bottom edge; 32-row stages so that most patches need several)."""
+    from omnihd_amd.plan import shared_tables_from
+    from oracle import cpu as OC
+    rb, rd, rf, st, ln, (X, Y, Z), rng = _tables()
+    N, D, H, W, C = 4, 8, 8, 12, 8
+    n_rows = Z * Y * X
+    order = np.lexsort((rb, rf))                                   # backward tables: by pixel, inside a pixel by row (stable)
+    brb, brd, brf = rb[order].astype(np.int32), rd[order].astype(np.int32), rf[order].astype(np.int32)
+    pix_ptr = np.concatenate([[0], np.cumsum(np.bincount(brf, minlength=N * H * W))]).astype(np.int32)
+    tb = shared_tables_from(torch.from_numpy(brb), torch.from_numpy(brd), torch.from_numpy(pix_ptr), N, D, (H, W), patch_w, rows_per_stage)
+    assert tb is not None and tb.sched.shape[0] % 8 == 0 and tb.reuse >= 1.0
+    depth = rng.random((1, N, D, H, W), dtype=np.float32)
+    feat = rng.standard_normal((1, N, H, W, C), dtype=np.float32)
+    out_grad = rng.standard_normal((n_rows, C), dtype=np.float32)
+    dg, fg, seen = _walk_shared_tables(out_grad, depth, feat, pix_ptr, tb, D, H, W)
+    n_patch = N * -(-W // patch_w) * -(-H // (16 // patch_w))
+    assert sorted(seen) == list(range(n_patch))                   # every patch exactly once
+    assert not np.isnan(dg).any() and not np.isnan(fg).any()      # both gradients written densely
+    bst = np.flatnonzero(np.r_[True, brf[1:] != brf[:-1]]).astype(np.int32)
+    bln = np.diff(np.r_[bst, len(brf)]).astype(np.int32)
+    want_dg, want_fg = OC.bev_pool_v2_bwd(out_grad.reshape(1, Z, Y, X, C), depth, feat, brd, brf, brb, bst, bln)
+    np.testing.assert_allclose(dg.reshape(want_dg.shape), want_dg, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fg.reshape(want_fg.shape), want_fg, rtol=1e-5, atol=1e-6)
+
+
+def test_shared_backward_tables_refuse_what_the_kernel_cannot_walk():
+    from omnihd_amd.plan import shared_tables_from
+    rows = torch.tensor([5, 3], dtype=torch.int32)                # one pixel whose two points are NOT sorted by row
+    rd = torch.tensor([0, 16], dtype=torch.int32)
+    pix_ptr = torch.zeros(17, dtype=torch.int32); pix_ptr[1:] = 2
+    assert shared_tables_from(rows, rd, pix_ptr, 1, 2, (4, 4), 4, 32) is None
+    ok = shared_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 4, 32)
+    assert ok is not None and ok.max_stages == 1 and ok.uniq_rows.tolist() == [3, 5]
+    assert shared_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 65, (4, 4), 4, 32) is None     # > 64 depth bins
+    assert shared_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 5, 32) is None      # patch width
