@@ -148,28 +148,37 @@ int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* depth, cons
                                  const int* patch_order, int n_slots, int n_img, int d_bins, int fhw,
                                  long long n_rows, float* depth_grad, float* feat_grad, int c, void* stream);
 
-/* Shared-row backward, C = 64 (round 4): the arithmetic of omnihd_bev_pool_v2_bwd_patch — replaces the reference's
+/* Stream backward, C = 64 (round 4, opt-in): the arithmetic of omnihd_bev_pool_v2_bwd_patch — replaces the reference's
  * bev_pool_grad_kernel (ops/bev_pool_v2/src/bev_pool_cuda.cu:67-121) + the re-sort in front of it (ops/bev_pool_v2/bev_pool.py:47-57) —
- * with every out_grad row that the pixels of a patch share gathered from global memory once and handed on through LDS; both
- * gradients bit-identical to omnihd_bev_pool_v2_bwd_patch's and written densely.
+ * with every out_grad row that the 16 pixels of a patch share gathered from global memory once and handed on through LDS.
+ * ONE WAVEFRONT per stream of stages (no workgroup barrier; the loads of a stage are in flight while earlier stages are
+ * consumed, across patch boundaries), 4 lanes per pixel.  feat_grad bit-identical to omnihd_bev_pool_v2_bwd_patch's (the
+ * reference's fma chain per channel); depth_grad a fixed-order channel sum (run-to-run identical; differs from the reference's
+ * serial loop by fp32 rounding).  Both written densely.
  * Patches are patch_w x (16/patch_w) pixel blocks of the (fh, fw) feature image, patch_w in {16, 8, 4}; patch id =
  * (image * ceil(fh / (16/patch_w)) + patch row) * ceil(fw / patch_w) + patch column; pixel g of a patch = row g / patch_w,
  * column g % patch_w of the block.
- *   uniq_rows     per patch: the sorted distinct output rows its points touch, cut into stages of rows_per_stage rows
- *                 (rows_per_stage in {32, 48, .. 192}; no patch may have more than 31 stages: max_stages is the plan's maximum);
- *   pt_word[i]    (backward order: points sorted by pixel, inside a pixel by output row) = 256 * (index of the point's row
- *                 inside its stage) | depth bin << 24   (d_bins <= 64);
- *   px_stage_off  per patch (S+1) x 16 ints: [k*16 + g] = offset inside pixel g's point list of its first point of stage k
- *                 ([S*16 + g] = length of the list);
- *   sched         8 * (n_slots/8) descriptors of 4 ints {patch, first entry of the patch in uniq_rows, #distinct rows,
- *                 first row of the patch in px_stage_off}, 16-byte aligned; entry [x*(n_slots/8) + i] is the i-th patch on
- *                 XCD x; patch = -1 marks an idle slot.  Every patch exactly once (also those without points).          */
-int omnihd_bev_pool_v2_bwd_shared(const float* out_grad, const float* depth, const float* feat, const int* pt_word,
-                                  const int* pix_ptr, const int* sched, const int* uniq_rows, const int* px_stage_off,
-                                  int n_slots, int n_img, int d_bins, int fh, int fw, int patch_w, int rows_per_stage,
-                                  int max_stages, long long n_rows, float* depth_grad, float* feat_grad, int c, void* stream);
-/* dynamic LDS bytes one workgroup of the kernel above asks for (<= 65536 or the launch is refused) */
-int omnihd_bev_pool_v2_bwd_shared_lds_bytes(int rows_per_stage, int d_bins);
+ *   uniq_rows   per patch: the sorted distinct output rows its points touch, cut into stages of rows_per_stage rows
+ *               (rows_per_stage in {32, 48, 64});
+ *   pt_word[i]  (backward order: points sorted by pixel, inside a pixel by output row) = 256 * (index of the point's row
+ *               inside its stage) | depth bin << 24   (d_bins <= 64);
+ *   px_off      (#offset rows + 1) x 16 ints: row r, column g = index into pt_word of pixel g's first point of the stage that
+ *               row stands for; the row behind a patch's last stage holds the ends of the 16 lists; a patch without points
+ *               has one (empty) stage;
+ *   stream      n_entries x 4 ints, 16-byte aligned; wave w walks entries [stream_ptr[w], stream_ptr[w+1]): two more than
+ *               it has stages.  Entry e of a wave (e = 0, 1, ..): {x, y, z, w} =
+ *                 x: patch of stage e-2 | 1<<30 if that stage is the first of its patch | 1<<29 if the last | 1<<28 (0 for e < 2),
+ *                 y: first entry of stage e in uniq_rows, z: px_off row of stage e | #rows of stage e << 24 (0, 0 past the end),
+ *                 w: the patch whose FIRST stage is stage e-1, else -1;
+ *   n_streams   a multiple of 8; wave (blockIdx & 7) * n_streams/8 + blockIdx / 8 walks one stream: consecutive streams of
+ *               one eighth share an XCD.  Every stage of every patch must appear in exactly one stream, in order.       */
+int omnihd_bev_pool_v2_bwd_stream(const float* out_grad, const float* depth, const float* feat, const int* pt_word,
+                                  long long n_points, const int* uniq_rows, long long n_uniq, const int* px_off, long long n_off,
+                                  const int* stream, long long n_entries, const int* stream_ptr, int n_streams, int n_img,
+                                  int d_bins, int fh, int fw, int patch_w, int rows_per_stage, long long n_rows,
+                                  float* depth_grad, float* feat_grad, int c, void* stream_handle);
+/* dynamic LDS bytes one wavefront of the kernel above asks for */
+int omnihd_bev_pool_v2_bwd_stream_lds_bytes(int rows_per_stage, int d_bins);
 
 /* Scheduled backward used by our own LSS module (same arithmetic as omnihd_bev_pool_v2_bwd).
  * pix_desc: 8 * groups_per_xcd descriptors of 4 ints {pixel row f, first point, #points, 0},

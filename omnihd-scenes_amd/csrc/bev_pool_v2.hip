@@ -1192,192 +1192,273 @@ __global__ __launch_bounds__(kBlock, 8) void k_pool_bwd_patch(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Shared-row backward (round 4, C = 64): k_pool_bwd_patch with every out_grad row of a patch fetched from global memory
-// ONCE and handed to the patch's pixels through LDS.
-//
-// Why: the patch backward is bound by the vector-L1 address path (TA busy 38.5 us of a 48 us launch at R1,
-// profiles/round4/pmc_units_r1.json): it issues one 256-byte row gather per frustum point, and neighbouring pixels ask for the
-// same rows (a voxel collects its points from adjacent rays).  Points per DISTINCT row inside a 16-pixel patch: 2.3 (16x1
-// run) / 2.9 (8x2) / 3.2 (4x4) at 256x704, 3.1 / 4.3 / 4.8 at 544x960 (profiles/round4/pool_bwd_row_reuse.txt): the cache
-// serves the repeats, but every repeat still costs the address unit a 16-byte-per-lane request.
-//
-// Here the plan lists, per patch, the distinct output rows its points touch (sorted: `uniq`) and cuts that list into STAGES
-// of R rows.  A pixel's points are sorted by output row (the backward tables are a stable sort of the row-sorted forward
-// tables by pixel), so the points of a pixel that fall into one stage are a contiguous piece of its list.  Per stage the
-// workgroup gathers the R rows once (16 lanes per row, M = R/16 rows per lane group, the NEXT stage's rows requested into
-// registers before the current one is consumed), stores them in LDS, and the 16 pixel groups walk their piece reading rows
-// with ds_read_b128.  Per point: one table word = LDS byte offset of its row inside the stage | depth bin << 24.
-// Same arithmetic in the same order as k_pool_bwd_patch: both gradients are bit-identical to that kernel's.
-//   sched[slot]   = {patch, first entry of the patch in uniq, #distinct rows, first row of the patch in px_stage_off} (-1: idle)
-//   px_stage_off  = per patch (S+1) x 16 ints: offset, inside pixel g's point list, of its first point of stage k
-//   patch         = (image, patch row, patch column) of a PW x (16/PW) pixel block, PW in {16, 8, 4}
+// Stream backward (round 4, C = 64; OPT-IN, OMNIHD_POOL_BWD_STREAM=1 — measured slower than k_pool_bwd_patch at 256x704 and equal at
+// 544x960): every out_grad row that the 16 pixels of a patch share is fetched from global memory ONCE and handed
+// on through LDS.  Why it was built: k_pool_bwd_patch issues one 256-byte row gather per frustum point and neighbouring pixels ask
+// for the same rows — points per DISTINCT row inside a 16-pixel patch: 2.3 (16x1 run) / 2.9 (8x2) / 3.2 (4x4) at 256x704, 3.1 / 4.3 /
+// 4.8 at 544x960 (profiles/round4/pool_bwd_row_reuse.txt); the L1 serves the repeats, but each still occupies the vector-memory path.
+// The plan lists, per patch, the distinct output rows its points touch (sorted: `uniq`) and cuts that list into STAGES of R rows; a
+// pixel's points are sorted by output row (the backward tables are a stable sort of the row-sorted forward tables by pixel), so its
+// points of one stage are a contiguous piece of its list.  A first form with one workgroup per patch and a barrier per stage
+// (scripts/lab/records/pool_bwd_shared_workgroup.inc.txt) paid 5-7 us of dependent loads in front of every workgroup's first stage;
+// this form removes that and halves the VALU work per point:
+//   * ONE WAVEFRONT walks a STREAM of stages (the stages of the patches the plan dealt to it, one after the other): no
+//     workgroup barrier anywhere, and the loads of a stage are issued while earlier stages are consumed, across patch
+//     boundaries.  In iteration t the wave stores the rows of stage t-2 (registers -> LDS) and consumes that stage, gathers
+//     the rows and the first table words of stage t-1, and reads the row ids and per-pixel offsets of stage t and the stream
+//     entry t+1.  Every load is unconditional (range-checked buffer loads: a missing row / word / entry is an address beyond
+//     the buffer and returns zeros), so no register that a pending load writes is copied before the point loop: the only
+//     place the wave waits for memory is the top of an iteration.
+//   * 4 lanes per pixel (16 channels each) instead of 16: one wave = the 16 pixels of a patch, one point-loop step = one point of
+//     every pixel: 16 packed FMAs for feat_grad + 9 packed ops and 2 quad exchanges for the depth gradient per 16 points (the
+//     16-lane version: 17 VALU per 4 points).  The four 16-byte slots a lane owns of a row are rotated by the pixel's position
+//     inside its ds_read_b128 lane group, so the 16 lanes of a group hit 16 distinct 16-byte bank slots whatever rows they read.
+// feat_grad: fg += depth * g per channel in table order (the reference's fma chain, bit-exact); depth_grad: a fixed-order
+// channel sum (16 in-lane packed FMAs, then two quad exchanges): run-to-run identical, differs from the reference's serial
+// channel loop by fp32 rounding.
+//   stream[e]   = {patch | flags of stage e-2 (bit 30: first stage of its patch, 29: last, 28: entry has a stage to consume),
+//                  first uniq entry of stage e, (row of stage e in px_off) | #rows << 24, patch whose first stage is e-1 or -1}
+//   px_off      = per stage 16 ints (+ the 16 of the next row): index into pt_word of pixel g's first point of the stage
 // ---------------------------------------------------------------------------------------------
-constexpr int kSharedMaxStages = 31;      // (S+1) x 16 offsets are kept in 2 KiB of LDS
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kStreamFirst = 1 << 30, kStreamLast = 1 << 29, kStreamValid = 1 << 28;
+constexpr int kStreamCellRegs = 16;       // D * 16 cells of a patch over 64 lanes, D <= 64
 
-template <int JJ>
-__device__ __forceinline__ void shared_point(const float4 g, float d, const float4 x, float4& fg, float& mydot, int sub) {
-  fg = fma4(d, g, fg);
-  float p = fmaf(g.w, x.w, fmaf(g.z, x.z, fmaf(g.y, x.y, g.x * x.x)));
-  p = dpp_ror_add<8>(p); p = dpp_ror_add<4>(p); p = dpp_ror_add<2>(p); p = dpp_ror_add<1>(p);
-  mydot = (sub == JJ) ? p : mydot;
+template <int CTRL>
+__device__ __forceinline__ int dpp_quad_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);             // quad_perm
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
-// points J0 .. J0+3 of the current chunk, rows read from the stage buffer
-template <int J0>
-__device__ __forceinline__ void shared_batch4(const char* s_lane, int off, float dval, const float4 x, float4& fg, float& mydot,
-                                              int sub) {
-  const float4 g0 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 0>(off));
-  const float4 g1 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 1>(off));
-  const float4 g2 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 2>(off));
-  const float4 g3 = *reinterpret_cast<const float4*>(s_lane + dpp_row_bcast_i<J0 + 3>(off));
-  shared_point<J0 + 0>(g0, dpp_row_bcast_f<J0 + 0>(dval), x, fg, mydot, sub);
-  shared_point<J0 + 1>(g1, dpp_row_bcast_f<J0 + 1>(dval), x, fg, mydot, sub);
-  shared_point<J0 + 2>(g2, dpp_row_bcast_f<J0 + 2>(dval), x, fg, mydot, sub);
-  shared_point<J0 + 3>(g3, dpp_row_bcast_f<J0 + 3>(dval), x, fg, mydot, sub);
-}
-
-// rows grp*M + m (m = 0..M-1) of a stage: lane m of the group holds the row id, every lane of the group fetches 16 bytes
-template <int M, int m = 0>
-struct SharedStage {
-  static __device__ __forceinline__ void gather(const __amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int my_row, u32x4t (&pre)[M]) {
-    if constexpr (m < M) {
-      pre[m] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)dpp_row_bcast_i<m>(my_row) << 8) | lane_off, 0, 0);
-      SharedStage<M, m + 1>::gather(rsrc, lane_off, my_row, pre);
-    }
-  }
+// One point-loop step = point t of every pixel's piece, in two halves so that the LDS reads of step t+1 are in flight while step
+// t is accumulated (with two waves per SIMD nothing else hides the LDS latency).
+struct StreamStep {
+  float4 g0, g1, g2, g3;      // my 16 channels of the point's out_grad row
+  float dv;                   // its depth value
+  int cell;                   // (depth bin * 16 + pixel): where its depth gradient goes
+  bool act;                   // the pixel's piece has a point t
 };
 
-template <int M>
-__global__ __launch_bounds__(kBlock) void k_pool_bwd_shared(
-    const float* __restrict__ og, unsigned og_bytes, const float* __restrict__ depth, const float4* __restrict__ feat4,
-    const int* __restrict__ pt_word, const int* __restrict__ pix_ptr, const int4* __restrict__ sched, const int* __restrict__ uniq,
-    const int* __restrict__ px_stage_off, int slots_per_xcd, int fh, int fw, int pw_shift, int d_bins,
-    float* __restrict__ depth_grad, float4* __restrict__ feat_grad4) {
-  constexpr int C4 = 16;
-  constexpr int R = M * 16;                        // rows per stage
-  extern __shared__ float s_dyn[];                 // [(R+1) rows x 64][D*16 depth values][D*16 depth gradients][(S+1)*16 offsets]
-  const int slot = (int)(blockIdx.x >> 3);
-  if (slot >= slots_per_xcd) return;
-  const int4 sd = sched[(size_t)(blockIdx.x & 7) * slots_per_xcd + slot];
-  const int patch = sd.x;
-  if (patch < 0) return;
-  const int nu = sd.z;
-  const int n_stage = (nu + R - 1) / R;
-  const int tid = threadIdx.x;
-  const int sub = tid % C4;
-  const int grp = tid / C4;
-  float* s_rows = s_dyn;
+// J = t % 4: lane q of a quad holds the table word of step 4*(t/4) + q in `wblk`
+template <int J, int R>
+__device__ __forceinline__ StreamStep stream_load(const char* s_rows, const float* s_dv, int wblk, int t, int cnt, int p, const int (&o)[4]) {
+  StreamStep st;
+  const int w = dpp_quad_i<J * 0x55>(wblk);
+  st.act = t < cnt;
+  const int off = st.act ? (w & 0x00ffffff) : R * 256;                         // past the piece: the zero row
+  st.cell = (int)(((unsigned)w >> 24) << 4) | p;
+  st.dv = s_dv[st.act ? st.cell : p];
+  st.g0 = *reinterpret_cast<const float4*>(s_rows + off + o[0]);
+  st.g1 = *reinterpret_cast<const float4*>(s_rows + off + o[1]);
+  st.g2 = *reinterpret_cast<const float4*>(s_rows + off + o[2]);
+  st.g3 = *reinterpret_cast<const float4*>(s_rows + off + o[3]);
+  return st;
+}
+
+__device__ __forceinline__ void stream_math(const StreamStep& st, float* s_dg, int q, const f32x2 (&x)[8], f32x2 (&fg)[8]) {
+  const float dv = st.act ? st.dv : 0.f;
+  // {dv, dv} as a REAL register pair: the compiler's own form is a packed op that broadcasts the low register and leaves the high
+  // one of the pair to whatever lives there — here the destination of a pending load, which the point loop then waited for
+  float dv_hi;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(dv_hi) : "v"(dv));
+  const f32x2 d2 = {dv, dv_hi};
+  const f32x2 ga[8] = {{st.g0.x, st.g0.y}, {st.g0.z, st.g0.w}, {st.g1.x, st.g1.y}, {st.g1.z, st.g1.w},
+                       {st.g2.x, st.g2.y}, {st.g2.z, st.g2.w}, {st.g3.x, st.g3.y}, {st.g3.z, st.g3.w}};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fg[i] = __builtin_elementwise_fma(d2, ga[i], fg[i]);
+  f32x2 acc = ga[0] * x[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) acc = __builtin_elementwise_fma(ga[i], x[i], acc);
+  float sum = acc.x + acc.y;
+  sum += dpp_quad_f<0xB1>(sum);                                                // lanes 1,0,3,2
+  sum += dpp_quad_f<0x4E>(sum);                                                // lanes 2,3,0,1
+  if (st.act && q == 0) s_dg[st.cell] = sum;
+}
+
+template <int RQ>          // RQ = rows per stage / 4 = row gathers per lane and stage
+__global__ __launch_bounds__(64, 2) void k_pool_bwd_stream(
+    const float* __restrict__ og, unsigned og_bytes, const float* __restrict__ depth, unsigned depth_bytes,
+    const float* __restrict__ feat, unsigned feat_bytes, const int* __restrict__ pt_word, unsigned word_bytes,
+    const int* __restrict__ uniq, unsigned uniq_bytes, const int* __restrict__ px_off, unsigned off_bytes,
+    const int4* __restrict__ stream, unsigned stream_bytes, const int* __restrict__ stream_ptr, int streams_per_xcd,
+    int fh, int fw, int pw_shift, int d_bins, float* __restrict__ depth_grad, float4* __restrict__ feat_grad4) {
+  constexpr int R = RQ * 4;
+  extern __shared__ float s_dyn[];                 // [(R+1) rows x 64][64*16 depth values][64*16 depth gradients]
+  char* s_rows = reinterpret_cast<char*>(s_dyn);
   float* s_dv = s_dyn + (R + 1) * 64;
-  float* s_dg = s_dv + d_bins * kPatch;
-  int* s_off = reinterpret_cast<int*>(s_dg + d_bins * kPatch);
+  float* s_dg = s_dv + 64 * kPatch;
+  const int lane = threadIdx.x;
+  const int p = lane >> 2, q = lane & 3;           // point loop: pixel of the patch, quarter of its channels
+  const int gq = lane & 15, gr = lane >> 4;        // row gathers and depth cells: 16-byte slot / pixel, row of a 4-row group
+  const int sid = (int)(blockIdx.x & 7) * streams_per_xcd + (int)(blockIdx.x >> 3);
+  const int sbeg = stream_ptr[sid], send = stream_ptr[sid + 1];
+  if (sbeg >= send) return;
+  if (lane < 16) reinterpret_cast<float4*>(s_rows)[R * 16 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const __amdgpu_buffer_rsrc_t og_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)og_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t depth_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)depth, 0, (int)depth_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t word_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pt_word, 0, (int)word_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t uniq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)uniq, 0, (int)uniq_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t off_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)px_off, 0, (int)off_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t stream_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, (int)stream_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dgrad_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)depth_grad, 0, (int)depth_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t fgrad_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat_grad4, 0, (int)feat_bytes, 0x00020000);
+  constexpr unsigned kBeyond = 0xfffffff0u;        // an offset no buffer reaches: the load returns zeros, the store is dropped
 
   const int fhw = fh * fw;
+  const int plane4 = 16 * fhw;                     // bytes of four depth planes
   const int pw = 1 << pw_shift, ph = kPatch >> pw_shift;
   const int pcols = (fw + pw - 1) >> pw_shift, prows = (fh + ph - 1) / ph;
-  const int img = patch / (pcols * prows);
-  const int pr = (patch - img * pcols * prows) / pcols, pc = patch - (img * prows + pr) * pcols;
-  const int h0 = pr * ph, w0 = pc << pw_shift;
-  const size_t img_base = (size_t)img * d_bins * fhw;
+  int o[4], slot[4];                               // my four 16-byte slots of a 256-byte row, rotated by the pixel's place in its lane group
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    slot[j] = 4 * ((((p >> 1) & 3) + j) & 3) + q;
+    o[j] = 16 * slot[j];
+  }
 
-  // ---- request the first stage's rows: nothing in front of them depends on LDS ---------------------------------
-  const __amdgpu_buffer_rsrc_t og_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)og_bytes, 0x00020000);
-  const unsigned lane_off = (unsigned)sub << 4;
-  u32x4t pre[M];
-  const int my_slot = grp * M + sub;               // lane `sub` (< M) of a group holds the id of the group's row `sub` of a stage
-  int row_next = 0x00ffffff;                       // a row beyond the buffer: the gather returns zeros
+  // ---- state carried from iteration to iteration ---------------------------------------------------------------
+  u32x4t pre[RQ];                                  // rows of the stage consumed NEXT iteration
+#pragma unroll
+  for (int m = 0; m < RQ; ++m) pre[m] = u32x4t{0u, 0u, 0u, 0u};
+  int w_next[4] = {0, 0, 0, 0};                    // first 16 table words of my pixel's piece of that stage
+  int ids_prev = 0, nrows_prev = 0;                // row ids of the stage whose rows are gathered this iteration
+  int oa1 = 0, ob1 = 0, oa2 = 0, ob2 = 0;          // my pixel's piece [oa, ob) of pt_word: stage t-1, stage t-2
+  f32x2 x[8], fg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = fg[i] = f32x2{0.f, 0.f};
+  u32x4t xn[4];                                    // feature row of my pixel in the NEXT patch, its depth cells
+  unsigned cn[kStreamCellRegs];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xn[j] = u32x4t{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int it = 0; it < kStreamCellRegs; ++it) cn[it] = 0u;
+  int f_cur = -1, f_next = -1;                     // my pixel's feature row (-1: outside the image)
+  int cell_cur = -1, cell_next = -1;               // index of (image, d = 0, pixel gq of the patch) in depth / depth_grad (-1: outside)
+
+  int ex, ey, ez, ew;
   {
-    int my_row = 0x00ffffff;
-    if (sub < M && my_slot < nu) my_row = uniq[sd.y + my_slot];
-    if (sub < M && R + my_slot < nu) row_next = uniq[sd.y + R + my_slot];      // ids are read two stages ahead, rows one
-    SharedStage<M>::gather(og_rsrc, lane_off, my_row, pre);
+    const u32x4t e = __builtin_amdgcn_raw_buffer_load_b128(stream_rsrc, (unsigned)sbeg << 4, 0, 0);
+    ex = __builtin_amdgcn_readfirstlane((int)e.x); ey = __builtin_amdgcn_readfirstlane((int)e.y);
+    ez = __builtin_amdgcn_readfirstlane((int)e.z); ew = __builtin_amdgcn_readfirstlane((int)e.w);
   }
-
-  // ---- depth values of the patch -> LDS, gradients start at zero, stage offsets of the 16 pixels -----------------
-  const int n_cell = d_bins * kPatch;
-  for (int i = tid; i < n_cell; i += kBlock) {
-    const int d = i / kPatch, px = i % kPatch;
-    const int hh = h0 + (px >> pw_shift), ww = w0 + (px & (pw - 1));
-    s_dv[i] = (hh < fh && ww < fw) ? depth[img_base + (size_t)d * fhw + hh * fw + ww] : 0.f;
-    s_dg[i] = 0.f;
-  }
-  for (int i = tid; i < (n_stage + 1) * kPatch; i += kBlock) s_off[i] = px_stage_off[(size_t)sd.w * kPatch + i];
-  if (grp == 0) reinterpret_cast<float4*>(s_rows)[R * C4 + sub] = make_float4(0.f, 0.f, 0.f, 0.f);     // the row of points past a list's end
-  const int hh = h0 + (grp >> pw_shift), ww = w0 + (grp & (pw - 1));
-  const bool valid = hh < fh && ww < fw;
-  const int f = img * fhw + hh * fw + ww;          // my pixel (feature row)
-  int s = 0, len = 0;
-  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) {
-    s = pix_ptr[f];
-    len = pix_ptr[f + 1] - s;
-    x = feat4[(size_t)f * C4 + sub];
-  }
-  const char* s_lane = reinterpret_cast<const char*>(s_rows) + lane_off;
-  constexpr int kZeroRow = R * 256;                // byte offset of the zero row
-  constexpr int kNoWord = kZeroRow;                // table word of "no point": zero row, depth bin 0
-  // Table words of my pixel's piece of a stage: chunk c, lane sub <-> point c*16 + sub of the piece (a pixel has at most
-  // d_bins <= 64 points).  The next stage's words are requested BEFORE its rows: memory returns in order, so nothing the point
-  // loop waits for may be queued behind the row gathers.  Two register sets (words, row ids) alternate between even and odd
-  // stages — rotating one set through copies would make the compiler wait for the loads at the copy.
-  int w_even[4], w_odd[4] = {kNoWord, kNoWord, kNoWord, kNoWord};
+  for (int j = sbeg; j < send; ++j) {
+    // ---- (1) what the previous iteration requested has arrived: rows of stage t-2 -> LDS, a new patch's pixel data ----
 #pragma unroll
-  for (int c = 0; c < 4; ++c) w_even[c] = (c * kPatch + sub < len) ? pt_word[s + c * kPatch + sub] : kNoWord;   // cut to stage 0 by `cnt`
-  float4 fg = make_float4(0.f, 0.f, 0.f, 0.f);
-  int a = 0, b = 0;
-  int id_odd = row_next, id_even = 0x00ffffff;     // ids of the rows of stage 1 / of the next even stage
-  // one stage: `wq` its table words, `wn` <- the next stage's; `id_n` the next stage's row ids, `id_nn` <- the ids after those
-  auto stage = [&](const int k, int (&wq)[4], int (&wn)[4], const int id_n, int& id_nn) {
+    for (int m = 0; m < RQ; ++m) reinterpret_cast<u32x4t*>(s_rows)[(4 * m + gr) * 16 + gq] = pre[m];
+    if (ex & kStreamFirst) {
 #pragma unroll
-    for (int m = 0; m < M; ++m)                     // rows of stage k: registers -> LDS
-      reinterpret_cast<u32x4t*>(s_rows)[(grp * M + m) * C4 + sub] = pre[m];
-    __syncthreads();
-    if (k == 0) b = valid ? s_off[kPatch + grp] : 0;         // s_off is readable only now; stage 0 starts at the head of the list
-    const int cnt = b - a;
-    int b_next = b;
-    if (k + 1 < n_stage) {
-      b_next = valid ? s_off[(k + 2) * kPatch + grp] : b;
-      const int cnt_next = b_next - b;
+      for (int i = 0; i < 4; ++i) {
+        x[2 * i] = f32x2{__uint_as_float(xn[i].x), __uint_as_float(xn[i].y)};
+        x[2 * i + 1] = f32x2{__uint_as_float(xn[i].z), __uint_as_float(xn[i].w)};
+      }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) wn[c] = (c * kPatch + sub < cnt_next) ? pt_word[s + b + c * kPatch + sub] : kNoWord;
-      const int i = (k + 2) * R + my_slot;
-      id_nn = (sub < M && i < nu) ? uniq[sd.y + i] : 0x00ffffff;
-      SharedStage<M>::gather(og_rsrc, lane_off, id_n, pre);
-    }
-    int ml = cnt;
-    ml = max(ml, __shfl_xor(ml, 16));
-    ml = max(ml, __shfl_xor(ml, 32));
-    const int wave_cnt = __builtin_amdgcn_readfirstlane(ml);
+      for (int i = 0; i < 8; ++i) fg[i] = f32x2{0.f, 0.f};
+      f_cur = f_next;
+      cell_cur = cell_next;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int cb = c * kPatch;
-      if (cb < wave_cnt) {
-        const bool inb = cb + sub < cnt;
-        const int w = wq[c];
-        const int off = inb ? (w & 0x00ffffff) : kZeroRow;
-        const int dk = inb ? (int)((unsigned)w >> 24) : 0;
-        const float dval = inb ? s_dv[dk * kPatch + grp] : 0.f;
-        float mydot = 0.f;
-        shared_batch4<0>(s_lane, off, dval, x, fg, mydot, sub);
-        if (cb + 4 < wave_cnt) shared_batch4<4>(s_lane, off, dval, x, fg, mydot, sub);
-        if (cb + 8 < wave_cnt) shared_batch4<8>(s_lane, off, dval, x, fg, mydot, sub);
-        if (cb + 12 < wave_cnt) shared_batch4<12>(s_lane, off, dval, x, fg, mydot, sub);
-        if (inb) s_dg[dk * kPatch + grp] = mydot;
+      for (int it = 0; it < kStreamCellRegs; ++it) {       // (64 bins are laid out: cells past d_bins hold the zeros their loads returned)
+        s_dv[(gr + 4 * it) * kPatch + gq] = __uint_as_float(cn[it]);
+        s_dg[(gr + 4 * it) * kPatch + gq] = 0.f;
       }
     }
-    a = b;
-    b = b_next;
-    __syncthreads();                               // every group is done with the stage buffer
-  };
-  for (int k = 0; k < n_stage; k += 2) {
-    stage(k, w_even, w_odd, id_odd, id_even);
-    if (k + 1 < n_stage) stage(k + 1, w_odd, w_even, id_even, id_odd);
-  }
-  if (n_stage == 0) __syncthreads();
-  if (valid) feat_grad4[(size_t)f * C4 + sub] = fg;
-  for (int i = tid; i < n_cell; i += kBlock) {
-    const int d = i / kPatch, px = i % kPatch;
-    const int h2 = h0 + (px >> pw_shift), w2 = w0 + (px & (pw - 1));
-    if (h2 < fh && w2 < fw) depth_grad[img_base + (size_t)d * fhw + h2 * fw + w2] = s_dg[i];
+    int wq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wq[c] = w_next[c];
+
+    // ---- (2) requests: entry t+1, ids + offsets of stage t, pixel data of a patch that starts at t-1, rows + words of t-1 ----
+    const u32x4t e_n = __builtin_amdgcn_raw_buffer_load_b128(stream_rsrc, (unsigned)(j + 1) << 4, 0, 0);
+    const int ids_n = (int)__builtin_amdgcn_raw_buffer_load_b32(uniq_rsrc, (unsigned)(ey + lane) << 2, 0, 0);
+    const int so = ez & 0x00ffffff;
+    const int oa_n = (int)__builtin_amdgcn_raw_buffer_load_b32(off_rsrc, (unsigned)(so * kPatch + p) << 2, 0, 0);
+    const int ob_n = (int)__builtin_amdgcn_raw_buffer_load_b32(off_rsrc, (unsigned)((so + 1) * kPatch + p) << 2, 0, 0);
+    if (ew >= 0) {
+      const int img = ew / (pcols * prows);
+      const int pr = (ew - img * pcols * prows) / pcols, pc = ew - (img * prows + pr) * pcols;
+      const int h0 = pr * ph, w0 = pc << pw_shift;
+      const int hh = h0 + (p >> pw_shift), ww = w0 + (p & (pw - 1));
+      f_next = (hh < fh && ww < fw) ? img * fhw + hh * fw + ww : -1;
+      const int hc = h0 + (gq >> pw_shift), wc = w0 + (gq & (pw - 1));
+      cell_next = (hc < fh && wc < fw) ? img * d_bins * fhw + hc * fw + wc : -1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xn[i] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, f_next >= 0 ? ((unsigned)f_next << 8) | (unsigned)o[i] : kBeyond, 0, 0);
+      // cell (d = gr + 4*it, pixel gq): the lane part of the address in the VGPR offset, 4*it depth planes in the scalar offset
+      const unsigned c_off = (unsigned)(cell_next + gr * fhw) << 2;
+#pragma unroll
+      for (int it = 0; it < kStreamCellRegs; ++it)
+        cn[it] = __builtin_amdgcn_raw_buffer_load_b32(depth_rsrc, (cell_next >= 0 && gr + 4 * it < d_bins) ? c_off : kBeyond, it * plane4, 0);
+    }
+    {
+      const int id_use = (lane < nrows_prev) ? ids_prev : 0x00ffffff;          // a row beyond out_grad: the gather returns zeros
+#pragma unroll
+      for (int m = 0; m < RQ; ++m) {
+        const int r = __builtin_amdgcn_ds_bpermute((4 * m + gr) << 2, id_use);
+        pre[m] = __builtin_amdgcn_raw_buffer_load_b128(og_rsrc, ((unsigned)r << 8) | ((unsigned)gq << 4), 0, 0);
+      }
+      const int cnt1 = ob1 - oa1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        w_next[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(word_rsrc, (4 * c + q < cnt1) ? (unsigned)(oa1 + 4 * c + q) << 2 : kBeyond, 0, 0);
+    }
+
+    // ---- (3) the points of stage t-2 ------------------------------------------------------------------------------
+    if (ex & kStreamValid) {
+      const int cnt = ob2 - oa2;
+      int ml = cnt;
+      ml = max(ml, __shfl_xor(ml, 4));
+      ml = max(ml, __shfl_xor(ml, 8));
+      ml = max(ml, __shfl_xor(ml, 16));
+      ml = max(ml, __shfl_xor(ml, 32));
+      const int trip = __builtin_amdgcn_readfirstlane(ml);
+      StreamStep sa = stream_load<0, R>(s_rows, s_dv, wq[0], 0, cnt, p, o), sb;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (4 * c < trip) {
+          sb = stream_load<1, R>(s_rows, s_dv, wq[c], 4 * c + 1, cnt, p, o);
+          stream_math(sa, s_dg, q, x, fg);
+          sa = stream_load<2, R>(s_rows, s_dv, wq[c], 4 * c + 2, cnt, p, o);
+          stream_math(sb, s_dg, q, x, fg);
+          sb = stream_load<3, R>(s_rows, s_dv, wq[c], 4 * c + 3, cnt, p, o);
+          stream_math(sa, s_dg, q, x, fg);
+          if (c < 3) sa = stream_load<0, R>(s_rows, s_dv, wq[c < 3 ? c + 1 : 3], 4 * c + 4, cnt, p, o);
+          stream_math(sb, s_dg, q, x, fg);
+        }
+      }
+      for (int c = 4; 4 * c < trip; ++c) {           // a piece longer than 16 points: its further words are read here
+        const int wl = (int)__builtin_amdgcn_raw_buffer_load_b32(word_rsrc, (4 * c + q < cnt) ? (unsigned)(oa2 + 4 * c + q) << 2 : kBeyond, 0, 0);
+        sa = stream_load<0, R>(s_rows, s_dv, wl, 4 * c + 0, cnt, p, o);
+        sb = stream_load<1, R>(s_rows, s_dv, wl, 4 * c + 1, cnt, p, o);
+        stream_math(sa, s_dg, q, x, fg);
+        sa = stream_load<2, R>(s_rows, s_dv, wl, 4 * c + 2, cnt, p, o);
+        stream_math(sb, s_dg, q, x, fg);
+        sb = stream_load<3, R>(s_rows, s_dv, wl, 4 * c + 3, cnt, p, o);
+        stream_math(sa, s_dg, q, x, fg);
+        stream_math(sb, s_dg, q, x, fg);
+      }
+      if (ex & kStreamLast) {                        // the patch is complete: its feature gradient rows, its D x 16 block of depth gradients
+#pragma unroll
+        for (int i = 0; i < 4; ++i)                  // a store beyond the buffer is dropped
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4t{__float_as_uint(fg[2 * i].x), __float_as_uint(fg[2 * i].y), __float_as_uint(fg[2 * i + 1].x),
+                                                        __float_as_uint(fg[2 * i + 1].y)},
+                                                 fgrad_rsrc, f_cur >= 0 ? ((unsigned)f_cur << 8) | (unsigned)o[i] : kBeyond, 0, 0);
+        const unsigned c_off = (unsigned)(cell_cur + gr * fhw) << 2;
+#pragma unroll
+        for (int it = 0; it < kStreamCellRegs; ++it)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_dg[(gr + 4 * it) * kPatch + gq]), dgrad_rsrc,
+                                                (cell_cur >= 0 && gr + 4 * it < d_bins) ? c_off : kBeyond, it * plane4, 0);
+      }
+    }
+
+    // ---- (4) rotate (the only copies of registers that pending loads write: after the point loop) -------------------
+    oa2 = oa1; ob2 = ob1; oa1 = oa_n; ob1 = ob_n;
+    ids_prev = ids_n;
+    nrows_prev = (int)((unsigned)ez >> 24);
+    ex = __builtin_amdgcn_readfirstlane((int)e_n.x); ey = __builtin_amdgcn_readfirstlane((int)e_n.y);
+    ez = __builtin_amdgcn_readfirstlane((int)e_n.z); ew = __builtin_amdgcn_readfirstlane((int)e_n.w);
   }
 }
 
@@ -1946,46 +2027,48 @@ extern "C" int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* 
   return check_launch("bev_pool_v2_bwd_patch");
 }
 
-extern "C" int omnihd_bev_pool_v2_bwd_shared_lds_bytes(int rows_per_stage, int d_bins) {
-  return (rows_per_stage + 1) * 256 + 2 * d_bins * kPatch * (int)sizeof(float) + (kSharedMaxStages + 1) * kPatch * (int)sizeof(int);
+extern "C" int omnihd_bev_pool_v2_bwd_stream_lds_bytes(int rows_per_stage, int d_bins) {
+  (void)d_bins;                                    // both depth blocks are laid out for 64 bins (16 cells per lane)
+  return (rows_per_stage + 1) * 256 + 2 * 64 * kPatch * (int)sizeof(float);
 }
 
-extern "C" int omnihd_bev_pool_v2_bwd_shared(const float* out_grad, const float* depth, const float* feat, const int* pt_word,
-                                             const int* pix_ptr, const int* sched, const int* uniq_rows,
-                                             const int* px_stage_off, int n_slots, int n_img, int d_bins, int fh, int fw,
-                                             int patch_w, int rows_per_stage, int max_stages, long long n_rows,
-                                             float* depth_grad, float* feat_grad, int c, void* stream) {
-  OMNIHD_REQUIRE(c == 64, "the shared-row backward is written for C = 64 (use omnihd_bev_pool_v2_bwd_sched otherwise)");
-  OMNIHD_REQUIRE(n_slots >= 0 && n_slots % 8 == 0 && n_img > 0 && d_bins > 0 && fh > 0 && fw > 0 && n_rows > 0, "sizes");
+extern "C" int omnihd_bev_pool_v2_bwd_stream(const float* out_grad, const float* depth, const float* feat, const int* pt_word,
+                                             long long n_points, const int* uniq_rows, long long n_uniq, const int* px_off,
+                                             long long n_off, const int* stream, long long n_entries, const int* stream_ptr,
+                                             int n_streams, int n_img, int d_bins, int fh, int fw, int patch_w,
+                                             int rows_per_stage, long long n_rows, float* depth_grad, float* feat_grad, int c,
+                                             void* stream_handle) {
+  OMNIHD_REQUIRE(c == 64, "the stream backward is written for C = 64 (use omnihd_bev_pool_v2_bwd_sched otherwise)");
+  OMNIHD_REQUIRE(n_streams >= 0 && n_streams % 8 == 0 && n_img > 0 && d_bins > 0 && fh > 0 && fw > 0 && n_rows > 0, "sizes");
   OMNIHD_REQUIRE(patch_w == 16 || patch_w == 8 || patch_w == 4, "patch width must be 16, 8 or 4 pixels");
-  OMNIHD_REQUIRE(rows_per_stage % 16 == 0 && rows_per_stage >= 32 && rows_per_stage <= 192, "rows per stage: 32, 48, ... 192");
-  OMNIHD_REQUIRE(max_stages >= 0 && max_stages <= kSharedMaxStages, "a patch has more stages than the kernel keeps offsets for");
-  if (n_slots == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(out_grad && depth && feat && pt_word && pix_ptr && sched && uniq_rows && px_stage_off && depth_grad && feat_grad,
+  OMNIHD_REQUIRE(rows_per_stage == 32 || rows_per_stage == 48 || rows_per_stage == 64, "rows per stage: 32, 48 or 64");
+  if (n_streams == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(out_grad && depth && feat && pt_word && uniq_rows && px_off && stream && stream_ptr && depth_grad && feat_grad,
                  "null pointer");
-  OMNIHD_REQUIRE(d_bins <= 64, "a pixel's piece of a stage is held as 4 x 16 table words: at most 64 depth bins");
+  OMNIHD_REQUIRE(d_bins <= 64, "the depth cells of a patch are held as 16 registers x 64 lanes: at most 64 depth bins");
   OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(out_grad) | reinterpret_cast<uintptr_t>(feat) |
-                   reinterpret_cast<uintptr_t>(feat_grad) | reinterpret_cast<uintptr_t>(sched)) & 15u) == 0, "16-byte alignment");
-  OMNIHD_REQUIRE(n_rows * 256 < (1ll << 32) && n_rows < 0x00ffffff, "out_grad must stay below 4 GiB (32-bit gather offsets)");
-  OMNIHD_REQUIRE((long long)d_bins * fh * fw * n_img < (1ll << 31), "depth tensor too large for int32 indices");
-  const size_t lds = (size_t)omnihd_bev_pool_v2_bwd_shared_lds_bytes(rows_per_stage, d_bins);
-  OMNIHD_REQUIRE(lds <= 64 * 1024, "stage buffer + depth blocks exceed 64 KiB of LDS");
-  hipStream_t st = (hipStream_t)stream;
-  int pw_shift = patch_w == 16 ? 4 : (patch_w == 8 ? 3 : 2);
-#define OMNIHD_SHARED_CASE(M)                                                                                              \
-  case M:                                                                                                                  \
-    hipLaunchKernelGGL(k_pool_bwd_shared<M>, dim3(n_slots), dim3(kBlock), lds, st, out_grad, (unsigned)(n_rows * 256), depth, \
-                       reinterpret_cast<const float4*>(feat), pt_word, pix_ptr, reinterpret_cast<const int4*>(sched),      \
-                       uniq_rows, px_stage_off, n_slots / 8, fh, fw, pw_shift, d_bins, depth_grad,                         \
+                   reinterpret_cast<uintptr_t>(feat_grad) | reinterpret_cast<uintptr_t>(stream)) & 15u) == 0, "16-byte alignment");
+  const long long n_px = (long long)n_img * fh * fw;
+  OMNIHD_REQUIRE(n_rows * 256 < (1ll << 32) - 256 && n_rows < 0x00ffffff, "out_grad must stay below 4 GiB (32-bit gather offsets)");
+  OMNIHD_REQUIRE(n_px * d_bins * 4 < (1ll << 32) - 256 && n_px * 256 < (1ll << 32) - 256, "depth / feat must stay below 4 GiB");
+  OMNIHD_REQUIRE(n_points * 4 < (1ll << 31) && n_uniq * 4 < (1ll << 31) && n_off * 4 < (1ll << 31) && n_entries * 16 < (1ll << 31),
+                 "tables must stay below 2 GiB");
+  const size_t lds = (size_t)omnihd_bev_pool_v2_bwd_stream_lds_bytes(rows_per_stage, d_bins);
+  hipStream_t st = (hipStream_t)stream_handle;
+  const int pw_shift = patch_w == 16 ? 4 : (patch_w == 8 ? 3 : 2);
+#define OMNIHD_STREAM_CASE(RQ)                                                                                             \
+  case RQ:                                                                                                                 \
+    hipLaunchKernelGGL(k_pool_bwd_stream<RQ>, dim3(n_streams), dim3(64), lds, st, out_grad, (unsigned)(n_rows * 256), depth, \
+                       (unsigned)(n_px * d_bins * 4), feat, (unsigned)(n_px * 256), pt_word, (unsigned)(n_points * 4),      \
+                       uniq_rows, (unsigned)(n_uniq * 4), px_off, (unsigned)(n_off * 4), reinterpret_cast<const int4*>(stream), \
+                       (unsigned)(n_entries * 16), stream_ptr, n_streams / 8, fh, fw, pw_shift, d_bins, depth_grad,          \
                        reinterpret_cast<float4*>(feat_grad));                                                              \
     break;
-  switch (rows_per_stage / 16) {
-    OMNIHD_SHARED_CASE(2) OMNIHD_SHARED_CASE(3) OMNIHD_SHARED_CASE(4) OMNIHD_SHARED_CASE(5) OMNIHD_SHARED_CASE(6)
-    OMNIHD_SHARED_CASE(7) OMNIHD_SHARED_CASE(8) OMNIHD_SHARED_CASE(9) OMNIHD_SHARED_CASE(10) OMNIHD_SHARED_CASE(11)
-    OMNIHD_SHARED_CASE(12)
+  switch (rows_per_stage / 4) {
+    OMNIHD_STREAM_CASE(8) OMNIHD_STREAM_CASE(12) OMNIHD_STREAM_CASE(16)
     default:
       return OMNIHD_ERR_ARG;
   }
-#undef OMNIHD_SHARED_CASE
-  return check_launch("bev_pool_v2_bwd_shared");
+#undef OMNIHD_STREAM_CASE
+  return check_launch("bev_pool_v2_bwd_stream");
 }

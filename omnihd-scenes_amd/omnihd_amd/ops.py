@@ -241,27 +241,28 @@ def bev_pool_v2_backward_patch(out_grad, depth, feat, ranks_depth, ranks_row, pi
               "omnihd_bev_pool_v2_bwd_patch")
 
 
-def bev_pool_v2_backward_shared(out_grad, depth, feat, tables, pix_ptr, depth_grad, feat_grad):
-    """Shared-row backward for C = 64 (see include/omnihd_hip.h): k_pool_bwd_patch's arithmetic with every out_grad row of a
-    16-pixel patch gathered once and shared through LDS; writes BOTH gradients densely.  ``tables``: plan.SharedBackwardTables."""
+def bev_pool_v2_backward_stream(out_grad, depth, feat, tables, depth_grad, feat_grad):
+    """Stream backward for C = 64 (see include/omnihd_hip.h): one wave per stream of stages, the distinct out_grad rows of a
+    16-pixel patch gathered once and shared through LDS; writes BOTH gradients densely.  ``tables``: plan.StreamBackwardTables."""
     for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad), ("feat_grad", feat_grad)):
         _want(t, torch.float32, n)
-    for n, t in (("pt_word", tables.pt_word), ("pix_ptr", pix_ptr), ("sched", tables.sched), ("uniq_rows", tables.uniq_rows),
-                 ("px_stage_off", tables.px_stage_off)):
+    for n, t in (("pt_word", tables.pt_word), ("uniq_rows", tables.uniq_rows), ("px_off", tables.px_off), ("stream", tables.stream),
+                 ("stream_ptr", tables.stream_ptr)):
         _want(t, torch.int32, n)
     if depth.dim() != 5 or feat.dim() != 5 or feat.size(-1) != 64:
         raise ValueError("depth must be (B,N,D,H,W) and feat (B,N,H,W,64)")
     B, N, D, H, W = depth.shape
-    if pix_ptr.numel() != B * N * H * W + 1 or tables.sched.size(0) % 8:
-        raise ValueError("pix_ptr must have B*N*H*W + 1 entries and the schedule 8*k slots")
-    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, tables.pt_word, pix_ptr, tables.sched, tables.uniq_rows,
-                       tables.px_stage_off)
+    if tables.stream_ptr.numel() != tables.n_streams + 1 or tables.n_streams % 8:
+        raise ValueError("stream_ptr must have n_streams + 1 entries, n_streams a multiple of 8")
+    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, tables.pt_word, tables.uniq_rows, tables.px_off, tables.stream,
+                       tables.stream_ptr)
     with _on(dev):
-        check(lib().omnihd_bev_pool_v2_bwd_shared(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(tables.pt_word), _ptr(pix_ptr),
-                                                  _ptr(tables.sched), _ptr(tables.uniq_rows), _ptr(tables.px_stage_off),
-                                                  tables.sched.size(0), B * N, D, H, W, tables.patch_w, tables.rows_per_stage,
-                                                  tables.max_stages, out_grad.numel() // 64, _ptr(depth_grad), _ptr(feat_grad), 64,
-                                                  _stream()), "omnihd_bev_pool_v2_bwd_shared")
+        check(lib().omnihd_bev_pool_v2_bwd_stream(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(tables.pt_word), tables.pt_word.numel(),
+                                                  _ptr(tables.uniq_rows), tables.uniq_rows.numel(), _ptr(tables.px_off),
+                                                  tables.px_off.numel(), _ptr(tables.stream), tables.stream.size(0),
+                                                  _ptr(tables.stream_ptr), tables.n_streams, B * N, D, H, W, tables.patch_w,
+                                                  tables.rows_per_stage, out_grad.numel() // 64, _ptr(depth_grad), _ptr(feat_grad),
+                                                  64, _stream()), "omnihd_bev_pool_v2_bwd_stream")
 
 
 def tile_descriptors(row_ptr, tile_row, tile_order=None):

@@ -256,22 +256,6 @@ def direct_tables(plan):
     return got
 
 
-SHARED_MAX_STAGES = 31      # kSharedMaxStages of csrc/bev_pool_v2.hip: (S+1) x 16 stage offsets live in 2 KiB of LDS
-
-
-@dataclass
-class SharedBackwardTables:
-    """Tables of the shared-row backward (include/omnihd_hip.h: omnihd_bev_pool_v2_bwd_shared)."""
-    patch_w: int                # patches are patch_w x (16 / patch_w) pixel blocks
-    rows_per_stage: int         # R: distinct output rows staged in LDS at a time
-    pt_word: torch.Tensor       # int32 [Npts] backward order: (index of the point's row inside its stage) * 256 | depth bin << 24
-    uniq_rows: torch.Tensor     # int32: per patch, the sorted distinct output rows its points touch
-    px_stage_off: torch.Tensor  # int32: per patch (S+1) x 16: offset inside pixel g's point list of its first point of stage k
-    sched: torch.Tensor         # int32 [8*k, 4] launch schedule {patch, first uniq entry, #distinct rows, first px_stage_off row}
-    max_stages: int
-    reuse: float                # points per distinct (patch, row): how many row gathers one staged row replaces
-
-
 def _patch_geometry(n_img, feat_hw, patch_w):
     fH, fW = feat_hw
     pw, ph = patch_w, PATCH // patch_w
@@ -280,7 +264,7 @@ def _patch_geometry(n_img, feat_hw, patch_w):
 
 
 def shared_schedule(n_img, feat_hw, patch_w, cost, n_xcd=8):
-    """Order of the patches of the shared-row backward: image by image in bands of 4 image rows, left to right inside a band
+    """Order of the patches of the stream (shared-row) backward: image by image in bands of 4 image rows, left to right inside a band
     (vertically adjacent patches touch the same output rows: what one fetched is in L2 for the next), cut into ``n_xcd``
     contiguous runs of equal COST (``cost`` per patch, points + a fixed cost), heaviest bands first inside a run (see
     ``patch_schedule``).  Returns a list of ``n_xcd`` int64 tensors of patch ids; every patch appears exactly once."""
@@ -311,17 +295,14 @@ def shared_schedule(n_img, feat_hw, patch_w, cost, n_xcd=8):
     return runs
 
 
-def shared_tables_from(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w=8, rows_per_stage=128):
-    """Tables of the shared-row backward from the backward tables (points sorted by pixel, inside a pixel by output row) — pure
-    torch, host-side planning once per calibration (works on CPU tensors for the tests).  None when the tables do not fit the
-    kernel: a pixel list that is not sorted by row, more than 64 depth bins, a patch with more than SHARED_MAX_STAGES stages."""
-    if patch_w not in (16, 8, 4) or rows_per_stage % 16 or not 32 <= rows_per_stage <= 192 or not 0 < depth_bins <= 64:
-        return None
+def _patch_rows(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w, R):
+    """What the shared-row (stream) backward needs of the backward tables (points sorted by pixel, inside a pixel by output row):
+    per patch the sorted distinct rows (``uniq_rows`` with CSR ``u_ptr``), per point the stage-relative word, per patch and stage
+    the 16 pixels' offsets into their point lists.  None when a pixel's list is not sorted by row."""
     dev = bp_ranks_row.device
     fH, fW = feat_hw
     fhw = fH * fW
     pw, ph, pcols, prows, n_patch = _patch_geometry(n_img, feat_hw, patch_w)
-    R = rows_per_stage
     n = int(bp_ranks_row.numel())
     pp = pix_ptr.long()
     lens = pp[1:] - pp[:-1]
@@ -334,54 +315,152 @@ def shared_tables_from(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins,
     g = (h % ph) * pw + w % pw                                                          # the pixel's lane group inside its patch
     key = patch * (1 << 24) + rows
     uk, inv = torch.unique(key, return_inverse=True)                                    # sorted: by patch, then by row
-    u_patch = uk >> 24
-    nu = torch.bincount(u_patch, minlength=n_patch)
+    nu = torch.bincount(uk >> 24, minlength=n_patch)
     u_ptr = torch.zeros(n_patch + 1, dtype=torch.int64, device=dev)
     u_ptr[1:] = nu.cumsum(0)
     n_stage = (nu + R - 1) // R
-    max_stages = int(n_stage.max().item()) if n_patch else 0
-    if max_stages > SHARED_MAX_STAGES:
-        return None
     idx = inv - u_ptr[patch]                                                            # index of the point's row among its patch's rows
     stage = idx // R
     dbin = torch.div(bp_ranks_depth.long(), fhw, rounding_mode="floor") % depth_bins
     pt_word = (((idx % R) << 8) | (dbin << 24)).to(torch.int32).contiguous()
+    rows_p = torch.clamp(n_stage, min=1) + 1                                            # offset rows of a patch: one per stage + the end (a patch without points: one empty stage)
     so_ptr = torch.zeros(n_patch + 1, dtype=torch.int64, device=dev)                    # first px_stage_off row of every patch
-    so_ptr[1:] = (n_stage + 1).cumsum(0)
+    so_ptr[1:] = rows_p.cumsum(0)
     total = int(so_ptr[-1].item())
     cnt = torch.zeros(total * PATCH, dtype=torch.int64, device=dev)
     if n:
         cnt.index_add_(0, (so_ptr[patch] + stage + 1) * PATCH + g, torch.ones(n, dtype=torch.int64, device=dev))
     cs = cnt.view(total, PATCH).cumsum(0)                                               # points of lane group g in all stages before this row
-    first = torch.repeat_interleave(so_ptr[:-1], n_stage + 1)
-    px_stage_off = (cs - cs[first]).to(torch.int32).contiguous().view(-1)
-    # launch schedule
+    first = torch.repeat_interleave(so_ptr[:-1], rows_p)
+    rel = cs - cs[first]                                                                # [total, 16] offsets inside the pixel's list
     pts = torch.bincount(patch, minlength=n_patch) if n else torch.zeros(n_patch, dtype=torch.int64, device=dev)
-    runs = shared_schedule(n_img, feat_hw, patch_w, (pts + PATCH_FIXED_COST).cpu())
-    per = max(1, max(r.numel() for r in runs))
-    order = torch.full((len(runs) * per,), -1, dtype=torch.int64)
-    for k_, r in enumerate(runs):
-        order[k_ * per:k_ * per + r.numel()] = r
-    order = order.to(dev)
-    safe = order.clamp(min=0)
-    sched = torch.stack([order, u_ptr[safe], nu[safe], so_ptr[safe]], dim=1)
-    sched[order < 0] = torch.tensor([-1, 0, 0, 0], device=dev)
-    reuse = float(n) / max(1, int(uk.numel()))
-    return SharedBackwardTables(patch_w, R, pt_word, (uk & 0xffffff).to(torch.int32).contiguous(), px_stage_off,
-                                sched.to(torch.int32).contiguous(), max_stages, reuse)
+    # first point (index into the backward tables) of pixel g of every patch; pixels outside the image: 0 (they have no points)
+    pid = torch.arange(n_patch, device=dev)
+    p_img, p_r, p_c = pid // (pcols * prows), (pid // pcols) % prows, pid % pcols
+    gg = torch.arange(PATCH, device=dev)
+    hh, ww = p_r[:, None] * ph + gg[None, :] // pw, p_c[:, None] * pw + gg[None, :] % pw
+    inside = (hh < fH) & (ww < fW)
+    fpix = (p_img[:, None] * fhw + hh * fW + ww).clamp(max=n_img * fhw - 1)
+    px_start = torch.where(inside, pp[fpix], torch.zeros_like(fpix))
+    return dict(n_patch=n_patch, uniq=(uk & 0xffffff).to(torch.int32).contiguous(), u_ptr=u_ptr, nu=nu, n_stage=n_stage,
+                pt_word=pt_word, so_ptr=so_ptr, rel=rel, pts=pts, px_start=px_start, reuse=float(n) / max(1, int(uk.numel())))
 
 
-SHARED_DEFAULT = (8, 128)       # (patch width, rows per stage) of the shared-row backward unless OMNIHD_POOL_BWD_SHARED_SHAPE="w,R"
+STREAM_FIRST, STREAM_LAST, STREAM_VALID = 1 << 30, 1 << 29, 1 << 28     # flags of a stream entry (csrc/bev_pool_v2.hip: kStream*)
+STREAM_STAGE_COST = 48        # cost model of the dealing: a stage costs as much as this many points, a patch as PATCH_FIXED_COST/4
 
 
-def shared_tables(plan, n_img, feat_hw2):
-    """The shared-row backward's tables of ``plan``, built on first use and kept with it (None: does not fit, see above)."""
-    shape = os.environ.get("OMNIHD_POOL_BWD_SHARED_SHAPE", "")
-    pw, R = (int(v) for v in shape.split(",")) if shape else SHARED_DEFAULT
-    cache = plan.__dict__.setdefault("_shared", {})
-    key = (pw, R, n_img, tuple(feat_hw2))
+@dataclass
+class StreamBackwardTables:
+    """Tables of the stream backward (include/omnihd_hip.h: omnihd_bev_pool_v2_bwd_stream)."""
+    patch_w: int
+    rows_per_stage: int
+    pt_word: torch.Tensor       # int32 [Npts]: 256 * (index of the point's row inside its stage) | depth bin << 24
+    uniq_rows: torch.Tensor     # int32: per patch, the sorted distinct output rows its points touch
+    px_off: torch.Tensor        # int32 [(rows + 1) * 16]: per patch and stage, the index into pt_word of pixel g's first point of the stage
+    stream: torch.Tensor        # int32 [n_entries, 4]
+    stream_ptr: torch.Tensor    # int32 [n_streams + 1] entries of wave w: [ptr[w], ptr[w+1])
+    n_streams: int
+    reuse: float
+    balance: float              # heaviest stream / mean stream (cost model)
+
+
+def stream_deal(runs, cost, streams_per_xcd):
+    """Deal the patches of every XCD run (in walk order) to ``streams_per_xcd`` waves: the next patch goes to the wave with the
+    least cost so far, so that the waves of an XCD move through the walk together and finish together.  Returns one list of
+    patch ids per stream (XCD-major)."""
+    import heapq
+    out = []
+    c = cost.tolist()
+    for run in runs:
+        heap = [(0.0, w) for w in range(streams_per_xcd)]
+        lists = [[] for _ in range(streams_per_xcd)]
+        for pid in run.tolist():
+            load, w = heapq.heappop(heap)
+            lists[w].append(pid)
+            heapq.heappush(heap, (load + c[pid], w))
+        out += lists
+    return out
+
+
+def stream_tables_from(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w=8, rows_per_stage=64,
+                       streams_per_xcd=192):
+    """Tables of the stream backward: the stages of ``_patch_rows`` laid out as one stream per wave (see the kernel's header
+    comment for the entry format).  Pure torch + a host heap for the dealing; None when the tables do not fit the kernel."""
+    if patch_w not in (16, 8, 4) or rows_per_stage not in (32, 48, 64) or not 0 < depth_bins <= 64:
+        return None
+    R = rows_per_stage
+    t = _patch_rows(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w, R)
+    if t is None or t["n_patch"] >= (1 << 28):
+        return None
+    dev = bp_ranks_row.device
+    n_stage = t["n_stage"].cpu()
+    n_ent = torch.clamp(n_stage, min=1)                         # a patch without points still has one (empty) stage: its gradients are zeros
+    cost = (t["pts"].cpu() + STREAM_STAGE_COST * n_ent + PATCH_FIXED_COST // 4).double()
+    runs = shared_schedule(n_img, feat_hw, patch_w, cost)
+    lists = stream_deal(runs, cost, streams_per_xcd)
+    n_streams = len(lists)
+    order = torch.tensor([pid for l in lists for pid in l], dtype=torch.int64)          # patches in stream order
+    per_stream = torch.tensor([len(l) for l in lists], dtype=torch.int64)
+    sid_of_patch = torch.repeat_interleave(torch.arange(n_streams), per_stream)
+    # global stage list G: stream-major, inside a stream patch by patch, stage by stage
+    ne = n_ent[order]
+    g_patch = torch.repeat_interleave(order, ne)
+    g_sid = torch.repeat_interleave(sid_of_patch, ne)
+    g_first_idx = torch.zeros(order.numel() + 1, dtype=torch.int64)
+    g_first_idx[1:] = ne.cumsum(0)
+    g_k = torch.arange(int(g_first_idx[-1])) - torch.repeat_interleave(g_first_idx[:-1], ne)
+    nu, u_ptr, so_ptr = t["nu"].cpu(), t["u_ptr"].cpu(), t["so_ptr"].cpu()
+    g_first = g_k == 0
+    g_last = g_k == ne[torch.repeat_interleave(torch.arange(order.numel()), ne)] - 1
+    g_ustart = u_ptr[g_patch] + g_k * R
+    g_nrows = torch.clamp(nu[g_patch] - g_k * R, min=0, max=R)
+    g_so = so_ptr[g_patch] + g_k
+    n_g = g_patch.numel()
+    stages_per_stream = torch.bincount(g_sid, minlength=n_streams)
+    gs = torch.zeros(n_streams + 1, dtype=torch.int64)
+    gs[1:] = stages_per_stream.cumsum(0)
+    es = gs + 2 * torch.arange(n_streams + 1)                   # entries: two more than stages per stream
+    n_entries = int(es[-1])
+    e_sid = torch.repeat_interleave(torch.arange(n_streams), stages_per_stream + 2)
+    e_j = torch.arange(n_entries) - es[e_sid]
+    ent = torch.zeros((n_entries, 4), dtype=torch.int64)
+    ent[:, 3] = -1
+    # x: the stage consumed in this iteration (entry j consumes stage j - 2 of its stream)
+    has = e_j >= 2
+    gi = (gs[e_sid] + e_j - 2)[has]
+    ent[has, 0] = g_patch[gi] | STREAM_VALID | torch.where(g_first[gi], STREAM_FIRST, 0) | torch.where(g_last[gi], STREAM_LAST, 0)
+    # y, z: the stage whose row ids / offsets are requested (stage j)
+    has = e_j < stages_per_stream[e_sid]
+    gi = (gs[e_sid] + e_j)[has]
+    ent[has, 1] = g_ustart[gi]
+    ent[has, 2] = g_so[gi] | (g_nrows[gi] << 24)
+    # w: the patch whose first stage is stage j - 1 (its pixel data are requested one iteration ahead)
+    has = (e_j >= 1) & (e_j <= stages_per_stream[e_sid])
+    gi = (gs[e_sid] + e_j - 1)[has]
+    ent[has, 3] = torch.where(g_first[gi], g_patch[gi], torch.full_like(gi, -1))
+    # absolute offsets into pt_word (+ one row of padding: the kernel reads the row behind a patch's last one)
+    rel, px_start = t["rel"], t["px_start"]
+    patch_of_row = torch.repeat_interleave(torch.arange(t["n_patch"], device=dev), torch.clamp(t["n_stage"], min=1) + 1)
+    px_off = rel + px_start[patch_of_row]
+    px_off = torch.cat([px_off, px_off.new_zeros(1, PATCH)]).to(torch.int32).contiguous().view(-1)
+    load = torch.zeros(n_streams, dtype=torch.float64).index_add_(0, sid_of_patch, cost[order])
+    return StreamBackwardTables(patch_w, R, t["pt_word"], t["uniq"], px_off, ent.to(torch.int32).contiguous().to(dev),
+                                es.to(torch.int32).contiguous().to(dev), n_streams, t["reuse"],
+                                float(load.max() / load.mean().clamp(min=1e-9)))
+
+
+STREAM_DEFAULT = (8, 32, 256)   # (patch width, rows per stage, waves per XCD) of the stream backward unless OMNIHD_POOL_BWD_STREAM_SHAPE="w,R,waves"
+
+
+def stream_tables(plan, n_img, feat_hw2):
+    """The stream backward's tables of ``plan``, built on first use and kept with it (None: does not fit, see above)."""
+    shape = os.environ.get("OMNIHD_POOL_BWD_STREAM_SHAPE", "")
+    pw, R, spx = (int(v) for v in shape.split(",")) if shape else STREAM_DEFAULT
+    cache = plan.__dict__.setdefault("_stream", {})
+    key = (pw, R, spx, n_img, tuple(feat_hw2))
     if key not in cache:
-        cache[key] = shared_tables_from(plan.bp_ranks_row, plan.bp_ranks_depth, plan.pix_ptr, n_img, plan.depth_bins, feat_hw2, pw, R)
+        cache[key] = stream_tables_from(plan.bp_ranks_row, plan.bp_ranks_depth, plan.pix_ptr, n_img, plan.depth_bins, feat_hw2, pw, R, spx)
     return cache[key]
 
 
@@ -677,6 +756,13 @@ class _PlannedPool(torch.autograd.Function):
             packed = _row_bin(plan)
             ops.prefetch([packed, depth, feat] if packed is not None else [plan.bp_ranks_depth, plan.bp_ranks_row, depth, feat])
         out_grad = out_grad.contiguous().float()
+        if patch and os.environ.get("OMNIHD_POOL_BWD_STREAM", "0") == "1" and plan.depth_bins <= 64 and depth.numel() * 4 < 2 ** 32 - 256:
+            # opt-in: the stream form of the same arithmetic (rows of a patch gathered once; DESIGN 4.2: not faster, so not the default)
+            st = stream_tables(plan, depth.size(0) * depth.size(1), (depth.size(3), depth.size(4)))
+            if st is not None:
+                depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
+                _timed("bwd", lambda: ops.bev_pool_v2_backward_stream(out_grad.view(plan.n_rows, c), depth, feat, st, depth_grad, feat_grad))
+                return depth_grad, feat_grad, None, None
         if patch:
             depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)   # both written densely
             packed = _row_bin(plan)

@@ -519,6 +519,72 @@ def test_patch_backward_full_size_against_the_reference_api_kernel(cuda, res):
     assert torch.equal(depth.grad == 0, dg == 0)
 
 
+@pytest.mark.parametrize("fH,fW,B,D,n_rows,pw,R,spx", [(5, 12, 1, 7, 3000, 8, 32, 1), (8, 12, 2, 7, 3000, 4, 32, 2), (4, 44, 1, 7, 3000, 16, 48, 1),
+                                                        (3, 7, 2, 7, 3000, 8, 64, 1), (6, 16, 1, 40, 50, 8, 64, 1), (6, 16, 1, 40, 700, 4, 32, 3)])
+def test_stream_backward_matches_oracle(cuda, fH, fW, B, D, n_rows, pw, R, spx):
+    """k_pool_bwd_stream (C = 64, opt-in): one wave per stream of stages, the distinct out_grad rows of a 16-pixel patch staged in
+    LDS.  Against the CPU restatement of the reference kernel: feat_grad bit-exact (same fma chain per channel), depth_grad 1e-5
+    (fixed-order channel sum), untouched entries exactly zero; patches cut by the image edge for every patch shape, pixels and depth
+    bins without points, streams of several patches (1-3 waves per XCD), patches of several stages (up to 112 distinct rows at 32
+    per stage) and pieces longer than the 16 table words read ahead (40 bins onto 50 rows: one stage holds a pixel's whole ray)."""
+    from omnihd_amd import ops
+    from omnihd_amd.plan import stream_tables_from
+    rng = np.random.default_rng(fH * 100 + fW + B + D)
+    N, c = 2, 64
+    fhw = fH * fW
+    n_depth = B * N * D * fhw
+    rd = np.sort(rng.permutation(n_depth)[:int(0.6 * n_depth)]).astype(np.int32)        # every frustum point at most once
+    rd = rd[(rd // fhw) % D != 3]                                                       # one depth bin never used
+    rd = rd[rd % fhw != 5]                                                              # one pixel column never used
+    rf = ((rd // (D * fhw)) * fhw + rd % fhw).astype(np.int32)
+    rows = rng.integers(0, n_rows, rd.size).astype(np.int32)
+    order = np.lexsort((rd, rows))
+    brb, brd, brf, bst, bln = O.backward_tables(rows[order], rd[order], rf[order])
+    depth = rng.random((B, N, D, fH, fW), dtype=np.float32)
+    feat = rng.standard_normal((B, N, fH, fW, c), dtype=np.float32)
+    og = rng.standard_normal((1, 1, 1, n_rows, c), dtype=np.float32)
+    want_dg, want_fg = OC.bev_pool_v2_bwd(og, depth, feat, brd, brf, brb, bst, bln)
+    pix_ptr = ops.csr_from_sorted_keys(t(brf, cuda), B * N * fhw)
+    tb = stream_tables_from(t(brb, cuda), t(brd, cuda), pix_ptr, B * N, D, (fH, fW), pw, R, spx)
+    assert tb is not None and tb.n_streams == 8 * spx
+    dg = torch.full((B, N, D, fH, fW), float("nan"), device=cuda)
+    fg = torch.full((B, N, fH, fW, c), float("nan"), device=cuda)
+    ops.bev_pool_v2_backward_stream(t(og.reshape(n_rows, c), cuda), t(depth, cuda), t(feat, cuda), tb, dg, fg)
+    assert not torch.isnan(dg).any() and not torch.isnan(fg).any()
+    assert np.array_equal(fg.cpu().numpy(), want_fg)
+    np.testing.assert_allclose(dg.cpu().numpy(), want_dg, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(dg.cpu().numpy() == 0, want_dg == 0)
+    dg2, fg2 = torch.empty_like(dg), torch.empty_like(fg)
+    ops.bev_pool_v2_backward_stream(t(og.reshape(n_rows, c), cuda), t(depth, cuda), t(feat, cuda), tb, dg2, fg2)
+    assert torch.equal(dg, dg2) and torch.equal(fg, fg2)                                # run-to-run identical
+
+
+@pytest.mark.parametrize("res", ["r1", "r2"])
+def test_stream_backward_full_size_equals_the_patch_backward(cuda, res, monkeypatch):
+    """R1 and R2 frame geometry through ``planned_pool``'s autograd path with OMNIHD_POOL_BWD_STREAM=1 against the default (patch)
+    backward of the same plan: feat_grad the same bits, depth_grad within 1e-5 of its largest entry, the same zeros."""
+    from omnihd_amd import build_plan
+    from omnihd_amd import plan as P
+    fH, fW, _ = FULL[res]
+    geom, dx, bx, nx = full_size_geometry(res)
+    plan = build_plan(t(geom, cuda), dx, bx, nx, layout="byxz")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    depth0 = torch.rand(1, 6, 59, fH, fW, generator=g).softmax(2).to(cuda)
+    feat0 = torch.randn(1, 6, fH, fW, 64, generator=g).to(cuda)
+    og = torch.randn(plan.n_rows, 64, generator=g).to(cuda).view(1, 160, 240, 16, 64).permute(0, 4, 3, 1, 2)
+    grads = []
+    for stream in ("0", "1"):
+        monkeypatch.setenv("OMNIHD_POOL_BWD_STREAM", stream)
+        depth, feat = depth0.clone().requires_grad_(), feat0.clone().requires_grad_()
+        P.planned_pool(depth, feat, plan).backward(og)
+        grads.append((depth.grad, feat.grad))
+    assert getattr(plan, "_stream", None), "the stream tables were not built: the opt-in path did not run"
+    (dg0, fg0), (dg1, fg1) = grads
+    assert torch.equal(fg0, fg1)
+    assert float((dg0 - dg1).abs().max()) <= 1e-5 * float(dg0.abs().max())
+    assert torch.equal(dg0 == 0, dg1 == 0)
+
+
 def test_kept_output_buffers_survive_consumers_that_write_in_place(cuda, monkeypatch):
     """``planned_pool(keep_empty_rows=True)`` reuses an output buffer whose empty rows are zero already.
     A consumer that writes into the result in place must never make a later forward silently wrong:

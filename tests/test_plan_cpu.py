@@ -243,9 +243,10 @@ def test_direct_forward_tables_walk_every_point_once_and_close_every_row(tile_ro
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
 
 
-def _walk_shared_tables(out_grad, depth, feat, pix_ptr, tb, d_bins, fh, fw):
-    """Host emulation of k_pool_bwd_shared's walk (csrc/bev_pool_v2.hip): per scheduled patch, stage by stage, the distinct rows
-    of the stage are 'staged' (a dict keyed by the word's row offset), every pixel group walks its piece of the stage."""
+def _walk_stream_tables(out_grad, depth, feat, tb, d_bins, fh, fw):
+    """Host emulation of k_pool_bwd_stream's walk (csrc/bev_pool_v2.hip), iteration by iteration as the kernel does it: entry t
+    names the stage consumed now (t-2), the stage whose rows are fetched now was named by entry t-1, the stage whose ids / offsets
+    are read now is entry t's own; the pixel data of a patch are fetched one iteration before its first stage."""
     C = feat.shape[-1]
     og = out_grad.reshape(-1, C).astype(np.float64)
     dflat = depth.reshape(-1).astype(np.float64)
@@ -256,67 +257,85 @@ def _walk_shared_tables(out_grad, depth, feat, pix_ptr, tb, d_bins, fh, fw):
     ph = 16 // pw
     pcols, prows = -(-fw // pw), -(-fh // ph)
     fhw = fh * fw
-    sched, uniq, off, word = tb.sched.numpy(), tb.uniq_rows.numpy(), tb.px_stage_off.numpy(), tb.pt_word.numpy()
-    seen = []
-    for patch, ustart, nu, so in sched:
-        if patch < 0:
-            continue
-        seen.append(int(patch))
+    stream, sptr = tb.stream.numpy().astype(np.int64), tb.stream_ptr.numpy()
+    uniq, off, word = tb.uniq_rows.numpy(), tb.px_off.numpy().reshape(-1, 16), tb.pt_word.numpy()
+    consumed = []
+
+    def geometry(patch):
         img, pr, pc = patch // (pcols * prows), (patch // pcols) % prows, patch % pcols
-        S = -(-nu // R)
-        assert S <= tb.max_stages
-        pix = []
-        for g in range(16):
-            hh, ww = pr * ph + g // pw, pc * pw + g % pw
-            pix.append(img * fhw + hh * fw + ww if (hh < fh and ww < fw) else None)
-        acc = {g: np.zeros(C) for g in range(16) if pix[g] is not None}
-        for g, f in enumerate(pix):                               # the dense D x 16 block of depth gradients starts at zero
-            if f is not None:
-                dg[(img * d_bins + np.arange(d_bins)) * fhw + f % fhw] = 0.0
-                assert off[so * 16 + g] == 0 and off[(so + S) * 16 + g] == pix_ptr[f + 1] - pix_ptr[f]
-        for k in range(S):
-            stage_rows = uniq[ustart + k * R:ustart + min(nu, (k + 1) * R)]
-            for g, f in enumerate(pix):
-                if f is None:
-                    continue
-                a, b = off[(so + k) * 16 + g], off[(so + k + 1) * 16 + g]
-                assert 0 <= b - a <= 64
-                for q in range(pix_ptr[f] + a, pix_ptr[f] + b):
-                    w = int(word[q])
-                    lid, dk = (w & 0xffffff) >> 8, (w >> 24) & 0xff
-                    assert (w & 0xff) == 0 and lid < len(stage_rows)
-                    row = og[stage_rows[lid]]
-                    rd = (img * d_bins + dk) * fhw + f % fhw
-                    acc[g] = acc[g] + dflat[rd] * row
-                    dg[rd] = float(row @ frows[f])
-        for g, f in enumerate(pix):
-            if f is not None:
-                fg[f] = acc[g]
-    return dg, fg, seen
+        return [(img, (pr * ph + g // pw) * fw + pc * pw + g % pw) if (pr * ph + g // pw < fh and pc * pw + g % pw < fw) else None
+                for g in range(16)]
+
+    for w in range(tb.n_streams):
+        ids_prev, nrows_prev, o1, o2, rows_lds, rows_regs, geo_next, geo, acc = None, 0, None, None, None, None, None, None, None
+        for e in range(sptr[w], sptr[w + 1]):
+            ex, ey, ez, ew = (int(v) for v in stream[e])
+            rows_lds = rows_regs                                            # (1) the rows requested last iteration -> LDS
+            if ex & (1 << 30):
+                geo = geo_next
+                acc = {g: np.zeros(C) for g in range(16) if geo[g] is not None}
+                for g, px in enumerate(geo):
+                    if px is not None:
+                        dg[(px[0] * d_bins + np.arange(d_bins)) * fhw + px[1]] = 0.0
+            ids_n = uniq[ey:ey + 64]                                        # (2) requests
+            so, nrows = ez & 0xffffff, (ez >> 24) & 0xff
+            o_n = (off[so].copy(), off[so + 1].copy())
+            if ew >= 0:
+                geo_next = geometry(ew)
+            rows_regs = None if ids_prev is None else [ids_prev[r] if r < nrows_prev else None for r in range(R)]
+            if ex & (1 << 28):                                              # (3) the points of stage t-2
+                assert (ex & 0x0fffffff) >= 0 and geo is not None
+                consumed.append((ex & 0x0fffffff, bool(ex & (1 << 30)), bool(ex & (1 << 29))))
+                a, b = o2
+                for g, px in enumerate(geo):
+                    if px is None:
+                        assert a[g] == b[g]
+                        continue
+                    assert 0 <= b[g] - a[g] <= 64
+                    f = px[0] * fhw + px[1]
+                    for q in range(a[g], b[g]):
+                        wd = int(word[q])
+                        lid, dk = (wd & 0xffffff) >> 8, (wd >> 24) & 0xff
+                        row = og[rows_lds[lid]]
+                        rd = (px[0] * d_bins + dk) * fhw + px[1]
+                        acc[g] = acc[g] + dflat[rd] * row
+                        dg[rd] = float(row @ frows[f])
+                if ex & (1 << 29):
+                    for g, px in enumerate(geo):
+                        if px is not None:
+                            fg[px[0] * fhw + px[1]] = acc[g]
+            o2, o1 = o1, o_n                                                # (4) rotate
+            ids_prev, nrows_prev = ids_n, nrows
+    return dg, fg, consumed
 
 
-@pytest.mark.parametrize("patch_w,rows_per_stage", [(16, 32), (8, 32), (4, 48), (8, 192)])
-def test_shared_backward_tables_walk_every_point_once(patch_w, rows_per_stage):
-    """plan.shared_tables_from: distinct rows per patch, stage-relative point words, per-pixel stage offsets and the launch
-    schedule drive a walk that equals the pooling oracle's backward (tiny rig whose 8 x 12 feature image is cut by every patch
-    shape: partial patches on the right / bottom edge; 32-row stages so that most patches need several)."""
-    from omnihd_amd.plan import shared_tables_from
+@pytest.mark.parametrize("patch_w,rows_per_stage,streams_per_xcd", [(16, 32, 1), (8, 32, 2), (4, 32, 1), (8, 64, 3)])
+def test_stream_backward_tables_walk_every_stage_once(patch_w, rows_per_stage, streams_per_xcd):
+    """plan.stream_tables_from: the per-wave streams (two entries more than stages, every entry naming the stage consumed, the
+    stage whose rows are on their way and the stage whose ids are read) drive a walk that equals the pooling oracle's backward;
+    every patch's stages appear once, in order, first/last flagged; patches without points still write their zeros."""
+    from omnihd_amd.plan import stream_tables_from
     from oracle import cpu as OC
     rb, rd, rf, st, ln, (X, Y, Z), rng = _tables()
     N, D, H, W, C = 4, 8, 8, 12, 8
     n_rows = Z * Y * X
-    order = np.lexsort((rb, rf))                                   # backward tables: by pixel, inside a pixel by row (stable)
+    keep = (rf // (H * W) != 2) | ((rf % (H * W)) // W >= 4)       # no points in the upper half of image 2: patches without a stage
+    rb, rd, rf = rb[keep], rd[keep], rf[keep]
+    order = np.lexsort((rb, rf))
     brb, brd, brf = rb[order].astype(np.int32), rd[order].astype(np.int32), rf[order].astype(np.int32)
     pix_ptr = np.concatenate([[0], np.cumsum(np.bincount(brf, minlength=N * H * W))]).astype(np.int32)
-    tb = shared_tables_from(torch.from_numpy(brb), torch.from_numpy(brd), torch.from_numpy(pix_ptr), N, D, (H, W), patch_w, rows_per_stage)
-    assert tb is not None and tb.sched.shape[0] % 8 == 0 and tb.reuse >= 1.0
+    tb = stream_tables_from(torch.from_numpy(brb), torch.from_numpy(brd), torch.from_numpy(pix_ptr), N, D, (H, W), patch_w, rows_per_stage,
+                            streams_per_xcd)
+    assert tb is not None and tb.n_streams == 8 * streams_per_xcd and tb.stream.shape[1] == 4 and tb.balance >= 1.0
     depth = rng.random((1, N, D, H, W), dtype=np.float32)
     feat = rng.standard_normal((1, N, H, W, C), dtype=np.float32)
     out_grad = rng.standard_normal((n_rows, C), dtype=np.float32)
-    dg, fg, seen = _walk_shared_tables(out_grad, depth, feat, pix_ptr, tb, D, H, W)
+    dg, fg, consumed = _walk_stream_tables(out_grad, depth, feat, tb, D, H, W)
     n_patch = N * -(-W // patch_w) * -(-H // (16 // patch_w))
-    assert sorted(seen) == list(range(n_patch))                   # every patch exactly once
-    assert not np.isnan(dg).any() and not np.isnan(fg).any()      # both gradients written densely
+    firsts = [p for p, first, last in consumed if first]
+    lasts = [p for p, first, last in consumed if last]
+    assert sorted(firsts) == list(range(n_patch)) and sorted(lasts) == list(range(n_patch))      # every patch opened and closed once
+    assert not np.isnan(dg).any() and not np.isnan(fg).any()
     bst = np.flatnonzero(np.r_[True, brf[1:] != brf[:-1]]).astype(np.int32)
     bln = np.diff(np.r_[bst, len(brf)]).astype(np.int32)
     want_dg, want_fg = OC.bev_pool_v2_bwd(out_grad.reshape(1, Z, Y, X, C), depth, feat, brd, brf, brb, bst, bln)
@@ -324,13 +343,15 @@ def test_shared_backward_tables_walk_every_point_once(patch_w, rows_per_stage):
     np.testing.assert_allclose(fg.reshape(want_fg.shape), want_fg, rtol=1e-5, atol=1e-6)
 
 
-def test_shared_backward_tables_refuse_what_the_kernel_cannot_walk():
-    from omnihd_amd.plan import shared_tables_from
+def test_stream_backward_tables_refuse_what_the_kernel_cannot_walk():
+    from omnihd_amd.plan import stream_tables_from
     rows = torch.tensor([5, 3], dtype=torch.int32)                # one pixel whose two points are NOT sorted by row
     rd = torch.tensor([0, 16], dtype=torch.int32)
     pix_ptr = torch.zeros(17, dtype=torch.int32); pix_ptr[1:] = 2
-    assert shared_tables_from(rows, rd, pix_ptr, 1, 2, (4, 4), 4, 32) is None
-    ok = shared_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 4, 32)
-    assert ok is not None and ok.max_stages == 1 and ok.uniq_rows.tolist() == [3, 5]
-    assert shared_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 65, (4, 4), 4, 32) is None     # > 64 depth bins
-    assert shared_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 5, 32) is None      # patch width
+    assert stream_tables_from(rows, rd, pix_ptr, 1, 2, (4, 4), 4, 32, 1) is None
+    ok = stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 4, 32, 1)
+    assert ok is not None and ok.uniq_rows.tolist() == [3, 5] and ok.stream.shape == (2 * 8 + 1, 4)        # one stage + two entries per wave
+    assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 65, (4, 4), 4, 32, 1) is None     # > 64 depth bins
+    assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 5, 32, 1) is None      # patch width
+    assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 4, 40, 1) is None      # rows per stage
+
