@@ -246,7 +246,12 @@ int plan_blocks(long long rows, int c8, long long* rows_per_block) {
   const int rpi = 256 / c8;
   long long iters = (rows + rpi - 1) / rpi;
   long long blocks = (iters + 15) / 16;                     // >= 16 row-iterations per workgroup
-  if (blocks > 512) blocks = 512;                           // the second stage reads blocks x 2c floats
+  static const long long cap = [] {                          // the second stage reads blocks x 2c floats
+    const char* e = getenv("OMNIHD_BN_MAX_BLOCKS");         // (lab override, scripts/lab/bn_parts_time.py)
+    const long long v = e ? atoll(e) : 0;
+    return v >= 1 && v <= 8192 ? v : 512ll;
+  }();
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   long long per = (rows + blocks - 1) / blocks;
   per = (per + rpi - 1) / rpi * rpi;

@@ -391,8 +391,8 @@ def stream_tables_from(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins,
         return None
     R = rows_per_stage
     t = _patch_rows(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w, R)
-    if t is None or t["n_patch"] >= (1 << 28):
-        return None
+    if t is None or t["n_patch"] >= (1 << 28) or int(t["so_ptr"][-1]) >= (1 << 24):
+        return None                                             # the entry fields: 28 bits of patch id, 24 bits of offset row
     dev = bp_ranks_row.device
     n_stage = t["n_stage"].cpu()
     n_ent = torch.clamp(n_stage, min=1)                         # a patch without points still has one (empty) stage: its gradients are zeros
