@@ -495,7 +495,9 @@ def comm_report(step, iters=3):
     t_sync = timed(False)
     try:
         data = ddp._get_ddp_logging_data()
-        sizes = str(data.get("bucket_sizes", "")).strip()
+        # after its first backward DDP re-buckets in the order the gradients arrived: those are the buckets that are reduced
+        sizes = str(data.get("rebuilt_bucket_sizes", "") if data.get("has_rebuilt_buckets") else "").strip() \
+            or str(data.get("bucket_sizes", "")).strip()
         if sizes:
             rep["buckets"] = len([s for s in sizes.split(",") if s.strip()])
     except Exception:
