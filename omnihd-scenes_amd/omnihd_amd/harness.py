@@ -394,7 +394,7 @@ class FusionTrainStep:
         with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.autocast):
             losses = self.model(return_loss=True, **b)
         total = sum(v if torch.is_tensor(v) else sum(v) for v in losses.values())
-        total.backward()
+        total.backward()          # (ends with ops.wgrad_overlap_join: the weight gradients computed on the side stream are joined)
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=35, norm_type=2)
         self.opt.step()
         if self.device.type == "cuda":

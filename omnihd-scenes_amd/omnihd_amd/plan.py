@@ -756,6 +756,15 @@ class _PlannedPool(torch.autograd.Function):
             packed = _row_bin(plan)
             ops.prefetch([packed, depth, feat] if packed is not None else [plan.bp_ranks_depth, plan.bp_ranks_row, depth, feat])
         out_grad = out_grad.contiguous().float()
+        ops.wgrad_overlap_fence(out_grad.device)       # (a no-op unless OMNIHD_WGRAD_OVERLAP=all put weight gradients in flight)
+        try:
+            return _PlannedPool._backward(ctx, out_grad, depth, feat, plan, c, patch)
+        finally:
+            if depth.is_cuda and not torch.is_grad_enabled():
+                ops.wgrad_overlap_arm()                # weight gradients recorded so far go behind this kernel; later ones overlap
+
+    @staticmethod
+    def _backward(ctx, out_grad, depth, feat, plan, c, patch):
         if patch and os.environ.get("OMNIHD_POOL_BWD_STREAM", "0") == "1" and plan.depth_bins <= 64 and depth.numel() * 4 < 2 ** 32 - 256:
             # opt-in: the stream form of the same arithmetic (rows of a patch gathered once; DESIGN 4.2: not faster, so not the default)
             st = stream_tables(plan, depth.size(0) * depth.size(1), (depth.size(3), depth.size(4)))

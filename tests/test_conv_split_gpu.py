@@ -241,3 +241,60 @@ def test_weight_images_follow_the_fused_optimiser_in_the_step_loop(cuda, dtype):
             assert all(torch.equal(a, b) for a, b in zip(planes, fresh)), "stale split planes"
             checked += 1
     assert checked > 10
+
+
+@pytest.mark.parametrize("weights_channels_last", [False, True])
+def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones(cuda, weights_channels_last, monkeypatch):
+    """OMNIHD_WGRAD_OVERLAP (one rank; by default armed by the pooling backward for the layers behind it, "all" = every layer,
+    what this test uses): the weight gradient of a split convolution is computed on a side stream while the
+    data-gradient chain goes on, and the autograd engine's end-of-backward callback joins that stream.  A chain of
+    convolutions big enough that the side stream is still busy when ``backward`` returns control to the engine: every gradient
+    must equal the in-line run's (same kernels, same order of arithmetic: 1e-6 where MIOpen's atomics decide the last bit),
+    for parameters in either memory format (autograd keeps a gradient in the parameter's layout as it is and would COPY any
+    other one on the main stream); a parameter that already holds a gradient accumulates correctly (in-line fallback)."""
+    from omnihd_amd import ops
+    torch.manual_seed(3)
+    chans = [64, 128, 256, 256, 128]
+    ws = [torch.randn(chans[i + 1], chans[i], 3, 3, device=cuda) * 0.05 for i in range(4)]
+    if weights_channels_last:
+        ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
+    x0 = torch.randn(2, 64, 96, 160, device=cuda).contiguous(memory_format=torch.channels_last)
+
+    class Arm(torch.autograd.Function):                   # stands in for the pooling backward: what is recorded in front of it
+        @staticmethod                                      # (in backward order) is enqueued here, what follows overlaps at once
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, gt):
+            ops.wgrad_overlap_arm()
+            return gt
+
+    def run(overlap, accumulate=False):
+        monkeypatch.setenv("OMNIHD_WGRAD_OVERLAP", overlap)
+        params = [w.clone().requires_grad_() for w in ws]
+        if weights_channels_last:
+            assert all(p.is_contiguous(memory_format=torch.channels_last) for p in params)
+        x = x0.clone().requires_grad_()
+        for rep in range(2 if accumulate else 1):
+            y = x
+            for i, p in enumerate(params):
+                y = torch.relu(ops.conv_split(y, p, None, (1, 1), (1, 1)))
+                if i == 1 and overlap == "1":
+                    y = Arm.apply(y)
+            (y * y).mean().backward()                         # the engine's callback joins the side stream here
+        return [p.grad.clone() for p in params] + [x.grad.clone()]
+
+    base = run("0")
+    from omnihd_amd import ops as _ops
+    for got, want in zip(run("all"), base):
+        assert got.shape == want.shape and torch.isfinite(got).all()
+        assert _rel(got, want) <= 1e-6
+    for got, want in zip(run("1"), base):                     # layers 3, 2 recorded and enqueued at the marker, layers 1, 0 at once
+        assert torch.isfinite(got).all() and _rel(got, want) <= 1e-6
+    assert not _ops._WGRAD_DEFERRED and not _ops._WGRAD_SIDE_USED and not _ops._WGRAD_ARMED
+    base2 = run("0", accumulate=True)
+    assert _ops._WGRAD_SIDE and not _ops._WGRAD_SIDE_USED and not _ops._WGRAD_ARMED     # the side stream was used and joined
+    for got, want in zip(run("all", accumulate=True), base2):
+        assert _rel(got, want) <= 1e-6
+    assert _rel(base2[0], 2 * base[0]) <= 1e-5                # two identical passes accumulated
