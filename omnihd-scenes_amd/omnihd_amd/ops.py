@@ -1621,31 +1621,19 @@ class _ConvSplit(torch.autograd.Function):
         # Weight gradient beside the data gradient (OMNIHD_WGRAD_OVERLAP, one rank): nothing reads a weight gradient before the end
         # of the backward pass, so its kernels go to a side stream that the autograd engine's final callback joins
         # (wgrad_overlap_join); the data-gradient chain on the main stream no longer waits for them, and the tails of either
-        # fill the other's idle CUs.  In front of the pooling backward the work is only RECORDED (the gradient tensor is handed to
-        # autograd empty) and enqueued behind that kernel (wgrad_overlap_flush), which must not share the memory system.
-        side, deferred = _wgrad_side_stream(dev, weight) if ctx.needs_input_grad[1] else (None, False)
+        # fill the other's idle CUs.  By default only for the layers BEHIND the pooling backward (wgrad_overlap_arm).
+        side = _wgrad_side_stream(dev, weight) if ctx.needs_input_grad[1] else None
         if side is not None:
-            def on_side(out=None):
-                for tns in (g, g_in, x_hi, x_lo, x_saved) + (tuple(gs) if gs is not None else ()):
-                    if tns is not None:
-                        tns.record_stream(side)          # allocated on the main stream, read on the side stream
-                with torch.cuda.stream(side):
-                    val = weight_gradient()
-                    if out is not None:
-                        return out.copy_(val)
-                    # autograd keeps a gradient that has the parameter's layout as it is; any other one it would COPY on the main
-                    # stream, before this stream is done
-                    return val if val.stride() == weight.stride() else torch.empty_like(weight).copy_(val)
-
-            if deferred:
-                gw = torch.empty_like(weight)
-                gw.record_stream(side)
-                # the job writes through an ALIAS (own tensor object, same storage): autograd keeps `gw` itself as the parameter's
-                # gradient only while nobody else holds it; a second owner would make it clone the still empty tensor
-                _WGRAD_DEFERRED.append((dev, lambda out=gw.detach(): on_side(out)))
-            else:
-                side.wait_stream(torch.cuda.current_stream(dev))
-                gw = on_side()
+            side.wait_stream(torch.cuda.current_stream(dev))
+            for tns in (g, g_in, x_hi, x_lo, x_saved) + (tuple(gs) if gs is not None else ()):
+                if tns is not None:
+                    tns.record_stream(side)              # allocated on the main stream, read on the side stream
+            with torch.cuda.stream(side):
+                gw = weight_gradient()
+                # autograd keeps a gradient that has the parameter's layout as it is; any other one it would COPY on the main
+                # stream, before this stream is done
+                if gw.stride() != weight.stride():
+                    gw = torch.empty_like(weight).copy_(gw)
         if ctx.needs_input_grad[0]:
             # (an uninitialised fp32 stand-in for the input: only its shape / layout matter to the data gradient)
             x_like = lambda: torch.empty(x_shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
@@ -1669,58 +1657,49 @@ class _ConvSplit(torch.autograd.Function):
 _WGRAD_SIDE = {}
 _WGRAD_SIDE_USED = set()
 _WGRAD_ARMED = []           # non-empty: the pooling backward of this backward pass has been launched (see wgrad_overlap_arm)
-_WGRAD_DEFERRED = []        # (device, job): weight gradients recorded in front of the pooling backward
-_WGRAD_PASS = [None]        # autograd graph-task id of the backward pass the three lists above belong to
+_WGRAD_PASS = [None]        # autograd graph-task id of the backward pass the two above belong to
 
 
 def _wgrad_side_stream(dev, weight):
-    """(side stream, deferred) for the weight gradient of ``weight``, or (None, False): OMNIHD_WGRAD_OVERLAP=0, more than one rank
-    (DDP's reducer reads a gradient as soon as autograd has accumulated it, on its own stream), a parameter that already holds a
-    gradient or carries hooks (autograd would then run kernels on the gradient on the main stream, before the side stream is
-    done), or a backward pass that builds a graph.  ``deferred``: the pooling backward of this pass has not run yet — record the
-    work, enqueue it behind that kernel (OMNIHD_WGRAD_OVERLAP=all: never deferred).  The first use inside a backward pass queues
+    """The side stream for the weight gradient of ``weight``, or None: OMNIHD_WGRAD_OVERLAP=0; a process group exists (a DDP
+    reducer, also a one-rank one, copies gradients into its buckets as autograd accumulates them, on its own stream); the
+    parameter already holds a gradient or carries hooks (autograd would then run kernels on the gradient on the main stream,
+    before the side stream is done); the backward pass builds a graph; or — the default mode — the pooling backward of this pass
+    has not run yet (OMNIHD_WGRAD_OVERLAP=all: every layer from the start of the pass).  The first use inside a backward pass queues
     ``wgrad_overlap_join`` as a final callback of the autograd engine, so whoever called ``backward`` finds the gradients
     complete on its stream — no caller has to know."""
     mode = os.environ.get("OMNIHD_WGRAD_OVERLAP", "1")
     if mode == "0" or torch.is_grad_enabled():
-        return None, False
+        return None
     if not weight.is_leaf or weight.grad is not None or weight._backward_hooks or getattr(weight, "_post_accumulate_grad_hooks", None):
-        return None, False
+        return None
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():     # any process group: a DDP reducer (also a one-rank one) copies gradients
-        return None, False                                 # into its buckets as they are accumulated
+    if dist.is_available() and dist.is_initialized():
+        return None
+    _wgrad_pass_begin()
+    if mode != "all" and not _WGRAD_ARMED:
+        return None
     s = _WGRAD_SIDE.get(dev.index)
     if s is None:
         s = _WGRAD_SIDE[dev.index] = torch.cuda.Stream(device=dev)
-    _wgrad_pass_begin()
     _WGRAD_SIDE_USED.add(dev.index)
-    return s, (mode != "all" and not _WGRAD_ARMED)
+    return s
 
 
 def _wgrad_pass_begin():
     """First touch of the overlap state inside a backward pass (autograd's graph-task id tells passes apart): this pass's join
-    is queued as a final callback of the engine."""
+    is queued as a final callback of the engine; what an aborted pass left behind is joined first."""
     task = torch._C._current_graph_task_id()
     if _WGRAD_PASS[0] != task:
-        if _WGRAD_DEFERRED or _WGRAD_SIDE_USED:      # leftovers (an aborted pass, or an outer pass around a re-entrant one): finish
-            wgrad_overlap_join()                     # them now — their gradient tensors must never stay unwritten
+        if _WGRAD_SIDE_USED:
+            wgrad_overlap_join()
         _WGRAD_ARMED.clear()
         _WGRAD_PASS[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(wgrad_overlap_join)
 
 
-def wgrad_overlap_flush():
-    """Enqueue the recorded weight gradients on the side stream, behind everything the current stream has been given so far."""
-    jobs, _WGRAD_DEFERRED[:] = list(_WGRAD_DEFERRED), []
-    for idx in {dev.index for dev, _ in jobs}:
-        _WGRAD_SIDE[idx].wait_stream(torch.cuda.current_stream(idx))
-    for _, job in jobs:
-        job()
-
-
 def wgrad_overlap_join():
     """End of a backward pass: the current stream waits for the weight gradients that were computed on the side stream."""
-    wgrad_overlap_flush()                        # (a pass without a pooling backward: nothing was flushed yet)
     for idx in list(_WGRAD_SIDE_USED):
         torch.cuda.current_stream(idx).wait_stream(_WGRAD_SIDE[idx])
     _WGRAD_SIDE_USED.clear()
@@ -1729,17 +1708,18 @@ def wgrad_overlap_join():
 
 
 def wgrad_overlap_arm():
-    """Called by the pooling backward once its kernel is enqueued: the weight gradients recorded in front of it (heads, fusion, BEV
-    encoder) are enqueued on the side stream BEHIND that kernel, and from here to the end of the backward pass (DepthNet, image
-    backbone) weight gradients go to the side stream at once.  So the bandwidth-bound pooling backward never shares the memory
-    system with a matrix kernel of the side stream (119 us instead of 55 us in the step when it does) and never waits for one
-    (0.6 ms per step when it fences a busy side stream)."""
+    """Called by the pooling backward once its kernel is enqueued: from here to the end of the backward pass (DepthNet and the
+    image backbone: ~90 convolutions of small and middle size) the weight gradients go to the side stream.  The layers in front
+    of it (heads, fusion, BEV encoder: few, GPU-filling kernels) keep theirs in line, so the bandwidth-bound pooling backward
+    never shares the memory system with a matrix kernel of the side stream (119 us instead of 53 us in the step when it does,
+    OMNIHD_WGRAD_OVERLAP=all with OMNIHD_POOL_BWD_EXCLUSIVE=0) and never waits for one.  Measured alternatives, same box: all layers
+    + a fence in front of the pooling backward 48.46 ms, recording the front layers' work and enqueueing it behind the pooling
+    kernel 48.23 ms (but that kernel then 64 us), this 48.47 ms, no overlap 50.0 ms."""
     if torch._C._current_graph_task_id() < 0 or os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") == "0":
         return
     _wgrad_pass_begin()
     if not _WGRAD_ARMED:
         _WGRAD_ARMED.append(True)
-    wgrad_overlap_flush()
 
 
 def wgrad_overlap_fence(dev):

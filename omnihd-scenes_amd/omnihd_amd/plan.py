@@ -761,7 +761,7 @@ class _PlannedPool(torch.autograd.Function):
             return _PlannedPool._backward(ctx, out_grad, depth, feat, plan, c, patch)
         finally:
             if depth.is_cuda and not torch.is_grad_enabled():
-                ops.wgrad_overlap_arm()                # weight gradients recorded so far go behind this kernel; later ones overlap
+                ops.wgrad_overlap_arm()                # the convolutions behind this point overlap their weight gradients
 
     @staticmethod
     def _backward(ctx, out_grad, depth, feat, plan, c, patch):

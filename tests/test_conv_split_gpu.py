@@ -260,8 +260,8 @@ def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones(cuda, weight
         ws = [w.contiguous(memory_format=torch.channels_last) for w in ws]
     x0 = torch.randn(2, 64, 96, 160, device=cuda).contiguous(memory_format=torch.channels_last)
 
-    class Arm(torch.autograd.Function):                   # stands in for the pooling backward: what is recorded in front of it
-        @staticmethod                                      # (in backward order) is enqueued here, what follows overlaps at once
+    class Arm(torch.autograd.Function):                   # stands in for the pooling backward: the layers in front of it (in
+        @staticmethod                                      # backward order) stay in line, what follows goes to the side stream
         def forward(ctx, t):
             return t.view_as(t)
 
@@ -290,9 +290,9 @@ def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones(cuda, weight
     for got, want in zip(run("all"), base):
         assert got.shape == want.shape and torch.isfinite(got).all()
         assert _rel(got, want) <= 1e-6
-    for got, want in zip(run("1"), base):                     # layers 3, 2 recorded and enqueued at the marker, layers 1, 0 at once
+    for got, want in zip(run("1"), base):                     # layers 3, 2 in line, layers 1, 0 (behind the marker) on the side stream
         assert torch.isfinite(got).all() and _rel(got, want) <= 1e-6
-    assert not _ops._WGRAD_DEFERRED and not _ops._WGRAD_SIDE_USED and not _ops._WGRAD_ARMED
+    assert not _ops._WGRAD_SIDE_USED and not _ops._WGRAD_ARMED
     base2 = run("0", accumulate=True)
     assert _ops._WGRAD_SIDE and not _ops._WGRAD_SIDE_USED and not _ops._WGRAD_ARMED     # the side stream was used and joined
     for got, want in zip(run("all", accumulate=True), base2):
