@@ -730,6 +730,14 @@ def main():
                                      if (main_dt != "bf16" and a.workload == "fusion") else
                                      "bf16 autocast for the dense convolutions, everything else fp32" if a.workload == "fusion" else "fp32 operators"),
                        "frames_per_gpu": a.batch, "n_points": n_points, "n_intervals": n_intervals,
+                       "streams": ("radar branch of the forward on a second stream (OMNIHD_DUAL_STREAM=%s); weight gradients of the split "
+                                   "convolutions behind the pooling backward on a side stream, joined at the end of backward "
+                                   "(OMNIHD_WGRAD_OVERLAP=%s, one rank and fp32 only: %s) — kernels inside the step share the chip, their in-step "
+                                   "durations are 3-5 %% above the isolated ones" % (
+                                       os.environ.get("OMNIHD_DUAL_STREAM", "1"), os.environ.get("OMNIHD_WGRAD_OVERLAP", "1"),
+                                       "active" if (world == 1 and main_dt != "bf16" and os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") != "0"
+                                                    and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen") else "inactive")
+                                   if a.workload == "fusion" else "one stream"),
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
                                        "overlapped with backward) + naiveSyncBN stat exchange" if a.workload == "fusion"
                                        else f"dp{world} (independent frames, no data-path collective)")},
