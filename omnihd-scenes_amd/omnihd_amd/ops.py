@@ -1658,6 +1658,8 @@ _WGRAD_SIDE = {}
 _WGRAD_SIDE_USED = set()
 _WGRAD_ARMED = []           # non-empty: the pooling backward of this backward pass has been launched (see wgrad_overlap_arm)
 _WGRAD_PASS = [None]        # autograd graph-task id of the backward pass the two above belong to
+# the two private hooks of the autograd engine this rests on; a torch without them keeps the in-line path
+_WGRAD_ENGINE_OK = hasattr(torch._C, "_current_graph_task_id") and hasattr(torch.autograd.Variable._execution_engine, "queue_callback")
 
 
 def _wgrad_side_stream(dev, weight):
@@ -1669,7 +1671,7 @@ def _wgrad_side_stream(dev, weight):
     ``wgrad_overlap_join`` as a final callback of the autograd engine, so whoever called ``backward`` finds the gradients
     complete on its stream — no caller has to know."""
     mode = os.environ.get("OMNIHD_WGRAD_OVERLAP", "1")
-    if mode == "0" or torch.is_grad_enabled():
+    if mode == "0" or torch.is_grad_enabled() or not _WGRAD_ENGINE_OK:
         return None
     if not weight.is_leaf or weight.grad is not None or weight._backward_hooks or getattr(weight, "_post_accumulate_grad_hooks", None):
         return None
@@ -1717,7 +1719,7 @@ def wgrad_overlap_arm():
     OMNIHD_WGRAD_OVERLAP=all with OMNIHD_POOL_BWD_EXCLUSIVE=0) and never waits for one.  Measured alternatives, same box: all layers
     + a fence in front of the pooling backward 48.46 ms, recording the front layers' work and enqueueing it behind the pooling
     kernel 48.23 ms (but that kernel then 64 us), this 48.47 ms, no overlap 50.0 ms."""
-    if torch._C._current_graph_task_id() < 0 or os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") == "0":
+    if not _WGRAD_ENGINE_OK or torch._C._current_graph_task_id() < 0 or os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") == "0":
         return
     _wgrad_pass_begin()
     if not _WGRAD_ARMED:
