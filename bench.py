@@ -732,8 +732,8 @@ def main():
                        "frames_per_gpu": a.batch, "n_points": n_points, "n_intervals": n_intervals,
                        "streams": ("radar branch of the forward on a second stream (OMNIHD_DUAL_STREAM=%s); weight gradients of the split "
                                    "convolutions behind the pooling backward on a side stream, joined at the end of backward "
-                                   "(OMNIHD_WGRAD_OVERLAP=%s, one rank and fp32 only: %s) — kernels inside the step share the chip, their in-step "
-                                   "durations are 3-5 %% above the isolated ones" % (
+                                   "(OMNIHD_WGRAD_OVERLAP=%s, one rank and fp32 only: %s) — kernels measured inside the step run 3-5 %% above their "
+                                   "isolated durations" % (
                                        os.environ.get("OMNIHD_DUAL_STREAM", "1"), os.environ.get("OMNIHD_WGRAD_OVERLAP", "1"),
                                        "active" if (world == 1 and main_dt != "bf16" and os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") != "0"
                                                     and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen") else "inactive")
