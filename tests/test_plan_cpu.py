@@ -355,3 +355,27 @@ def test_stream_backward_tables_refuse_what_the_kernel_cannot_walk():
     assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 5, 32, 1) is None      # patch width
     assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 4, 40, 1) is None      # rows per stage
 
+
+
+def test_stream_dealing_keeps_the_walk_order_and_balances_the_waves():
+    """plan.shared_schedule + plan.stream_deal: every patch of every patch shape lands in exactly one stream, a stream's patches
+    keep the walk order of their XCD run (neighbouring patches close in time), and the dealt cost per wave is even (each next
+    patch goes to the least loaded wave) although patch costs vary by 10x."""
+    from omnihd_amd.plan import shared_schedule, stream_deal
+    rng = np.random.default_rng(5)
+    n_img, feat_hw = 6, (64, 176)
+    for patch_w in (16, 8, 4):
+        n_patch = n_img * -(-feat_hw[1] // patch_w) * -(-feat_hw[0] // (16 // patch_w))
+        cost = torch.from_numpy(rng.integers(100, 1000, n_patch)).double()
+        runs = shared_schedule(n_img, feat_hw, patch_w, cost)
+        assert len(runs) == 8 and sorted(torch.cat(runs).tolist()) == list(range(n_patch))
+        run_cost = [float(cost[r].sum()) for r in runs]
+        assert max(run_cost) / min(run_cost) < 1.02                                      # XCD runs cut by cost
+        lists = stream_deal(runs, cost, 24)
+        assert len(lists) == 8 * 24 and sorted(p for l in lists for p in l) == list(range(n_patch))
+        for x, run in enumerate(runs):
+            pos = {int(p): i for i, p in enumerate(run.tolist())}
+            for l in lists[x * 24:(x + 1) * 24]:
+                assert all(p in pos for p in l) and [pos[p] for p in l] == sorted(pos[p] for p in l)   # same XCD, walk order kept
+        load = np.array([float(cost[l].sum()) for l in lists])
+        assert load.max() / load.mean() < 1.15
