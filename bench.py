@@ -667,9 +667,10 @@ def main():
                 wl.step()
             wl.sync_choices()                 # N > 1: every rank runs the kernels rank 0 measured best
             runs[dt] = timed(wl)
-            if rank == 0:
-                from omnihd_amd.harness import count_step_flops
-                flops[dt] = count_step_flops(wl)
+            # every rank counts (one eval-mode forward: no collective, no BatchNorm statistics touched): the ranks' control flow
+            # stays identical, whatever a module of a future config does in its forward
+            from omnihd_amd.harness import count_step_flops
+            flops[dt] = count_step_flops(wl)
             if world > 1 and dt == ("fp32" if a.dtype == "both" else a.dtype):
                 from omnihd_amd.harness import comm_report
                 comm = comm_report(wl)        # after the timed region: its no_sync steps let the ranks' weights drift

@@ -437,12 +437,21 @@ def count_step_flops(step):
 
     handles = [m.register_forward_hook(hook) for m in step.raw_model.modules()
                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear, DeformConv2dPack))]
+    # The counting forward runs with every module in eval(): layer shapes and requires_grad flags are those of the training
+    # pass, but no BatchNorm takes batch statistics — so it issues NO collective (naiveSyncBN / the fused pillar net all-reduce
+    # only in training mode: a rank that counts alone, as bench.py's rank 0 once did, would otherwise leave dozens of
+    # unmatched all-reduces in the process group's queue) and leaves the running statistics of this rank untouched.
+    modes = [(m, m.training) for m in step.raw_model.modules()]
     try:
+        for m, _ in modes:
+            m.training = False
         b = step.batches[0]
-        with torch.autocast(step.device.type, dtype=torch.bfloat16, enabled=step.autocast):
+        with torch.enable_grad(), torch.autocast(step.device.type, dtype=torch.bfloat16, enabled=step.autocast):
             losses = step.raw_model(return_loss=True, **b)
         del losses
     finally:
+        for m, was in modes:
+            m.training = was
         for h in handles:
             h.remove()
     return {"forward": fwd[0], "backward": bwd[0], "total": fwd[0] + bwd[0]}

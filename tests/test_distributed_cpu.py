@@ -75,7 +75,23 @@ def _ddp_worker(rank, world, port, out, task="det"):
         gathered = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
         comm = None
-        if task == "det":                                 # what bench.py reports as `comm` at N > 1 (runs no_sync steps: last)
+        if task == "det":
+            # bench.py's rank 0 counted the step's FLOPs alone with a training-mode forward — every
+            # naiveSyncBN of it an all-reduce no other rank matched.  The count must be safe to run on ONE rank: it issues no
+            # collective (the all_gather below would pair up with a stray all-reduce and fail or hang) and leaves the
+            # BatchNorm buffers alone.
+            from omnihd_amd.harness import count_step_flops
+            bufs = {k: v.clone() for k, v in st.raw_model.state_dict().items() if "running_" in k or "num_batches" in k}
+            fl = count_step_flops(st) if rank == 0 else None
+            now = st.raw_model.state_dict()
+            assert all(torch.equal(now[k], v) for k, v in bufs.items()), "the counting forward moved BatchNorm buffers"
+            assert st.raw_model.training and all(m.training for m in st.raw_model.pts_backbone.modules())
+            probe = [torch.zeros(1) for _ in range(world)]
+            dist.all_gather(probe, torch.tensor([float(rank + 1)]))
+            assert [float(t) for t in probe] == [1.0, 2.0]
+            if rank == 0:
+                assert fl["forward"] > 0 and fl["backward"] > fl["forward"] and fl["total"] == fl["forward"] + fl["backward"]
+            # what bench.py reports as `comm` at N > 1 (runs no_sync steps: last)
             from omnihd_amd.harness import comm_report
             comm = comm_report(st, iters=1)
     out[rank] = (losses, bool(torch.equal(gathered[0], gathered[1])), float(flat.abs().sum()), comm)
