@@ -173,12 +173,19 @@ extern "C" int omnihd_pillar_canvas(const float* feats, int* cell_map, int c, in
       ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(canvas)) & 15u) == 0) {
     const unsigned total = (unsigned)(cells * (c / 4));
     const int grid = grid_for(total, kBlock * 2);
-    if (reset_map)
+    // The in-kernel reset is ordered only inside ONE wavefront: lane sub == 0 clears the entry its cell's other lanes read in
+    // the same load instruction.  That holds when the c/4 lanes of a cell are consecutive lanes of one 64-aligned group, i.e.
+    // c/4 a power of two <= 64 (c = 4 ... 256); with c = 48, 96, 320 ... a cell straddles wavefronts or workgroups and a later
+    // one would read the cleared entry and store zeros for part of a pillar row — those take the memset.
+    const int c4 = c / 4;
+    const bool reset_in_kernel = reset_map && (c4 & (c4 - 1)) == 0 && c4 <= 64;
+    if (reset_in_kernel)
       hipLaunchKernelGGL(k_canvas_nhwc4<true>, dim3(grid), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(feats), cell_map,
-                         c / 4, total, reinterpret_cast<float4*>(canvas));
+                         c4, total, reinterpret_cast<float4*>(canvas));
     else
       hipLaunchKernelGGL(k_canvas_nhwc4<false>, dim3(grid), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(feats), cell_map,
-                         c / 4, total, reinterpret_cast<float4*>(canvas));
+                         c4, total, reinterpret_cast<float4*>(canvas));
+    if (reset_map && !reset_in_kernel) OMNIHD_HIP_TRY(hipMemsetAsync(cell_map, 0xFF, cells * sizeof(int), st));
     return check_launch("pillar_canvas(nhwc4)");
   }
   if (channels_last) {

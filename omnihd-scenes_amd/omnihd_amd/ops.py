@@ -964,10 +964,33 @@ def _persisted_choices():
             import json
             raw = open(path, "rb").read()
             doc = json.loads(raw)
-            for name in ("conv", "wgrad", "split"):
-                _PERSISTED[name] = {_tuplify(json.loads(k)): v for k, v in doc.get(name, {}).items()}
-            _CHOICE_INFO.update(path=path, sha256=hashlib.sha256(raw).hexdigest(), entries=sum(len(v) for v in _PERSISTED.values()))
+            # The winners are properties of ONE chip generation and of the MIOpen mode they were measured against (find-mode
+            # kernels beat ours on geometries where the immediate-mode ones lose).  A table captured on another architecture is
+            # ignored (everything is measured, every geometry a miss); a table captured in the other MIOpen mode is still used —
+            # a run's kernels stay reproducible — unless OMNIHD_CHOICE_TABLE_STRICT=1, and the mismatch is reported.
+            want_arch = str(doc.get("arch", "gfx950"))
+            arch = _device_arch()
+            arch_ok = arch is None or arch.split(":")[0] == want_arch
+            find_now = bool(torch.backends.cudnn.benchmark)
+            mode_ok = bool(doc.get("miopen_find", True)) == find_now
+            _CHOICE_INFO.update(arch=arch, table_arch=want_arch, miopen_find=find_now, table_miopen_find=bool(doc.get("miopen_find", True)))
+            if arch_ok and (mode_ok or os.environ.get("OMNIHD_CHOICE_TABLE_STRICT", "0") != "1"):
+                for name in ("conv", "wgrad", "split"):
+                    _PERSISTED[name] = {_tuplify(json.loads(k)): v for k, v in doc.get(name, {}).items()}
+                _CHOICE_INFO.update(path=path, sha256=hashlib.sha256(raw).hexdigest(), entries=sum(len(v) for v in _PERSISTED.values()))
+            else:
+                _CHOICE_INFO.update(path=path, sha256=hashlib.sha256(raw).hexdigest(), entries=0,
+                                    ignored="architecture" if not arch_ok else "miopen mode (OMNIHD_CHOICE_TABLE_STRICT=1)")
     return _PERSISTED
+
+
+def _device_arch():
+    try:
+        if torch.cuda.is_available():
+            return str(torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName)
+    except Exception:
+        pass
+    return None
 
 
 def choice_table_info():
@@ -975,6 +998,9 @@ def choice_table_info():
     geometries that had to be measured here because the table did not hold them)."""
     _persisted_choices()
     info = {k: _CHOICE_INFO[k] for k in ("path", "sha256", "entries", "misses")}
+    for k in ("arch", "table_arch", "miopen_find", "table_miopen_find", "ignored"):
+        if k in _CHOICE_INFO:
+            info[k] = _CHOICE_INFO[k]
     if info["path"]:
         root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         if os.path.abspath(info["path"]).startswith(root + os.sep):
@@ -985,7 +1011,8 @@ def choice_table_info():
 def save_choice_table(path, note=""):
     """Write every choice known to this process (persisted + measured) as the table ``_ChoiceTable`` reads; returns the count."""
     import json
-    doc = {"note": note or "kernel choices per convolution geometry, measured on MI355X (gfx950); keys = geometry tuples without the device index"}
+    doc = {"note": note or "kernel choices per convolution geometry, measured on MI355X (gfx950); keys = geometry tuples without the device index",
+           "arch": (_device_arch() or "gfx950").split(":")[0], "miopen_find": bool(torch.backends.cudnn.benchmark)}
     n = 0
     for name, table in (("conv", _CONV_CHOICE), ("wgrad", _WGRAD_CHOICE), ("split", _SPLIT_CHOICE)):
         merged = dict(_persisted_choices().get(name, {}))
@@ -1634,6 +1661,8 @@ class _ConvSplit(torch.autograd.Function):
                 # stream, before this stream is done
                 if gw.stride() != weight.stride():
                     gw = torch.empty_like(weight).copy_(gw)
+            # allocated on the side stream, consumed (clip, AdamW, zero_grad's free) on the caller's
+            gw.record_stream(torch.cuda.current_stream(dev))
         if ctx.needs_input_grad[0]:
             # (an uninitialised fp32 stand-in for the input: only its shape / layout matter to the data gradient)
             x_like = lambda: torch.empty(x_shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
@@ -1656,6 +1685,7 @@ class _ConvSplit(torch.autograd.Function):
 
 _WGRAD_SIDE = {}
 _WGRAD_SIDE_USED = set()
+_WGRAD_SEEN = set()         # ids of the weights whose gradient went to the side stream in this backward pass
 _WGRAD_ARMED = []           # non-empty: the pooling backward of this backward pass has been launched (see wgrad_overlap_arm)
 _WGRAD_PASS = [None]        # autograd graph-task id of the backward pass the two above belong to
 # the two private hooks of the autograd engine this rests on; a torch without them keeps the in-line path
@@ -1681,6 +1711,14 @@ def _wgrad_side_stream(dev, weight):
     _wgrad_pass_begin()
     if mode != "all" and not _WGRAD_ARMED:
         return None
+    # A weight that feeds SEVERAL convolutions of one pass: the engine sums their gradients on the caller's stream as soon as the
+    # last one has arrived — from the second sighting on, the caller's stream first waits for what the side stream holds and the
+    # layer stays in line (tests/test_conv_split_gpu.py::test_shared_weight...)
+    if id(weight) in _WGRAD_SEEN:
+        if dev.index in _WGRAD_SIDE_USED:
+            torch.cuda.current_stream(dev).wait_stream(_WGRAD_SIDE[dev.index])
+        return None
+    _WGRAD_SEEN.add(id(weight))
     s = _WGRAD_SIDE.get(dev.index)
     if s is None:
         # (stream priorities do not help here: this device offers two, high and normal, so the side stream cannot be put BELOW the
@@ -1698,6 +1736,7 @@ def _wgrad_pass_begin():
         if _WGRAD_SIDE_USED:
             wgrad_overlap_join()
         _WGRAD_ARMED.clear()
+        _WGRAD_SEEN.clear()
         _WGRAD_PASS[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(wgrad_overlap_join)
 
@@ -1708,6 +1747,7 @@ def wgrad_overlap_join():
         torch.cuda.current_stream(idx).wait_stream(_WGRAD_SIDE[idx])
     _WGRAD_SIDE_USED.clear()
     _WGRAD_ARMED.clear()
+    _WGRAD_SEEN.clear()
     _WGRAD_PASS[0] = None
 
 

@@ -298,3 +298,34 @@ def test_weight_gradients_on_the_side_stream_equal_the_in_line_ones(cuda, weight
     for got, want in zip(run("all", accumulate=True), base2):
         assert _rel(got, want) <= 1e-6
     assert _rel(base2[0], 2 * base[0]) <= 1e-5                # two identical passes accumulated
+
+
+def test_shared_weight_of_two_convolutions_with_the_side_stream(cuda, monkeypatch):
+    """a weight used by TWO split convolutions of one graph.  `weight.grad` is None at both backward calls, and
+    the engine sums the two gradients on the caller's stream when the second arrives — the first must not still be in flight on
+    the side stream then.  From the second sighting of a weight inside a pass the layer stays in line and the caller's stream
+    waits for the side stream first; a long kernel parked on the side stream makes a missing wait visible."""
+    from omnihd_amd import ops
+    torch.manual_seed(11)
+    w0 = torch.randn(128, 128, 3, 3, device=cuda) * 0.05
+    x0 = torch.randn(2, 128, 96, 160, device=cuda).contiguous(memory_format=torch.channels_last)
+
+    def run(overlap):
+        monkeypatch.setenv("OMNIHD_WGRAD_OVERLAP", overlap)
+        p = w0.clone().requires_grad_()
+        x = x0.clone().requires_grad_()
+        y = torch.relu(ops.conv_split(x, p, None, (1, 1), (1, 1)))
+        y = torch.relu(ops.conv_split(y, p, None, (1, 1), (1, 1)))            # the same parameter again
+        if overlap != "0" and cuda.index in ops._WGRAD_SIDE:
+            with torch.cuda.stream(ops._WGRAD_SIDE[cuda.index]):
+                torch.cuda._sleep(20_000_000)                                  # ~10 ms in front of whatever goes there next
+        (y * y).mean().backward()
+        return p.grad.clone(), x.grad.clone()
+
+    base = run("0")
+    run("all")                                                                 # creates the side stream
+    for _ in range(2):
+        got = run("all")
+        for g, wnt in zip(got, base):
+            assert torch.isfinite(g).all() and _rel(g, wnt) <= 1e-6
+    assert not ops._WGRAD_SIDE_USED and not ops._WGRAD_SEEN

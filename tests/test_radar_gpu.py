@@ -89,6 +89,22 @@ def test_pillar_scatter_and_backward(cuda, channels_last):
     assert torch.equal(f.grad, w[c[:, 0], :, c[:, 2], c[:, 3]])
 
 
+@pytest.mark.parametrize("C", [8, 48, 96, 256, 320])
+def test_channels_last_scatter_with_channel_counts_whose_cells_straddle_wavefronts(cuda, C):
+    """the float4 canvas kernel resets the caller-kept cell map in the kernel only when the C/4 lanes of a cell
+    sit in one wavefront (C/4 a power of two <= 64); C = 48, 96, 320 must take the separate reset.  Twice on the same map: the
+    second call sees whatever the first left behind."""
+    from omnihd_amd import ops
+    rng = np.random.default_rng(C)
+    B, ny, nx = 1, 96, 160
+    for rep in range(2):
+        cells = rng.permutation(ny * nx)[:6000]
+        coors = np.stack([np.zeros(6000, int), np.zeros(6000, int), cells // nx, cells % nx], 1).astype(np.int32)
+        feats = rng.standard_normal((6000, C), dtype=np.float32)
+        canvas = ops.pillar_scatter(t(feats, cuda), t(coors, cuda), B, ny, nx, channels_last=True)
+        assert np.array_equal(canvas.cpu().numpy(), OC.pillar_scatter(feats, coors, B, ny, nx)), (C, rep)
+
+
 def test_pillar_scatter_odd_plane_and_empty(cuda):
     from omnihd_amd import ops
     feats = torch.arange(6, dtype=torch.float32, device=cuda).view(2, 3) + 1
