@@ -362,6 +362,11 @@ class FusionTrainStep:
             self.model = nn.parallel.DistributedDataParallel(
                 model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 broadcast_buffers=False, bucket_cap_mb=25, gradient_as_bucket_view=True)
+            if os.environ.get("OMNIHD_DDP_HOOK", "1") != "0":
+                from . import ops
+                # bucket all-reduces on a stream that also waits for the weight-gradient side stream; side-stream weight
+                # gradients written straight into the reducer's bucket views: the N > 1 step is the N = 1 step (ops.py)
+                ops.ddp_wgrad_overlap(self.model)
         params = [p for p in model.parameters() if p.requires_grad]
         self.opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=self.device.type == "cuda")
         self.params = params
@@ -518,3 +523,35 @@ def comm_report(step, iters=3):
     rep["step_no_allreduce_ms"] = round(t_nosync * 1e3, 3)
     rep["exposed_comm_ms"] = round(max(t_sync - t_nosync, 0.0) * 1e3, 3)
     return rep
+
+
+def syncbn_exchange_probe(step, iters=20):
+    """The naiveSyncBN statistic exchanges of ONE training step of ``step`` (reference ops/norm.py:55-82: per layer one
+    exchange of the 2*C statistics forward and one of the 2*C gradient sums backward; here one all-reduce each), issued back to
+    back on the current stream in the default process group: wall time per step's worth of exchanges and per call.  Inside a
+    one-rank group the step itself skips them (plain BatchNorm, norm.py:58), so this is how one GPU measures their launch cost."""
+    import time
+    import torch.distributed as dist
+    from .mm.sync_bn import _NaiveSyncBN
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    chans = [m.num_features for m in step.raw_model.modules()
+             if (isinstance(m, _NaiveSyncBN) or isinstance(m, nn.SyncBatchNorm)) and m.training]
+    if not chans:
+        return {"exchanges_per_step": 0, "total_us_per_step": 0.0, "per_call_us": 0.0}
+    bufs = [torch.zeros(2 * c, dtype=torch.float32, device=step.device) for c in chans] * 2        # forward + backward
+    def sync():
+        if step.device.type == "cuda":
+            torch.cuda.synchronize(step.device)
+    for b in bufs:
+        dist.all_reduce(b)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        for b in bufs:
+            dist.all_reduce(b)
+    sync()
+    dt = (time.perf_counter() - t0) / iters
+    return {"exchanges_per_step": len(bufs), "total_us_per_step": round(dt * 1e6, 1), "per_call_us": round(dt * 1e6 / len(bufs), 2),
+            "message_floats": [2 * c for c in sorted(set(chans))],
+            "note": "all-reduces issued back to back by one thread; in the step the radar branch's exchanges run on the second stream"}

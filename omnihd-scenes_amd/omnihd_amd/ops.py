@@ -1650,19 +1650,31 @@ class _ConvSplit(torch.autograd.Function):
         # (wgrad_overlap_join); the data-gradient chain on the main stream no longer waits for them, and the tails of either
         # fill the other's idle CUs.  By default only for the layers BEHIND the pooling backward (wgrad_overlap_arm).
         side = _wgrad_side_stream(dev, weight) if ctx.needs_input_grad[1] else None
+        if side is None and ctx.needs_input_grad[1]:
+            FAST_PATHS["wgrad_in_line"] += 1
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(dev))
             for tns in (g, g_in, x_hi, x_lo, x_saved) + (tuple(gs) if gs is not None else ()):
                 if tns is not None:
                     tns.record_stream(side)              # allocated on the main stream, read on the side stream
+            view = _ddp_bucket_view(weight)
             with torch.cuda.stream(side):
                 gw = weight_gradient()
-                # autograd keeps a gradient that has the parameter's layout as it is; any other one it would COPY on the main
-                # stream, before this stream is done
-                if gw.stride() != weight.stride():
+                if view is not None:
+                    # under DistributedDataParallel: straight into the reducer's bucket.  What autograd gets back is a fresh
+                    # alias of that memory in the parameter's layout — AccumulateGrad keeps it as .grad without a kernel, the
+                    # reducer sees "already in the bucket" and copies nothing, and the bucket's all-reduce (our comm hook)
+                    # waits for this stream.  No kernel of the caller's stream touches the gradient before the pass ends.
+                    view.copy_(gw)
+                    gw = view.detach()
+                    _DDP["direct"] += 1
+                elif gw.stride() != weight.stride():
+                    # autograd keeps a gradient that has the parameter's layout as it is; any other one it would COPY on the
+                    # main stream, before this stream is done
                     gw = torch.empty_like(weight).copy_(gw)
             # allocated on the side stream, consumed (clip, AdamW, zero_grad's free) on the caller's
-            gw.record_stream(torch.cuda.current_stream(dev))
+            if view is None:
+                gw.record_stream(torch.cuda.current_stream(dev))
         if ctx.needs_input_grad[0]:
             # (an uninitialised fp32 stand-in for the input: only its shape / layout matter to the data gradient)
             x_like = lambda: torch.empty(x_shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
@@ -1683,6 +1695,34 @@ class _ConvSplit(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+# counters of the optional fast paths actually taken in this process (bench.py: `fast_paths`)
+FAST_PATHS = {"wgrad_side_stream": 0, "wgrad_in_line": 0, "dual_stream_forward": 0, "single_stream_forward": 0}
+
+
+def fast_paths_report():
+    """What ran, from live counters — not from the environment switches: the kept pooling buffers and the weight-gradient side
+    stream rest on private torch hooks (``torch._C._storage_Use_Count``, ``torch._C._current_graph_task_id`` +
+    ``queue_callback``) that are probed and fall back silently when a torch build lacks them."""
+    from . import plan as _plan
+    calls = max(1, _plan.FAST_PATHS["pool_fwd_calls"])
+    wg = FAST_PATHS["wgrad_side_stream"] + FAST_PATHS["wgrad_in_line"]
+    fw = FAST_PATHS["dual_stream_forward"] + FAST_PATHS["single_stream_forward"]
+    return {"kept_output": {"active": _plan.FAST_PATHS["kept_output"] > 0, "share_of_pool_forwards": round(_plan.FAST_PATHS["kept_output"] / calls, 3),
+                            "private_hook_ok": bool(_plan._use_count_works())},
+            "direct_fwd": {"active": _plan.FAST_PATHS["direct_fwd"] > 0, "share_of_pool_forwards": round(_plan.FAST_PATHS["direct_fwd"] / calls, 3)},
+            "wgrad_overlap": {"active": FAST_PATHS["wgrad_side_stream"] > 0, "share_of_split_weight_gradients": round(FAST_PATHS["wgrad_side_stream"] / max(1, wg), 3),
+                              "private_hooks_ok": bool(_WGRAD_ENGINE_OK), "ddp": ddp_overlap_info()},
+            "dual_stream": {"active": FAST_PATHS["dual_stream_forward"] > 0, "share_of_forwards": round(FAST_PATHS["dual_stream_forward"] / max(1, fw), 3)},
+            "choice_table_misses": int(_CHOICE_INFO["misses"])}
+
+
+def fast_paths_reset():
+    from . import plan as _plan
+    for d in (FAST_PATHS, _plan.FAST_PATHS):
+        for k in d:
+            d[k] = 0
+
+
 _WGRAD_SIDE = {}
 _WGRAD_SIDE_USED = set()
 _WGRAD_SEEN = set()         # ids of the weights whose gradient went to the side stream in this backward pass
@@ -1690,6 +1730,107 @@ _WGRAD_ARMED = []           # non-empty: the pooling backward of this backward p
 _WGRAD_PASS = [None]        # autograd graph-task id of the backward pass the two above belong to
 # the two private hooks of the autograd engine this rests on; a torch without them keeps the in-line path
 _WGRAD_ENGINE_OK = hasattr(torch._C, "_current_graph_task_id") and hasattr(torch.autograd.Variable._execution_engine, "queue_callback")
+
+
+# ---- weight-gradient overlap under DistributedDataParallel (round 5) ---------------------------------------------------------
+# The reference overlaps its reducer with backward on every rank (bevformer/apis/mmdet_train.py:76-80); round 4 switched the side
+# stream OFF whenever a process group existed, so the N = 1 headline rested on an optimisation N > 1 could not use.  Now the N > 1
+# step is the N = 1 step: `ddp_wgrad_overlap(ddp)` registers a communication hook on the reducer that (a) all-reduces a bucket on a
+# communication stream that waits for BOTH the caller's stream and the weight-gradient side stream, and (b) remembers, per
+# parameter, the reducer's view of its gradient inside the bucket (gradient_as_bucket_view=True) once the reducer has re-bucketed
+# (it does so once, before the second forward): the side stream then writes weight gradients straight into those views.
+_DDP = {"ref": None, "views": {}, "settled": False, "comm": {}, "hook_calls": 0, "direct": 0, "layout": {}, "dirty": False}
+
+
+def ddp_wgrad_overlap(ddp):
+    """Register the bucket hook on a DistributedDataParallel module (built with gradient_as_bucket_view=True).  Returns True when
+    registered.  Without it a process group keeps every weight gradient in line, as before."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if not isinstance(ddp, DDP) or not getattr(ddp, "gradient_as_bucket_view", False):
+        return False
+    _DDP.update(ref=weakref.ref(ddp), views={}, settled=False, hook_calls=0, direct=0, layout={}, dirty=False)
+    ddp.register_comm_hook(None, _ddp_bucket_hook)
+    return True
+
+
+def _dense(t):
+    try:
+        from torch._prims_common import is_non_overlapping_and_dense
+        return bool(is_non_overlapping_and_dense(t))
+    except Exception:
+        return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _ddp_bucket_hook(_state, bucket):
+    import torch.distributed as dist
+    ddp = _DDP["ref"]() if _DDP["ref"] is not None else None
+    buf = bucket.buffer()
+    group = ddp.process_group if ddp is not None else None
+    world = dist.get_world_size(group)
+    _DDP["hook_calls"] += 1
+    if ddp is not None:
+        # Are the reducer's buckets settled?  It re-buckets once, before its second forward, in the order the gradients arrived
+        # (new buffers, new views).  The reducer calls this hook under its own mutex, so its logging data cannot be asked here
+        # (that deadlocks); instead: a pass whose every bucket (index, buffer address, size) is what the previous pass saw.
+        # Any change drops the remembered views and starts over.
+        key = (int(buf.data_ptr()), int(buf.numel()))
+        if _DDP["layout"].get(bucket.index()) != key:
+            _DDP["layout"][bucket.index()] = key
+            _DDP["dirty"] = True
+            _DDP["settled"] = False
+            _DDP["views"] = {}
+        # the reducer's own views follow the parameter's strides (dense parameters); GradBucket.gradients() hands out row-major
+        # views of the same memory, so only their offsets are taken from it
+        for p, g in zip(bucket.parameters(), bucket.gradients()):
+            hit = _DDP["views"].get(id(p))
+            if hit is None or hit[1].data_ptr() != g.data_ptr():
+                v = buf.as_strided(p.size(), p.stride(), g.storage_offset()) if _dense(p) else g
+                _DDP["views"][id(p)] = (weakref.ref(p), v)
+        if bucket.is_last():
+            if not _DDP["dirty"]:
+                _DDP["settled"] = True
+            _DDP["dirty"] = False
+    if buf.is_cuda:
+        dev = buf.device
+        comm = _DDP["comm"].get(dev.index)
+        if comm is None:
+            comm = _DDP["comm"][dev.index] = torch.cuda.Stream(device=dev)
+        comm.wait_stream(torch.cuda.current_stream(dev))
+        if dev.index in _WGRAD_SIDE:
+            comm.wait_stream(_WGRAD_SIDE[dev.index])
+        with torch.cuda.stream(comm):
+            if world > 1:
+                buf.div_(world)
+            fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
+    else:
+        if world > 1:
+            buf.div_(world)
+        fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
+    return fut.then(lambda f: f.value()[0])
+
+
+def _ddp_bucket_view(weight):
+    """The reducer's view of ``weight``'s gradient inside its bucket, or None (no hooked reducer, buckets not settled yet, the
+    reducer not synchronising this pass — DDP.no_sync() — or a stale entry)."""
+    if _DDP["ref"] is None or not _DDP["settled"]:
+        return None
+    ddp = _DDP["ref"]()
+    if ddp is None or not ddp.require_backward_grad_sync:
+        return None
+    hit = _DDP["views"].get(id(weight))
+    if hit is None or hit[0]() is not weight:
+        return None
+    v = hit[1]
+    if v.shape != weight.shape or v.stride() != weight.stride() or v.dtype != weight.dtype or v.device != weight.device:
+        return None
+    return v
+
+
+def ddp_overlap_info():
+    """{'hooked', 'settled', 'views', 'hook_calls'} — what bench.py reports as fast_paths.wgrad_overlap under a process group."""
+    return {"hooked": _DDP["ref"] is not None and _DDP["ref"]() is not None, "settled": bool(_DDP["settled"]),
+            "views": len(_DDP["views"]), "hook_calls": int(_DDP["hook_calls"]), "direct_writes": int(_DDP["direct"])}
 
 
 def _wgrad_side_stream(dev, weight):
@@ -1706,7 +1847,9 @@ def _wgrad_side_stream(dev, weight):
     if not weight.is_leaf or weight.grad is not None or weight._backward_hooks or getattr(weight, "_post_accumulate_grad_hooks", None):
         return None
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    if dist.is_available() and dist.is_initialized() and _ddp_bucket_view(weight) is None:
+        # a process group without our comm hook on the reducer (or before the reducer's buckets have settled): a DDP reducer
+        # copies gradients into its buckets as autograd accumulates them, on the caller's stream
         return None
     _wgrad_pass_begin()
     if mode != "all" and not _WGRAD_ARMED:
@@ -1725,6 +1868,7 @@ def _wgrad_side_stream(dev, weight):
         # default stream; the whole step on a high-priority stream instead measured 54 ms, not 48.5)
         s = _WGRAD_SIDE[dev.index] = torch.cuda.Stream(device=dev)
     _WGRAD_SIDE_USED.add(dev.index)
+    FAST_PATHS["wgrad_side_stream"] += 1
     return s
 
 

@@ -549,6 +549,10 @@ def _patch_backward():
     return os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"
 
 
+# How often the optional fast paths of the pooling forward were actually taken in this process (bench.py reports them as
+# `fast_paths`: two of them rest on private torch hooks that are probed and may silently be off after a torch upgrade)
+FAST_PATHS = {"pool_fwd_calls": 0, "kept_output": 0, "direct_fwd": 0}
+
 # bench.py sets this to a list to collect (start, end) event pairs around every pooling forward / backward kernel launched
 # inside the training step (the in-step launch duration the roofline line is computed from); None = no events
 TIMING = None
@@ -721,6 +725,9 @@ class _PlannedPool(torch.autograd.Function):
         # only the direct and the second-generation lean kernel know how to leave the empty rows alone
         can_keep = direct or (lean and os.environ.get("OMNIHD_POOL_LEAN2", "1") != "0" and feat.numel() * 4 < 2 ** 31)
         keeper = _kept_output(plan, feat.size(-1), feat.device) if (keep_empty_rows and can_keep) else None
+        FAST_PATHS["pool_fwd_calls"] += 1
+        FAST_PATHS["kept_output"] += keeper is not None
+        FAST_PATHS["direct_fwd"] += bool(direct)
         if keeper is not None:
             out = keeper.tensor.view(plan.n_rows, feat.size(-1))    # a VIEW: see the guards listed in _kept_output
         else:

@@ -175,6 +175,9 @@ class BEVFUSION_depth(MVXFasterRCNN):
         if vox is not None and img is not None and img.is_cuda and self.training \
                 and os.environ.get("OMNIHD_DUAL_STREAM", "1") != "0" and self._side_thread_is_safe():
             radar = self._radar_branch_async(points, img_metas, vox)     # second host thread + second stream
+        if img is not None and img.is_cuda and self.training:
+            from omnihd_amd import ops as _ops
+            _ops.FAST_PATHS["dual_stream_forward" if radar is not None else "single_stream_forward"] += 1
         img_feats = self.extract_img_feat(img, img_metas)
         if radar is None:
             pts_feats = self.extract_pts_feat(points, img_feats, img_metas,

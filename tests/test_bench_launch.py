@@ -53,3 +53,25 @@ def test_gpus_2_sharing_one_device_reports_two_ranks(cuda):
     line = _json_line(out)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
     assert line["scaling"] == "weak" and "roofline" in line and "ops_roofline" in line
+
+
+@pytest.mark.gpu
+def test_fp32_bench_line_carries_the_one_rank_ddp_block_and_the_live_fast_paths(cuda):
+    """the default line says which fast paths were live (counters, not switches) and carries the same
+    step inside a one-rank RCCL group with the naiveSyncBN exchanges timed there.  Short run (2 timed steps): the numbers are
+    not measurements, the blocks and their consistency are what is asserted."""
+    out = _run(["--dtype", "fp32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--kernel-launches", "5"], timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _json_line(out)
+    fp = line["fast_paths"]
+    assert fp["kept_output"]["active"] and fp["direct_fwd"]["active"] and fp["dual_stream"]["active"], fp
+    assert fp["wgrad_overlap"]["active"] and fp["wgrad_overlap"]["private_hooks_ok"] and fp["choice_table_misses"] == 0, fp
+    d = line["ddp_1rank"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["ms_per_step"] > 0 and d["plain_ms_per_step"] == line["ms_per_step"]
+    ov = d["wgrad_overlap"]
+    assert ov["active"] and ov["ddp"]["hooked"] and ov["ddp"]["settled"] and ov["ddp"]["direct_writes"] > 0, ov
+    sb = d["syncbn_exchange_us"]
+    assert sb["exchanges_per_step"] >= 40 and sb["total_us_per_step"] > 0, sb
+    r = line["roofline"]
+    assert r["copy_peak_measured"] > 3000 and abs(r["frac_vs_copy_peak"] - r["achieved"] / r["copy_peak_measured"]) < 1e-3
+    assert "bwd_frac_of_copy_peak" in r and "frac_on_moved_bytes" in r

@@ -329,3 +329,78 @@ def test_shared_weight_of_two_convolutions_with_the_side_stream(cuda, monkeypatc
         for g, wnt in zip(got, base):
             assert torch.isfinite(g).all() and _rel(g, wnt) <= 1e-6
     assert not ops._WGRAD_SIDE_USED and not ops._WGRAD_SEEN
+
+
+def test_side_stream_weight_gradients_under_ddp_go_straight_into_the_bucket_views(cuda):
+    """the N > 1 step must be the N = 1 step.  A chain of split convolutions under DistributedDataParallel
+    (one-rank RCCL group, several buckets) with `ops.ddp_wgrad_overlap`: once the reducer has re-bucketed, the weight gradients
+    are computed on the side stream INTO the reducer's bucket views, autograd keeps an alias as `.grad` (no copy on the caller's
+    stream), and every bucket's all-reduce waits for the side stream.  A long kernel parked on the side stream before each
+    backward makes any consumer that does not wait read the PREVIOUS iteration's reduced gradient (different input each
+    iteration).  Gradients must equal the plain in-line run's, iteration by iteration.  Child process: the process group must
+    not leak into the other tests."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import copy, os, sys, torch, torch.distributed as dist
+from torch import nn
+sys.path[:0] = [%r, %r]
+os.environ["OMNIHD_FP32_CONV"] = "split"
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+from omnihd_amd import ops
+from omnihd_amd.mm.bricks import use_bev_conv
+torch.manual_seed(5)
+chans = [64, 128, 256, 256, 128]
+net = nn.Sequential(*[m for i in range(4) for m in (nn.Conv2d(chans[i], chans[i + 1], 3, padding=1, bias=False), nn.ReLU())]).to(dev)
+net = net.to(memory_format=torch.channels_last)
+use_bev_conv(net)
+ref = copy.deepcopy(net)
+xs = [torch.randn(2, 64, 96, 160, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(5)]
+
+def grads_of(model, x):
+    for p in model.parameters():
+        p.grad = None
+    y = model(x)
+    (y * y).mean().backward()
+    torch.cuda.synchronize()
+    return [p.grad.clone() for p in model.parameters()]
+
+os.environ["OMNIHD_WGRAD_OVERLAP"] = "0"
+want = [grads_of(ref, x) for x in xs]
+os.environ["OMNIHD_WGRAD_OVERLAP"] = "all"
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=False, bucket_cap_mb=1, gradient_as_bucket_view=True)
+assert ops.ddp_wgrad_overlap(ddp)
+rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+worst = 0.0
+for it, x in enumerate(xs):
+    for p in ddp.parameters():
+        p.grad = None
+    if 0 in ops._WGRAD_SIDE:
+        with torch.cuda.stream(ops._WGRAD_SIDE[0]):
+            torch.cuda._sleep(20_000_000)
+    y = ddp(x)
+    (y * y).mean().backward()
+    got = [p.grad for p in net.parameters()]          # read on the caller's stream right behind backward, like clip / AdamW
+    got = [g.clone() for g in got]
+    torch.cuda.synchronize()
+    info = ops.ddp_overlap_info()
+    for g, w in zip(got, want[it]):
+        assert torch.isfinite(g).all()
+        worst = max(worst, rel(g, w))
+    if it >= 2:
+        for p in net.parameters():
+            v = ops._ddp_bucket_view(p)
+            assert v is not None and p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == p.stride()
+info = ops.ddp_overlap_info()
+assert info["hooked"] and info["settled"] and info["views"] == 4 and info["direct_writes"] >= 4 * 2, info
+assert worst <= 1e-6, worst
+with ddp.no_sync():                                    # no synchronisation this pass: the views must not be used
+    assert all(ops._ddp_bucket_view(p) is None for p in net.parameters())
+dist.destroy_process_group()
+print("DDP_OVERLAP_OK", worst, info)
+''' % (root, os.path.join(root, "omnihd-scenes_amd"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DDP_OVERLAP_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -92,8 +92,13 @@ def _ddp_worker(rank, world, port, out, task="det"):
             if rank == 0:
                 assert fl["forward"] > 0 and fl["backward"] > fl["forward"] and fl["total"] == fl["forward"] + fl["backward"]
             # what bench.py reports as `comm` at N > 1 (runs no_sync steps: last)
-            from omnihd_amd.harness import comm_report
+            from omnihd_amd.harness import comm_report, syncbn_exchange_probe
+            probe = syncbn_exchange_probe(st, iters=2)     # bench.py: ddp_1rank.syncbn_exchange_us
             comm = comm_report(st, iters=1)
+            assert probe["exchanges_per_step"] == comm["syncbn_exchanges_per_step"] and probe["total_us_per_step"] > 0
+            from omnihd_amd import ops
+            info = ops.ddp_overlap_info()                  # the bucket hook of ops.ddp_wgrad_overlap ran (over gloo, CPU buffers)
+            assert info["hooked"] and info["hook_calls"] >= 2 and info["direct_writes"] == 0
     out[rank] = (losses, bool(torch.equal(gathered[0], gathered[1])), float(flat.abs().sum()), comm)
     dist.destroy_process_group()
 
