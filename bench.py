@@ -519,6 +519,19 @@ def pooling_at_r2(dev, launches):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def emit_line(line):
+    """The ONE JSON line, on the process's real stdout (see main: fd 1 is pointed at stderr while the GPU libraries run)."""
+    data = (json.dumps(line) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, data)
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def measure_copy_peak(dev, mib=1024, reps=8):
     """Practical HBM rate of this box: a device-to-device copy of `mib` MiB (read + write = 2x bytes), best of `reps`.  The
     microarchitecture guide quotes 6.29 TB/s for a float4 copy kernel; roofline fractions are reported against the 8 TB/s
@@ -641,6 +654,13 @@ def main():
         return selftest_launch(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # The driver reads ONE JSON line from stdout.  RCCL prints its version banner on stdout when its first communicator comes up
+    # (C code, not sys.stdout), MIOpen and others may do likewise: everything that is not the line goes to stderr from here on,
+    # the line itself is written to the real stdout (emit_line).
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     # OMNIHD_BENCH_SHARE_GPU=1: every rank on cuda:0 over gloo — a functional check of the multi-rank path (DDP, SyncBN
     # exchange, max-over-ranks timing) on a one-GPU box; RCCL refuses two ranks on one device.  Not a measurement.
     share = os.environ.get("OMNIHD_BENCH_SHARE_GPU") == "1"
@@ -873,7 +893,7 @@ def main():
                 line["cpu_baseline"] = run_cpu_baseline_child(a.res, radar_dims)
             else:
                 line["cpu_baseline"] = cpu_baseline(a.res)
-        print(json.dumps(line), flush=True)
+        emit_line(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

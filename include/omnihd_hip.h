@@ -489,6 +489,32 @@ int omnihd_conv_wgrad_split(const void* x_hi, const void* x_lo, const void* g_hi
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Strided and transposed convolutions on the matrix cores (round 5): the general form of the implicit GEMM above
+ * ref: the stage-entry convolutions of SECOND (3x3, stride 2: projects/configs/bevfusion_NewScenes/bevfusion.py:62-68,
+ *      layer_strides=[2,2,2]), the strided 3x3 / 1x1 layers of ResNet-50 (bevfusion.py:77-85), SECONDFPN's transposed
+ *      convolutions with kernel == stride (bevfusion.py:69-74) — torch.nn.functional.conv2d / conv_transpose2d and their
+ *      data gradients (torch.ops.aten.convolution_backward).  No atomics: results are run-to-run identical.
+ * ---------------------------------------------------------------------------------------- */
+
+/* 1 when omnihd_conv_gen takes the pass: mode 0 / 1, square kernel with k*k <= 16, stride*stride <= 16, (ho, wo) the
+ * convolution's output size for (h, w, k, stride, pad, dil), SOURCE channels (mode 0: cin, mode 1: cout) a multiple of 8,
+ * operands below 1 GiB per plane.                                                                                        */
+int omnihd_conv_gen_supported(int mode, int batch, int h, int w, int cin, int ho, int wo, int cout, int ksize, int stride,
+                              int pad, int dil);
+/* The convolution  y = conv2d(x (batch,h,w,cin), w, stride, pad, dil) -> (batch,ho,wo,cout), all tensors NHWC:
+ *   mode 0, forward:        src = x,    w = (cout,k,k,cin) image,                     dst = y  (+ bias (cout) f32 or NULL)
+ *   mode 1, data gradient:  src = gout (batch,ho,wo,cout), w = (cin,k,k,cout) image with MIRRORED taps
+ *                           (omnihd_conv_dgrad_weights / the d images of omnihd_weight_images),  dst = gx (batch,h,w,cin):
+ *                           every input pixel is written exactly once (zeros where no tap reaches it), no atomics.
+ * A transposed convolution with kernel == stride (weight (Cin_t,Cout_t,k,k)) is mode 1 of the stride-k convolution whose
+ * weight is that tensor read as (cout = Cin_t, cin = Cout_t); its data gradient is mode 0 of the same convolution.
+ * src_lo / w_lo NULL: bf16 operands, dst bf16, fp32 accumulation.  Both non-NULL: the fp32-grade split form
+ * (hi*hi + hi*lo + lo*hi), dst F32.  128x128 tiles, one launch for all stride classes.                                   */
+int omnihd_conv_gen(int mode, const void* src_hi, const void* src_lo, const void* w_hi, const void* w_lo, const float* bias,
+                    void* dst, int batch, int h, int w, int cin, int ho, int wo, int cout, int ksize, int stride, int pad,
+                    int dil, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depth-head epilogue of the LSS camera stream: softmax over D + depth / context split + pooling layouts
  * ref: CamEncode.get_depth_dist / get_depth_feat  bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:134-143
  *      (x[:, :D].softmax(dim=1), x[:, D:D+C]), the layout copy in front of the pooling  :290

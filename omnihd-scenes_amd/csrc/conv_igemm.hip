@@ -744,7 +744,7 @@ struct WeightImageEntry {
 };
 
 __global__ __launch_bounds__(256) void k_weight_images(const WeightImageEntry* __restrict__ table, int n_entries) {
-  __shared__ float s[32][9][33];
+  __shared__ float s[32][16][33];       // up to 4 x 4 taps (SECONDFPN's transposed convolutions with kernel == stride 4)
   // binary search for the layer of this workgroup (first_block is increasing; the table has a closing sentinel entry)
   int lo_e = 0, hi_e = n_entries - 1;
   while (lo_e < hi_e) {
@@ -805,7 +805,7 @@ extern "C" int omnihd_weight_images(const void* table_dev, int n_entries, int to
 }
 
 extern "C" int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream) {
-  OMNIHD_REQUIRE(w_ohwi && wt_ihwo && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "arguments");
+  OMNIHD_REQUIRE(w_ohwi && wt_ihwo && cout > 0 && cin > 0 && ksize >= 1 && ksize <= 4, "arguments");
   hipLaunchKernelGGL(k_dgrad_weights, dim3((cout + 63) / 64, (cin + 63) / 64, ksize * ksize), dim3(256), 0,
                      (hipStream_t)stream, static_cast<const unsigned short*>(w_ohwi), static_cast<unsigned short*>(wt_ihwo),
                      cout, cin, ksize * ksize);

@@ -341,6 +341,12 @@ class FusionTrainStep:
             # taking the immediate-mode heuristic (41.0 -> 37.9 ms per step at R1; costs ~1 min of warm-up, so it is
             # opt-in: bench.py and the profiling scripts ask for it, the tests do not)
             torch.backends.cudnn.benchmark = True
+        if self.device.type == "cuda":
+            from . import ops as _ops
+            if _ops.deterministic():
+                # OMNIHD_DETERMINISTIC=1: every convolution pass with a kernel in this library runs on it (fixed-order sums);
+                # the few passes that stay on the library (7x7 stem, the 59-channel depth logits) must not pick its atomic solvers
+                torch.backends.cudnn.deterministic = True
         torch.manual_seed(0)                         # identical initial weights on every rank
         cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)
         if task == "occ":

@@ -240,6 +240,12 @@ class BevConvTranspose2d(nn.ConvTranspose2d):
                                     self.groups, self.dilation, self.bias):
                 return ops.deconv_hip_wgrad(xb.contiguous(memory_format=torch.channels_last), self.weight,
                                             self.kernel_size[0])
+        if (output_size is None and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and ops.deconv_split_supported(x, self.weight, self.kernel_size, self.stride, self.padding, self.output_padding,
+                                               self.groups, self.dilation, self.bias)
+                and (ops.deterministic() or os.environ.get("OMNIHD_DECONV_SPLIT", "1") != "0")):
+            # the reference-precision (fp32) step: forward / data gradient on the general implicit-GEMM kernel in split form
+            return ops.deconv_split(x, self.weight, self.kernel_size[0])
         return super().forward(x, output_size)
 
 

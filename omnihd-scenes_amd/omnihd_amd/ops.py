@@ -910,6 +910,69 @@ def conv_dgrad_weights(w_cl, out=None):
     return wt
 
 
+_GEN_OK = {}
+
+
+def _conv_out_hw(H, W, k, s, p, d):
+    return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def conv_gen_supported(mode, x_shape, cout, k, stride, padding, dilation):
+    """The general implicit-GEMM kernel (csrc/conv_gen.hip) takes this pass of conv2d(x (B,Cin,H,W), w (Cout,Cin,k,k), stride,
+    padding, dilation): mode 0 = forward, mode 1 = data gradient (strided forms included; OMNIHD_CONV_GEN=0 turns it off)."""
+    if os.environ.get("OMNIHD_CONV_GEN", "1") == "0":
+        return False
+    key = (int(mode), tuple(x_shape), int(cout), int(k), int(stride), int(padding), int(dilation))
+    hit = _GEN_OK.get(key)
+    if hit is None:
+        B, cin, H, W = x_shape
+        s, p, d = int(stride), int(padding), int(dilation)
+        if s < 1 or H + 2 * p - d * (k - 1) - 1 < 0 or W + 2 * p - d * (k - 1) - 1 < 0:
+            hit = False
+        else:
+            Ho, Wo = _conv_out_hw(H, W, k, s, p, d)
+            hit = bool(lib().omnihd_conv_gen_supported(int(mode), B, H, W, cin, Ho, Wo, int(cout), int(k), s, p, d))
+        if len(_GEN_OK) > 4096:
+            _GEN_OK.clear()
+        _GEN_OK[key] = hit
+    return hit
+
+
+def conv_gen(mode, src, w, bias, x_shape, cout, k, stride, padding, dilation):
+    """One pass of conv2d(x (B,Cin,H,W), w (Cout,Cin,k,k), stride, padding, dilation) on the general implicit-GEMM kernel:
+      mode 0: src = x,    w = weight image in (Cout,k,k,Cin) memory          -> y  (B,Cout,Ho,Wo)   (+ fp32 bias)
+      mode 1: src = gout, w = data-gradient image ((Cin,k,k,Cout), mirrored) -> gx (B,Cin,H,W), every pixel written once
+    ``src`` / ``w``: bf16 channels-last tensors (bf16 result) or (hi, lo) pairs of them (fp32-grade split form, fp32 result)."""
+    split = isinstance(src, (tuple, list))
+    s0 = src[0] if split else src
+    w0 = w[0] if split else w
+    B, cin, H, W = x_shape
+    s_, p_, d_ = int(stride), int(padding), int(dilation)
+    Ho, Wo = _conv_out_hw(H, W, k, s_, p_, d_)
+    want = (B, cin, H, W) if mode == 0 else (B, cout, Ho, Wo)
+    for t in (tuple(src) if split else (src,)):
+        _want_cl(t, "source")
+        if tuple(t.shape) != want:
+            raise ValueError(f"conv_gen: source {tuple(t.shape)}, the pass reads {want}")
+    for t in (tuple(w) if split else (w,)):
+        if t.dtype != torch.bfloat16 or t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise TypeError("weight images must be 4-D bf16 tensors in channels_last memory format")
+    out_shape = (B, cout, Ho, Wo) if mode == 0 else (B, cin, H, W)
+    y = torch.empty(out_shape, dtype=torch.float32 if split else torch.bfloat16, device=s0.device, memory_format=torch.channels_last)
+    with _on(y.device):
+        check(lib().omnihd_conv_gen(int(mode), s0.data_ptr(), src[1].data_ptr() if split else None, w0.data_ptr(),
+                                    w[1].data_ptr() if split else None, None if bias is None else _f32c(bias).data_ptr(), y.data_ptr(),
+                                    B, H, W, cin, Ho, Wo, int(cout), int(k), s_, p_, d_, _raw_stream()), "omnihd_conv_gen")
+    return y
+
+
+def deterministic():
+    """OMNIHD_DETERMINISTIC=1: every convolution pass this library has a kernel for runs on it (no per-geometry race against the
+    library kernels, whose fp32 solvers for strided layers and small weight gradients accumulate with atomics), so that a
+    training step is run-to-run identical bit for bit (tests/test_determinism_gpu.py)."""
+    return os.environ.get("OMNIHD_DETERMINISTIC", "0") == "1"
+
+
 # Which implementation computes the weight gradient of a given convolution geometry: the MFMA kernel chain of
 # this library ("hip") or MIOpen ("miopen").  The staged GEMM wins by 2-4x on the BEV-sized convolutions and on
 # small feature maps, MIOpen's direct implicit GEMM wins where the pixel axis is long and the channel counts are
@@ -1034,7 +1097,7 @@ def _miopen_wgrad(x, g, weight, stride, padding, dilation):
 
 
 def _tuned_wgrad(x, g, weight, stride, padding, dilation):
-    policy = os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
+    policy = "hip" if deterministic() else os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
     k = weight.shape[2]
     run_hip = lambda: conv_wgrad(x, g, k, stride[0], padding[0], dilation[0])
     if policy == "hip":
@@ -1053,7 +1116,7 @@ def _tuned_wgrad(x, g, weight, stride, padding, dilation):
 
 def wgrad_choice_for(x_shape, cout, k, stride, padding, dilation, device_index):
     """'hip' | 'miopen' | None (not measured yet) for a convolution geometry under the current policy."""
-    policy = os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
+    policy = "hip" if deterministic() else os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
     if policy != "tune":
         return policy
     return _WGRAD_CHOICE.get((tuple(x_shape), cout, k, stride, padding, dilation, device_index))
@@ -1064,15 +1127,23 @@ def conv_all_miopen(x_shape, cout, k, stride, padding, dilation, device_index):
     the layer is then a plain torch convolution again (no Python in its backward)."""
     if wgrad_choice_for(x_shape, cout, k, stride, padding, dilation, device_index) != "miopen":
         return False
-    if os.environ.get("OMNIHD_CONV_POLICY", "tune") == "miopen":
+    if _conv_policy() == "miopen":
         return True
+    if _conv_policy() == "hip":
+        return False
     B, cin, H, W = x_shape
     same = stride == 1 and k in (1, 3) and padding == dilation * (k // 2)
     if same and cin % 64 == 0 and cout % 8 == 0:
         if _CONV_CHOICE.get(("fwd", tuple(x_shape), cout, k, dilation, device_index)) != "miopen":
             return False
+    elif cout % 8 == 0 and k <= 4 and conv_gen_supported(0, tuple(x_shape), cout, k, stride, padding, dilation):
+        if _CONV_CHOICE.get(("fwd_gen", tuple(x_shape), cout, k, stride, padding, dilation, device_index)) != "miopen":
+            return False
     if same and cout % 64 == 0 and cin % 8 == 0:
         if _CONV_CHOICE.get(("dgrad", (B, cout, H, W), cin, k, dilation, device_index)) != "miopen":
+            return False
+    elif cin % 8 == 0 and cout % 8 == 0 and k in (1, 3) and conv_gen_supported(1, tuple(x_shape), cout, k, stride, padding, dilation):
+        if _CONV_CHOICE.get(("dgrad_gen", tuple(x_shape), cout, k, stride, padding, dilation, device_index)) != "miopen":
             return False
     return True
 
@@ -1245,17 +1316,36 @@ _CONV_CHOICE = _ChoiceTable("conv")
 _CONV_IMPLS = ("hip", "hip128x256", "miopen")
 
 
-def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=None, n_out=None, k=None):
+def _conv_policy():
+    return "hip" if deterministic() else os.environ.get("OMNIHD_CONV_POLICY", "tune")
+
+
+def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=None, n_out=None, k=None, in_shape=None):
     """Run one direction ('fwd': x = input, w_cl = weights; 'dgrad': x = grad_out, w_cl = data-gradient weights) with the
     implementation chosen for its geometry.  ``w_cl`` may be a function returning the weights (with ``n_out`` = their
-    output channels and ``k``): the data gradient's mirrored / transposed weights are then only made when our kernel runs."""
+    output channels and ``k``): the data gradient's mirrored / transposed weights are then only made when our kernel runs.
+    ``in_shape``: the convolution's INPUT shape (B,Cin,H,W) — with it, geometries the stride-1 kernels do not take (strides,
+    other paddings, channel counts that are multiples of 8 only) run on the general kernel of csrc/conv_gen.hip."""
     lazy = callable(w_cl)
     weights = (lambda: w_cl()) if lazy else (lambda: w_cl)
     if not lazy:
         n_out, k = w_cl.shape[0], w_cl.shape[2]
-    policy = os.environ.get("OMNIHD_CONV_POLICY", "tune")
-    ours = (x.dtype == torch.bfloat16 and conv_fwd_supported(x.shape, n_out, k, stride[0], padding[0], dilation[0])
-            and stride[0] == stride[1] and padding[0] == padding[1] and dilation[0] == dilation[1])
+    policy = _conv_policy()
+    square = stride[0] == stride[1] and padding[0] == padding[1] and dilation[0] == dilation[1]
+    ours = (x.dtype == torch.bfloat16 and square and conv_fwd_supported(x.shape, n_out, k, stride[0], padding[0], dilation[0]))
+    if not ours and policy != "miopen" and in_shape is not None and x.dtype == torch.bfloat16 and square and k <= 4:
+        mode = 0 if direction == "fwd" else 1
+        cout_conv = n_out if mode == 0 else x.shape[1]
+        if n_out % 8 == 0 and conv_gen_supported(mode, tuple(in_shape), cout_conv, k, stride[0], padding[0], dilation[0]):
+            run_gen = lambda: conv_gen(mode, x, weights(), bias, tuple(in_shape), cout_conv, k, stride[0], padding[0], dilation[0])
+            if policy == "hip":
+                return run_gen()
+            key = (direction + "_gen", tuple(in_shape), cout_conv, k, stride[0], padding[0], dilation[0], x.device.index)
+            choice = _CONV_CHOICE.get(key)
+            if choice is None:
+                clock = lambda fn: _clock(fn, x.device, n=5, warm=2)
+                choice = _CONV_CHOICE.measured(key, "hip" if clock(run_gen) <= clock(run_miopen) else "miopen")
+            return run_gen() if choice == "hip" else run_miopen()
     if not ours or policy == "miopen":
         return run_miopen()
     made = []
@@ -1515,8 +1605,14 @@ def conv_split_geometry(x_shape, cout, k, stride, padding, dilation, groups=1):
     if groups != 1 or s is None or p is None or d is None or k not in (1, 3):
         return False, False, False
     same = s == 1 and p == d * (k // 2)
-    fwd = same and cin % 64 == 0 and cout % 8 == 0 and B * H * W < 2 ** 30
-    dgrad = same and cout % 64 == 0 and cin % 8 == 0 and B * H * W < 2 ** 30
+    # "igemm": the stride-1 kernels of csrc/conv_igemm.hip (256-wide tiles, row-shift reuse); "gen": the general kernel of
+    # csrc/conv_gen.hip (any stride / padding, channel counts that are multiples of 8) — both truthy
+    fwd = "igemm" if (same and cin % 64 == 0 and cout % 8 == 0 and B * H * W < 2 ** 30) else False
+    dgrad = "igemm" if (same and cout % 64 == 0 and cin % 8 == 0 and B * H * W < 2 ** 30) else False
+    if not fwd and cout % 8 == 0 and conv_gen_supported(0, x_shape, cout, k, s, p, d):
+        fwd = "gen"
+    if not dgrad and cin % 8 == 0 and conv_gen_supported(1, x_shape, cout, k, s, p, d):
+        dgrad = "gen"
     wgrad = cin % 8 == 0 and cout % 8 == 0 and not (k == 3 and s == 1 and p == d and d > 18)
     return fwd, dgrad, wgrad
 
@@ -1544,8 +1640,12 @@ def _clock(fn, dev, n=3, warm=1):
     return best
 
 
+def _fp32_policy():
+    return "split" if deterministic() else os.environ.get("OMNIHD_FP32_CONV", "tune")
+
+
 def _split_pick(key, run_split, run_miopen, dev):
-    policy = os.environ.get("OMNIHD_FP32_CONV", "tune")
+    policy = _fp32_policy()
     if policy == "split":
         return run_split()
     if policy == "miopen":
@@ -1563,7 +1663,7 @@ def split_choices():
 def conv_split_all_miopen(x_shape, cout, k, stride, padding, dilation, device_index):
     """True once every direction the split kernels could take for this geometry has been measured in MIOpen's favour: the
     layer is then a plain torch convolution again (no operand split, no Python in its backward)."""
-    if os.environ.get("OMNIHD_FP32_CONV", "tune") != "tune":
+    if _fp32_policy() != "tune":
         return False
     geo = (tuple(x_shape), cout, k, stride[0], padding[0], dilation[0], device_index)
     oks = conv_split_geometry(x_shape, cout, k, stride, padding, dilation)
@@ -1585,8 +1685,8 @@ class _ConvSplit(torch.autograd.Function):
         ok_f, ok_d, ok_w = conv_split_geometry(x.shape, weight.shape[0], k, stride, padding, dilation)
         # what the backward needs of x: its two bf16 planes for the split weight-gradient chain, or x itself where MIOpen's
         # fp32 weight gradient has measured faster for this geometry (no reconstruction of x from the planes then)
-        wg_miopen = (not ok_w) or (os.environ.get("OMNIHD_FP32_CONV", "tune") == "tune" and _SPLIT_CHOICE.get(("wgrad",) + geo) == "miopen")
-        use_split_fwd = ok_f and not (os.environ.get("OMNIHD_FP32_CONV", "tune") == "tune" and _SPLIT_CHOICE.get(("fwd",) + geo) == "miopen")
+        wg_miopen = (not ok_w) or (_fp32_policy() == "tune" and _SPLIT_CHOICE.get(("wgrad",) + geo) == "miopen")
+        use_split_fwd = ok_f and not (_fp32_policy() == "tune" and _SPLIT_CHOICE.get(("fwd",) + geo) == "miopen")
         xs = None
         if use_split_fwd or not wg_miopen:
             xs = take_planes(x)
@@ -1604,7 +1704,11 @@ class _ConvSplit(torch.autograd.Function):
                                                          padding, dilation)
         if not use_split_fwd:
             return run_miopen()
-        run_split = lambda: conv_fwd_split(xs, split_weight(weight), None if bias is None else bias.detach(), dilation[0])
+        if ok_f == "gen":
+            run_split = lambda: conv_gen(0, xs, split_weight(weight), None if bias is None else bias.detach(), tuple(x.shape),
+                                         weight.shape[0], k, stride[0], padding[0], dilation[0])
+        else:
+            run_split = lambda: conv_fwd_split(xs, split_weight(weight), None if bias is None else bias.detach(), dilation[0])
         return _split_pick(("fwd",) + geo, run_split, run_miopen, dev)
 
     @staticmethod
@@ -1680,7 +1784,11 @@ class _ConvSplit(torch.autograd.Function):
             x_like = lambda: torch.empty(x_shape, dtype=torch.float32, device=dev, memory_format=torch.channels_last)
             run_miopen = lambda: torch.ops.aten.convolution_backward(g, x_like(), weight.detach(), None, stride, padding, dilation,
                                                                      False, [0, 0], 1, [True, False, False])[0]
-            if ok_d:
+            if ok_d == "gen":
+                run_split = lambda: conv_gen(1, gs, split_weight(weight, dgrad=True), None, tuple(x_shape), weight.shape[0],
+                                             weight.shape[2], stride[0], padding[0], dilation[0])
+                gx = _split_pick(("dgrad",) + geo, run_split, run_miopen, dev)
+            elif ok_d:
                 run_split = lambda: conv_fwd_split(gs, split_weight(weight, dgrad=True), None, dilation[0])
                 gx = _split_pick(("dgrad",) + geo, run_split, run_miopen, dev)
             else:
@@ -2001,7 +2109,7 @@ class _ConvHipWgrad(torch.autograd.Function):
                                                          padding, dilation)
         if x.dtype == torch.bfloat16 and x.dim() == 4:
             return _conv_impl("fwd", x, wb.contiguous(memory_format=torch.channels_last), stride, padding, dilation, run_miopen,
-                              None if bias is None else bias.detach())
+                              None if bias is None else bias.detach(), in_shape=tuple(x.shape))
         return run_miopen()
 
     @staticmethod
@@ -2014,16 +2122,18 @@ class _ConvHipWgrad(torch.autograd.Function):
             run_miopen = lambda: torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0],
                                                                      1, [True, False, False])[0]
             k = weight.shape[2]
-            if (g.dtype == torch.bfloat16 and stride[0] == 1 and weight.shape[0] % 64 == 0 and weight.shape[1] % 8 == 0
-                    and k in (1, 3) and padding[0] == dilation[0] * (k // 2)
-                    and os.environ.get("OMNIHD_CONV_POLICY", "tune") != "miopen"):
+            if (g.dtype == torch.bfloat16 and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0 and k in (1, 3)
+                    and _conv_policy() != "miopen"):
                 wt = lambda: bf16_dgrad_image(None if ctx.wparam is None else ctx.wparam(), weight)
-                gx = _conv_impl("dgrad", g, wt, stride, padding, dilation, run_miopen, n_out=weight.shape[1], k=k)
+                gx = _conv_impl("dgrad", g, wt, stride, padding, dilation, run_miopen, n_out=weight.shape[1], k=k,
+                                in_shape=tuple(x.shape))
             else:
                 gx = run_miopen()
         else:
             # no data gradient asked for (first trainable layer behind a frozen trunk): nothing to measure in this direction
             _CONV_CHOICE.setdefault(("dgrad", tuple(g.shape), weight.shape[1], weight.shape[2], dilation[0], g.device.index), "miopen")
+            _CONV_CHOICE.setdefault(("dgrad_gen", tuple(x.shape), weight.shape[0], weight.shape[2], stride[0], padding[0], dilation[0],
+                                     g.device.index), "miopen")
         if ctx.needs_input_grad[1]:
             gw = _tuned_wgrad(x.contiguous(memory_format=torch.channels_last), g, weight, stride, padding,
                               dilation).to(ctx.param_dtypes[0])
@@ -2040,17 +2150,47 @@ def conv_hip_wgrad(x, weight, bias, stride, padding, dilation=(1, 1)):
     return _ConvHipWgrad.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation))
 
 
+def _gen_or_library(key, run_gen, run_lib, dev, policy):
+    """The general kernel or the library's, per geometry: 'hip' / 'miopen' policies decide, 'tune' measures once (_CONV_CHOICE)."""
+    if policy == "miopen":
+        return run_lib()
+    if policy in ("hip", "split"):
+        return run_gen()
+    choice = _CONV_CHOICE.get(key)
+    if choice is None:
+        clock = lambda fn: _clock(fn, dev, n=5, warm=2)
+        choice = _CONV_CHOICE.measured(key, "hip" if clock(run_gen) <= clock(run_lib) else "miopen")
+    return run_gen() if choice == "hip" else run_lib()
+
+
+def _deconv_as_conv(x_shape, weight_shape, k):
+    """A transposed convolution with kernel == stride k, weight (Cin_t, Cout_t, k, k), on x (B, Cin_t, H, W) IS the data gradient
+    of the stride-k convolution whose weight is that tensor read as (cout = Cin_t, cin = Cout_t): returns that convolution's
+    (input shape, cout)."""
+    B, cin_t, H, W = x_shape
+    return (B, weight_shape[1], H * k, W * k), cin_t
+
+
 class _DeconvHipWgrad(torch.autograd.Function):
-    """ConvTranspose2d with kernel == stride (non-overlapping up-sampling, SECONDFPN's ``deblocks``): forward
-    and data gradient on MIOpen; the weight gradient dW[cin][cout][ky][kx] = sum_m X[m][cin] * G[(s*y+ky,
-    s*x+kx)][cout] is a 1x1 weight gradient once G is viewed as rows of (ky, kx, cout) per INPUT pixel."""
+    """ConvTranspose2d with kernel == stride (non-overlapping up-sampling, SECONDFPN's ``deblocks``): forward and data gradient on
+    the general implicit-GEMM kernel (csrc/conv_gen.hip: k*k one-tap classes in one launch / a stride-k forward) or MIOpen,
+    measured per geometry; the weight gradient dW[cin][cout][ky][kx] = sum_m X[m][cin] * G[(s*y+ky, s*x+kx)][cout] is a 1x1
+    weight gradient once G is viewed as rows of (ky, kx, cout) per INPUT pixel."""
 
     @staticmethod
     def forward(ctx, x, weight, k):
         wb = bf16_of(weight) if x.dtype == torch.bfloat16 else weight.detach().to(x.dtype)
         ctx.save_for_backward(x, wb)
         ctx.k, ctx.wdtype = k, weight.dtype
-        return torch.nn.functional.conv_transpose2d(x, wb, None, stride=k)
+        ctx.wparam = weakref.ref(weight) if (weight.dtype == torch.float32 and x.dtype == torch.bfloat16) else None
+        run_lib = lambda: torch.nn.functional.conv_transpose2d(x, wb, None, stride=k)
+        conv_in, conv_cout = _deconv_as_conv(x.shape, weight.shape, k)
+        if (x.dtype == torch.bfloat16 and weight.shape[1] % 8 == 0 and conv_gen_supported(1, conv_in, conv_cout, k, k, 0, 1)):
+            wt = lambda: bf16_dgrad_image(None if ctx.wparam is None else ctx.wparam(), wb)
+            run_gen = lambda: conv_gen(1, x.contiguous(memory_format=torch.channels_last), wt(), None, conv_in, conv_cout, k, k, 0, 1)
+            return _gen_or_library(("deconv_fwd", tuple(x.shape), weight.shape[1], k, x.device.index), run_gen, run_lib, x.device,
+                                   _conv_policy())
+        return run_lib()
 
     @staticmethod
     def backward(ctx, g):
@@ -2059,7 +2199,15 @@ class _DeconvHipWgrad(torch.autograd.Function):
         gx = gw = None
         g = g.contiguous(memory_format=torch.channels_last)
         if ctx.needs_input_grad[0]:
-            gx = torch.nn.functional.conv2d(g, weight, None, stride=k)          # adjoint of the transposed conv
+            run_lib = lambda: torch.nn.functional.conv2d(g, weight, None, stride=k)          # adjoint of the transposed conv
+            conv_in, conv_cout = _deconv_as_conv(x.shape, weight.shape, k)
+            if g.dtype == torch.bfloat16 and conv_cout % 8 == 0 and conv_gen_supported(0, conv_in, conv_cout, k, k, 0, 1):
+                w_cl = weight if weight.is_contiguous(memory_format=torch.channels_last) else weight.contiguous(memory_format=torch.channels_last)
+                run_gen = lambda: conv_gen(0, g, w_cl, None, conv_in, conv_cout, k, k, 0, 1)
+                gx = _gen_or_library(("deconv_dgrad", tuple(x.shape), weight.shape[1], k, g.device.index), run_gen, run_lib, g.device,
+                                     _conv_policy())
+            else:
+                gx = run_lib()
         if ctx.needs_input_grad[1]:
             B, cout, Ho, Wo = g.shape
             H, W = Ho // k, Wo // k
@@ -2071,6 +2219,56 @@ class _DeconvHipWgrad(torch.autograd.Function):
             cin = x.shape[1]
             gw = dw.reshape(k, k, cout, cin).permute(3, 2, 0, 1).to(ctx.wdtype)
         return gx, gw, None
+
+
+class _DeconvSplit(torch.autograd.Function):
+    """The same transposed convolution in the fp32 step: forward and data gradient on the general kernel in its fp32-grade split
+    form, weight gradient on the split chain through the same space-to-depth view.  No library kernel, no atomics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, k):
+        x = x.contiguous(memory_format=torch.channels_last)
+        xs = take_planes(x)
+        if xs is None:
+            xs = split_f32(x)
+        ctx.save_for_backward(xs[0], xs[1], weight)
+        ctx.k = k
+        conv_in, conv_cout = _deconv_as_conv(x.shape, weight.shape, k)
+        return conv_gen(1, xs, split_weight(weight, dgrad=True), None, conv_in, conv_cout, k, k, 0, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x_hi, x_lo, weight = ctx.saved_tensors
+        k = ctx.k
+        gx = gw = None
+        g = g.float().contiguous(memory_format=torch.channels_last)
+        conv_in, conv_cout = _deconv_as_conv(x_hi.shape, weight.shape, k)
+        if ctx.needs_input_grad[0]:
+            gx = conv_gen(0, split_f32(g), split_weight(weight), None, conv_in, conv_cout, k, k, 0, 1)
+        if ctx.needs_input_grad[1]:
+            B, cout, Ho, Wo = g.shape
+            H, W = Ho // k, Wo // k
+            rows = g.permute(0, 2, 3, 1).reshape(B, H, k, W, k, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, k * k * cout)
+            rows = rows.permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+            dw = conv_wgrad_split((x_hi, x_lo), split_f32(rows), 1, 1, 0, 1)           # (k*k*cout, cin, 1, 1)
+            cin = x_hi.shape[1]
+            gw = dw.reshape(k, k, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
+        return gx, gw, None
+
+
+def deconv_split_supported(x, weight, kernel_size, stride, padding, output_padding, groups, dilation, bias):
+    k, s = _pair_same(kernel_size), _pair_same(stride)
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dtype == torch.float32 and k is not None and k == s
+            and 1 <= k <= 4 and _pair_same(padding) == 0 and _pair_same(output_padding) == 0 and groups == 1
+            and _pair_same(dilation) == 1 and bias is None and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0):
+        return False
+    conv_in, conv_cout = _deconv_as_conv(x.shape, weight.shape, k)
+    return (conv_gen_supported(1, conv_in, conv_cout, k, k, 0, 1) and conv_gen_supported(0, conv_in, conv_cout, k, k, 0, 1)
+            and _fp32_policy() != "miopen")
+
+
+def deconv_split(x, weight, k):
+    return _DeconvSplit.apply(x, weight, int(k))
 
 
 def deconv_supported(x, weight, kernel_size, stride, padding, output_padding, groups, dilation, bias):
