@@ -32,6 +32,7 @@
 // a K-step covers 32 channels, reads 8 fragments (4 hi, 4 lo) per 16-deep slice and issues 12 MFMAs on them (0.67 LDS reads
 // per MFMA against 1.0 in the bf16 kernel, which is bound by the bytes streamed into LDS).  The result is written in fp32.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace omnihd {
@@ -520,7 +521,18 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
 #pragma unroll
     for (int ks = 0; ks < NS; ++ks) load_slice(A, B, dx, ks, fr[ks]);
     __builtin_amdgcn_sched_barrier(0);
-    if (KX == 0) {
+    if constexpr (SPREAD) {
+      // the A tile of the next group in two instalments (3 + 2 calls behind kx = 0 and kx = 1) instead of all five behind
+      // kx = 0: the LOAD segments then carry 5 / 4 / 2 LDS-DMA calls instead of 7 / 2 / 2 against COMPUTE segments of
+      // equal length (an LDS-DMA call costs the issuing wave 60-185 cycles: the 7-call segment was the longest of the three)
+      if (KX == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) issue_a(g + 1, q);
+      } else if (KX == 1) {
+#pragma unroll
+        for (int q = 3; q < 5; ++q) issue_a(g + 1, q);
+      }
+    } else if (KX == 0) {
 #pragma unroll
       for (int q = 0; q < 5; ++q) issue_a(g + 1, q);
     }
@@ -547,9 +559,18 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
   };
   // (sched_barrier(0) on both sides: hipcc moves register-only MFMAs across s_barrier and inline-asm waits — the first
   // build of this schedule had the MFMAs of one segment sunk into the fragment reads of the next)
+  // Program order of a wavefront's fills in the steady state (g = group, k = 3g + kx):
+  //   all-at-once:  L(3g): A(g+1) x5, B(3g+3) x2 | L(3g+1): B(3g+4) x2 | L(3g+2): B(3g+5) x2
+  //                 before K-step 3g+1 / 3g+2 the fills of B(3g+1) / B(3g+2) must have landed: 9 younger calls may be in flight;
+  //                 before 3g+3: A(g+1) and B(3g+3): 4 younger calls
+  //   spread:       L(3g): A(g+1) q0-2, B(3g+3) x2 | L(3g+1): A(g+1) q3-4, B(3g+4) x2 | L(3g+2): B(3g+5) x2
+  //                 before 3g+1: B(3g+1) was issued in L(3g-2); younger: L(3g-1) 2 + L(3g) 5 = 7
+  //                 before 3g+2: B(3g+2) from L(3g-1); younger: L(3g) 5 + L(3g+1) 4 = 9
+  //                 before 3g+3: A(g+1) q4 from L(3g+1); younger: B(3g+4) x2 + L(3g+2) 2 = 4
   auto wait_stage = [&](int kx_next) {                 // this wave's fills of the NEXT K-step have landed
     __builtin_amdgcn_sched_barrier(0);
     if (kx_next == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (SPREAD && kx_next == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -651,6 +672,12 @@ bool rs_addressable(const void* hi, const void* lo, size_t plane_bytes) {
   return span < (1ull << 31);
 }
 
+// OMNIHD_CONV_RS_SPREAD=0: the A fill of a group issued at once (read once per process)
+bool rs_spread() {
+  static const bool on = [] { const char* e = getenv("OMNIHD_CONV_RS_SPREAD"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 const unsigned short* igemm_zero_page() {
   static void* pages[64] = {nullptr};
   int dev = 0;
@@ -693,13 +720,17 @@ extern "C" int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, cons
   OMNIHD_REQUIRE(rs_addressable(X, nullptr, (size_t)M * cin * 2) && rs_addressable(Wt, nullptr, (size_t)cout * ksize * ksize * cin * 2),
                  "operands of 2 GiB and more are not addressable (32-bit buffer offsets)");
   const bool rs_ok = ksize == 3 && dil <= kHalo;
-  if (tile == 300 || (tile == 0 && rs_ok && big_tiles >= 2 * kCUs)) {
-    // 3x3 with row-shift reuse of the activation tile
+  if (tile == 300 || tile == 301 || (tile == 0 && rs_ok && big_tiles >= 2 * kCUs)) {
+    // 3x3 with row-shift reuse of the activation tile (301: the A fill of a group issued at once, round 3's schedule)
     OMNIHD_REQUIRE(rs_ok, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
     const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm_rs<true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout, dil,
-                       tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
+    if (tile == 301 || !rs_spread())
+      hipLaunchKernelGGL((k_conv_igemm_rs<false>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout, dil,
+                         tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
+    else
+      hipLaunchKernelGGL((k_conv_igemm_rs<true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)Y, M, h, w, cin, cout, dil,
+                         tiles_m, tiles_n, per, (const unsigned short*)nullptr, (const unsigned short*)nullptr);
   } else if (tile == 129 || (tile == 0 && !big && (long long)((M + 127) / 128) * ((cout + 127) / 128) >= kCUs)) {
     // 128x128 tile, 2-stage ring (64 KB): two workgroups per CU cover each other's fills — where there are enough tiles for
     // two per CU (scripts/lab/conv_small_tiles.py: 1.4x on the 6 x 64 x 176 1x1 layers, a loss on deep small maps)
@@ -841,12 +872,16 @@ extern "C" int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const v
   OMNIHD_REQUIRE(rs_addressable(X, X2, (size_t)M * cin * 2) && rs_addressable(Wt, Wt2, (size_t)cout * ksize * ksize * cin * 2),
                  "the two planes of a split operand must lie within 2 GiB of each other (32-bit buffer offsets)");
   const bool rs_ok = ksize == 3 && dil <= kHalo;
-  if (tile == 300 || (tile == 0 && rs_ok && big_tiles >= 2 * kCUs)) {
+  if (tile == 300 || tile == 301 || (tile == 0 && rs_ok && big_tiles >= 2 * kCUs)) {
     OMNIHD_REQUIRE(rs_ok, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
     const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;
-    hipLaunchKernelGGL((k_conv_igemm_rs<true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc, M, h, w, cin,
-                       cout, dil, tiles_m, tiles_n, per, X2, Wt2);
+    if (tile == 301 || !rs_spread())
+      hipLaunchKernelGGL((k_conv_igemm_rs<false, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc, M, h, w, cin,
+                         cout, dil, tiles_m, tiles_n, per, X2, Wt2);
+    else
+      hipLaunchKernelGGL((k_conv_igemm_rs<true, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc, M, h, w, cin,
+                         cout, dil, tiles_m, tiles_n, per, X2, Wt2);
   } else if (tile == 129 || (tile == 0 && !big && (long long)((M + 127) / 128) * ((cout + 127) / 128) >= kCUs)) {
     const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
     const int per = (tiles_m * tiles_n + 7) / 8;

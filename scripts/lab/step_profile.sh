@@ -1,7 +1,7 @@
 #!/bin/bash
 # Steady-state kernel statistics of the bf16 training step (MIOpen db seeded, immediate find lookups): launches per step
 # and GPU time by kernel.  Usage: bash scripts/lab/step_profile.sh [bf16|fp32] [steps]
-export TMPDIR=/tmp; DT=${1:-bf16}; N=${2:-10}; out=gpurun_out/r3v_$DT; mkdir -p $out
+export TMPDIR=/tmp; DT=${1:-bf16}; N=${2:-10}; out=${STEP_PROFILE_OUT:-gpurun_out/r3v_$DT}; mkdir -p $out
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/prof -o st -- python3 scripts/lab/step_few.py $DT $N > $out/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
@@ -12,7 +12,7 @@ names = [r["Kernel_Name"] for r in rows]
 opt = [i for i, n in enumerate(names) if "multi_tensor_apply" in n and "adam" in n.lower()]
 print("total launches", len(rows), "adam launches", len(opt))
 # take the last $N steps: find boundaries by the last adam kernel of each step (fused adamw = a few launches per step)
-per_step = max(1, len(opt) // ($N + 3))
+per_step = max(1, len(opt) // ($N + int('${STEP_PROFILE_WARM:-3}')))
 cut = opt[-per_step * $N - 1] + 1 if len(opt) > per_step * $N else 0
 ss = rows[cut:]
 t0, t1 = int(ss[0]["Start_Timestamp"]), int(ss[-1]["End_Timestamp"])
