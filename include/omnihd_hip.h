@@ -288,6 +288,20 @@ int omnihd_permute_rows_zyx_to_yxz(const int* rows_in, int64_t n, int nz, int ny
  * coors [M,3] = (z,y,x), num_points [M].  voxel_num (device int) = M; if h_voxel_num is
  * non-null the stream is synchronised and M copied back.                                   */
 size_t omnihd_voxelize_workspace_bytes(int n_points);
+/* The same result in THREE launches for sparse clouds on small grids (round 5: the radar stream, <= 20 k returns on 480x320x1
+ * cells, 10 points per pillar): a per-cell atomicMin / list push, a one-workgroup numbering scan in point order, and a writer
+ * that keeps each voxel's first max_points points by index.  No sort, no memset, nothing read back; bit-identical outputs for
+ * rows < voxel_num (rows beyond it are NOT defined here — the sort path zero-fills them).
+ * cell_state: a PERSISTENT device buffer of omnihd_voxelize_grid_state_bytes() bytes (0 = grid too large for this path),
+ * initialised once by omnihd_voxelize_grid_state_init and left idle again by every completed call (one call at a time per
+ * buffer).  max_points <= 16.  workspace: omnihd_voxelize_grid_workspace_bytes(n) bytes.                                  */
+size_t omnihd_voxelize_grid_state_bytes(const float* h_voxel_size3, const float* h_range6);
+int omnihd_voxelize_grid_state_init(void* cell_state, size_t state_bytes, void* stream);
+size_t omnihd_voxelize_grid_workspace_bytes(int n_points);
+int omnihd_voxelize_hard_grid(const float* points, int n_points, int n_feat, const float* h_voxel_size3,
+                              const float* h_range6, int max_points, int max_voxels, float* voxels, int* coors,
+                              int* num_points, int* voxel_num, void* cell_state, size_t state_bytes, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int omnihd_voxelize_hard(const float* points, int n_points, int n_feat,
                          const float* h_voxel_size3, const float* h_range6,
                          int max_points, int max_voxels,

@@ -160,10 +160,198 @@ int vox_ws_layout(int n, VoxWs* w) {
   return OMNIHD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the same result in THREE launches for sparse clouds on small grids (the radar stream: <= 20 k returns per frame on a
+// 480 x 320 x 1 grid, 10 points per pillar) — no sort, no memsets, nothing read back.
+//   k_grid_enter   per point: its cell; atomicMin of the point index into first[cell] (the voxel's first point decides its
+//                  number) and a push onto the cell's list (next[i] = atomicExch(head[cell], i): arrival order, fixed below)
+//   k_grid_number  ONE workgroup: exclusive scan over "point i is the first point of its cell" in POINT order -> voxel numbers
+//                  in first-occurrence order, voxel count clamped to max_voxels
+//   k_grid_write   the first point of every accepted voxel walks its cell's list, keeps the MAXP smallest point indices in
+//                  ascending order (register insertion with compile-time slots: the kept points are the voxel's first MAXP
+//                  in point order, whatever order the atomics arrived in), writes the voxel's rows (zero padded), coordinates
+//                  and count, and puts first[cell] / head[cell] back to their idle values — the persistent cell state is
+//                  clean again when the call ends.
+// Deterministic: atomicMin / the SET of a list do not depend on arrival order; everything else is index arithmetic.
+// ---------------------------------------------------------------------------------------------
+constexpr int kIdleFirst = 0x7fffffff;
+
+__global__ __launch_bounds__(kBlock) void k_grid_enter(const float* __restrict__ pts, int n, int f, VoxSpec s,
+                                                        int* __restrict__ first, int* __restrict__ head,
+                                                        int* __restrict__ cell_of, int* __restrict__ next) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float* p = pts + (size_t)i * f;
+    const float tx = (p[0] - s.lo[0]) / s.vs[0];
+    const float ty = (p[1] - s.lo[1]) / s.vs[1];
+    const float tz = (p[2] - s.lo[2]) / s.vs[2];
+    const bool ok = tx >= 0.f && tx < (float)s.grid[0] && ty >= 0.f && ty < (float)s.grid[1] &&
+                    tz >= 0.f && tz < (float)s.grid[2];
+    int cell = -1;
+    if (ok) {
+      const int x = (int)floorf(tx), y = (int)floorf(ty), z = (int)floorf(tz);
+      cell = (z * s.grid[1] + y) * s.grid[0] + x;
+      atomicMin(&first[cell], i);
+      next[i] = atomicExch(&head[cell], i);
+    }
+    cell_of[i] = cell;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_grid_number(const int* __restrict__ cell_of, const int* __restrict__ first, int n,
+                                                       int max_voxels, int* __restrict__ voxid, int* __restrict__ voxel_num) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(n, lo + chunk);
+  int mine = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int c = cell_of[i];
+    mine += (c >= 0 && first[c] == i) ? 1 : 0;
+  }
+  part[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the 1024 partial counts
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - mine;                          // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) {
+    const int c = cell_of[i];
+    const bool is_first = c >= 0 && first[c] == i;
+    voxid[i] = is_first ? run : -1;
+    run += is_first ? 1 : 0;
+  }
+  if (tid == 1023) *voxel_num = min(part[1023], max_voxels);
+}
+
+template <int MAXP>
+__global__ __launch_bounds__(kBlock) void k_grid_write(const float* __restrict__ pts, int n, int f, VoxSpec s, int max_points,
+                                                        int max_voxels, const int* __restrict__ cell_of,
+                                                        const int* __restrict__ voxid, const int* __restrict__ next,
+                                                        int* __restrict__ first, int* __restrict__ head,
+                                                        float* __restrict__ voxels, int* __restrict__ coors,
+                                                        int* __restrict__ num_points) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int v = voxid[i];
+    if (v < 0) continue;                               // not the first point of a cell
+    const int cell = cell_of[i];
+    if (v < max_voxels) {
+      int best[MAXP];
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) best[k] = kIdleFirst;
+      int count = 0;
+      for (int j = head[cell]; j >= 0; j = next[j]) {
+        ++count;
+        int val = j;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {               // keep the MAXP smallest indices, ascending (static slots: registers)
+          const int b = best[k];
+          const bool sw = val < b;
+          best[k] = sw ? val : b;
+          val = sw ? b : val;
+        }
+      }
+      const int kept = min(count, max_points);
+      float* dst = voxels + (size_t)v * max_points * f;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        if (k < max_points) {
+          if (k < kept) {
+            const float* src = pts + (size_t)best[k] * f;
+            for (int q = 0; q < f; ++q) dst[(size_t)k * f + q] = src[q];
+          } else {
+            for (int q = 0; q < f; ++q) dst[(size_t)k * f + q] = 0.f;
+          }
+        }
+      }
+      int key = cell;
+      const int x = key % s.grid[0]; key /= s.grid[0];
+      const int y = key % s.grid[1];
+      const int z = key / s.grid[1];
+      coors[(size_t)v * 3 + 0] = z;
+      coors[(size_t)v * 3 + 1] = y;
+      coors[(size_t)v * 3 + 2] = x;
+      num_points[v] = kept;
+    }
+    first[cell] = kIdleFirst;                          // accepted or refused: the cell state goes back to idle
+    head[cell] = -1;
+  }
+}
+
 }  // namespace
 }  // namespace omnihd
 
 using namespace omnihd;
+
+extern "C" size_t omnihd_voxelize_grid_state_bytes(const float* h_voxel_size3, const float* h_range6) {
+  if (!h_voxel_size3 || !h_range6) return 0;
+  int64_t cells = 1;
+  for (int a = 0; a < 3; ++a) {
+    const int g = (int)lroundf((h_range6[a + 3] - h_range6[a]) / h_voxel_size3[a]);
+    if (g <= 0) return 0;
+    cells *= g;
+  }
+  if (cells > (1 << 22)) return 0;                     // 4 M cells = 32 MB of state: beyond that the sort path is the better one
+  return (size_t)cells * 2 * sizeof(int);
+}
+
+extern "C" int omnihd_voxelize_grid_state_init(void* cell_state, size_t state_bytes, void* stream) {
+  OMNIHD_REQUIRE(cell_state && state_bytes % (2 * sizeof(int)) == 0, "arguments");
+  const size_t cells = state_bytes / (2 * sizeof(int));
+  // first[] = 0x7fffffff, head[] = -1
+  OMNIHD_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)cell_state, kIdleFirst, cells, (hipStream_t)stream));
+  OMNIHD_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(static_cast<int*>(cell_state) + cells), -1, cells, (hipStream_t)stream));
+  return OMNIHD_OK;
+}
+
+extern "C" size_t omnihd_voxelize_grid_workspace_bytes(int n_points) {
+  return n_points <= 0 ? 256 : align_up((size_t)n_points * 3 * sizeof(int), 256);
+}
+
+extern "C" int omnihd_voxelize_hard_grid(const float* points, int n_points, int n_feat, const float* h_voxel_size3,
+                                         const float* h_range6, int max_points, int max_voxels, float* voxels, int* coors,
+                                         int* num_points, int* voxel_num, void* cell_state, size_t state_bytes, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  OMNIHD_REQUIRE(n_points >= 0 && n_feat >= 3 && max_points > 0 && max_points <= 16 && max_voxels > 0, "sizes (max_points <= 16)");
+  OMNIHD_REQUIRE(h_voxel_size3 && h_range6 && voxel_num && cell_state, "null pointer");
+  VoxSpec s;
+  int64_t cells = 1;
+  for (int a = 0; a < 3; ++a) {
+    s.vs[a] = h_voxel_size3[a];
+    s.lo[a] = h_range6[a];
+    s.grid[a] = (int)lroundf((h_range6[a + 3] - h_range6[a]) / h_voxel_size3[a]);
+    OMNIHD_REQUIRE(s.grid[a] > 0, "empty grid");
+    cells *= s.grid[a];
+  }
+  OMNIHD_REQUIRE(cells <= (1 << 22) && state_bytes >= (size_t)cells * 2 * sizeof(int), "cell state too small for the grid");
+  if (n_points == 0) {
+    OMNIHD_HIP_TRY(hipMemsetAsync(voxel_num, 0, sizeof(int), st));
+    return OMNIHD_OK;
+  }
+  OMNIHD_REQUIRE(points && voxels && coors && num_points && workspace, "null pointer");
+  if (workspace_bytes < (size_t)n_points * 3 * sizeof(int)) {
+    set_error("voxelize_grid: workspace %zu < required %zu", workspace_bytes, (size_t)n_points * 3 * sizeof(int));
+    return OMNIHD_ERR_WORKSPACE;
+  }
+  int* first = static_cast<int*>(cell_state);
+  int* head = first + cells;
+  int* cell_of = static_cast<int*>(workspace);
+  int* next = cell_of + n_points;
+  int* voxid = next + n_points;
+  const int grid = grid_for(n_points, kBlock);
+  hipLaunchKernelGGL(k_grid_enter, dim3(grid), dim3(kBlock), 0, st, points, n_points, n_feat, s, first, head, cell_of, next);
+  hipLaunchKernelGGL(k_grid_number, dim3(1), dim3(1024), 0, st, cell_of, first, n_points, max_voxels, voxid, voxel_num);
+  if (max_points <= 10)
+    hipLaunchKernelGGL((k_grid_write<10>), dim3(grid), dim3(kBlock), 0, st, points, n_points, n_feat, s, max_points, max_voxels, cell_of,
+                       voxid, next, first, head, voxels, coors, num_points);
+  else
+    hipLaunchKernelGGL((k_grid_write<16>), dim3(grid), dim3(kBlock), 0, st, points, n_points, n_feat, s, max_points, max_voxels, cell_of,
+                       voxid, next, first, head, voxels, coors, num_points);
+  return check_launch("voxelize_hard_grid");
+}
 
 extern "C" size_t omnihd_voxelize_workspace_bytes(int n_points) {
   if (n_points <= 0) return 256;

@@ -42,6 +42,11 @@ PROTOTYPES = {
     "omnihd_voxelize_workspace_bytes": (c_size_t, [c_int]),
     "omnihd_voxelize_hard": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int] +
                              [c_void_p] * 6 + [c_size_t, c_void_p]),
+    "omnihd_voxelize_grid_state_bytes": (c_size_t, [c_void_p, c_void_p]),
+    "omnihd_voxelize_grid_state_init": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "omnihd_voxelize_grid_workspace_bytes": (c_size_t, [c_int]),
+    "omnihd_voxelize_hard_grid": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5 +
+                                  [c_size_t, c_void_p, c_size_t, c_void_p]),
     "omnihd_pillar_scatter_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "omnihd_pillar_scatter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -364,7 +364,16 @@ class FusionTrainStep:
         model.train()
         self.raw_model = model
         self.model = model
+        self.small_params = []
         if ddp:
+            # The ~200 parameters of at most 4096 elements (BatchNorm weights / biases, convolution biases) stay outside the
+            # reducer: inside it every one of them costs a copy launch into its bucket per step (hipMemcpyAsync: 211 launches and
+            # 1.2 ms of device time per R1 step, profiles/round5/step_fp32_ddp1_before.txt).  Their gradients (0.4 MB) are
+            # flattened, all-reduced in ONE message and scattered back right behind backward (``_reduce_small_params``).
+            if os.environ.get("OMNIHD_DDP_SMALL_FLAT", "1") != "0":
+                named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.numel() <= 4096]
+                self.small_params = [p for _, p in named]
+                nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, [n for n, _ in named])
             self.model = nn.parallel.DistributedDataParallel(
                 model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 broadcast_buffers=False, bucket_cap_mb=25, gradient_as_bucket_view=True)
@@ -390,6 +399,15 @@ class FusionTrainStep:
         self.last_losses = None
         self.ddp = bool(ddp)
 
+    def _reduce_small_params(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            ddp = self.model if isinstance(self.model, nn.parallel.DistributedDataParallel) else None
+            if ddp is not None and not ddp.require_backward_grad_sync:
+                return 0                                  # DDP.no_sync(): gradients accumulate locally
+            return _reduce_small(self.small_params, None if ddp is None else ddp.process_group)
+        return 0
+
     def sync_choices(self):
         """After the set-up steps of a multi-rank run: every rank takes rank 0's measured per-geometry kernel choices, so all
         ranks (and the bf16 summation order of their convolutions) agree from here on."""
@@ -406,6 +424,8 @@ class FusionTrainStep:
             losses = self.model(return_loss=True, **b)
         total = sum(v if torch.is_tensor(v) else sum(v) for v in losses.values())
         total.backward()          # (ends with ops.wgrad_overlap_join: the weight gradients computed on the side stream are joined)
+        if self.small_params:
+            self._reduce_small_params()
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=35, norm_type=2)
         self.opt.step()
         if self.device.type == "cuda":
@@ -414,6 +434,22 @@ class FusionTrainStep:
             ops.refresh_split_shadows()           # fp32 step: forward + data-gradient planes of every split convolution, one launch
         self.last_losses = losses
         return total
+
+
+def _reduce_small(params, group=None):
+    """Mean over the ranks of the gradients of ``params`` through ONE flat all-reduce (cat -> all_reduce -> multi-tensor copy
+    back): what the reducer would do with one copy launch per parameter."""
+    import torch.distributed as dist
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return 0
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    world = dist.get_world_size(group)
+    if world > 1:
+        flat.mul_(1.0 / world)
+    dist.all_reduce(flat, group=group)
+    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    return flat.numel()
 
 
 def count_step_flops(step):
@@ -485,7 +521,9 @@ def comm_report(step, iters=3):
         return None
     params = [p for p in step.raw_model.parameters() if p.requires_grad]
     nbytes = sum(p.numel() * p.element_size() for p in params)
+    small = getattr(step, "small_params", [])
     rep = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes_per_step": int(nbytes),
+           "small_params_flat_allreduce": {"tensors": len(small), "bytes": int(sum(p.numel() * p.element_size() for p in small))},
            "bucket_cap_mb": 25, "buckets": None, "exposed_comm_ms": None,
            "syncbn_exchanges_per_step": 2 * sum(1 for m in step.raw_model.modules()
                                                 if (isinstance(m, _NaiveSyncBN) or isinstance(m, nn.SyncBatchNorm)) and m.training)}

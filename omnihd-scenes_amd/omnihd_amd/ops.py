@@ -557,6 +557,9 @@ class PendingVoxels:
         return self.voxels[:m], self.coors[:m], self.num_points[:m]
 
 
+_VOXEL_STATE = {}
+
+
 def hard_voxelize_async(points, voxel_size, point_cloud_range, max_points, max_voxels):
     """One sample: points (N,F) fp32 -> PendingVoxels of (voxels (M,max_points,F), coors (M,3)=(z,y,x) int32,
     num_points (M,) int32).  mmdet3d Voxelization semantics (see include/omnihd_hip.h)."""
@@ -566,18 +569,42 @@ def hard_voxelize_async(points, voxel_size, point_cloud_range, max_points, max_v
     voxels = torch.empty((max_voxels, max_points, f), dtype=torch.float32, device=dev)
     coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
     num_points = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
-    voxel_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    voxel_num = torch.empty(1, dtype=torch.int32, device=dev)          # written by both paths (also for n = 0)
     h_vs = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in voxel_size])
     h_rg = (ctypes.c_float * 6)(*[float(np.float32(v)) for v in point_cloud_range])
     with _on(dev):
-        ws_bytes = lib().omnihd_voxelize_workspace_bytes(n)
-        if ws_bytes == 0:
-            check(-4, "omnihd_voxelize_workspace_bytes")
-        ws = _workspace(ws_bytes, dev)
-        check(lib().omnihd_voxelize_hard(_ptr(points), n, f, ctypes.cast(h_vs, ctypes.c_void_p),
+        st = _raw_stream()
+        L = lib()
+        state = None
+        if max_points <= 16 and os.environ.get("OMNIHD_VOXELIZE_GRID", "1") != "0":
+            # three launches on a persistent per-cell state (idle between calls), for grids of up to 4 M cells
+            skey = (dev.index, st, tuple(h_vs), tuple(h_rg))
+            ent = _VOXEL_STATE.get(skey)
+            if ent is None or ent[1]:
+                nbytes = L.omnihd_voxelize_grid_state_bytes(ctypes.cast(h_vs, ctypes.c_void_p), ctypes.cast(h_rg, ctypes.c_void_p))
+                if nbytes:
+                    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    check(L.omnihd_voxelize_grid_state_init(_ptr(buf), nbytes, st), "omnihd_voxelize_grid_state_init")
+                    ent = _VOXEL_STATE[skey] = [buf, False]
+                else:
+                    ent = _VOXEL_STATE[skey] = [None, False]
+            state = ent[0]
+        if state is not None:
+            ws = _workspace(L.omnihd_voxelize_grid_workspace_bytes(n), dev)
+            ent[1] = True                          # a call that fails in between leaves the state dirty: rebuilt next time
+            check(L.omnihd_voxelize_hard_grid(_ptr(points), n, f, ctypes.cast(h_vs, ctypes.c_void_p), ctypes.cast(h_rg, ctypes.c_void_p),
+                                              max_points, max_voxels, _ptr(voxels), _ptr(coors), _ptr(num_points), _ptr(voxel_num),
+                                              _ptr(state), state.numel(), _ptr(ws), ws.numel(), st), "omnihd_voxelize_hard_grid")
+            ent[1] = False
+        else:
+            ws_bytes = L.omnihd_voxelize_workspace_bytes(n)
+            if ws_bytes == 0:
+                check(-4, "omnihd_voxelize_workspace_bytes")
+            ws = _workspace(ws_bytes, dev)
+            check(L.omnihd_voxelize_hard(_ptr(points), n, f, ctypes.cast(h_vs, ctypes.c_void_p),
                                          ctypes.cast(h_rg, ctypes.c_void_p), max_points, max_voxels,
                                          _ptr(voxels), _ptr(coors), _ptr(num_points), _ptr(voxel_num), None,
-                                         _ptr(ws), ws.numel(), _stream()), "omnihd_voxelize_hard")
+                                         _ptr(ws), ws.numel(), st), "omnihd_voxelize_hard")
         host = torch.empty(1, dtype=torch.int32, pin_memory=True)
         host.copy_(voxel_num, non_blocking=True)
         ev = torch.cuda.Event()
@@ -797,16 +824,23 @@ def conv_wgrad(x, grad_out, kernel_size, stride=1, padding=0, dilation=1):
     return dw.permute(0, 3, 1, 2)
 
 
-def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1):
+def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1, out=None):
     """fp32-grade weight gradient from split operands: xs = (x_hi, x_lo), gs = (g_hi, g_lo) bf16 channels-last ->
-    dW (Cout,Cin,k,k) fp32 in channels-last memory (omnihd_conv_wgrad_split: one staging pass, one three-term GEMM launch)."""
+    dW (Cout,Cin,k,k) fp32 in channels-last memory (omnihd_conv_wgrad_split: one staging pass, one three-term GEMM launch).
+    ``out``: an fp32 (Cout,Cin,k,k) tensor in channels_last memory to write into (a DDP reducer's view of the gradient inside
+    its bucket: no copy afterwards); the returned tensor then aliases it."""
     for t in (*xs, *gs):
         _want_cl(t, "operand plane")
     B, cin, H, W = xs[0].shape
     _, cout, Ho, Wo = gs[0].shape
     k = int(kernel_size)
     dev = xs[0].device
-    dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
+    if out is not None:
+        dw = out.permute(0, 2, 3, 1)
+        if not (out.dtype == torch.float32 and tuple(out.shape) == (cout, cin, k, k) and dw.is_contiguous() and out.device == dev):
+            raise ValueError("conv_wgrad_split: `out` must be an fp32 (Cout,Cin,k,k) tensor in channels_last memory on the operands' device")
+    else:
+        dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
     geo = (B, H, W, cin, Ho, Wo, cout, k, k, int(stride), int(padding), int(dilation))
     L = lib()
     with _on(dev):
@@ -1740,14 +1774,21 @@ class _ConvSplit(torch.autograd.Function):
                 x_f32.append(x_hi.float().add_(x_lo))
             return x_f32[0]
 
-        def weight_gradient():
+        def weight_gradient(out=None):
             run_miopen = lambda: torch.ops.aten.convolution_backward(g, x_full(), weight.detach(), None, stride, padding, dilation,
                                                                      False, [0, 0], 1, [False, True, False])[1]
             if want_w_split:
                 k = weight.shape[2]
-                run_split = lambda: conv_wgrad_split((x_hi, x_lo), gs, k, stride[0], padding[0], dilation[0])
+                run_split = lambda: conv_wgrad_split((x_hi, x_lo), gs, k, stride[0], padding[0], dilation[0], out=out)
                 return _split_pick(("wgrad",) + geo, run_split, run_miopen, dev).to(ctx.param_dtypes[0])
             return run_miopen().to(ctx.param_dtypes[0])
+
+        def into_view(view, gw):
+            """The weight gradient inside the reducer's bucket: our kernel wrote it there already, a library result is copied."""
+            if gw.data_ptr() != view.data_ptr():
+                view.copy_(gw)
+            _DDP["direct"] += 1
+            return view.detach()             # a fresh alias in the parameter's layout: autograd keeps it as .grad without a kernel
 
         # Weight gradient beside the data gradient (OMNIHD_WGRAD_OVERLAP, one rank): nothing reads a weight gradient before the end
         # of the backward pass, so its kernels go to a side stream that the autograd engine's final callback joins
@@ -1763,15 +1804,13 @@ class _ConvSplit(torch.autograd.Function):
                     tns.record_stream(side)              # allocated on the main stream, read on the side stream
             view = _ddp_bucket_view(weight)
             with torch.cuda.stream(side):
-                gw = weight_gradient()
+                gw = weight_gradient(view if _view_writable(view, weight) else None)
                 if view is not None:
                     # under DistributedDataParallel: straight into the reducer's bucket.  What autograd gets back is a fresh
                     # alias of that memory in the parameter's layout — AccumulateGrad keeps it as .grad without a kernel, the
                     # reducer sees "already in the bucket" and copies nothing, and the bucket's all-reduce (our comm hook)
                     # waits for this stream.  No kernel of the caller's stream touches the gradient before the pass ends.
-                    view.copy_(gw)
-                    gw = view.detach()
-                    _DDP["direct"] += 1
+                    gw = into_view(view, gw)
                 elif gw.stride() != weight.stride():
                     # autograd keeps a gradient that has the parameter's layout as it is; any other one it would COPY on the
                     # main stream, before this stream is done
@@ -1796,7 +1835,12 @@ class _ConvSplit(torch.autograd.Function):
         elif ok_d:
             _SPLIT_CHOICE.setdefault(("dgrad",) + geo, "miopen")          # never asked for: nothing to measure
         if ctx.needs_input_grad[1] and side is None:
-            gw = weight_gradient()
+            # in line; under a hooked reducer still straight into the bucket view (the reducer then has nothing to copy)
+            view = _ddp_bucket_view(weight) if (weight.is_leaf and weight.grad is None and not torch.is_grad_enabled()) else None
+            if _view_writable(view, weight) and want_w_split:
+                gw = into_view(view, weight_gradient(view))
+            else:
+                gw = weight_gradient()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             n, c, h, w = g.shape
             gb = column_sums(g.permute(0, 2, 3, 1).reshape(n * h * w, c)).to(ctx.param_dtypes[1])
@@ -1933,6 +1977,11 @@ def _ddp_bucket_view(weight):
     if v.shape != weight.shape or v.stride() != weight.stride() or v.dtype != weight.dtype or v.device != weight.device:
         return None
     return v
+
+
+def _view_writable(view, weight):
+    """Can our weight-gradient kernel write straight into ``view``?  fp32, 4-D, (Cout,k,k,Cin) memory."""
+    return (view is not None and view.dtype == torch.float32 and view.dim() == 4 and view.permute(0, 2, 3, 1).is_contiguous())
 
 
 def ddp_overlap_info():

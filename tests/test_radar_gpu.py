@@ -67,6 +67,42 @@ def test_voxelize_edges_nan_and_all_outside(cuda):
     assert out[0].shape[0] == 0
 
 
+def test_three_launch_voxelisation_equals_the_sort_path_and_the_oracle(cuda, monkeypatch):
+    """Round 5: the per-cell atomicMin / list / one-workgroup scan path (three launches, persistent idle cell state) against
+    the stable-sort path and the sequential oracle: one crowded cell (5 000 points: the kept points are the FIRST ten by
+    index, whatever order the atomics arrived in), both caps binding, NaN / out-of-range points, an empty cloud, and repeated
+    calls on the same persistent state."""
+    from omnihd_amd import ops
+    rng = np.random.default_rng(17)
+    clouds = []
+    crowd = np.tile(np.array([[1.1, 2.2, 0.5]], np.float32), (5000, 1)) + rng.uniform(0, 0.2, (5000, 3)).astype(np.float32)
+    clouds.append(np.concatenate([crowd, rng.standard_normal((5000, 4)).astype(np.float32)], 1))
+    dense = np.concatenate([rng.uniform(-60, 60, (20000, 1)), rng.uniform(-40, 40, (20000, 1)), rng.uniform(-3, 5, (20000, 1)),
+                            rng.standard_normal((20000, 4))], 1).astype(np.float32)
+    dense[::97, 0] = np.nan; dense[::89, 1] = 1e9
+    clouds.append(dense)
+    small = dense[:3000].copy(); small[:, :2] *= 0.05                     # many points per cell: the 10-point cap binds
+    clouds.append(small)
+    for pts in clouds:
+        for max_voxels in (30000, 700):                                   # 700: the voxel cap binds
+            want = OC.hard_voxelize(pts, VS, RNG6, 10, max_voxels)
+            monkeypatch.setenv("OMNIHD_VOXELIZE_GRID", "1")
+            got = ops.hard_voxelize(t(pts, cuda), VS, RNG6, 10, max_voxels)
+            monkeypatch.setenv("OMNIHD_VOXELIZE_GRID", "0")
+            srt = ops.hard_voxelize(t(pts, cuda), VS, RNG6, 10, max_voxels)
+            for g, s_, w in zip(got, srt, want):
+                assert g.shape == w.shape and np.array_equal(g.cpu().numpy(), w) and torch.equal(g, s_)
+    monkeypatch.setenv("OMNIHD_VOXELIZE_GRID", "1")
+    out = ops.hard_voxelize(torch.empty(0, 7, device=cuda), VS, RNG6, 10, 100)
+    assert out[0].shape[0] == 0
+    state = [v[0] for k, v in ops._VOXEL_STATE.items() if v[0] is not None]
+    assert state, "the grid path did not run"
+    for buf in state:                                                     # idle again after every call
+        words = buf.view(torch.int32)
+        half = words.numel() // 2
+        assert bool((words[:half] == 0x7fffffff).all()) and bool((words[half:] == -1).all())
+
+
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_pillar_scatter_and_backward(cuda, channels_last):
     from omnihd_amd import ops
