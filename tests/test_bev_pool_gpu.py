@@ -519,6 +519,37 @@ def test_patch_backward_full_size_against_the_reference_api_kernel(cuda, res):
     assert torch.equal(depth.grad == 0, dg == 0)
 
 
+def test_patch_backward_full_size_r1_directly_against_the_oracle(cuda):
+    """the headline backward kernel (k_pool_bwd_patch through ``planned_pool``'s autograd path) at the
+    full R1 frame size DIRECTLY against the CPU restatement of the reference kernel (oracle/bev_pool_oracle.c, following
+    ops/bev_pool_v2/src/bev_pool_cuda.cu:67-121) on the reference's own backward tables (re-sort by ranks_feat,
+    ops/bev_pool_v2/bev_pool.py:47-57) — not through this library's reference-API kernel: feat_grad bit-exact (the same fma
+    chain per channel in table order), depth_grad 1e-5 (fixed-order channel sum), the same zero pattern."""
+    from omnihd_amd import build_plan
+    from omnihd_amd.plan import planned_pool
+    fH, fW, n_ref = FULL["r1"]
+    geom, dx, bx, nx = full_size_geometry("r1")
+    plan = build_plan(t(geom, cuda), dx, bx, nx, layout="bzyx")               # the reference's (B,Z,Y,X,C) row order
+    assert plan.patch_order is not None                                       # the patch kernel is what the autograd path launches
+    rng = np.random.default_rng(11)
+    depth = rng.random((1, 6, 59, fH, fW), dtype=np.float32)
+    depth /= depth.sum(2, keepdims=True)
+    feat = rng.standard_normal((1, 6, fH, fW, 64), dtype=np.float32)
+    og = rng.standard_normal((1, 16, 160, 240, 64), dtype=np.float32)         # (B,Z,Y,X,C)
+    rb, rd, rf, st, ln = O.voxel_pooling_prepare_v2(geom, dx, bx, nx)
+    assert len(rb) == n_ref
+    brb, brd, brf, bst, bln = O.backward_tables(rb, rd, rf)
+    want_dg, want_fg = OC.bev_pool_v2_bwd(og, depth, feat, brd, brf, brb, bst, bln, threads=True)
+    d = t(depth, cuda).requires_grad_()
+    f = t(feat, cuda).requires_grad_()
+    out = planned_pool(d, f, plan)                                            # logical (B,C,Z,Y,X)
+    out.backward(t(og, cuda).permute(0, 4, 1, 2, 3))
+    got_dg, got_fg = d.grad.cpu().numpy(), f.grad.cpu().numpy()
+    assert np.array_equal(got_fg, want_fg)
+    assert float(np.abs(got_dg - want_dg).max()) <= 1e-5 * float(np.abs(want_dg).max())
+    assert np.array_equal(got_dg == 0, want_dg == 0)
+
+
 @pytest.mark.parametrize("fH,fW,B,D,n_rows,pw,R,spx", [(5, 12, 1, 7, 3000, 8, 32, 1), (8, 12, 2, 7, 3000, 4, 32, 2), (4, 44, 1, 7, 3000, 16, 48, 1),
                                                         (3, 7, 2, 7, 3000, 8, 64, 1), (6, 16, 1, 40, 50, 8, 64, 1), (6, 16, 1, 40, 700, 4, 32, 3)])
 def test_stream_backward_matches_oracle(cuda, fH, fW, B, D, n_rows, pw, R, spx):
