@@ -529,6 +529,32 @@ int omnihd_conv_gen(int mode, const void* src_hi, const void* src_lo, const void
                     int dil, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Anchor target assignment + the three detection losses of Anchor3DHead, fused (round 5)
+ * ref: Anchor3DHead.loss / loss_single as the reference vendors it (bevfusion/dense_heads/det_anchor3d_head.py:192-372),
+ *      config projects/configs/bevfusion_NewScenes/bevfusion.py:96-155: MaxIoUAssigner over BboxOverlapsNearest3D (pos 0.6 /
+ *      neg 0.3 / min_pos 0.3, every anchor reaching a box's best IoU matched, later boxes win), DeltaXYZWLHRBBoxCoder targets,
+ *      sigmoid FocalLoss, SmoothL1Loss with the sine-difference yaw encoding and code weights, 2-way CrossEntropyLoss of the
+ *      direction bin; avg_factor = sum over samples of max(positives, 1).  One feature level.
+ * anchors (A, code_size) f32 in (y, x, anchor-per-location) order, A = h*w*anchors_per_loc; gt_boxes (total_gt, code_size) f32
+ * and gt_labels (total_gt) i32 concatenated over the batch, gt_offsets (batch+1) i32 (at most 128 boxes per sample);
+ * cls_score (batch, anchors_per_loc*num_classes, h, w), bbox_pred (batch, anchors_per_loc*code_size, h, w), dir_pred
+ * (batch, anchors_per_loc*2, h, w) f32 with the 12 element strides (b, c, y, x per map) in h_strides12.
+ * Writes the UNSCALED gradient maps g_cls / g_box / g_dir (same strides as the inputs) and out[0..2] = the three losses times
+ * h_loss_weights3, out[3] = avg_factor, out[4 + b] = positives of sample b.  Three launches (+ one memset); the backward
+ * (omnihd_anchor_loss_bwd) scales the three gradient maps (dense memory of n_* floats) by upstream * weight / avg_factor in one.
+ * No atomic sums: run-to-run identical.                                                                                   */
+size_t omnihd_anchor_loss_workspace_bytes(int batch, int anchors_per_sample, int total_gt);
+int omnihd_anchor_loss_fwd(const float* anchors, const float* gt_boxes, const int* gt_labels, const int* gt_offsets,
+                           int total_gt, const float* cls_score, const float* bbox_pred, const float* dir_pred, int batch,
+                           int h, int w, int anchors_per_loc, int num_classes, int code_size, const long long* h_strides12,
+                           const float* h_params7, int sin_diff, const float* h_code_weight, const float* h_loss_weights3,
+                           float* g_cls, float* g_box, float* g_dir, float* out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int omnihd_anchor_loss_bwd(float* g_cls, long long n_cls, float* g_box, long long n_box, float* g_dir, long long n_dir,
+                           const float* up_cls, const float* up_box, const float* up_dir, const float* fin,
+                           const float* h_loss_weights3, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depth-head epilogue of the LSS camera stream: softmax over D + depth / context split + pooling layouts
  * ref: CamEncode.get_depth_dist / get_depth_feat  bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:134-143
  *      (x[:, :D].softmax(dim=1), x[:, D:D+C]), the layout copy in front of the pooling  :290

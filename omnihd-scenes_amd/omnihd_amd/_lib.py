@@ -72,6 +72,10 @@ PROTOTYPES = {
     "omnihd_split_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     "omnihd_conv_fwd_split": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
     "omnihd_conv_dgrad_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "omnihd_anchor_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "omnihd_anchor_loss_fwd": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+                               + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    "omnihd_anchor_loss_bwd": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong] + [c_void_p] * 6),
     "omnihd_conv_gen_supported": (c_int, [c_int] * 12),
     "omnihd_conv_gen": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
     "omnihd_weight_images": (c_int, [c_void_p, c_int, c_int, c_void_p]),

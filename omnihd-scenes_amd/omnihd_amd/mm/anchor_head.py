@@ -316,6 +316,9 @@ class Anchor3DHead(nn.Module):
         """Same arithmetic as the vendored head's ``loss`` / ``loss_single`` (det_anchor3d_head.py:192-372);
         one feature level (the config has a single scale)."""
         assert len(cls_scores) == 1
+        fused = self._fused_loss(cls_scores[0], bbox_preds[0], dir_cls_preds[0], gt_bboxes, gt_labels)
+        if fused is not None:
+            return fused
         cls_score, bbox_pred, dir_pred = cls_scores[0].float(), bbox_preds[0].float(), dir_cls_preds[0].float()
         B = cls_score.shape[0]
         anchors = self.anchor_generator.grid_anchors([cls_score.shape[-2:]], device=cls_score.device)[0]
@@ -329,6 +332,42 @@ class Anchor3DHead(nn.Module):
         num_total_samples = torch.stack([t[6] for t in tg]).clamp(min=1).sum().to(cls_score.dtype)   # stays on the device
         return self.loss_from_targets(cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,
                                       dir_targets, dir_weights, num_total_samples)
+
+    def _fused_loss(self, cls_score, bbox_pred, dir_pred, gt_bboxes, gt_labels):
+        """The same losses from the fused kernels of csrc/anchor_loss.hip (target assignment + three losses + the gradient maps in
+        three launches instead of ~150), where the head is configured as the reference configures it; None = not applicable (the
+        torch formulation below runs).  OMNIHD_ANCHOR_LOSS=0 turns it off."""
+        import os
+        if os.environ.get("OMNIHD_ANCHOR_LOSS", "1") == "0" or not cls_score.is_cuda or not self.use_direction_classifier:
+            return None
+        asg = self.bbox_assigner
+        if not (isinstance(self.loss_cls, FocalLoss) and isinstance(self.loss_bbox, SmoothL1Loss) and isinstance(self.loss_dir, CrossEntropyLoss)
+                and isinstance(asg, MaxIoUAssigner) and isinstance(asg.iou_calculator, BboxOverlapsNearest3D)
+                and asg.match_low_quality and asg.gt_max_assign_all and type(self.bbox_coder) is DeltaXYZWLHRBBoxCoder
+                and self.num_classes <= 8 and 7 <= self.box_code_size <= 12):
+            return None
+        from .. import ops
+        dev = cls_score.device
+        gts = [_gt_tensor(g).to(dev).float().reshape(-1, self.box_code_size) for g in gt_bboxes]
+        if any(g.shape[0] > 128 for g in gts):
+            return None
+        offs = np.zeros(len(gts) + 1, dtype=np.int32)
+        offs[1:] = np.cumsum([g.shape[0] for g in gts])
+        key = tuple(int(v) for v in offs)
+        cache = getattr(self, "_gt_off_cache", None)
+        if cache is None or cache[0] != (key, str(dev)):
+            cache = self._gt_off_cache = ((key, str(dev)), torch.from_numpy(offs).to(dev))
+        gt_cat = torch.cat(gts) if len(gts) > 1 else gts[0]
+        lab_cat = torch.cat([l.to(dev).reshape(-1) for l in gt_labels]).to(torch.int32) if len(gt_labels) > 1 \
+            else gt_labels[0].to(dev).reshape(-1).to(torch.int32)
+        anchors = self.anchor_generator.grid_anchors([cls_score.shape[-2:]], device=dev)[0]
+        cw = self.train_cfg.get("code_weight", None) or [1.0] * self.box_code_size
+        l_cls, l_box, l_dir, _info = ops.anchor_loss(
+            cls_score, bbox_pred, dir_pred, anchors.contiguous(), gt_cat.contiguous(), lab_cat.contiguous(), cache[1], self.num_classes,
+            self.box_code_size, self.num_anchors, asg.pos_iou_thr, asg.neg_iou_thr, asg.min_pos_iou, self.loss_cls.gamma, self.loss_cls.alpha,
+            self.loss_bbox.beta, self.dir_offset, self.diff_rad_by_sin, cw,
+            (self.loss_cls.loss_weight, self.loss_bbox.loss_weight, self.loss_dir.loss_weight))
+        return dict(loss_cls=[l_cls], loss_bbox=[l_box], loss_dir=[l_dir])
 
     def loss_from_targets(self, cls_score, bbox_pred, dir_pred, labels, label_weights, bbox_targets, bbox_weights,
                           dir_targets, dir_weights, num_total_samples):

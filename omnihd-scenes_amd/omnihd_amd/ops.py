@@ -1317,7 +1317,7 @@ def refresh_bf16_shadows():
                 continue
             if not w.requires_grad or w.device != shadow.device or w.shape != shadow.shape:
                 continue                          # frozen weights change only through torch (version counter): bf16_of sees that
-            if (w.dim() == 4 and w.dtype == torch.float32 and w.is_cuda and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)
+            if (w.dim() == 4 and w.dtype == torch.float32 and w.is_cuda and w.shape[2] == w.shape[3] and 1 <= w.shape[2] <= 4
                     and shadow.is_contiguous(memory_format=torch.channels_last)):
                 d = _BF16_DGRAD.get(k)
                 d = d[2] if d is not None and d[0]() is w and d[2].device == w.device else None
@@ -2611,6 +2611,69 @@ def bn_train_act(x, weight, bias, running_mean, running_var, momentum, eps, relu
     cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if x.dim() == 4 else (lambda t: t.contiguous())
     return _BnTrainAct.apply(cl(x), weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), group,
                              None if residual is None else cl(residual), bool(unbiased_sync))
+
+
+# --------------------------------------------------------------------------------------------
+# Anchor target assignment + detection losses, fused (csrc/anchor_loss.hip)
+# --------------------------------------------------------------------------------------------
+class _AnchorLoss(torch.autograd.Function):
+    """(cls_score, bbox_pred, dir_pred) -> (loss_cls, loss_bbox, loss_dir) of Anchor3DHead.loss for one feature level: target
+    assignment, the three losses and the (unscaled) gradients of the three maps in three launches; the backward scales the saved
+    gradient maps in one.  See include/omnihd_hip.h: omnihd_anchor_loss_fwd."""
+
+    @staticmethod
+    def forward(ctx, cls_score, bbox_pred, dir_pred, anchors, gt_boxes, gt_labels, gt_offsets, meta):
+        (num_classes, code_size, na, params7, sin_diff, code_weight, loss_weights) = meta
+        # (fp32 and dense in NCHW or NHWC memory: ``anchor_loss`` casts / copies OUTSIDE the function where needed)
+        B, _, H, W = cls_score.shape
+        dev = cls_score.device
+        total_gt = int(gt_boxes.shape[0])
+        g_cls, g_box, g_dir = torch.empty_like(cls_score), torch.empty_like(bbox_pred), torch.empty_like(dir_pred)
+        assert g_cls.stride() == cls_score.stride() and g_box.stride() == bbox_pred.stride() and g_dir.stride() == dir_pred.stride()
+        out = torch.empty(4 + B, dtype=torch.float32, device=dev)
+        strides = (ctypes.c_longlong * 12)(*cls_score.stride(), *bbox_pred.stride(), *dir_pred.stride())
+        h_par = (ctypes.c_float * 7)(*[float(v) for v in params7])
+        h_cw = (ctypes.c_float * code_size)(*[float(v) for v in code_weight])
+        h_lw = (ctypes.c_float * 3)(*[float(v) for v in loss_weights])
+        L = lib()
+        with _on(dev):
+            ws = _workspace(L.omnihd_anchor_loss_workspace_bytes(B, H * W * na, total_gt), dev)
+            check(L.omnihd_anchor_loss_fwd(_ptr(anchors), _ptr(gt_boxes) if total_gt else None, _ptr(gt_labels) if total_gt else None,
+                                           _ptr(gt_offsets), total_gt, _ptr(cls_score), _ptr(bbox_pred), _ptr(dir_pred), B, H, W, na,
+                                           num_classes, code_size, ctypes.cast(strides, ctypes.c_void_p), ctypes.cast(h_par, ctypes.c_void_p),
+                                           1 if sin_diff else 0, ctypes.cast(h_cw, ctypes.c_void_p), ctypes.cast(h_lw, ctypes.c_void_p),
+                                           _ptr(g_cls), _ptr(g_box), _ptr(g_dir), _ptr(out), _ptr(ws), ws.numel(), _raw_stream()),
+                  "omnihd_anchor_loss_fwd")
+        ctx.save_for_backward(g_cls, g_box, g_dir, out)
+        ctx.loss_weights = tuple(float(v) for v in loss_weights)
+        info = out[3:]
+        ctx.mark_non_differentiable(info)
+        return out[0], out[1], out[2], info
+
+    @staticmethod
+    def backward(ctx, up_cls, up_box, up_dir, _up_info):
+        g_cls, g_box, g_dir, out = ctx.saved_tensors
+        dev = g_cls.device
+        h_lw = (ctypes.c_float * 3)(*ctx.loss_weights)
+        ups = [None if u is None else u.to(torch.float32).contiguous() for u in (up_cls, up_box, up_dir)]
+        with _on(dev):
+            check(lib().omnihd_anchor_loss_bwd(_ptr(g_cls), g_cls.numel(), _ptr(g_box), g_box.numel(), _ptr(g_dir), g_dir.numel(),
+                                               None if ups[0] is None else _ptr(ups[0]), None if ups[1] is None else _ptr(ups[1]),
+                                               None if ups[2] is None else _ptr(ups[2]), _ptr(out), ctypes.cast(h_lw, ctypes.c_void_p),
+                                               _raw_stream()), "omnihd_anchor_loss_bwd")
+        return g_cls, g_box, g_dir, None, None, None, None, None
+
+
+def anchor_loss(cls_score, bbox_pred, dir_pred, anchors, gt_boxes, gt_labels, gt_offsets, num_classes, code_size, anchors_per_loc,
+                pos_iou_thr, neg_iou_thr, min_pos_iou, gamma, alpha, beta, dir_offset, sin_diff, code_weight, loss_weights):
+    """Fused Anchor3DHead loss (one feature level).  gt_boxes (total, code_size) fp32 / gt_labels (total,) int32 concatenated over
+    the batch, gt_offsets (B+1,) int32 on the device.  Returns (loss_cls, loss_bbox, loss_dir, info) with info = [avg_factor,
+    positives per sample...]."""
+    meta = (int(num_classes), int(code_size), int(anchors_per_loc),
+            (pos_iou_thr, neg_iou_thr, min_pos_iou, gamma, alpha, beta, dir_offset), bool(sin_diff), tuple(code_weight), tuple(loss_weights))
+    dense = lambda t: t if (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)) else t.contiguous()
+    maps = [dense(t.float()) for t in (cls_score, bbox_pred, dir_pred)]          # differentiable casts: bf16 maps get bf16 gradients
+    return _AnchorLoss.apply(maps[0], maps[1], maps[2], anchors, gt_boxes, gt_labels, gt_offsets, meta)
 
 
 # --------------------------------------------------------------------------------------------
