@@ -289,7 +289,7 @@ int omnihd_permute_rows_zyx_to_yxz(const int* rows_in, int64_t n, int nz, int ny
  * non-null the stream is synchronised and M copied back.                                   */
 size_t omnihd_voxelize_workspace_bytes(int n_points);
 /* The same result in THREE launches for sparse clouds on small grids (round 5: the radar stream, <= 20 k returns on 480x320x1
- * cells, 10 points per pillar): a per-cell atomicMin / list push, a one-workgroup numbering scan in point order, and a writer
+ * cells, 10 points per pillar): a per-cell atomicMin / list push, a flag pass with per-workgroup counts, and a writer that numbers the voxels in point order from those counts and
  * that keeps each voxel's first max_points points by index.  No sort, no memset, nothing read back; bit-identical outputs for
  * rows < voxel_num (rows beyond it are NOT defined here — the sort path zero-fills them).
  * cell_state: a PERSISTENT device buffer of omnihd_voxelize_grid_state_bytes() bytes (0 = grid too large for this path),

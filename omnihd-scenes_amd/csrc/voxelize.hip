@@ -165,9 +165,10 @@ int vox_ws_layout(int n, VoxWs* w) {
 // 480 x 320 x 1 grid, 10 points per pillar) — no sort, no memsets, nothing read back.
 //   k_grid_enter   per point: its cell; atomicMin of the point index into first[cell] (the voxel's first point decides its
 //                  number) and a push onto the cell's list (next[i] = atomicExch(head[cell], i): arrival order, fixed below)
-//   k_grid_number  ONE workgroup: exclusive scan over "point i is the first point of its cell" in POINT order -> voxel numbers
-//                  in first-occurrence order, voxel count clamped to max_voxels
-//   k_grid_write   the first point of every accepted voxel walks its cell's list, keeps the MAXP smallest point indices in
+//   k_grid_flags   per point: is it the first point of its cell (first[cell] == i)?  + the count of first points per workgroup of
+//                  256 points
+//   k_grid_write   voxel number = first points in the workgroups before + before it in its own (ballots): first-occurrence order;
+//                  the first point of every accepted voxel walks its cell's list, keeps the MAXP smallest point indices in
 //                  ascending order (register insertion with compile-time slots: the kept points are the voxel's first MAXP
 //                  in point order, whatever order the atomics arrived in), writes the voxel's rows (zero padded), coordinates
 //                  and count, and puts first[cell] / head[cell] back to their idle values — the persistent cell state is
@@ -197,33 +198,26 @@ __global__ __launch_bounds__(kBlock) void k_grid_enter(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(1024) void k_grid_number(const int* __restrict__ cell_of, const int* __restrict__ first, int n,
-                                                       int max_voxels, int* __restrict__ voxid, int* __restrict__ voxel_num) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int chunk = (n + 1023) / 1024;
-  const int lo = tid * chunk, hi = min(n, lo + chunk);
-  int mine = 0;
-  for (int i = lo; i < hi; ++i) {
+// per point: is it the first point of its cell?  flag + per-workgroup counts (fixed grid: one workgroup per 256 points, so that
+// the writer can rebuild every workgroup's offset from the counts alone)
+__global__ __launch_bounds__(kBlock) void k_grid_flags(const int* __restrict__ cell_of, const int* __restrict__ first, int n,
+                                                       int* __restrict__ voxid, int* __restrict__ block_count) {
+  __shared__ int wave_cnt[kBlock / 64];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  bool is_first = false;
+  if (i < n) {
     const int c = cell_of[i];
-    mine += (c >= 0 && first[c] == i) ? 1 : 0;
+    is_first = c >= 0 && first[c] == i;
+    voxid[i] = is_first ? 0 : -1;                       // numbered by the writer
   }
-  part[tid] = mine;
+  const unsigned long long m = __ballot(is_first);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the 1024 partial counts
-    const int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < kBlock / 64; ++w) t += wave_cnt[w];
+    block_count[blockIdx.x] = t;
   }
-  int run = part[tid] - mine;                          // exclusive prefix of this thread's chunk
-  for (int i = lo; i < hi; ++i) {
-    const int c = cell_of[i];
-    const bool is_first = c >= 0 && first[c] == i;
-    voxid[i] = is_first ? run : -1;
-    run += is_first ? 1 : 0;
-  }
-  if (tid == 1023) *voxel_num = min(part[1023], max_voxels);
 }
 
 template <int MAXP>
@@ -232,10 +226,36 @@ __global__ __launch_bounds__(kBlock) void k_grid_write(const float* __restrict__
                                                         const int* __restrict__ voxid, const int* __restrict__ next,
                                                         int* __restrict__ first, int* __restrict__ head,
                                                         float* __restrict__ voxels, int* __restrict__ coors,
-                                                        int* __restrict__ num_points) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const int v = voxid[i];
-    if (v < 0) continue;                               // not the first point of a cell
+                                                        int* __restrict__ num_points, const int* __restrict__ block_count,
+                                                        int* __restrict__ voxel_num) {
+  // voxel number of a first point = first points in the workgroups before this one + first points before it in this workgroup
+  // (one workgroup per 256 points, the grid of k_grid_flags: no grid-stride loop here)
+  __shared__ int s_part[kBlock];
+  __shared__ int wave_base[kBlock / 64 + 1];
+  int acc = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) acc += block_count[b];
+  s_part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+    __syncthreads();
+  }
+  const int block_base = s_part[0];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool is_first = i < n && voxid[i] >= 0;
+  const unsigned long long m = __ballot(is_first);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wave_base[wv + 1] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    wave_base[0] = 0;
+    for (int w = 1; w <= kBlock / 64; ++w) wave_base[w] += wave_base[w - 1];
+    if (blockIdx.x == gridDim.x - 1) *voxel_num = min(block_base + wave_base[kBlock / 64], max_voxels);
+  }
+  __syncthreads();
+  {
+    if (!is_first) return;                             // not the first point of a cell
+    const int v = block_base + wave_base[wv] + __popcll(m & ((1ull << lane) - 1ull));
     const int cell = cell_of[i];
     if (v < max_voxels) {
       int best[MAXP];
@@ -307,7 +327,8 @@ extern "C" int omnihd_voxelize_grid_state_init(void* cell_state, size_t state_by
 }
 
 extern "C" size_t omnihd_voxelize_grid_workspace_bytes(int n_points) {
-  return n_points <= 0 ? 256 : align_up((size_t)n_points * 3 * sizeof(int), 256);
+  if (n_points <= 0) return 256;
+  return align_up(((size_t)n_points * 3 + (size_t)(n_points + kBlock - 1) / kBlock) * sizeof(int), 256);
 }
 
 extern "C" int omnihd_voxelize_hard_grid(const float* points, int n_points, int n_feat, const float* h_voxel_size3,
@@ -332,8 +353,8 @@ extern "C" int omnihd_voxelize_hard_grid(const float* points, int n_points, int 
     return OMNIHD_OK;
   }
   OMNIHD_REQUIRE(points && voxels && coors && num_points && workspace, "null pointer");
-  if (workspace_bytes < (size_t)n_points * 3 * sizeof(int)) {
-    set_error("voxelize_grid: workspace %zu < required %zu", workspace_bytes, (size_t)n_points * 3 * sizeof(int));
+  if (workspace_bytes < omnihd_voxelize_grid_workspace_bytes(n_points)) {
+    set_error("voxelize_grid: workspace %zu < required %zu", workspace_bytes, omnihd_voxelize_grid_workspace_bytes(n_points));
     return OMNIHD_ERR_WORKSPACE;
   }
   int* first = static_cast<int*>(cell_state);
@@ -341,15 +362,16 @@ extern "C" int omnihd_voxelize_hard_grid(const float* points, int n_points, int 
   int* cell_of = static_cast<int*>(workspace);
   int* next = cell_of + n_points;
   int* voxid = next + n_points;
-  const int grid = grid_for(n_points, kBlock);
-  hipLaunchKernelGGL(k_grid_enter, dim3(grid), dim3(kBlock), 0, st, points, n_points, n_feat, s, first, head, cell_of, next);
-  hipLaunchKernelGGL(k_grid_number, dim3(1), dim3(1024), 0, st, cell_of, first, n_points, max_voxels, voxid, voxel_num);
+  int* block_count = voxid + n_points;
+  const int blocks = (n_points + kBlock - 1) / kBlock;          // exactly one workgroup per 256 points in the last two kernels
+  hipLaunchKernelGGL(k_grid_enter, dim3(grid_for(n_points, kBlock)), dim3(kBlock), 0, st, points, n_points, n_feat, s, first, head, cell_of, next);
+  hipLaunchKernelGGL(k_grid_flags, dim3(blocks), dim3(kBlock), 0, st, cell_of, first, n_points, voxid, block_count);
   if (max_points <= 10)
-    hipLaunchKernelGGL((k_grid_write<10>), dim3(grid), dim3(kBlock), 0, st, points, n_points, n_feat, s, max_points, max_voxels, cell_of,
-                       voxid, next, first, head, voxels, coors, num_points);
+    hipLaunchKernelGGL((k_grid_write<10>), dim3(blocks), dim3(kBlock), 0, st, points, n_points, n_feat, s, max_points, max_voxels, cell_of,
+                       voxid, next, first, head, voxels, coors, num_points, block_count, voxel_num);
   else
-    hipLaunchKernelGGL((k_grid_write<16>), dim3(grid), dim3(kBlock), 0, st, points, n_points, n_feat, s, max_points, max_voxels, cell_of,
-                       voxid, next, first, head, voxels, coors, num_points);
+    hipLaunchKernelGGL((k_grid_write<16>), dim3(blocks), dim3(kBlock), 0, st, points, n_points, n_feat, s, max_points, max_voxels, cell_of,
+                       voxid, next, first, head, voxels, coors, num_points, block_count, voxel_num);
   return check_launch("voxelize_hard_grid");
 }
 

@@ -336,7 +336,7 @@ class FusionTrainStep:
                  channels_last=True, sets=2, task="det", miopen_find=False, frames=4):
         from .mm.config import build_detector
         self.device = torch.device(device)
-        if self.device.type == "cuda" and miopen_find:
+        if self.device.type == "cuda" and miopen_find and os.environ.get("OMNIHD_DETERMINISTIC", "0") != "1":
             # MIOpen "find" mode: every convolution geometry is timed once over the applicable solvers instead of
             # taking the immediate-mode heuristic (41.0 -> 37.9 ms per step at R1; costs ~1 min of warm-up, so it is
             # opt-in: bench.py and the profiling scripts ask for it, the tests do not)
@@ -346,7 +346,10 @@ class FusionTrainStep:
             if _ops.deterministic():
                 # OMNIHD_DETERMINISTIC=1: every convolution pass with a kernel in this library runs on it (fixed-order sums);
                 # the few passes that stay on the library (7x7 stem, the 59-channel depth logits) must not pick its atomic solvers
+                # — and not through the find step: with the deterministic attribute set, find mode ends up on the library's
+                # naive reference kernels for them (28 ms each: the first deterministic bench ran 272 ms per step)
                 torch.backends.cudnn.deterministic = True
+                torch.backends.cudnn.benchmark = False
         torch.manual_seed(0)                         # identical initial weights on every rank
         cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)
         if task == "occ":

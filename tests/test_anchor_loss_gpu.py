@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _head(cuda, num_classes=4):
     from omnihd_amd.harness import reference_model_cfg
+    from omnihd_amd.mm import anchor_head  # noqa: F401  (registers the head and its helpers)
     from omnihd_amd.mm.registry import HEADS, build_from_cfg
     cfg = reference_model_cfg()
     h = dict(cfg["pts_bbox_head"], train_cfg=cfg["train_cfg"]["pts"], test_cfg=cfg["test_cfg"]["pts"], num_classes=num_classes)
