@@ -661,7 +661,9 @@ int omnihd_bn_train_fwd_f32(const float* x, const float* res, const float* gamma
 int omnihd_bn_train_bwd_f32(const float* gy, const float* y_mask, int relu_from_x, const float* x, const float* gamma,
                             const float* consts4c, float* gx, float* gres, float* sums2c, float* out5c, long long rows,
                             int c, void* workspace, size_t workspace_bytes, void* stream);
-/* One-call forms that also write the bf16 planes of their output (y resp. gx) for the adjacent fp32-grade convolution. */
+/* One-call forms that also write the bf16 planes of their output (y resp. gx) for the adjacent fp32-grade convolution.
+ * omnihd_bn_train_bwd_f32_planes with gx == NULL writes the planes ONLY (round 5: the convolution in front of the layer is the
+ * sole consumer of that gradient and reads planes anyway — no fp32 copy, no split pass).                                  */
 int omnihd_bn_train_fwd_f32_planes(const float* x, const float* res, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float var_correction, int relu, float* y,
                                    void* y_hi, void* y_lo, float* stats2c, float* consts4c, long long rows, int c, void* workspace,

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ gy, 
       masked[k] = g;
       out[k] = fmaf(g, ca[k], fmaf(xv[k], cb[k], cc[k]));
     }
-    store8(gx, i, out);
+    if (gx) store8(gx, i, out);                      // (gx NULL: the convolution behind this layer takes the planes ONLY)
     if (gx_hi) store_planes8(gx_hi, gx_lo, i, out);  // the convolution behind this layer reads these instead of a split pass over gx
     if (gres) store8(gres, i, masked);             // gradient of a residual added before the ReLU
   }
@@ -387,7 +387,7 @@ int bwd_apply_t(const void* gy, const void* y_mask, const float* fwd_scale_shift
                 bf16_t* gx_hi = nullptr, bf16_t* gx_lo = nullptr) {
   OMNIHD_REQUIRE(rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
   if (rows == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && gx, "null pointer");
+  OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && (gx || (gx_hi && gx_lo)), "null pointer");
   const int64_t n_vec = (int64_t)rows * (c / 8);
   const dim3 grid(grid_for(n_vec, 256 * 2));
 #define OMNIHD_APPLY(M)                                                                                                     \

@@ -348,7 +348,8 @@ class FusionTrainStep:
                 # the few passes that stay on the library (7x7 stem, the 59-channel depth logits) must not pick its atomic solvers
                 # — and not through the find step: with the deterministic attribute set, find mode ends up on the library's
                 # naive reference kernels for them (28 ms each: the first deterministic bench ran 272 ms per step)
-                torch.backends.cudnn.deterministic = True
+                if os.environ.get("OMNIHD_DET_CUDNN", "1") != "0":
+                    torch.backends.cudnn.deterministic = True
                 torch.backends.cudnn.benchmark = False
         torch.manual_seed(0)                         # identical initial weights on every rank
         cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)

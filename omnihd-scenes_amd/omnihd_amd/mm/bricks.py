@@ -122,7 +122,47 @@ def _count_batch(bn):
     bn._omnihd_pending_batches += 1
 
 
-def bn_act(x, bn, relu=True, residual=None, inplace=True):
+def _bn_train_fused_applies(channels, bn):
+    """Will ``bn_act`` take its fused training branch on ONE rank for an fp32 (N, channels, H, W) device tensor?  (What the
+    planes-only gradient contract needs to know before the convolution runs; mirrors ops.bn_train_supported.)"""
+    if not (isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training and bn.affine and bn.momentum is not None
+            and bn.track_running_stats and channels % 8 == 0 and channels <= 2048):
+        return False
+    if getattr(bn, "_omnihd_sync", False) or isinstance(bn, nn.SyncBatchNorm):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False                              # the exchange form of the backward has no plane output (yet)
+    return True
+
+
+def _hooked(*mods):
+    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in mods)
+
+
+def conv_bn_act(conv, bn, x, relu=True, residual=None):
+    """``relu(bn(conv(x)))`` for a convolution directly followed by its BatchNorm (nothing else sees the tensor between them).
+    fp32 step, split kernels in both backward directions of the convolution, fused training BatchNorm: the gradient between
+    the two travels as bf16 planes ONLY — the BatchNorm backward writes hi / lo instead of the fp32 tensor, the convolution's
+    backward reads them, and the split pass over that gradient (one launch + a read and a write of the whole tensor per layer)
+    is gone.  Everything else: the plain composition ``bn_act(conv(x), bn)``."""
+    from .. import ops
+    if (isinstance(conv, BevConv2d) and not _hooked(conv, bn) and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and torch.is_grad_enabled() and conv.groups == 1 and conv.padding_mode == "zeros" and not isinstance(conv.padding, str)
+            and x.dim() == 4 and ops._fp32_policy() != "miopen"
+            and ops.conv_split_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation)
+            and not ops.conv_split_all_miopen(x.shape, conv.weight.shape[0], conv.weight.shape[2], conv.stride, conv.padding,
+                                              conv.dilation, x.device.index)
+            and x.numel() > 0 and _bn_train_fused_applies(conv.out_channels, bn)
+            and (residual is None or (residual.is_cuda and residual.dtype == torch.float32))
+            and ops.conv_grad_planes_ok(x.shape, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, x.device.index)):
+        y = ops.conv_split(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, grad_planes_only=True)
+        if residual is None or (residual.shape == y.shape and residual.dtype == y.dtype):
+            return bn_act(y, bn, relu=relu, residual=residual, _grad_planes_only=True)
+        raise RuntimeError("conv_bn_act: the residual does not have the convolution's output shape / dtype")
+    return bn_act(conv(x), bn, relu=relu, residual=residual)
+
+
+def bn_act(x, bn, relu=True, residual=None, inplace=True, _grad_planes_only=False):
     """``relu(bn(x) + residual)``.  A frozen BatchNorm (eval mode, affine parameters without gradient) on a bf16 or fp32
     device tensor is an affine map with constant coefficients: ONE fused channels-last pass each way
     (csrc/affine_act.hip).  A training-mode BatchNorm on a device tensor runs on csrc/batch_norm.hip in either precision
@@ -160,7 +200,7 @@ def bn_act(x, bn, relu=True, residual=None, inplace=True):
         if bn.num_batches_tracked is not None:
             _count_batch(bn)
         return ops.bn_train_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, group,
-                                residual, unbiased_sync)
+                                residual, unbiased_sync, grad_planes_only=_grad_planes_only and group is None)
     if getattr(bn, "_omnihd_pending_batches", 0):
         _flush_batches_tracked(bn)                # torch's own forward may read the counter (momentum=None)
     out = bn(x)
@@ -175,6 +215,11 @@ def run_fused(seq, x):
     i = 0
     while i < len(mods):
         m = mods[i]
+        if isinstance(m, BevConv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.modules.batchnorm._BatchNorm):
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            x = conv_bn_act(m, mods[i + 1], x, relu=relu)
+            i += 3 if relu else 2
+            continue
         if isinstance(m, nn.modules.batchnorm._BatchNorm):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             x = bn_act(x, m, relu=relu)
@@ -332,8 +377,13 @@ class ConvModule(nn.Module):
         return getattr(self, self.norm_name) if self.with_norm else None
 
     def forward(self, x):
-        x = self.conv(x)
         relu = self.with_activation and isinstance(self.activate, nn.ReLU)
+        if self.with_norm and isinstance(self.norm, nn.modules.batchnorm._BatchNorm) and isinstance(self.conv, BevConv2d):
+            x = conv_bn_act(self.conv, self.norm, x, relu=relu)       # the tensor between conv and norm is seen by nobody else
+            if self.with_activation and not relu:
+                x = self.activate(x)
+            return x
+        x = self.conv(x)
         if self.with_norm:
             x = bn_act(x, self.norm, relu=relu) if isinstance(self.norm, nn.modules.batchnorm._BatchNorm) else self.norm(x)
             if self.with_activation and not (relu and isinstance(self.norm, nn.modules.batchnorm._BatchNorm)):

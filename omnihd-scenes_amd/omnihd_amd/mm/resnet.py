@@ -5,14 +5,14 @@ bevfusion.py:76-85) and ``BasicBlock`` inside DepthNet (cam_stream_lss_bevpoolv2
 Dense convolutions: executed by MIOpen through torch (channels-last bf16 when the harness enables it)."""
 from torch import nn
 
-from .bricks import bn_act, build_norm_layer
+from .bricks import conv_bn_act, bn_act, build_norm_layer
 from .registry import BACKBONES
 
 
 def _downsample(seq, x):
     """``downsample`` is Sequential(conv, norm) (mmdet naming downsample.0 / downsample.1)."""
     if isinstance(seq, nn.Sequential) and len(seq) == 2:
-        return bn_act(seq[0](x), seq[1], relu=False)
+        return conv_bn_act(seq[0], seq[1], x, relu=False)
     return seq(x)
 
 
@@ -32,10 +32,10 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = bn_act(self.conv1(x), getattr(self, self.norm1_name))
+        out = conv_bn_act(self.conv1, getattr(self, self.norm1_name), x)
         if self.downsample is not None:
             identity = _downsample(self.downsample, x)
-        return bn_act(self.conv2(out), getattr(self, self.norm2_name), residual=identity)
+        return conv_bn_act(self.conv2, getattr(self, self.norm2_name), out, residual=identity)
 
 
 class Bottleneck(nn.Module):
@@ -59,11 +59,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = bn_act(self.conv1(x), getattr(self, self.norm1_name))
-        out = bn_act(self.conv2(out), getattr(self, self.norm2_name))
+        out = conv_bn_act(self.conv1, getattr(self, self.norm1_name), x)
+        out = conv_bn_act(self.conv2, getattr(self, self.norm2_name), out)
         if self.downsample is not None:
             identity = _downsample(self.downsample, x)
-        return bn_act(self.conv3(out), getattr(self, self.norm3_name), residual=identity)
+        return conv_bn_act(self.conv3, getattr(self, self.norm3_name), out, residual=identity)
 
 
 @BACKBONES.register_module()

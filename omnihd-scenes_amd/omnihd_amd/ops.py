@@ -1711,8 +1711,9 @@ class _ConvSplit(torch.autograd.Function):
     bf16 planes (the same bytes as the fp32 tensor)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, grad_planes_only=False):
         dev = x.device
+        ctx.grad_planes_only = bool(grad_planes_only)
         x = x.contiguous(memory_format=torch.channels_last)
         k = weight.shape[2]
         geo = (tuple(x.shape), weight.shape[0], k, stride[0], padding[0], dilation[0], dev.index)
@@ -1757,12 +1758,17 @@ class _ConvSplit(torch.autograd.Function):
         stride, padding, dilation, geo, ok_d, ok_w = ctx.conv
         dev = g.device
         g_in = g
+        if getattr(g_in, "_omnihd_planes_only", False) and not ctx.grad_planes_only:
+            raise RuntimeError("a planes-only gradient reached a convolution that did not ask for one (conv_bn_act's contract)")
         g = g.float().contiguous(memory_format=torch.channels_last)
         want_w_split = ok_w and ctx.needs_input_grad[1] and not ctx.x_is_full
         gs = None
         if (ok_d and ctx.needs_input_grad[0]) or want_w_split:
             gs = take_planes(g_in) if g is g_in else None
             if gs is None:
+                if ctx.grad_planes_only:
+                    raise RuntimeError("the BatchNorm behind this convolution promised its input gradient as planes and did not "
+                                       "deliver them (conv_bn_act's contract)")
                 gs = split_f32(g)
         gx = gw = gb = None
         x_f32 = []
@@ -1844,7 +1850,7 @@ class _ConvSplit(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             n, c, h, w = g.shape
             gb = column_sums(g.permute(0, 2, 3, 1).reshape(n * h * w, c)).to(ctx.param_dtypes[1])
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 # counters of the optional fast paths actually taken in this process (bench.py: `fast_paths`)
@@ -2082,8 +2088,27 @@ def conv_split_supported(x, weight, stride, padding, dilation, groups=1):
     return any(conv_split_geometry(x.shape, weight.shape[0], weight.shape[2], stride, padding, dilation, groups))
 
 
-def conv_split(x, weight, bias, stride, padding, dilation=(1, 1)):
-    return _ConvSplit.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation))
+def conv_split(x, weight, bias, stride, padding, dilation=(1, 1), grad_planes_only=False):
+    return _ConvSplit.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(grad_planes_only))
+
+
+def conv_grad_planes_ok(x_shape, weight, bias, stride, padding, dilation, device_index):
+    """May the backward of this fp32 convolution take its output gradient as hi / lo planes ONLY?  Yes when every consumer of
+    that gradient inside ``_ConvSplit.backward`` is a split kernel: no bias (its gradient sums the fp32 tensor), data and weight
+    gradient on the split kernels under the current policy / persisted choices (a geometry not measured yet: no)."""
+    if bias is not None or os.environ.get("OMNIHD_GRAD_PLANES_ONLY", "1") == "0":
+        return False
+    k = weight.shape[2]
+    ok_f, ok_d, ok_w = conv_split_geometry(x_shape, weight.shape[0], k, stride, padding, dilation)
+    if not (ok_d and ok_w and weight.requires_grad):
+        return False
+    pol = _fp32_policy()
+    if pol == "split":
+        return True
+    if pol != "tune":
+        return False
+    geo = (tuple(x_shape), weight.shape[0], k, stride[0], padding[0], dilation[0], device_index)
+    return _SPLIT_CHOICE.get(("dgrad",) + geo) == "split" and _SPLIT_CHOICE.get(("wgrad",) + geo) == "split"
 
 
 def column_sums(rows2d):
@@ -2481,8 +2506,10 @@ def _f32c(t):
 
 class _BnTrainAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group, res, unbiased_sync=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group, res, unbiased_sync=False,
+                grad_planes_only=False):
         import torch.distributed as dist
+        ctx.grad_planes_only = bool(grad_planes_only)
         rows, c = _rows_view(x)
         dev = x.device
         ranks = dist.get_world_size(group) if group is not None else 1
@@ -2566,6 +2593,23 @@ class _BnTrainAct(torch.autograd.Function):
         st = _raw_stream()
         with _on(dev):
             ws = _wgrad_workspace(_SIZE_CACHE[("bn", rows, c)], dev)
+            if ctx.grad_planes_only and ctx.ranks == 1 and x.dtype == torch.float32 and x.numel() % 8 == 0:
+                # The convolution in front of this layer is the ONLY consumer of gx (conv_bn_act keeps the tensor between them
+                # to itself) and reads it as hi / lo planes: write the planes only.  The fp32-typed tensor autograd carries
+                # between the two nodes is a view of the plane buffer (same byte count) — its fp32 values are never read.
+                n = x.numel()
+                buf = torch.empty(2 * n, dtype=torch.bfloat16, device=dev)
+                gx_planes = tuple(buf[i * n:(i + 1) * n].as_strided(x.shape, x.stride()) for i in (0, 1))
+                gx = buf.view(torch.float32).as_strided(x.shape, x.stride())
+                check(L.omnihd_bn_train_bwd_f32_planes(
+                    gy.data_ptr(), yp, 1 if ctx.relu else 0, x.data_ptr(), gamma.data_ptr(), consts.data_ptr(), None,
+                    gx_planes[0].data_ptr(), gx_planes[1].data_ptr(), gresp, local.data_ptr(), out.data_ptr(), rows, c,
+                    ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_bwd_f32_planes")
+                gx._omnihd_planes = (gx_planes, gx._version, ("bn_gx_only", 0))
+                gx._omnihd_planes_only = True
+                FAST_PATHS["grad_planes_only"] = FAST_PATHS.get("grad_planes_only", 0) + 1
+                return (gx, out[0].to(ctx.param_dtypes[0]), out[1].to(ctx.param_dtypes[1]), None, None, None, None, None, None,
+                        gres, None, None)
             gx_planes = _alloc_planes(gx) if (ctx.gkey is not None and ctx.ranks == 1 and planes_wanted(ctx.gkey)) else None
             if gx_planes is not None:
                 check(L.omnihd_bn_train_bwd_f32_planes(
@@ -2593,7 +2637,7 @@ class _BnTrainAct(torch.autograd.Function):
                                                               out[3].data_ptr(), out[4].data_ptr(), gx.data_ptr(), gresp, rows, c,
                                                               st), "omnihd_bn_bwd_apply")
         return (gx, out[0].to(ctx.param_dtypes[0]), out[1].to(ctx.param_dtypes[1]), None, None, None, None, None, None,
-                gres, None)
+                gres, None, None)
 
 
 def bn_train_supported(x):
@@ -2604,13 +2648,13 @@ def bn_train_supported(x):
 
 
 def bn_train_act(x, weight, bias, running_mean, running_var, momentum, eps, relu=False, group=None, residual=None,
-                 unbiased_sync=False):
+                 unbiased_sync=False, grad_planes_only=False):
     """``act(BatchNorm_train(x) + residual)`` of a bf16 or fp32 (N,C,H,W) [made channels-last] or (N,C) tensor; statistics
     are the mean over ``group``'s ranks of the per-rank mean / mean of squares when a group with more than one rank is
     given (``unbiased_sync``: running_var takes the unbiased variance over all ranks' rows, as torch's SyncBatchNorm)."""
     cl = (lambda t: t.contiguous(memory_format=torch.channels_last)) if x.dim() == 4 else (lambda t: t.contiguous())
     return _BnTrainAct.apply(cl(x), weight, bias, running_mean, running_var, float(momentum), float(eps), bool(relu), group,
-                             None if residual is None else cl(residual), bool(unbiased_sync))
+                             None if residual is None else cl(residual), bool(unbiased_sync), bool(grad_planes_only))
 
 
 # --------------------------------------------------------------------------------------------

@@ -188,8 +188,15 @@ class BEVFUSION_depth(MVXFasterRCNN):
             BN, C, H, W = img_feats[0].shape
             view = img_feats[0].view(BN // self.num_views, self.num_views, C, H, W)
             rots, trans = self._cam_inverse(img_metas, view.device)
+            # OMNIHD_RADAR_JOIN=early: meet the radar branch BEFORE the view transformer, so that the bandwidth-bound pooling
+            # kernel and the BEV encoder have the memory system to themselves (the radar branch then overlaps the image backbone
+            # and neck only); late (default): after it
+            early = os.environ.get("OMNIHD_RADAR_JOIN", "late") == "early"
+            if early:
+                pts_feats = radar()
             img_bev_feat, depth_dist = self.lift_splat_shot_vis(view, rots, trans, lidar2img_rt=None, img_metas=img_metas)
-            pts_feats = radar()
+            if not early:
+                pts_feats = radar()
             if self.lc_fusion:
                 if img_bev_feat.shape[2:] != pts_feats[0].shape[2:]:
                     img_bev_feat = F.interpolate(img_bev_feat, pts_feats[0].shape[2:], mode="bilinear", align_corners=True)

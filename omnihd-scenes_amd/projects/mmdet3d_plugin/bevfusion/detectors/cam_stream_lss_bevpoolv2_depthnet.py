@@ -27,7 +27,7 @@ from torch import nn
 import omnihd_amd
 from omnihd_amd import ops as _ops
 from omnihd_amd.mm import build_conv_layer, build_norm_layer
-from omnihd_amd.mm.bricks import bn_act, run_fused
+from omnihd_amd.mm.bricks import bn_act, conv_bn_act, run_fused
 from omnihd_amd.mm.resnet import BasicBlock
 from omnihd_amd.plan import forward_tables, planned_pool
 from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2  # noqa: F401  (API parity)
@@ -55,7 +55,7 @@ class _ASPPModule(nn.Module):
         nn.init.kaiming_normal_(self.atrous_conv.weight)
 
     def forward(self, x):
-        return bn_act(self.atrous_conv(x), self.bn, relu=True, inplace=False)
+        return conv_bn_act(self.atrous_conv, self.bn, x, relu=True)
 
 
 class ASPP(nn.Module):
@@ -90,7 +90,7 @@ class ASPP(nn.Module):
         # concatenate in NHWC: the result is channels-last whatever the layout of the broadcast branch
         # (torch.cat of mixed layouts falls back to an NCHW result that the next conv has to re-lay out)
         cat = torch.cat([b.permute(0, 2, 3, 1) for b in branches], dim=3).permute(0, 3, 1, 2)
-        x = bn_act(self.conv1(cat), self.bn1, relu=True, inplace=False)
+        x = conv_bn_act(self.conv1, self.bn1, cat, relu=True)
         return self.dropout(x)
 
 
