@@ -336,7 +336,7 @@ class FusionTrainStep:
                  channels_last=True, sets=2, task="det", miopen_find=False, frames=4):
         from .mm.config import build_detector
         self.device = torch.device(device)
-        if self.device.type == "cuda" and miopen_find and os.environ.get("OMNIHD_DETERMINISTIC", "0") != "1":
+        if self.device.type == "cuda" and miopen_find:
             # MIOpen "find" mode: every convolution geometry is timed once over the applicable solvers instead of
             # taking the immediate-mode heuristic (41.0 -> 37.9 ms per step at R1; costs ~1 min of warm-up, so it is
             # opt-in: bench.py and the profiling scripts ask for it, the tests do not)
@@ -344,13 +344,14 @@ class FusionTrainStep:
         if self.device.type == "cuda":
             from . import ops as _ops
             if _ops.deterministic():
-                # OMNIHD_DETERMINISTIC=1: every convolution pass with a kernel in this library runs on it (fixed-order sums);
-                # the few passes that stay on the library (7x7 stem, the 59-channel depth logits) must not pick its atomic solvers
-                # — and not through the find step: with the deterministic attribute set, find mode ends up on the library's
-                # naive reference kernels for them (28 ms each: the first deterministic bench ran 272 ms per step)
-                if os.environ.get("OMNIHD_DET_CUDNN", "1") != "0":
+                # OMNIHD_DETERMINISTIC=1: every convolution pass with a kernel in this library runs on it (fixed-order sums).  What
+                # stays on the library — the 7x7 stem's forward, forward / data gradient of the 59-channel depth logits and of the
+                # deformable convolution's 18 offsets — measured run-to-run identical; their WEIGHT gradients were not (atomics)
+                # and run on this library with the output gradient padded to a multiple of 8 (ops.wgrad_split_padded)
+                # (torch.backends.cudnn.deterministic is NOT set: with that attribute the library ends up on its naive reference
+                # kernels for the leftovers — 28 ms each, 273 ms per step measured; OMNIHD_DET_CUDNN=1 sets it anyway)
+                if os.environ.get("OMNIHD_DET_CUDNN", "0") == "1":
                     torch.backends.cudnn.deterministic = True
-                torch.backends.cudnn.benchmark = False
         torch.manual_seed(0)                         # identical initial weights on every rank
         cfg = tiny_model_cfg(radar_dims) if res == "tiny" else model_cfg_for(res, radar_dims)
         if task == "occ":

@@ -2146,14 +2146,34 @@ class _ConvBiasColsum(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, padding, dilation, groups = ctx.conv
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        own_w = (ctx.needs_input_grad[1] and deterministic() and groups == 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                 and x.shape[1] % 8 == 0 and weight.shape[2] == weight.shape[3] and weight.shape[2] in (1, 3)
+                 and _pair_same(stride) is not None and _pair_same(padding) is not None and _pair_same(dilation) is not None)
+        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not own_w):
             gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0], groups,
-                                                            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+                                                            [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1] and not own_w), False])
+        if own_w:
+            # OMNIHD_DETERMINISTIC=1: the library's fp32 weight-gradient solvers for these layers (59 depth logits, the 18 offsets
+            # of the deformable convolution) accumulate with atomics — the only two gradients of the step that differed between
+            # runs (profiles/round5/determinism_leftovers.txt).  Ours with the output gradient zero-padded to a multiple of 8.
+            gw = wgrad_split_padded(x, g, weight.shape[2], stride[0], padding[0], dilation[0]).to(weight.dtype)
         if ctx.needs_input_grad[2]:
             gc = g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
             n, c, h, w = gc.shape
             gb = column_sums(gc.permute(0, 2, 3, 1).reshape(n * h * w, c)).to(ctx.bdtype)    # a view of the NHWC memory
         return gx, gw, gb, None, None, None, None
+
+
+def wgrad_split_padded(x, g, k, stride, padding, dilation):
+    """fp32-grade weight gradient (Cout,Cin,k,k) of a convolution whose output channel count is NOT a multiple of 8: the output
+    gradient is zero-padded to the next multiple (one small copy), the split chain runs, the padding rows are dropped."""
+    cout = g.shape[1]
+    cp = (cout + 7) // 8 * 8
+    xc = x.float().contiguous(memory_format=torch.channels_last)
+    gp = torch.zeros((g.shape[0], cp, g.shape[2], g.shape[3]), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+    gp[:, :cout].copy_(g)
+    dw = conv_wgrad_split(split_f32(xc), split_f32(gp), int(k), int(stride), int(padding), int(dilation))
+    return dw[:cout]
 
 
 def conv_bias_colsum_supported(x, weight, bias):
