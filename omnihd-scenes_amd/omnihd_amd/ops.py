@@ -2170,7 +2170,8 @@ def wgrad_split_padded(x, g, k, stride, padding, dilation):
     cout = g.shape[1]
     cp = (cout + 7) // 8 * 8
     xc = x.float().contiguous(memory_format=torch.channels_last)
-    gp = torch.zeros((g.shape[0], cp, g.shape[2], g.shape[3]), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+    gp = torch.empty((g.shape[0], cp, g.shape[2], g.shape[3]), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+    gp[:, cout:].zero_()
     gp[:, :cout].copy_(g)
     dw = conv_wgrad_split(split_f32(xc), split_f32(gp), int(k), int(stride), int(padding), int(dilation))
     return dw[:cout]
