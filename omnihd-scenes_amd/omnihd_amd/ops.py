@@ -812,6 +812,16 @@ def conv_wgrad(x, grad_out, kernel_size, stride=1, padding=0, dilation=1):
     dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
     geo = (B, H, W, cin, Ho, Wo, cout, k, k, int(stride), int(padding), int(dilation))
     L = lib()
+    if wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, int(stride), int(padding), int(dilation)):
+        g11 = (B, H, W, cin, Ho, Wo, cout, k, int(stride), int(padding), int(dilation))
+        with _on(dev):
+            nbytes = _SIZE_CACHE.get(("nhwc",) + g11)
+            if nbytes is None:
+                nbytes = _SIZE_CACHE[("nhwc",) + g11] = L.omnihd_conv_wgrad_nhwc_workspace_bytes(*g11)
+            ws = _wgrad_workspace(nbytes, dev)
+            check(L.omnihd_conv_wgrad_nhwc(x.data_ptr(), None, grad_out.data_ptr(), None, dw.data_ptr(), *g11, ws.data_ptr(), ws.numel(),
+                                           _raw_stream()), "omnihd_conv_wgrad_nhwc")
+        return dw.permute(0, 3, 1, 2)
     with _on(dev):
         nbytes = _SIZE_CACHE.get(geo)
         if nbytes is None:
@@ -843,6 +853,17 @@ def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1, out=N
         dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
     geo = (B, H, W, cin, Ho, Wo, cout, k, k, int(stride), int(padding), int(dilation))
     L = lib()
+    if wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, int(stride), int(padding), int(dilation)):
+        # straight from the NHWC planes (csrc/conv_wgrad_nhwc.hip): no staging launches — the small and middle-sized layers
+        g11 = (B, H, W, cin, Ho, Wo, cout, k, int(stride), int(padding), int(dilation))
+        with _on(dev):
+            nbytes = _SIZE_CACHE.get(("nhwc",) + g11)
+            if nbytes is None:
+                nbytes = _SIZE_CACHE[("nhwc",) + g11] = L.omnihd_conv_wgrad_nhwc_workspace_bytes(*g11)
+            ws = _wgrad_workspace(nbytes, dev)
+            check(L.omnihd_conv_wgrad_nhwc(xs[0].data_ptr(), xs[1].data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), dw.data_ptr(), *g11,
+                                           ws.data_ptr(), ws.numel(), _raw_stream()), "omnihd_conv_wgrad_nhwc")
+        return dw.permute(0, 3, 1, 2)
     with _on(dev):
         nbytes = _SIZE_CACHE.get(("split",) + geo)
         if nbytes is None:
@@ -853,6 +874,28 @@ def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1, out=N
         check(L.omnihd_conv_wgrad_split(xs[0].data_ptr(), xs[1].data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), dw.data_ptr(), *geo,
                                         ws.data_ptr(), ws.numel(), _raw_stream()), "omnihd_conv_wgrad_split")
     return dw.permute(0, 3, 1, 2)
+
+
+def wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation):
+    """Which of this library's two weight-gradient forms takes a geometry?  A RULE, not a measurement, so that a run's kernels —
+    and the last bits of its gradients — never depend on timing noise: the staged chain (pixel-major staging + the three-taps
+    kernel with register-shifted taps) keeps the 3x3 / stride-1 / pad-1 layers whose (Cout, Cin) tiles fill the chip with
+    three-tap workgroups (the BEV-sized layers: its staging pass is small beside its GEMM there); everything else — 1x1, strided,
+    dilated, small maps, narrow layers — goes straight from NHWC.  OMNIHD_WGRAD_NHWC=0 / 1 forces never / always."""
+    mode = os.environ.get("OMNIHD_WGRAD_NHWC", "auto")
+    if mode == "0" or k > 4:
+        return False
+    if not lib().omnihd_conv_wgrad_nhwc_workspace_bytes(B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation):
+        return False
+    if mode == "1":
+        return True
+    if k == 3 and stride == 1 and padding == 1 and dilation == 1:
+        tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * 3
+        mp = B * H * (((W + 1) + 7) // 8 * 8)
+        max_s = max(1, min(16, mp // (32 * 8)))
+        if tiles * max_s >= 192:                      # pick_split3 of csrc/conv_wgrad.hip finds a split: the chain's best case
+            return False
+    return True
 
 
 def conv3x3_wgrad(x, grad_out):

@@ -188,10 +188,12 @@ class BEVFUSION_depth(MVXFasterRCNN):
             BN, C, H, W = img_feats[0].shape
             view = img_feats[0].view(BN // self.num_views, self.num_views, C, H, W)
             rots, trans = self._cam_inverse(img_metas, view.device)
-            # OMNIHD_RADAR_JOIN=early: meet the radar branch BEFORE the view transformer, so that the bandwidth-bound pooling
-            # kernel and the BEV encoder have the memory system to themselves (the radar branch then overlaps the image backbone
-            # and neck only); late (default): after it
-            early = os.environ.get("OMNIHD_RADAR_JOIN", "late") == "early"
+            # Meet the radar branch BEFORE the view transformer (OMNIHD_RADAR_JOIN=early, the default since round 5), so that the
+            # bandwidth-bound pooling kernel and the BEV encoder have the memory system to themselves — the radar branch then
+            # overlaps the image backbone and neck only; late: after it.  A/B in the bench, two runs each
+            # (profiles/round5/radar_join_ab.txt): fp32 step 46.36 / 46.35 -> 46.01 / 46.01 ms, pooling forward in the step
+            # 41.9 / 41.4 -> 41.2 / 40.2 us; the pooling BACKWARD meets the radar branch's backward instead (54.4 -> 59 us).
+            early = os.environ.get("OMNIHD_RADAR_JOIN", "early") != "late"
             if early:
                 pts_feats = radar()
             img_bev_feat, depth_dist = self.lift_splat_shot_vis(view, rots, trans, lidar2img_rt=None, img_metas=img_metas)
