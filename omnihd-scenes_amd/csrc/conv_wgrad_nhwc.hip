@@ -1,64 +1,124 @@
 // Weight gradient of a convolution straight from the NHWC operands: no pixel-major staging pass (round 5).
 //
-// Where it sits: the weight gradients of the small and middle-sized layers of the detector — ResNet-50's bottlenecks
-// (reference config projects/configs/bevfusion_NewScenes/bevfusion.py:77-85), FPN / FPNC adapters, DepthNet's 3x3 layers
-// (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:563-609), SECOND / SECONDFPN (bevfusion.py:62-74), the anchor head —
-// 58 geometries per step on which the staged chain of csrc/conv_wgrad.hip (two pixel-major staging launches per plane pair + GEMM
-// + slab sum) lost to the library's fp32 kernels, which cost 4-5 launches each and accumulate with atomics.
+// Where it sits: the weight gradients of the detector's convolutions — ResNet-50's bottlenecks (reference config
+// projects/configs/bevfusion_NewScenes/bevfusion.py:77-85), FPN / FPNC adapters, DepthNet's 3x3 layers
+// (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:563-609), SECOND / SECONDFPN (bevfusion.py:62-74), the BEV encoder and
+// the anchor head.
 //
 //   dW[n][tap][c] = sum over output pixels m of  G[m][n] * X[src_tap(m)][c]
 //
 // is a GEMM whose reduction index is the PIXEL — the slow dimension of both NHWC operands.  csrc/conv_wgrad.hip re-lays both operands
-// pixel-major first; here the tiles go into LDS as they lie in memory ([pixel][channel], LDS-DMA, 256-byte rows) and the MFMA
-// fragments — 8 consecutive PIXELS of one channel per lane — are fetched with gfx950's transposing LDS read
+// pixel-major first (k_to_kmajor); here the tiles go into LDS as they lie in memory ([pixel][channel], LDS-DMA, 256-byte rows) and the
+// MFMA fragments — 8 consecutive PIXELS of one channel per lane — are fetched with gfx950's transposing LDS read
 // `ds_read_b64_tr_b16`: each 16-lane group reads a [4 pixel][16 channel] block (lane i supplies the address of pixel i/4, channels
 // 4*(i%4)..+3) and lane i receives channel i of the 4 pixels (checked on the device: scripts/micro/tr_read.hip, 0 mismatches).
-// A workgroup computes a 128 x 128 tile of (Cout, Cin) for ONE tap over its share of the pixels (split-K, fp32 slabs summed in a
-// fixed order: deterministic).  The source pixel of every tile row is computed by the lane that fetches it (any stride, padding,
-// dilation); a source pixel outside the image is an out-of-range buffer offset and arrives as a row of zeros, so no fragment is
-// ever masked.  SPLIT: fp32-grade sums from hi / lo planes (G_hi X_hi + G_hi X_lo + G_lo X_hi).
-// Two LDS stages (32 / 64 KB per workgroup): the next K-step is in flight while this one multiplies, and 2-4 workgroups per CU cover
-// each other's fills.  (A deeper ring does not pay with the transposing read as a compiler builtin: hipcc puts `s_waitcnt vmcnt(0)`
-// in front of every `ds_read_b64_tr_b16` while an LDS-DMA is pending — it does not for plain LDS loads — so every fill is drained at
-// the top of a K-step anyway; ISA checked.  Inline-asm reads with hand-counted lgkmcnt would lift that.)
+//
+// A workgroup computes a 128 x 128 tile of (Cout, Cin) over its share of the pixels (split-K, fp32 slabs summed in a fixed order:
+// deterministic) in one of two forms:
+//   one tap    any kernel <= 4x4, stride, padding, dilation: the source pixel of every tile row is computed by the lane that
+//              fetches it; a source pixel outside the image is an out-of-range buffer offset and arrives as a row of zeros.
+//   three taps 3x3 / stride 1 / pad 1 / dilation 1: the reduction runs over a PADDED raster (one zero column behind every image row,
+//              one zero row above every image — both are out-of-range fetches, nothing is materialised), on which the three taps
+//              of a kernel row are the same X rows shifted by one pixel: a 34-row X tile serves three 128 x 128 accumulators, so
+//              a K-step's MFMAs triple over nearly the same L2 -> LDS traffic.
+// LDS rows are 256 bytes = the bank period, so the four pixel rows a 16-lane group reads would collide on the same banks: the
+// 32-byte units of a row are XOR-swizzled by f(row) = 2 * (row % 4) + (row / 8) % 2 on the way in (each loader lane simply fetches
+// a different 16-byte chunk) and again on the fragment reads — any four consecutive rows x two adjacent units then cover all eight
+// units, for shifted taps as well.
+// The transposing reads are inline assembly: as a compiler builtin every one of them is preceded by `s_waitcnt vmcnt(0)` while an
+// LDS-DMA is pending (hipcc 7.2; it does not do that for plain LDS loads), which drains the fill ring at the top of every K-step.
+// With hand-counted lgkmcnt / vmcnt the ring runs STAGES deep and the reads of the next tap are in flight under the MFMAs of this one.
+// SPLIT: fp32-grade sums from hi / lo planes (G_hi X_hi + G_hi X_lo + G_lo X_hi).
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace omnihd {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_ptr_t;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int kKP = 32;          // pixels per K-step
 constexpr int kT = 128;          // tile edge (channels)
+constexpr int kRowBytes = kT * 2;
 
 struct WgNhwcArgs {
   int B, H, W, Cin, Ho, Wo, Cout;
   int k, stride, pad, dil;
   int tiles_n, tiles_c, n_split, px_per_split;   // px_per_split: a multiple of kKP
   long long slab_stride;                          // floats between the slabs of consecutive splits (0: n_split == 1, dst = dw)
+  int three;                                      // three-taps form
+  int total, per_xcd;                             // workgroups with work; launched: 8 * per_xcd
+  int RW, RH;                                     // the raster the reduction runs over: (Wo, Ho), or (W + 1, H + 1) padded
 };
 
-template <bool SPLIT, int STAGES>
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int OFF>
+__device__ __forceinline__ void tr_read(v2i& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void tie(v2i& r) { asm volatile("" : "+v"(r)); }       // "r was written by the asm above": orders its users
+__device__ __forceinline__ bf16x8 frag_of(v2i lo, v2i hi) {
+  const v4i v = {lo.x, lo.y, hi.x, hi.y};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | ((row >> 3) & 1); }
+
+struct RowPos { int cx, cy, cb; };
+
+template <bool SPLIT, bool T3, int STAGES>
 __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __restrict__ G, const unsigned short* __restrict__ G2,
                                                     const unsigned short* __restrict__ X, const unsigned short* __restrict__ X2,
                                                     float* __restrict__ dst, const WgNhwcArgs a) {
   constexpr int PLANES = SPLIT ? 2 : 1;
-  constexpr int TILE = kKP * kT;                                  // elements of one [32 pixel][128 channel] tile (8 KB)
-  constexpr int STAGE = 2 * PLANES * TILE;                        // G_hi [, G_lo], X_hi [, X_lo]
-  constexpr int CALLS = 4 * PLANES;                               // LDS-DMA calls (1 KB = 4 pixel rows) per wavefront and K-step
-  __shared__ __attribute__((aligned(16))) unsigned short sm[STAGES * STAGE];
+  constexpr int NT = T3 ? 3 : 1;                                  // taps (accumulator sets) per workgroup
+  constexpr int XROWS = T3 ? 48 : 32;                             // rows of an X tile (three taps: 34 used, 36 fetched, 48 addressed)
+  constexpr int XR = T3 ? 3 : 2;                                  // X rows per loader lane
+  constexpr int GB = kKP * kRowBytes;                             // bytes of a G tile (8 KB)
+  constexpr int XB = XROWS * kRowBytes;                           // bytes of an X tile
+  constexpr int XBASE = PLANES * GB;                              // first X tile inside a stage
+  constexpr int STAGE_B = PLANES * (GB + XB);
+  constexpr int CALLS = PLANES * (2 + XR);                        // LDS-DMA calls (1 KB = 4 pixel rows) per wavefront and K-step
+  constexpr int PER = 4 * PLANES;                                 // transposing reads per fragment group (2 blocks x planes x 2 halves)
+  __shared__ __attribute__((aligned(16))) unsigned char sm[STAGES * STAGE_B];
 
   const int taps = a.k * a.k;
-  int t = blockIdx.x;
-  const int sp = t % a.n_split; t /= a.n_split;
-  const int tap = t % taps; t /= taps;
-  const int ct = t % a.tiles_c, nt = t / a.tiles_c;
-  const int ky = tap / a.k, kx = tap - ky * a.k;
-  const int M = a.B * a.Ho * a.Wo;
+  // Work order: the list of (split, Cout tile, Cin tile, tap group) — tap group fastest — is cut into 8 contiguous runs, one per
+  // XCD (workgroup b runs on XCD b % 8): the ~32 workgroups an XCD runs at a time are then neighbours in that list, i.e. the same
+  // pixel range and mostly the same G / X channel slices, which they fetch into their shared L2 once.  (Split-fastest order, the
+  // first version, had every workgroup of an XCD stream its own pixel range: 5 TB/s of L2 misses on 1024 -> 1024 at 160 x 240.)
+  const int t_lin = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  if (t_lin >= a.total) return;
+  const int n_tg = T3 ? 3 : taps;
+  int t = t_lin;
+  const int tg = t % n_tg; t /= n_tg;                            // tap group: kernel row (three taps) or tap
+  const int ct = t % a.tiles_c; t /= a.tiles_c;
+  const int nt = t % a.tiles_n;
+  const int sp = t / a.tiles_n;
+  const int ky = T3 ? tg : tg / a.k, kx0 = T3 ? 0 : tg - ky * a.k;
+  const int RW = a.RW, RH = a.RH;
+  const int M = a.B * RH * RW;                                    // raster positions
   const int m_begin = sp * a.px_per_split;
   const int m_end = min(M, m_begin + a.px_per_split);
   const int n_steps = m_begin < m_end ? (m_end - m_begin + kKP - 1) / kKP : 0;
@@ -68,152 +128,246 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
   const int n0 = nt * kT, c0 = ct * kT;
 
   constexpr unsigned kOOB = 0x80000000u;
-  const unsigned g_bytes = (unsigned)((size_t)M * a.Cout * 2);
+  const unsigned g_bytes = (unsigned)((size_t)a.B * a.Ho * a.Wo * a.Cout * 2);
   const unsigned x_bytes = (unsigned)((size_t)a.B * a.H * a.W * a.Cin * 2);
   const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)G, 0, (int)g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t g2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? G2 : G), 0, (int)g_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t x2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? X2 : X), 0, (int)x_bytes, 0x00020000);
 
-  // ---- loader state: this lane fetches chunk q (16 bytes = 8 channels) of the tile rows p0 = 4 * wave + lane / 16 and p0 + 16 -----
+  // ---- loader: this lane fills LDS chunk q of the tile rows prow + 16 r; the chunk it fetches is the swizzled one -------------
   const int q = lane & 15;
   const int prow = 4 * wave + (lane >> 4);
-  const bool g_chan_ok = n0 + q * 8 < a.Cout, x_chan_ok = c0 + q * 8 < a.Cin;
-  int ox[2], oy[2], ob[2];                        // output pixel of the two rows at the NEXT K-step to issue
+  auto src_chunk = [&](int row) { return ((((q >> 1) ^ swz(row)) << 1) | (q & 1)) * 8; };     // first channel of the fetched chunk
+  auto locate = [&](long long u) {            // raster position (may be up to one image before the first) -> (column, row, image)
+    RowPos p;
+    const long long img = (long long)RH * RW;
+    const long long u2 = u + img;
+    p.cx = (int)(u2 % RW);
+    const long long r = u2 / RW;
+    p.cy = (int)(r % RH);
+    p.cb = (int)(r / RH) - 1;
+    return p;
+  };
+  // one K-step further: + 32 positions in the mixed radix (RW, RH), branch-free (32 = (sb * RH + sy) * RW + sx)
+  const int sx = kKP % RW, sy = (kKP / RW) % RH, sb = (kKP / RW) / RH;
+  auto advance = [&](RowPos& p) {
+    p.cx += sx;
+    const int c1 = p.cx >= RW;
+    p.cx -= c1 ? RW : 0;
+    p.cy += sy + c1;
+    const int c2 = p.cy >= RH;
+    p.cy -= c2 ? RH : 0;
+    p.cb += sb + c2;
+  };
+  RowPos gp[2], xp[XR];
+  int g_ch[2], x_ch[XR];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    const int m = m_begin + prow + 16 * r;
-    ox[r] = m % a.Wo;
-    const int rest = m / a.Wo;
-    oy[r] = rest % a.Ho;
-    ob[r] = rest / a.Ho;
+    gp[r] = locate((long long)m_begin + prow + 16 * r);
+    g_ch[r] = n0 + src_chunk(prow + 16 * r);
   }
-  int m_issue = m_begin;                          // first pixel of the next K-step to issue
-  auto issue = [&](int stage, bool real) {
-    unsigned short* base = sm + stage * STAGE;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int p = prow + 16 * r;
-      const int m = m_issue + p;
-      const bool live = real && m < m_end;
-      // G row: output pixel m, channels n0 + 8 q ..
-      const unsigned goff = (live && g_chan_ok) ? (unsigned)(((size_t)m * a.Cout + n0 + q * 8) * 2) : kOOB;
-      // X row: the tap's source pixel of output pixel m (outside the image: zeros)
-      const int iy = oy[r] * a.stride - a.pad + ky * a.dil, ix = ox[r] * a.stride - a.pad + kx * a.dil;
-      const bool inside = live && x_chan_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      const unsigned xoff = inside ? (unsigned)((((size_t)ob[r] * a.H + iy) * a.W + ix) * a.Cin * 2 + (c0 + q * 8) * 2) : kOOB;
-      // LDS destination of the call: 4 rows x 256 B starting at row 4 * wave + 16 r (lane-linear: row lane / 16, chunk lane % 16)
-      unsigned short* gd = base + (4 * wave + 16 * r) * kT;
-      unsigned short* xd = base + PLANES * TILE + (4 * wave + 16 * r) * kT;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t*)gd, 16, goff, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t*)xd, 16, xoff, 0, 0, 0);
-      if constexpr (SPLIT) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(g2_rsrc, (lds_ptr_t*)(gd + TILE), 16, goff, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x2_rsrc, (lds_ptr_t*)(xd + TILE), 16, xoff, 0, 0, 0);
+  for (int r = 0; r < XR; ++r) {
+    // three taps: X tile row j holds raster position (K-step start) + j - 1, one raster row up / down for the outer kernel rows
+    xp[r] = T3 ? locate((long long)m_begin + prow + 16 * r - 1 + (long long)(ky - 1) * RW) : gp[r < 2 ? r : 0];
+    x_ch[r] = c0 + src_chunk(prow + 16 * r);
+  }
+  int m_issue = m_begin;                          // first raster position of the next K-step to issue
+  auto issue_g = [&](int stage, bool real) {
+    unsigned char* base = sm + stage * STAGE_B;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                 // G rows
+      const RowPos p = gp[r];
+      bool ok = real & ((m_issue + prow + 16 * r) < m_end) & (g_ch[r] < a.Cout);
+      unsigned off;
+      if constexpr (T3) {
+        ok = ok & (p.cx < a.W) & (p.cy >= 1);     // (image index < B follows from the position < M)
+        off = (unsigned)((((size_t)p.cb * a.H + (p.cy - 1)) * a.W + p.cx) * a.Cout + g_ch[r]) * 2u;
+      } else {
+        off = (unsigned)((((size_t)p.cb * RH + p.cy) * RW + p.cx) * a.Cout + g_ch[r]) * 2u;
       }
+      const unsigned goff = ok ? off : kOOB;
+      unsigned char* gd = base + (4 * wave + 16 * r) * kRowBytes;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t*)gd, 16, goff, 0, 0, 0);
+      if constexpr (SPLIT) __builtin_amdgcn_raw_ptr_buffer_load_lds(g2_rsrc, (lds_ptr_t*)(gd + GB), 16, goff, 0, 0, 0);
     }
-    // advance the two rows by one K-step of pixels
+  };
+  auto issue_x = [&](int stage, bool real) {      // ... then the X rows, and one K-step further
+    unsigned char* base = sm + stage * STAGE_B;
+#pragma unroll
+    for (int r = 0; r < XR; ++r) {
+      const RowPos p = xp[r];
+      bool ok = real & (x_ch[r] < a.Cin);
+      unsigned off;
+      if constexpr (T3) {
+        ok = ok & (p.cx < a.W) & (p.cy >= 1) & ((unsigned)p.cb < (unsigned)a.B) & (r < 2 || wave == 0);
+        off = (unsigned)((((size_t)p.cb * a.H + (p.cy - 1)) * a.W + p.cx) * a.Cin + x_ch[r]) * 2u;
+      } else {
+        const int iy = p.cy * a.stride - a.pad + ky * a.dil, ix = p.cx * a.stride - a.pad + kx0 * a.dil;
+        ok = ok & ((m_issue + prow + 16 * r) < m_end) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        off = (unsigned)((((size_t)p.cb * a.H + iy) * a.W + ix) * a.Cin + x_ch[r]) * 2u;
+      }
+      const unsigned xoff = ok ? off : kOOB;
+      unsigned char* xd = base + XBASE + (4 * wave + 16 * r) * kRowBytes;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t*)xd, 16, xoff, 0, 0, 0);
+      if constexpr (SPLIT) __builtin_amdgcn_raw_ptr_buffer_load_lds(x2_rsrc, (lds_ptr_t*)(xd + XB), 16, xoff, 0, 0, 0);
+    }
     m_issue += kKP;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      ox[r] += kKP;
-      while (ox[r] >= a.Wo) {
-        ox[r] -= a.Wo;
-        if (++oy[r] == a.Ho) { oy[r] = 0; ++ob[r]; }
-      }
+    for (int r = 0; r < 2; ++r) advance(gp[r]);
+    if constexpr (T3) {
+#pragma unroll
+      for (int r = 0; r < XR; ++r) advance(xp[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < XR; ++r) xp[r] = gp[r];
     }
   };
+  auto issue = [&](int stage, bool real) { issue_g(stage, real); issue_x(stage, real); };
 
-  f32x16 acc[2][2];
+  f32x16 acc[NT][2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][i][j][r] = 0.f;
 
   // ---- fragment reads: wave (wm, wn) owns rows n = wm*64 .. +63 of the tile's Cout range and c = wn*64 .. +63 of its Cin range ----
+  // A 16-lane group fetches a [4 pixel][16 channel] block: this lane's 8-byte piece is pixel row 8 * (grp / 2) + li / 4 (+ 4 for the
+  // second half of its 8 pixels, + the tap's shift), 32-byte unit (block base / 16 + grp % 2) ^ swz(row), bytes 8 * (li % 4) ..
   const int wm = wave >> 1, wn = wave & 1;
   const int grp = lane >> 4, li = lane & 15;
-  // byte offset inside a [32][128] tile of this lane's 8-byte piece for slice 0, first half (pixels 0-3 of the lane's 8), block 0:
-  // pixel 8 * (grp / 2) + li / 4, channel 16 * (grp % 2) + 4 * (li % 4)
-  const int frag_px = 8 * (grp >> 1) + (li >> 2);
-  const int frag_ch = 16 * (grp & 1) + 4 * (li & 3);
-  auto tr8 = [&](const unsigned short* tile, int slice, int ch_base) {
-    // 8 pixels (16 * slice + 8 * (lane / 32) ..+7) of channel ch_base + lane % 32, as one MFMA operand
-    const unsigned short* p0 = tile + (16 * slice + frag_px) * kT + ch_base + frag_ch;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * kT));
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-    u.s.a = lo; u.s.b = hi;
-    return u.v;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sm;
+  auto piece = [&](int row, int unit0) {       // byte offset inside a tile, MFMA block i = 0 (block 1: ^ 64)
+    return (unsigned)(row * kRowBytes + (((unit0 + (grp & 1)) ^ swz(row)) << 5) + 8 * (li & 3));
   };
-  auto wait_stage = [&]() {   // this wave's fills of the next K-step have landed: (STAGES - 2) younger K-steps may be outstanding
-    __builtin_amdgcn_sched_barrier(0);
-    if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (CALLS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // STAGES == 3
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  static_assert(STAGES == 2 || STAGES == 3, "literal vmcnt counts");
+  unsigned ga[2][2], xa[NT][2][2];              // [half][block], [tap][half][block]
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * (grp >> 1) + (li >> 2) + 4 * h;
+    ga[h][0] = piece(row, wm * 4);
+    ga[h][1] = ga[h][0] ^ 64u;
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+      xa[tp][h][0] = piece(row + tp, wn * 4);
+      xa[tp][h][1] = xa[tp][h][0] ^ 64u;
+    }
+  }
+
+  v2i gq[2][2][PLANES][2];                       // [slice][block][plane][half]
+  v2i xq[2][2][PLANES][2];                       // [buffer][block][plane][half]
 
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s, s < n_steps);
   int stage = 0;
   for (int step = 0; step < n_steps; ++step) {
-    wait_stage();
-    __builtin_amdgcn_s_barrier();
-    const unsigned short* base = sm + stage * STAGE;
-    const unsigned short* g_hi = base;
-    const unsigned short* x_hi = base + PLANES * TILE;
-    bf16x8 fa[2][2], fb[2][2], fa2[2][2], fb2[2][2];                  // [slice][block]
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm<CALLS*(STAGES - 2)>();               // this wave's fills of this K-step have landed
+    __builtin_amdgcn_s_barrier();                // ... everybody's; and everybody is done reading the stage before this one
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned sbase = lds0 + (unsigned)stage * (unsigned)STAGE_B;
+
+    auto read_g = [&](auto S) {
+      static_for<2>([&](auto I) {
+        static_for<PLANES>([&](auto P) {
+          static_for<2>([&](auto Hh) {
+            tr_read<P * GB + S * 16 * kRowBytes>(gq[S][I][P][Hh], sbase + ga[Hh][I]);
+          });
+        });
+      });
+    };
+    auto read_x = [&](auto Q) {                  // group Q = slice * NT + tap -> buffer Q % 2
+      constexpr int S = Q / NT, TP = Q % NT, BUF = Q % 2;
+      static_for<2>([&](auto I) {
+        static_for<PLANES>([&](auto P) {
+          static_for<2>([&](auto Hh) {
+            tr_read<XBASE + P * XB + S * 16 * kRowBytes>(xq[BUF][I][P][Hh], sbase + xa[TP][Hh][I]);
+          });
+        });
+      });
+    };
+    auto tie_x = [&](auto BUF) {
+      static_for<2>([&](auto I) { static_for<PLANES>([&](auto P) { static_for<2>([&](auto Hh) { tie(xq[BUF][I][P][Hh]); }); }); });
+    };
+    auto mma = [&](auto Q) {
+      constexpr int S = Q / NT, TP = Q % NT, BUF = Q % 2;
+      bf16x8 fa[2], fb[2], fa2[2], fb2[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[s][i] = tr8(g_hi, s, wm * 64 + i * 32);
-        fb[s][i] = tr8(x_hi, s, wn * 64 + i * 32);
+        fa[i] = frag_of(gq[S][i][0][0], gq[S][i][0][1]);
+        fb[i] = frag_of(xq[BUF][i][0][0], xq[BUF][i][0][1]);
         if constexpr (SPLIT) {
-          fa2[s][i] = tr8(g_hi + TILE, s, wm * 64 + i * 32);
-          fb2[s][i] = tr8(x_hi + TILE, s, wn * 64 + i * 32);
+          fa2[i] = frag_of(gq[S][i][PLANES - 1][0], gq[S][i][PLANES - 1][1]);
+          fb2[i] = frag_of(xq[BUF][i][PLANES - 1][0], xq[BUF][i][PLANES - 1][1]);
         }
       }
-    __builtin_amdgcn_sched_barrier(0);
-    issue((stage + STAGES - 1) % STAGES, step + STAGES - 1 < n_steps);   // its buffer was last read before this barrier
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
       if constexpr (SPLIT) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i], fb[j], acc[TP][i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb2[s][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb2[j], acc[TP][i][j], 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < 2; ++j) acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[TP][i][j], 0, 0, 0);
+    };
+
+    read_g(std::integral_constant<int, 0>{});
+    read_g(std::integral_constant<int, 1>{});
+    read_x(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    // the fills of K-step + STAGES - 1 go into the stage everybody left before this barrier; their address arithmetic and DMA calls
+    // are handed to the scheduler together with the first MFMA groups (G rows with group 0, X rows with group 1 / 0)
+    const int fill_stage = (stage + STAGES - 1) % STAGES;
+    const bool fill_real = step + STAGES - 1 < n_steps;
+    static_for<2 * NT>([&](auto Q) {
+      if constexpr (Q + 1 < 2 * NT) {
+        read_x(std::integral_constant<int, Q + 1>{});
+        wait_lgkm<PER>();                        // all but the group just requested
+      } else {
+        wait_lgkm<0>();
+      }
+      if constexpr (Q == 0) {
+        static_for<2>([&](auto S) {
+          static_for<2>([&](auto I) { static_for<PLANES>([&](auto P) { static_for<2>([&](auto Hh) { tie(gq[S][I][P][Hh]); }); }); });
+        });
+      }
+      tie_x(std::integral_constant<int, Q % 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(Q);
+      if constexpr (Q == 0) issue_g(fill_stage, fill_real);
+      if constexpr (Q == (NT > 1 ? 1 : 0)) issue_x(fill_stage, fill_real);
+      __builtin_amdgcn_sched_barrier(0);
+    });
     stage = (stage + 1) % STAGES;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // drain the dummy tail fills before the epilogue
+  wait_vm<0>();                                  // drain the dummy tail fills before the epilogue
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (B row = input channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* out = dst + (size_t)sp * a.slab_stride;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int tp = 0; tp < NT; ++tp) {
+    const int tap = T3 ? ky * 3 + tp : tg;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int c = c0 + wn * 64 + j * 32 + (lane & 31);
-        if (n < a.Cout && c < a.Cin) out[((size_t)n * taps + tap) * a.Cin + c] = acc[i][j][r];
-      }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int c = c0 + wn * 64 + j * 32 + (lane & 31);
+          if (n < a.Cout && c < a.Cin) out[((size_t)n * taps + tap) * a.Cin + c] = acc[tp][i][j][r];
+        }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_sum_slabs_nhwc(const float* __restrict__ slab, int n_split, size_t n, float* __restrict__ out) {
@@ -224,26 +378,62 @@ __global__ __launch_bounds__(256) void k_sum_slabs_nhwc(const float* __restrict_
   }
 }
 
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 bool nhwc_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int k, int stride, int pad, int dil, WgNhwcArgs* a) {
   if (batch <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ho <= 0 || wo <= 0) return false;
   if (k < 1 || k > 4 || stride < 1 || dil < 1 || pad < 0 || cin % 8 || cout % 8) return false;
   if (ho != (h + 2 * pad - dil * (k - 1) - 1) / stride + 1 || wo != (w + 2 * pad - dil * (k - 1) - 1) / stride + 1) return false;
-  const long long M = (long long)batch * ho * wo;
-  if (M * cout * 2 >= (1ll << 31) || (long long)batch * h * w * cin * 2 >= (1ll << 31)) return false;    // 32-bit buffer offsets
+  const long long Mo = (long long)batch * ho * wo;
+  if (Mo * cout * 2 >= (1ll << 31) || (long long)batch * h * w * cin * 2 >= (1ll << 31)) return false;    // 32-bit buffer offsets
   a->B = batch; a->H = h; a->W = w; a->Cin = cin; a->Ho = ho; a->Wo = wo; a->Cout = cout;
   a->k = k; a->stride = stride; a->pad = pad; a->dil = dil;
   a->tiles_n = (cout + kT - 1) / kT; a->tiles_c = (cin + kT - 1) / kT;
-  const long long tiles = (long long)a->tiles_n * a->tiles_c * k * k;
+  static const int three_mode = env_int("OMNIHD_WGRAD_NHWC_THREE", 1);
+  const long long tiles_cn = (long long)a->tiles_n * a->tiles_c;
+  // three taps: where the (Cout, Cin) tiles x 3 kernel rows still give the chip work (one workgroup per CU: 120 KB of LDS)
+  a->three = three_mode && k == 3 && stride == 1 && pad == 1 && dil == 1 && (long long)(h + 1) * (w + 1) * batch < (1ll << 30);
+  if (a->three) {
+    a->RW = w + 1; a->RH = h + 1;
+  } else {
+    a->RW = wo; a->RH = ho;
+  }
+  const long long M = (long long)batch * a->RH * a->RW;
   const int steps = (int)((M + kKP - 1) / kKP);
-  long long sp = (3 * kCUs + tiles - 1) / tiles;                 // aim at >= 3 workgroups per CU
-  const long long max_sp = steps / 4 > 0 ? steps / 4 : 1;         // at least 4 K-steps per split
-  if (sp > max_sp) sp = max_sp;
-  if (sp > 64) sp = 64;
+  const long long groups = tiles_cn * (a->three ? 3 : k * k);
+  const long long slab_floats = (long long)cout * k * k * cin;
+  long long sp;
+  if (a->three) {
+    // whole rounds of kCUs workgroups; the fewest rounds that fill >= 93 % of their slots, at least 8 K-steps per split
+    const long long max_sp = steps / 8 > 0 ? steps / 8 : 1;
+    sp = 1;
+    double best = 0.0;
+    for (int rounds = 1; rounds <= 4; ++rounds) {
+      long long s = (long long)kCUs * rounds / groups;
+      if (s < 1) s = 1;
+      if (s > max_sp) s = max_sp;
+      const long long wgs = groups * s;
+      const double eff = (double)wgs / (double)(((wgs + kCUs - 1) / kCUs) * kCUs);
+      if (eff > best + 1e-9) { best = eff; sp = s; }
+      if (eff >= 0.93 || s == max_sp) break;
+    }
+  } else {
+    sp = (3 * kCUs + groups - 1) / groups;                           // aim at >= 3 workgroups per CU
+    const long long max_sp = steps / 4 > 0 ? steps / 4 : 1;           // at least 4 K-steps per split
+    if (sp > max_sp) sp = max_sp;
+  }
+  if (sp > (a->three ? 512 : 64)) sp = a->three ? 512 : 64;    // (the slab sum is one thread per element over all splits)
+  while (sp > 1 && sp * slab_floats * 4 > (64ll << 20)) --sp;        // slabs of at most 64 MB
   if (sp < 1) sp = 1;
   const int steps_per = (int)((steps + sp - 1) / sp);
   a->n_split = (steps + steps_per - 1) / steps_per;               // no empty split
   a->px_per_split = steps_per * kKP;
-  a->slab_stride = a->n_split > 1 ? (long long)cout * k * k * cin : 0;
+  a->slab_stride = a->n_split > 1 ? slab_floats : 0;
+  a->total = (int)(groups * a->n_split);
+  a->per_xcd = (a->total + 7) / 8;
   return true;
 }
 
@@ -276,11 +466,20 @@ extern "C" int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const 
   hipStream_t st = (hipStream_t)stream;
   const bool split = x_lo != nullptr;
   float* slab = a.n_split > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 256) : dw;
-  const int blocks = a.tiles_n * a.tiles_c * ksize * ksize * a.n_split;
+  const int blocks = 8 * a.per_xcd;
   const unsigned short *G = static_cast<const unsigned short*>(g_hi), *G2 = static_cast<const unsigned short*>(g_lo);
   const unsigned short *X = static_cast<const unsigned short*>(x_hi), *X2 = static_cast<const unsigned short*>(x_lo);
-  if (split) hipLaunchKernelGGL((k_wgrad_nhwc<true, 2>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
-  else hipLaunchKernelGGL((k_wgrad_nhwc<false, 2>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+  static const int one_tap_stages = env_int("OMNIHD_WGRAD_NHWC_STAGES", 2);
+  if (a.three) {
+    if (split) hipLaunchKernelGGL((k_wgrad_nhwc<true, true, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+    else hipLaunchKernelGGL((k_wgrad_nhwc<false, true, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+  } else if (one_tap_stages == 3) {
+    if (split) hipLaunchKernelGGL((k_wgrad_nhwc<true, false, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+    else hipLaunchKernelGGL((k_wgrad_nhwc<false, false, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+  } else {
+    if (split) hipLaunchKernelGGL((k_wgrad_nhwc<true, false, 2>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+    else hipLaunchKernelGGL((k_wgrad_nhwc<false, false, 2>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+  }
   if (a.n_split > 1) {
     const size_t n = (size_t)cout * ksize * ksize * cin;
     hipLaunchKernelGGL(k_sum_slabs_nhwc, dim3(grid_for((int64_t)n, 256 * 4)), dim3(256), 0, st, slab, a.n_split, n, dw);

@@ -878,24 +878,22 @@ def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1, out=N
 
 def wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation):
     """Which of this library's two weight-gradient forms takes a geometry?  A RULE, not a measurement, so that a run's kernels —
-    and the last bits of its gradients — never depend on timing noise: the staged chain (pixel-major staging + the three-taps
-    kernel with register-shifted taps) keeps the 3x3 / stride-1 / pad-1 layers whose (Cout, Cin) tiles fill the chip with
-    three-tap workgroups (the BEV-sized layers: its staging pass is small beside its GEMM there); everything else — 1x1, strided,
-    dilated, small maps, narrow layers — goes straight from NHWC.  OMNIHD_WGRAD_NHWC=0 / 1 forces never / always."""
+    and the last bits of its gradients — never depend on timing noise.  Since the three-taps form and the XCD-aware work order
+    (csrc/conv_wgrad_nhwc.hip) the NHWC kernel is the faster one on every geometry of the detector it takes (scripts/lab/
+    wgrad_nhwc_bench.py, profiles/round5/wgrad_nhwc_vs_chain.txt), so the rule is: wherever it applies.  The staged chain
+    (k_to_kmajor + k_wgrad_shift / k_wgrad_split3) stays for kernels larger than 4x4, operands of 2 GiB and more, and behind
+    OMNIHD_WGRAD_NHWC=0."""
     mode = os.environ.get("OMNIHD_WGRAD_NHWC", "auto")
     if mode == "0" or k > 4:
         return False
-    if not lib().omnihd_conv_wgrad_nhwc_workspace_bytes(B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation):
-        return False
-    if mode == "1":
-        return True
-    if k == 3 and stride == 1 and padding == 1 and dilation == 1:
-        tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * 3
-        mp = B * H * (((W + 1) + 7) // 8 * 8)
-        max_s = max(1, min(16, mp // (32 * 8)))
-        if tiles * max_s >= 192:                      # pick_split3 of csrc/conv_wgrad.hip finds a split: the chain's best case
-            return False
-    return True
+    key = (B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation)
+    hit = _NHWC_OK.get(key)
+    if hit is None:
+        hit = _NHWC_OK[key] = bool(lib().omnihd_conv_wgrad_nhwc_workspace_bytes(*key))
+    return hit
+
+
+_NHWC_OK = {}
 
 
 def conv3x3_wgrad(x, grad_out):
@@ -2226,6 +2224,18 @@ def conv_bias_colsum_supported(x, weight, bias):
 
 
 def conv_bias_colsum(x, weight, bias, stride, padding, dilation, groups=1):
+    if (deterministic() and groups == 1 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and weight.shape[2] == weight.shape[3]):
+        # OMNIHD_DETERMINISTIC=1: no pass of these layers on the library (its choice of solver — and with it the last bits —
+        # follows whatever tuning records the box holds; tests/test_determinism_gpu.py failed exactly when the user database was
+        # seeded).  Output channels zero-padded to a multiple of 8, all three passes on the split kernels, padding cut off.
+        cout = weight.shape[0]
+        cp = (cout + 7) // 8 * 8
+        if all(conv_split_geometry(x.shape, cp, weight.shape[2], tuple(stride), tuple(padding), tuple(dilation))):
+            wp = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, cp - cout))
+            bp = torch.nn.functional.pad(bias.float(), (0, cp - cout))
+            y = conv_split(x, wp, bp, tuple(stride), tuple(padding), tuple(dilation))
+            return y[:, :cout].contiguous(memory_format=torch.channels_last)
     return _ConvBiasColsum.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), int(groups))
 
 

@@ -14,7 +14,11 @@ GEOMS = [(6, 64, 176, 256, 64, 1, 1, 0), (6, 64, 176, 64, 64, 3, 1, 1), (6, 64, 
          (6, 32, 88, 128, 128, 3, 1, 1), (6, 32, 88, 512, 128, 1, 1, 0), (6, 16, 44, 256, 256, 3, 1, 1), (6, 16, 44, 1024, 256, 1, 1, 0),
          (6, 8, 22, 512, 512, 3, 1, 1), (6, 8, 22, 512, 2048, 1, 1, 0), (6, 64, 176, 256, 256, 3, 1, 1), (6, 64, 176, 256, 256, 1, 1, 0),
          (1, 160, 240, 64, 64, 3, 1, 1), (1, 80, 120, 128, 128, 3, 1, 1), (1, 40, 60, 256, 256, 3, 1, 1), (1, 160, 240, 384, 72, 1, 1, 0),
-         (1, 160, 240, 512, 256, 3, 1, 1)]
+         (1, 160, 240, 512, 256, 3, 1, 1), (1, 160, 240, 256, 256, 3, 1, 1), (1, 160, 240, 1024, 1024, 3, 1, 1), (1, 160, 240, 640, 384, 3, 1, 1),
+         (6, 16, 44, 512, 512, 3, 1, 1), (6, 64, 176, 512, 256, 3, 1, 1)]
+if os.environ.get("WGRAD_BENCH_3X3_ONLY", "0") == "1":
+    GEOMS = [g for g in GEOMS if g[5] == 3 and g[6] == 1]
+LIB = os.environ.get("WGRAD_BENCH_LIBRARY", "1") == "1"
 
 
 def clock(fn, n=10):
@@ -44,7 +48,7 @@ for B, H, W, cin, cout, k, s, p in GEOMS:
     t_n = clock(lambda: ops.conv_wgrad_split(xs, gs, k, s, p, 1))
     os.environ["OMNIHD_WGRAD_NHWC"] = "0"
     t_c = clock(lambda: ops.conv_wgrad_split(xs, gs, k, s, p, 1))
-    t_m = clock(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+    t_m = clock(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [False, True, False])[1]) if LIB else float("nan")
     os.environ.pop("OMNIHD_WGRAD_NHWC")
     rule = ops.wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, s, p, 1)
     print(f"{B}x{H}x{W} {cin:4d}->{cout:4d} k{k} s{s} | nhwc {t_n:7.1f} us ({flops/t_n/1e6:5.0f} TF eff) | chain {t_c:7.1f} us | library fp32 {t_m:7.1f} us | rule picks {'nhwc' if rule else 'chain'}", flush=True)

@@ -56,6 +56,8 @@ def _run(res, steps, env_extra):
 def _same(a, b):
     (da, pa), (db, pb) = a, b
     diff = [k for k in pa if pa[k] != pb.get(k)]
+    if diff:
+        print("differing tensors (%d of %d): %s" % (len(diff), len(pa), " | ".join(diff)))
     assert da == db, ("losses %s vs %s; first differing tensors: %s" % (da[1], db[1], diff[:12]), len(diff))
 
 

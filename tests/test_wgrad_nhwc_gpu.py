@@ -27,6 +27,11 @@ GEOMS = [  # B, H, W, cin, cout, k, stride, pad, dil
     (1, 30, 41, 64, 24, 3, 1, 2, 2),          # dilation 2
     (1, 9, 7, 8, 8, 3, 1, 1, 1),              # 63 pixels: one short split
     (2, 16, 20, 96, 48, 2, 2, 0, 1),          # kernel == stride 2
+    (6, 64, 176, 256, 256, 3, 1, 1, 1),       # DepthNet 3x3: three-taps form, 2 x 2 channel tiles
+    (2, 33, 51, 72, 40, 3, 1, 1, 1),          # three taps, odd sizes, ragged channel tiles
+    (6, 8, 22, 512, 512, 3, 1, 1, 1),         # three taps, image rows shorter than a K-step
+    (3, 5, 4, 16, 24, 3, 1, 1, 1),            # three taps, rows of 4 pixels
+    (1, 2, 3, 8, 8, 3, 1, 1, 1),              # three taps, six pixels
 ]
 
 
@@ -54,11 +59,15 @@ def test_split_and_bf16_forms_match_the_fp32_weight_gradient(cuda, B, H, W, cin,
         assert _rel(got, chain) <= 1e-4
 
 
-def test_the_routing_rule_keeps_bev_sized_layers_on_the_staged_chain(cuda, monkeypatch):
+def test_the_routing_rule_takes_every_detector_geometry_and_leaves_the_rest_to_the_chain(cuda, monkeypatch):
     from omnihd_amd import ops
     monkeypatch.delenv("OMNIHD_WGRAD_NHWC", raising=False)
-    assert not ops.wgrad_nhwc_preferred(1, 160, 240, 1024, 160, 240, 1024, 3, 1, 1, 1)      # BEV encoder: three-taps chain
-    assert not ops.wgrad_nhwc_preferred(6, 64, 176, 256, 64, 176, 256, 3, 1, 1, 1)          # DepthNet 3x3 at 6 x 64 x 176
-    assert ops.wgrad_nhwc_preferred(1, 160, 240, 64, 160, 240, 64, 3, 1, 1, 1)              # SECOND stage 0: too few tiles
+    assert ops.wgrad_nhwc_preferred(1, 160, 240, 1024, 160, 240, 1024, 3, 1, 1, 1)          # BEV encoder (three-taps form)
+    assert ops.wgrad_nhwc_preferred(6, 64, 176, 256, 64, 176, 256, 3, 1, 1, 1)              # DepthNet 3x3 at 6 x 64 x 176
+    assert ops.wgrad_nhwc_preferred(1, 160, 240, 64, 160, 240, 64, 3, 1, 1, 1)              # SECOND stage 0
     assert ops.wgrad_nhwc_preferred(6, 64, 176, 256, 64, 176, 64, 1, 1, 0, 1)               # 1x1
     assert ops.wgrad_nhwc_preferred(6, 64, 176, 128, 32, 88, 128, 3, 2, 1, 1)               # strided
+    assert not ops.wgrad_nhwc_preferred(1, 64, 64, 64, 64, 64, 64, 5, 1, 2, 1)              # 5x5: not taken
+    assert not ops.wgrad_nhwc_preferred(1, 64, 64, 60, 64, 64, 64, 3, 1, 1, 1)              # channels not a multiple of 8
+    monkeypatch.setenv("OMNIHD_WGRAD_NHWC", "0")
+    assert not ops.wgrad_nhwc_preferred(6, 64, 176, 256, 64, 176, 64, 1, 1, 0, 1)
