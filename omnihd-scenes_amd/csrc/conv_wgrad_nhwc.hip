@@ -53,7 +53,8 @@ struct WgNhwcArgs {
   int tiles_n, tiles_c, n_split, px_per_split;   // px_per_split: a multiple of kKP
   long long slab_stride;                          // floats between the slabs of consecutive splits (0: n_split == 1, dst = dw)
   int three;                                      // three-taps form
-  int total, per_xcd;                             // workgroups with work; launched: 8 * per_xcd
+  int total, per_xcd;                             // work items; items per XCD run (launched: 8 * min(per_xcd, resident workgroups per XCD))
+  unsigned long long* trace;                      // lab (OMNIHD_WGRAD_NHWC_TRACE): per workgroup {start, end} in 10 ns ticks, hardware id, XCC id
   int RW, RH;                                     // the raster the reduction runs over: (Wo, Ho), or (W + 1, H + 1) padded
 };
 
@@ -108,8 +109,14 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
   // XCD (workgroup b runs on XCD b % 8): the ~32 workgroups an XCD runs at a time are then neighbours in that list, i.e. the same
   // pixel range and mostly the same G / X channel slices, which they fetch into their shared L2 once.  (Split-fastest order, the
   // first version, had every workgroup of an XCD stream its own pixel range: 5 TB/s of L2 misses on 1024 -> 1024 at 160 x 240.)
-  const int t_lin = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
-  if (t_lin >= a.total) return;
+  // PERSISTENT: the launch holds at most as many workgroups as the chip runs at a time (a.wgs_per_xcd per XCD); workgroup j of
+  // XCD x walks the items x * per_xcd + j, + wgs_per_xcd, ... of its XCD's run.  (Launched as one workgroup per item, 768 items on
+  // 1024 -> 1024 at 160 x 240 kept only ~182 of 256 CUs occupied on average — SQ_WAVE_CYCLES against the kernel's duration — and a
+  // launch of 192 took exactly as long as one of 768 or 1536: rounds of large-LDS workgroups do not back-fill.)
+  const unsigned long long t_start = a.trace ? wall_clock64() : 0ull;
+  const int xcd = (int)(blockIdx.x & 7), wg_j = (int)(blockIdx.x >> 3), wgs_per_xcd = (int)(gridDim.x >> 3);
+  const int item_end = min(a.total, (xcd + 1) * a.per_xcd);
+  for (int t_lin = xcd * a.per_xcd + wg_j; t_lin < item_end; t_lin += wgs_per_xcd) {
   const int n_tg = T3 ? 3 : taps;
   int t = t_lin;
   const int tg = t % n_tg; t /= n_tg;                            // tap group: kernel row (three taps) or tap
@@ -160,22 +167,48 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
     p.cy -= c2 ? RH : 0;
     p.cb += sb + c2;
   };
+  // Per fetched row: its position on the raster (column, row[, image]) and — three-taps form — the byte offset of its source
+  // pixel, carried from K-step to K-step: with p = (image * H + row - 1) * W + column a step of 32 raster positions changes p by
+  // (sb * H * W + sy * W + sx) - [column wrapped] - W * [row wrapped], so the update is adds and selects (no multiply in the loop).
   RowPos gp[2], xp[XR];
   int g_ch[2], x_ch[XR];
+  unsigned g_off[2], x_off[XR];                 // three taps: byte offset of the row's chunk (meaningful where the position is real)
+  int g_du[2], x_du[XR];                        // three taps: raster position of the row minus the K-step start
+  bool x_row_ok[XR];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    gp[r] = locate((long long)m_begin + prow + 16 * r);
+    g_du[r] = prow + 16 * r;
+    gp[r] = locate((long long)m_begin + g_du[r]);
     g_ch[r] = n0 + src_chunk(prow + 16 * r);
+    g_off[r] = (unsigned)(((((long long)gp[r].cb * a.H + (gp[r].cy - 1)) * a.W + gp[r].cx) * a.Cout + g_ch[r]) * 2);
   }
 #pragma unroll
   for (int r = 0; r < XR; ++r) {
     // three taps: X tile row j holds raster position (K-step start) + j - 1, one raster row up / down for the outer kernel rows
-    xp[r] = T3 ? locate((long long)m_begin + prow + 16 * r - 1 + (long long)(ky - 1) * RW) : gp[r < 2 ? r : 0];
+    x_du[r] = prow + 16 * r - 1 + (ky - 1) * RW;
+    xp[r] = T3 ? locate((long long)m_begin + x_du[r]) : gp[r < 2 ? r : 0];
     x_ch[r] = c0 + src_chunk(prow + 16 * r);
+    x_off[r] = (unsigned)(((((long long)xp[r].cb * a.H + (xp[r].cy - 1)) * a.W + xp[r].cx) * a.Cin + x_ch[r]) * 2);
+    x_row_ok[r] = x_ch[r] < a.Cin && (r < 2 || wave == 0);      // (rows 36..47 of the tile: dummy calls, equal DMA counts per wave)
   }
+  const unsigned g_step = (unsigned)(((long long)sb * a.H * a.W + (long long)sy * a.W + sx) * a.Cout * 2);
+  const unsigned x_step = (unsigned)(((long long)sb * a.H * a.W + (long long)sy * a.W + sx) * a.Cin * 2);
+  const unsigned g_c1 = (unsigned)a.Cout * 2u, g_c2 = (unsigned)a.W * (unsigned)a.Cout * 2u;
+  const unsigned x_c1 = (unsigned)a.Cin * 2u, x_c2 = (unsigned)a.W * (unsigned)a.Cin * 2u;
+  auto advance3 = [&](RowPos& p, unsigned& off, unsigned step, unsigned c1b, unsigned c2b) {
+    p.cx += sx;
+    const bool c1 = p.cx >= RW;
+    p.cx -= c1 ? RW : 0;
+    p.cy += sy + (c1 ? 1 : 0);
+    const bool c2 = p.cy >= RH;
+    p.cy -= c2 ? RH : 0;
+    off += step - (c1 ? c1b : 0u) - (c2 ? c2b : 0u);
+  };
   int m_issue = m_begin;                          // first raster position of the next K-step to issue
-  auto issue_g = [&](int stage, bool real) {
-    unsigned char* base = sm + stage * STAGE_B;
+  // A fill in three parts, so that each can be placed among the MFMAs: (1) the offsets of this lane's 2 + XR rows (VALU only),
+  // (2) the CALLS LDS-DMA calls one by one, (3) the position update.
+  unsigned fill_off[2 + XR];                      // byte offset of each row's chunk for the fill being issued, or out of range
+  auto fill_addr = [&](bool real) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {                 // G rows
       const RowPos p = gp[r];
@@ -183,48 +216,60 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
       unsigned off;
       if constexpr (T3) {
         ok = ok & (p.cx < a.W) & (p.cy >= 1);     // (image index < B follows from the position < M)
-        off = (unsigned)((((size_t)p.cb * a.H + (p.cy - 1)) * a.W + p.cx) * a.Cout + g_ch[r]) * 2u;
+        off = g_off[r];
       } else {
         off = (unsigned)((((size_t)p.cb * RH + p.cy) * RW + p.cx) * a.Cout + g_ch[r]) * 2u;
       }
-      const unsigned goff = ok ? off : kOOB;
-      unsigned char* gd = base + (4 * wave + 16 * r) * kRowBytes;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t*)gd, 16, goff, 0, 0, 0);
-      if constexpr (SPLIT) __builtin_amdgcn_raw_ptr_buffer_load_lds(g2_rsrc, (lds_ptr_t*)(gd + GB), 16, goff, 0, 0, 0);
+      fill_off[r] = ok ? off : kOOB;
     }
-  };
-  auto issue_x = [&](int stage, bool real) {      // ... then the X rows, and one K-step further
-    unsigned char* base = sm + stage * STAGE_B;
 #pragma unroll
-    for (int r = 0; r < XR; ++r) {
+    for (int r = 0; r < XR; ++r) {                // X rows
       const RowPos p = xp[r];
-      bool ok = real & (x_ch[r] < a.Cin);
+      bool ok = real & x_row_ok[r];
       unsigned off;
       if constexpr (T3) {
-        ok = ok & (p.cx < a.W) & (p.cy >= 1) & ((unsigned)p.cb < (unsigned)a.B) & (r < 2 || wave == 0);
-        off = (unsigned)((((size_t)p.cb * a.H + (p.cy - 1)) * a.W + p.cx) * a.Cin + x_ch[r]) * 2u;
+        ok = ok & (p.cx < a.W) & (p.cy >= 1) & ((unsigned)(m_issue + x_du[r]) < (unsigned)M);
+        off = x_off[r];
       } else {
         const int iy = p.cy * a.stride - a.pad + ky * a.dil, ix = p.cx * a.stride - a.pad + kx0 * a.dil;
         ok = ok & ((m_issue + prow + 16 * r) < m_end) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
         off = (unsigned)((((size_t)p.cb * a.H + iy) * a.W + ix) * a.Cin + x_ch[r]) * 2u;
       }
-      const unsigned xoff = ok ? off : kOOB;
-      unsigned char* xd = base + XBASE + (4 * wave + 16 * r) * kRowBytes;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t*)xd, 16, xoff, 0, 0, 0);
-      if constexpr (SPLIT) __builtin_amdgcn_raw_ptr_buffer_load_lds(x2_rsrc, (lds_ptr_t*)(xd + XB), 16, xoff, 0, 0, 0);
+      fill_off[2 + r] = ok ? off : kOOB;
     }
+  };
+  // (the DMA builtin sits in a NON-generic lambda: inside a generic one hipcc 7.2's host pass silently drops the kernel's launch stub)
+  auto dma16 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned char* dst, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t*)dst, 16, off, 0, 0, 0);
+  };
+  auto fill_call = [&](auto K, int stage) {       // call K of CALLS: row K / PLANES (G rows first), plane K % PLANES
+    constexpr int ROW = K / PLANES, PL = K % PLANES;
+    unsigned char* base = sm + stage * STAGE_B;
+    if constexpr (ROW < 2) {
+      dma16(PL ? g2_rsrc : g_rsrc, base + (4 * wave + 16 * ROW) * kRowBytes + PL * GB, fill_off[ROW]);
+    } else {
+      dma16(PL ? x2_rsrc : x_rsrc, base + XBASE + (4 * wave + 16 * (ROW - 2)) * kRowBytes + PL * XB, fill_off[ROW]);
+    }
+  };
+  auto issue_adv = [&]() {                        // ... and every row one K-step further
     m_issue += kKP;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) advance(gp[r]);
     if constexpr (T3) {
 #pragma unroll
-      for (int r = 0; r < XR; ++r) advance(xp[r]);
+      for (int r = 0; r < 2; ++r) advance3(gp[r], g_off[r], g_step, g_c1, g_c2);
+#pragma unroll
+      for (int r = 0; r < XR; ++r) advance3(xp[r], x_off[r], x_step, x_c1, x_c2);
     } else {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) advance(gp[r]);
 #pragma unroll
       for (int r = 0; r < XR; ++r) xp[r] = gp[r];
     }
   };
-  auto issue = [&](int stage, bool real) { issue_g(stage, real); issue_x(stage, real); };
+  auto issue = [&](int stage, bool real) {
+    fill_addr(real);
+    static_for<CALLS>([&](auto K) { fill_call(K, stage); });
+    issue_adv();
+  };
 
   f32x16 acc[NT][2][2];
 #pragma unroll
@@ -261,94 +306,144 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
   v2i gq[2][2][PLANES][2];                       // [slice][block][plane][half]
   v2i xq[2][2][PLANES][2];                       // [buffer][block][plane][half]
 
+  auto read_g = [&](auto S, unsigned sbase) {
+    static_for<2>([&](auto I) {
+      static_for<PLANES>([&](auto P) {
+        static_for<2>([&](auto Hh) { tr_read<P * GB + S * 16 * kRowBytes>(gq[S][I][P][Hh], sbase + ga[Hh][I]); });
+      });
+    });
+  };
+  auto read_g_half = [&](auto S, auto I, unsigned sbase) {      // MFMA block I of slice S
+    static_for<PLANES>([&](auto P) {
+      static_for<2>([&](auto Hh) { tr_read<P * GB + S * 16 * kRowBytes>(gq[S][I][P][Hh], sbase + ga[Hh][I]); });
+    });
+  };
+  auto read_x = [&](auto Q, unsigned sbase) {    // group Q = slice * NT + tap -> buffer Q % 2
+    constexpr int S = Q / NT, TP = Q % NT, BUF = Q % 2;
+    static_for<2>([&](auto I) {
+      static_for<PLANES>([&](auto P) {
+        static_for<2>([&](auto Hh) { tr_read<XBASE + P * XB + S * 16 * kRowBytes>(xq[BUF][I][P][Hh], sbase + xa[TP][Hh][I]); });
+      });
+    });
+  };
+  auto tie_x = [&](auto BUF) {
+    static_for<2>([&](auto I) { static_for<PLANES>([&](auto P) { static_for<2>([&](auto Hh) { tie(xq[BUF][I][P][Hh]); }); }); });
+  };
+  auto tie_g = [&](auto S) {
+    static_for<2>([&](auto I) { static_for<PLANES>([&](auto P) { static_for<2>([&](auto Hh) { tie(gq[S][I][P][Hh]); }); }); });
+  };
+  auto mma = [&](auto Q, auto&& hook) {          // hook(K) runs behind MFMA K of the group, pinned there
+    constexpr int S = Q / NT, TP = Q % NT, BUF = Q % 2;
+    bf16x8 fa[2], fb[2], fa2[2], fb2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[i] = frag_of(gq[S][i][0][0], gq[S][i][0][1]);
+      fb[i] = frag_of(xq[BUF][i][0][0], xq[BUF][i][0][1]);
+      if constexpr (SPLIT) {
+        fa2[i] = frag_of(gq[S][i][PLANES - 1][0], gq[S][i][PLANES - 1][1]);
+        fb2[i] = frag_of(xq[BUF][i][PLANES - 1][0], xq[BUF][i][PLANES - 1][1]);
+      }
+    }
+    static_for<SPLIT ? 3 : 1>([&](auto TERM) {     // split: lo*hi, hi*lo, hi*hi
+      static_for<4>([&](auto IJ) {
+        constexpr int i = IJ / 2, j = IJ % 2;
+        const bf16x8 av = (SPLIT && TERM == 0) ? fa2[i] : fa[i];
+        const bf16x8 bv = (SPLIT && TERM == 1) ? fb2[j] : fb[j];
+        acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[TP][i][j], 0, 0, 0);
+        hook(std::integral_constant<int, TERM * 4 + IJ>{});
+      });
+    });
+  };
+  auto no_hook = [](auto) {};
+  // one MFMA, then a few of the fill's address / DMA instructions: the pattern handed to the scheduler for the MFMA groups that
+  // carry a part of the fill (left to itself it clusters the address arithmetic behind the MFMAs and the matrix pipe idles)
+  auto interleave = [&](auto N_VALU) {
+#pragma unroll
+    for (int e = 0; e < 4 * (SPLIT ? 3 : 1); ++e) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x016, N_VALU, 0);     // VALU | SALU | VMEM (the LDS-DMA calls and their m0 moves)
+    }
+  };
+  constexpr int LAST = 2 * NT - 1;
+  constexpr int Q_ADDR = 0, Q_CALLS = 1, Q_ADV = 2;               // three taps: which MFMA group carries which part of the fill
+  constexpr int MPG = 4 * (SPLIT ? 3 : 1);                        // MFMAs per group
+
+  // The pipeline, per K-step (stage = step % STAGES):
+  //   [G slice 1 fragments requested]  group 0 .. LAST: { request the X fragments of the next group; wait for this group's; MFMAs }
+  //   groups 0 / 1 / 2 also carry the fills of K-step + STAGES - 1: G rows / X rows / position update;
+  //   in front of the LAST group's MFMAs: this wave's fills of the next K-step have landed (vmcnt), barrier (everybody's have, and
+  //   everybody is done reading this stage — every read of it was waited for), then the next step's first fragments (G slice 0, X
+  //   group 0) are requested: their latency, and the barrier's, hide behind the LAST group's 12 MFMAs.
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) issue(s, s < n_steps);
+  __builtin_amdgcn_sched_barrier(0);
+  wait_vm<CALLS*(STAGES - 2)>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_g(std::integral_constant<int, 0>{}, lds0);
+  read_x(std::integral_constant<int, 0>{}, lds0);
   int stage = 0;
   for (int step = 0; step < n_steps; ++step) {
     __builtin_amdgcn_sched_barrier(0);
-    wait_vm<CALLS*(STAGES - 2)>();               // this wave's fills of this K-step have landed
-    __builtin_amdgcn_s_barrier();                // ... everybody's; and everybody is done reading the stage before this one
-    __builtin_amdgcn_sched_barrier(0);
     const unsigned sbase = lds0 + (unsigned)stage * (unsigned)STAGE_B;
-
-    auto read_g = [&](auto S) {
-      static_for<2>([&](auto I) {
-        static_for<PLANES>([&](auto P) {
-          static_for<2>([&](auto Hh) {
-            tr_read<P * GB + S * 16 * kRowBytes>(gq[S][I][P][Hh], sbase + ga[Hh][I]);
-          });
-        });
-      });
-    };
-    auto read_x = [&](auto Q) {                  // group Q = slice * NT + tap -> buffer Q % 2
-      constexpr int S = Q / NT, TP = Q % NT, BUF = Q % 2;
-      static_for<2>([&](auto I) {
-        static_for<PLANES>([&](auto P) {
-          static_for<2>([&](auto Hh) {
-            tr_read<XBASE + P * XB + S * 16 * kRowBytes>(xq[BUF][I][P][Hh], sbase + xa[TP][Hh][I]);
-          });
-        });
-      });
-    };
-    auto tie_x = [&](auto BUF) {
-      static_for<2>([&](auto I) { static_for<PLANES>([&](auto P) { static_for<2>([&](auto Hh) { tie(xq[BUF][I][P][Hh]); }); }); });
-    };
-    auto mma = [&](auto Q) {
-      constexpr int S = Q / NT, TP = Q % NT, BUF = Q % 2;
-      bf16x8 fa[2], fb[2], fa2[2], fb2[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = frag_of(gq[S][i][0][0], gq[S][i][0][1]);
-        fb[i] = frag_of(xq[BUF][i][0][0], xq[BUF][i][0][1]);
-        if constexpr (SPLIT) {
-          fa2[i] = frag_of(gq[S][i][PLANES - 1][0], gq[S][i][PLANES - 1][1]);
-          fb2[i] = frag_of(xq[BUF][i][PLANES - 1][0], xq[BUF][i][PLANES - 1][1]);
-        }
-      }
-      if constexpr (SPLIT) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2[i], fb[j], acc[TP][i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb2[j], acc[TP][i][j], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[TP][i][j], 0, 0, 0);
-    };
-
-    read_g(std::integral_constant<int, 0>{});
-    read_g(std::integral_constant<int, 1>{});
-    read_x(std::integral_constant<int, 0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    // the fills of K-step + STAGES - 1 go into the stage everybody left before this barrier; their address arithmetic and DMA calls
-    // are handed to the scheduler together with the first MFMA groups (G rows with group 0, X rows with group 1 / 0)
-    const int fill_stage = (stage + STAGES - 1) % STAGES;
+    const int next_stage = stage + 1 == STAGES ? 0 : stage + 1;
+    const int fill_stage = stage == 0 ? STAGES - 1 : stage - 1;        // (stage + STAGES - 1) % STAGES: left by everybody one barrier ago
     const bool fill_real = step + STAGES - 1 < n_steps;
     static_for<2 * NT>([&](auto Q) {
-      if constexpr (Q + 1 < 2 * NT) {
-        read_x(std::integral_constant<int, Q + 1>{});
-        wait_lgkm<PER>();                        // all but the group just requested
+      // the G fragments of slice 1 (needed from group NT on) are requested in two halves IN FRONT of the X requests of groups
+      // NT - 2 and NT - 1: every wait below then leaves at most PER + PER / 2 <= 12 younger reads outstanding (lgkmcnt is 4 bits)
+      // and never waits for a read that was only just requested
+      constexpr bool G1A = NT >= 3 && Q == NT - 2, G1B = NT >= 3 && Q == NT - 1;
+      if constexpr (G1A) read_g_half(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, sbase);
+      if constexpr (G1B) read_g_half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sbase);
+      if constexpr (Q < LAST) {
+        read_x(std::integral_constant<int, Q + 1>{}, sbase);
+        wait_lgkm<PER + ((G1A || G1B) ? PER / 2 : 0)>();       // all but the X group just requested (and the G half requested with it)
       } else {
         wait_lgkm<0>();
       }
-      if constexpr (Q == 0) {
-        static_for<2>([&](auto S) {
-          static_for<2>([&](auto I) { static_for<PLANES>([&](auto P) { static_for<2>([&](auto Hh) { tie(gq[S][I][P][Hh]); }); }); });
-        });
-      }
+      if constexpr (Q == 0) tie_g(std::integral_constant<int, 0>{});
+      if constexpr (NT < 3 && Q == 0) read_g(std::integral_constant<int, 1>{}, sbase);   // one tap: under group 0's MFMAs, waited for by group 1
+      if constexpr (Q == NT) tie_g(std::integral_constant<int, 1>{});
       tie_x(std::integral_constant<int, Q % 2>{});
+      if constexpr (Q == LAST) {
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm<CALLS*(STAGES - 2)>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned nbase = lds0 + (unsigned)next_stage * (unsigned)STAGE_B;
+        read_g(std::integral_constant<int, 0>{}, nbase);          // (behind the last K-step: a stage of dummy fills, never used)
+        read_x(std::integral_constant<int, 0>{}, nbase);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      mma(Q);
-      if constexpr (Q == 0) issue_g(fill_stage, fill_real);
-      if constexpr (Q == (NT > 1 ? 1 : 0)) issue_x(fill_stage, fill_real);
+      if constexpr (NT > 1 && Q == Q_ADDR) {
+        // offsets of the fill's rows: VALU / SALU only, a few behind every MFMA
+        fill_addr(fill_real);
+        mma(Q, no_hook);
+        interleave(std::integral_constant<int, 4>{});
+      } else if constexpr (NT > 1 && Q == Q_CALLS) {
+        // the DMA calls, one behind each of the first CALLS MFMAs (pinned: the scheduler keeps m0-chained calls in one clump)
+        mma(Q, [&](auto K) {
+          if constexpr (K < CALLS) {
+            __builtin_amdgcn_sched_barrier(0);
+            fill_call(K, fill_stage);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        if constexpr (CALLS > MPG) static_for<CALLS - MPG>([&](auto K) { fill_call(std::integral_constant<int, MPG + K>{}, fill_stage); });
+      } else if constexpr (NT > 1 && Q == Q_ADV) {
+        issue_adv();
+        mma(Q, no_hook);
+        interleave(std::integral_constant<int, 7>{});
+      } else if constexpr (NT == 1 && Q == 0) {
+        mma(Q, no_hook);
+        issue(fill_stage, fill_real);
+      } else {
+        mma(Q, no_hook);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
-    stage = (stage + 1) % STAGES;
+    stage = next_stage;
   }
   wait_vm<0>();                                  // drain the dummy tail fills before the epilogue
 
@@ -367,6 +462,15 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
           const int c = c0 + wn * 64 + j * 32 + (lane & 31);
           if (n < a.Cout && c < a.Cin) out[((size_t)n * taps + tap) * a.Cin + c] = acc[tp][i][j][r];
         }
+  }
+  __builtin_amdgcn_s_barrier();                  // the next item's first fills overwrite stages a slower wave may still be reading
+  }                                              // item loop
+  if (a.trace && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* t = a.trace + 4 * (size_t)blockIdx.x;
+    t[0] = t_start; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
   }
 }
 
@@ -426,12 +530,15 @@ bool nhwc_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int k
     if (sp > max_sp) sp = max_sp;
   }
   if (sp > (a->three ? 512 : 64)) sp = a->three ? 512 : 64;    // (the slab sum is one thread per element over all splits)
-  while (sp > 1 && sp * slab_floats * 4 > (64ll << 20)) --sp;        // slabs of at most 64 MB
+  static const int forced = env_int("OMNIHD_WGRAD_NHWC_SPLITS", 0);  // (lab: scripts/lab/wgrad_nhwc_bench.py sweeps it)
+  if (forced > 0) sp = forced;
+  while (sp > 1 && sp * slab_floats * 4 > (256ll << 20)) --sp;       // slabs of at most 256 MB (1024 -> 1024 3x3: 4 x 38 MB)
   if (sp < 1) sp = 1;
   const int steps_per = (int)((steps + sp - 1) / sp);
   a->n_split = (steps + steps_per - 1) / steps_per;               // no empty split
   a->px_per_split = steps_per * kKP;
   a->slab_stride = a->n_split > 1 ? slab_floats : 0;
+  a->trace = nullptr;
   a->total = (int)(groups * a->n_split);
   a->per_xcd = (a->total + 7) / 8;
   return true;
@@ -466,10 +573,17 @@ extern "C" int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const 
   hipStream_t st = (hipStream_t)stream;
   const bool split = x_lo != nullptr;
   float* slab = a.n_split > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 256) : dw;
-  const int blocks = 8 * a.per_xcd;
+  // persistent launch: one workgroup per CU for the three-taps form (192 accumulator registers: one wave per SIMD), two otherwise
+  const int resident_per_xcd = (kCUs / 8) * (a.three ? 1 : 2);
+  const int blocks = 8 * (a.per_xcd < resident_per_xcd ? a.per_xcd : resident_per_xcd);
   const unsigned short *G = static_cast<const unsigned short*>(g_hi), *G2 = static_cast<const unsigned short*>(g_lo);
   const unsigned short *X = static_cast<const unsigned short*>(x_hi), *X2 = static_cast<const unsigned short*>(x_lo);
   static const int one_tap_stages = env_int("OMNIHD_WGRAD_NHWC_STAGES", 2);
+  static const char* trace_path = getenv("OMNIHD_WGRAD_NHWC_TRACE");        // lab only: synchronises and dumps every launch
+  if (trace_path) {
+    if (hipMalloc((void**)&a.trace, (size_t)blocks * 32) != hipSuccess) a.trace = nullptr;
+    else (void)hipMemsetAsync(a.trace, 0, (size_t)blocks * 32, st);
+  }
   if (a.three) {
     if (split) hipLaunchKernelGGL((k_wgrad_nhwc<true, true, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
     else hipLaunchKernelGGL((k_wgrad_nhwc<false, true, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
@@ -479,6 +593,19 @@ extern "C" int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const 
   } else {
     if (split) hipLaunchKernelGGL((k_wgrad_nhwc<true, false, 2>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
     else hipLaunchKernelGGL((k_wgrad_nhwc<false, false, 2>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+  }
+  if (a.trace) {
+    unsigned long long* h = (unsigned long long*)malloc((size_t)blocks * 32);
+    if (h && hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, a.trace, (size_t)blocks * 32, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE* f = fopen(trace_path, "a")) {
+        fprintf(f, "launch cin %d cout %d k %d three %d blocks %d items %d\n", cin, cout, ksize, a.three, blocks, a.total);
+        for (int b = 0; b < blocks; ++b)
+          fprintf(f, "%d %llu %llu %llu %llu\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2], h[4 * b + 3]);
+        fclose(f);
+      }
+    }
+    free(h);
+    (void)hipFree(a.trace);
   }
   if (a.n_split > 1) {
     const size_t n = (size_t)cout * ksize * ksize * cin;

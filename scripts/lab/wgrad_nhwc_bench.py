@@ -19,6 +19,9 @@ GEOMS = [(6, 64, 176, 256, 64, 1, 1, 0), (6, 64, 176, 64, 64, 3, 1, 1), (6, 64, 
 if os.environ.get("WGRAD_BENCH_3X3_ONLY", "0") == "1":
     GEOMS = [g for g in GEOMS if g[5] == 3 and g[6] == 1]
 LIB = os.environ.get("WGRAD_BENCH_LIBRARY", "1") == "1"
+if os.environ.get("WGRAD_BENCH_ONE"):                      # "B,H,W,cin,cout,k,s,p": one geometry (counter passes)
+    GEOMS = [tuple(int(v) for v in os.environ["WGRAD_BENCH_ONE"].split(","))]
+CHAIN = os.environ.get("WGRAD_BENCH_CHAIN", "1") == "1"
 
 
 def clock(fn, n=10):
@@ -47,7 +50,7 @@ for B, H, W, cin, cout, k, s, p in GEOMS:
     os.environ["OMNIHD_WGRAD_NHWC"] = "1"
     t_n = clock(lambda: ops.conv_wgrad_split(xs, gs, k, s, p, 1))
     os.environ["OMNIHD_WGRAD_NHWC"] = "0"
-    t_c = clock(lambda: ops.conv_wgrad_split(xs, gs, k, s, p, 1))
+    t_c = clock(lambda: ops.conv_wgrad_split(xs, gs, k, s, p, 1)) if CHAIN else float("nan")
     t_m = clock(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [False, True, False])[1]) if LIB else float("nan")
     os.environ.pop("OMNIHD_WGRAD_NHWC")
     rule = ops.wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, s, p, 1)
