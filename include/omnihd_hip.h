@@ -472,6 +472,10 @@ int omnihd_conv_fwd_bf16(const void* x_nhwc, const void* w_ohwi, const float* bi
  * in increasing first_block order; total_blocks = that sum over all records.  Replaces, per layer and step, a layout copy +
  * omnihd_split_f32 + two omnihd_conv_dgrad_weights launches.                                                              */
 int omnihd_weight_images(const void* table, int n_entries, int total_blocks, void* stream);
+/* The same for records whose weights lie in channels_last memory (si == 1; what the training step holds): one workgroup per
+ * 64 x 64 (cout, cin) tile of ONE tap — 256-byte reads, 128-byte writes.  first_block = sum over the earlier records of
+ * ceil(cout/64)*ceil(cin/64)*k*k.                                                                                           */
+int omnihd_weight_images_cl(const void* table, int n_entries, int total_blocks, void* stream);
 
 /* wt[c,k-1-ky,k-1-kx,n] = w[n,ky,kx,c]: the weights with which the DATA GRADIENT of the convolution above is the same
  * convolution applied to the output gradient:  omnihd_conv_fwd_bf16(gout, wt, NULL, gx, batch, h, w, cout, cin, ...).  */

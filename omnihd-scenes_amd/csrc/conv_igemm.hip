@@ -833,12 +833,75 @@ __global__ __launch_bounds__(256) void k_weight_images(const WeightImageEntry* _
   }
 }
 
+// The same for master weights in channels_last memory (input channel fastest: what model.to(channels_last) leaves — every layer
+// of the training step): one workgroup = a 64 x 64 (cout, cin) tile of ONE tap.  Reads are 256-byte runs, both images are written
+// in 128-byte runs (the all-taps tile above: 128-byte reads, 64-byte writes, 68 KB of LDS = two workgroups per CU; 0.65 ms per fp32
+// step for 66 M parameters, round 5 profile), 17 KB of LDS.  first_block counts tiles x taps (mode 1 of omnihd_weight_images).
+__global__ __launch_bounds__(256) void k_weight_images_cl(const WeightImageEntry* __restrict__ table, int n_entries) {
+  __shared__ float s[64][65];
+  int lo_e = 0, hi_e = n_entries - 1;
+  while (lo_e < hi_e) {
+    const int mid = (lo_e + hi_e + 1) >> 1;
+    if (table[mid].first_block <= (int)blockIdx.x) lo_e = mid; else hi_e = mid - 1;
+  }
+  const WeightImageEntry e = table[lo_e];
+  const int taps = e.k * e.k;
+  const int tiles_i = (e.cin + 63) / 64;
+  int b = (int)blockIdx.x - e.first_block;
+  const int t = b % taps; b /= taps;
+  const int o0 = (b / tiles_i) * 64, i0 = (b % tiles_i) * 64;
+  const int tid = threadIdx.x;
+  const long long tap_off = (long long)(t / e.k) * e.sy + (long long)(t % e.k) * e.sx;
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int i = idx & 63, o = idx >> 6;
+    float v = 0.f;
+    if (o0 + o < e.cout && i0 + i < e.cin) v = e.src[(long long)(o0 + o) * e.so + tap_off + (long long)(i0 + i) * e.si];
+    s[o][i] = v;
+  }
+  __syncthreads();
+  auto split = [](float v, unsigned short& h, unsigned short& l) {
+    h = f2bf_rn(v);
+    const float hv = __uint_as_float((unsigned)h << 16);
+    l = ((h & 0x7f80) != 0x7f80) ? f2bf_rn(v - hv) : (unsigned short)0;
+  };
+  for (int idx = tid; idx < 64 * 64; idx += 256) {            // forward image (o, tap, i): i fastest
+    const int i = idx & 63, o = idx >> 6;
+    if (o0 + o < e.cout && i0 + i < e.cin) {
+      unsigned short h, l;
+      split(s[o][i], h, l);
+      const size_t at = ((size_t)(o0 + o) * taps + t) * e.cin + i0 + i;
+      e.f_hi[at] = h;
+      if (e.f_lo) e.f_lo[at] = l;
+    }
+  }
+  if (e.d_hi) {
+    for (int idx = tid; idx < 64 * 64; idx += 256) {          // data-gradient image (i, mirrored tap, o): o fastest
+      const int o = idx & 63, i = idx >> 6;
+      if (o0 + o < e.cout && i0 + i < e.cin) {
+        unsigned short h, l;
+        split(s[o][i], h, l);
+        const size_t at = ((size_t)(i0 + i) * taps + (taps - 1 - t)) * e.cout + o0 + o;
+        e.d_hi[at] = h;
+        if (e.d_lo) e.d_lo[at] = l;
+      }
+    }
+  }
+}
+
 extern "C" int omnihd_weight_images(const void* table_dev, int n_entries, int total_blocks, void* stream) {
   OMNIHD_REQUIRE(n_entries >= 0 && total_blocks >= 0 && (n_entries == 0 || table_dev), "arguments");
   if (n_entries == 0 || total_blocks == 0) return OMNIHD_OK;
   hipLaunchKernelGGL(k_weight_images, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                      static_cast<const WeightImageEntry*>(table_dev), n_entries);
   return check_launch("weight_images");
+}
+
+extern "C" int omnihd_weight_images_cl(const void* table_dev, int n_entries, int total_blocks, void* stream) {
+  OMNIHD_REQUIRE(n_entries >= 0 && total_blocks >= 0 && (n_entries == 0 || table_dev), "arguments");
+  if (n_entries == 0 || total_blocks == 0) return OMNIHD_OK;
+  hipLaunchKernelGGL(k_weight_images_cl, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const WeightImageEntry*>(table_dev), n_entries);
+  return check_launch("weight_images_cl");
 }
 
 extern "C" int omnihd_conv_dgrad_weights(const void* w_ohwi, void* wt_ihwo, int cout, int cin, int ksize, void* stream) {

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "omnihd_conv_gen_supported": (c_int, [c_int] * 12),
     "omnihd_conv_gen": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 11 + [c_void_p]),
     "omnihd_weight_images": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "omnihd_weight_images_cl": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "omnihd_dcn3x3_sample_fwd": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "omnihd_dcn3x3_sample_bwd": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "omnihd_dcn3x3_sample_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

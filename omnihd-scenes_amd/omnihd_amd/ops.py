@@ -1592,21 +1592,24 @@ _WIMG_DTYPE = None
 _WIMG_TABLES = {}
 
 
-def _weight_image_table(records, dev):
+def _weight_image_table(records, dev, per_tap=False):
     """Device table of omnihd_weight_images records (cached while the same buffers are asked for)."""
     global _WIMG_DTYPE
     import numpy as np
     if _WIMG_DTYPE is None:
         _WIMG_DTYPE = np.dtype([("src", "<u8"), ("so", "<i8"), ("si", "<i8"), ("sy", "<i8"), ("sx", "<i8"), ("f_hi", "<u8"), ("f_lo", "<u8"),
                                 ("d_hi", "<u8"), ("d_lo", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("k", "<i4"), ("first_block", "<i4")])
-    key = (dev.index, tuple(records))
+    key = (dev.index, bool(per_tap), tuple(records))
     hit = _WIMG_TABLES.get(key)
     if hit is None:
         arr = np.zeros(len(records), dtype=_WIMG_DTYPE)
         first = 0
         for n, r in enumerate(records):
             arr[n] = r + (first,)
-            first += ((r[9] + 31) // 32) * ((r[10] + 31) // 32)
+            if per_tap:
+                first += ((r[9] + 63) // 64) * ((r[10] + 63) // 64) * r[11] * r[11]
+            else:
+                first += ((r[9] + 31) // 32) * ((r[10] + 31) // 32)
         if len(_WIMG_TABLES) > 8:
             _WIMG_TABLES.clear()
         hit = _WIMG_TABLES[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(dev), first)
@@ -1614,12 +1617,20 @@ def _weight_image_table(records, dev):
 
 
 def weight_images(records, dev):
-    """One launch of omnihd_weight_images over ``records`` = tuples (src_ptr, so, si, sy, sx, f_hi, f_lo, d_hi, d_lo, cout, cin, k)."""
+    """The images of ``records`` = tuples (src_ptr, so, si, sy, sx, f_hi, f_lo, d_hi, d_lo, cout, cin, k): one launch of
+    omnihd_weight_images_cl for the weights in channels_last memory (si == 1: the training step's), one of omnihd_weight_images
+    for the others."""
     if not records:
         return
-    table, blocks = _weight_image_table(records, dev)
+    cl = [r for r in records if r[2] == 1 and os.environ.get("OMNIHD_WEIGHT_IMAGES_CL", "1") != "0"]
+    rest = [r for r in records if not (r[2] == 1 and os.environ.get("OMNIHD_WEIGHT_IMAGES_CL", "1") != "0")]
     with _on(dev):
-        check(lib().omnihd_weight_images(table.data_ptr(), len(records), blocks, _raw_stream()), "omnihd_weight_images")
+        if cl:
+            table, blocks = _weight_image_table(cl, dev, per_tap=True)
+            check(lib().omnihd_weight_images_cl(table.data_ptr(), len(cl), blocks, _raw_stream()), "omnihd_weight_images_cl")
+        if rest:
+            table, blocks = _weight_image_table(rest, dev)
+            check(lib().omnihd_weight_images(table.data_ptr(), len(rest), blocks, _raw_stream()), "omnihd_weight_images")
 
 
 def refresh_split_shadows():
