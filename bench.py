@@ -720,8 +720,10 @@ def main():
         el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
+        raw = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
+        per = sorted(raw)
         q = lambda f: per[min(len(per) - 1, int(f * len(per)))]
+        slow = [(k, round(v, 2)) for k, v in enumerate(raw) if v > 1.08 * q(0.5)]     # which of the timed steps ran long (index, ms)
         pool = {}
         for kind, e0, e1 in plan_mod.TIMING:
             pool.setdefault(kind, []).append(e0.elapsed_time(e1) * 1e-3)
@@ -731,7 +733,8 @@ def main():
         ops_mod.CONV_TIMING = None
         in_step = {k: sum(v) / len(v) for k, v in pool.items() if v}
         in_step.update({"n_" + k: len(v) for k, v in pool.items()})
-        return float(el.item()), {"median": round(q(0.5), 3), "p10": round(q(0.1), 3), "p90": round(q(0.9), 3)}, in_step
+        return float(el.item()), {"median": round(q(0.5), 3), "p10": round(q(0.1), 3), "p90": round(q(0.9), 3), "max": round(per[-1], 3),
+                                  "slow_steps": slow}, in_step
 
     runs, flops, comm, fast, ddp1, r2_step = {}, {}, None, {}, None, None
     if a.workload == "fusion":

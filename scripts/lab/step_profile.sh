@@ -51,6 +51,26 @@ if pairs:
     print("--- (previous, grid, next) around", pairs)
     for k, (c, t) in sorted(hist.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{c/$N:6.1f} x {t/1e3/max(c,1):7.1f} us  prev {k[0]} | grid {k[1]} | next {k[2]}")
+if os.environ.get("STEP_PROFILE_GAPS"):                 # when is no kernel running at all?  (union of the kernel intervals over all streams)
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), i) for i, r in enumerate(ss))
+    busy_u, cur_s, cur_e, cur_i = 0, iv[0][0], iv[0][1], iv[0][2]
+    gaps = []
+    for s_, e_, i in iv[1:]:
+        if s_ > cur_e:
+            busy_u += cur_e - cur_s
+            gaps.append((s_ - cur_e, cur_i, i))
+            cur_s, cur_e, cur_i = s_, e_, i
+        elif e_ > cur_e:
+            cur_e, cur_i = e_, i
+    busy_u += cur_e - cur_s
+    short3 = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
+    print(f"--- GPU idle: some kernel running {busy_u/1e6/$N:.2f} ms/step, none {(t1-t0-busy_u)/1e6/$N:.2f} ms/step in {len(gaps)/$N:.0f} gaps/step")
+    hist = collections.defaultdict(lambda: [0, 0])
+    for g, a_, b_ in gaps:
+        key = (short3(ss[a_]["Kernel_Name"]), short3(ss[b_]["Kernel_Name"]))
+        hist[key][0] += 1; hist[key][1] += g
+    for k, (c, t) in sorted(hist.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"{t/1e6/$N:7.3f} ms/step {c/$N:6.1f} x {t/1e3/c:7.1f} us  after {k[0]} | before {k[1]}")
 print("--- by launch count")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:22]:
     print(f"{c/$N:7.1f} calls/step {t/1e6/$N:7.3f} ms/step  {k}")
