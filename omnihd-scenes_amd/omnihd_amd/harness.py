@@ -422,6 +422,14 @@ class FusionTrainStep:
         return 0
 
     def step(self):
+        from ._env import epoch_begin, epoch_end
+        epoch_begin()                 # environment switches are looked up once per step from here on (omnihd_amd/_env.py)
+        try:
+            return self._step()
+        finally:
+            epoch_end()
+
+    def _step(self):
         b = self.batches[self.i % len(self.batches)]
         self.i += 1
         self.opt.zero_grad(set_to_none=True)

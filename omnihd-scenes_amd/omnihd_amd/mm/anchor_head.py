@@ -10,6 +10,7 @@ upstream release's documented behaviour (parity unpinned by the reference; pinne
 tests/test_model_cpu.py known-answer cases).  Boxes are (x, y, z_bottom, w, l, h, yaw, vx, vy) in
 the LiDAR frame.  Everything is dense torch tensor math on the device (no host loops over anchors).
 """
+from .._env import env as _env
 import math
 
 import numpy as np
@@ -338,7 +339,7 @@ class Anchor3DHead(nn.Module):
         three launches instead of ~150), where the head is configured as the reference configures it; None = not applicable (the
         torch formulation below runs).  OMNIHD_ANCHOR_LOSS=0 turns it off."""
         import os
-        if os.environ.get("OMNIHD_ANCHOR_LOSS", "1") == "0" or not cls_score.is_cuda or not self.use_direction_classifier:
+        if _env("OMNIHD_ANCHOR_LOSS", "1") == "0" or not cls_score.is_cuda or not self.use_direction_classifier:
             return None
         asg = self.bbox_assigner
         if not (isinstance(self.loss_cls, FocalLoss) and isinstance(self.loss_bbox, SmoothL1Loss) and isinstance(self.loss_dir, CrossEntropyLoss)

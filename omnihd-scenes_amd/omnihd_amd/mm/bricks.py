@@ -1,5 +1,6 @@
 """Layer builders with mmcv's call signatures: build_norm_layer, build_conv_layer, ConvModule."""
 import os
+from .._env import env as _env
 
 import torch
 import torch.nn.functional as F
@@ -251,7 +252,7 @@ class BevConv2d(nn.Conv2d):
                 return ops.conv_hip_wgrad(xb, weight, bias, self.stride, self.padding, self.dilation)
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and self.groups == 1
                 and self.padding_mode == "zeros" and not isinstance(self.padding, str)
-                and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen"
+                and _env("OMNIHD_FP32_CONV", "tune") != "miopen"
                 and ops.conv_split_supported(x, weight, self.stride, self.padding, self.dilation)
                 and not ops.conv_split_all_miopen(x.shape, weight.shape[0], weight.shape[2], self.stride, self.padding,
                                                   self.dilation, x.device.index)):
@@ -288,7 +289,7 @@ class BevConvTranspose2d(nn.ConvTranspose2d):
         if (output_size is None and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
                 and ops.deconv_split_supported(x, self.weight, self.kernel_size, self.stride, self.padding, self.output_padding,
                                                self.groups, self.dilation, self.bias)
-                and (ops.deterministic() or os.environ.get("OMNIHD_DECONV_SPLIT", "1") != "0")):
+                and (ops.deterministic() or _env("OMNIHD_DECONV_SPLIT", "1") != "0")):
             # the reference-precision (fp32) step: forward / data gradient on the general implicit-GEMM kernel in split form
             return ops.deconv_split(x, self.weight, self.kernel_size[0])
         return super().forward(x, output_size)

@@ -12,6 +12,7 @@ as a plain grouped conv), zero padding outside the image, offset channel order
 (deform_group, tap, (dy, dx)) as in mmcv.
 """
 import os
+from .._env import env as _env
 
 import torch
 import torch.nn.functional as F
@@ -57,7 +58,7 @@ class DeformConv2dPack(nn.Module):
         col = ops.dcn3x3_sample(xb, ob, self.stride, self.padding, self.dilation)
         Ho, Wo = ob.shape[1:3]
         wmat = self._grouped_weight()                                            # (9*Cin, Cout) fp32, block-diagonal
-        if gemm_dtype == torch.float32 and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen":
+        if gemm_dtype == torch.float32 and _env("OMNIHD_FP32_CONV", "tune") != "miopen":
             # the fp32 step: the contraction is a 1x1 convolution over the column rows — on the fp32-grade split kernels
             # (3-term bf16 MFMA, csrc/conv_igemm.hip) where they apply and measure faster than the fp32 GEMM library.  w4 is a
             # temporary of this forward: ops.split_weight does not cache the planes of non-leaf weights.

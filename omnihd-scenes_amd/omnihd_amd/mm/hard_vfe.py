@@ -27,6 +27,7 @@ weight T - n.  Work and traffic then scale with the number of points, not slots 
 with identical outputs, running statistics and gradients (tests/test_pillars_cpu.py).  Real points are
 packed without any host synchronisation into a buffer of the stream's input size (a cumulative sum
 over the slot mask gives every real slot its place)."""
+from .._env import env as _env
 import os
 
 import torch
@@ -95,7 +96,7 @@ class HardVFE(nn.Module):
         self.fusion_layer = None
 
     def forward(self, features, num_points, coors, img_feats=None, img_metas=None, max_real_points=None):
-        packed = self.packed if self.packed is not None else os.environ.get("OMNIHD_VFE_PACKED", "0") == "1"
+        packed = self.packed if self.packed is not None else _env("OMNIHD_VFE_PACKED", "0") == "1"
         if packed:
             return self._forward_packed(features, num_points, coors, max_real_points)
         parts = [features]

@@ -2,6 +2,7 @@
 import contextlib
 import ctypes
 import os
+from ._env import env as _env
 import weakref
 
 import numpy as np
@@ -576,7 +577,7 @@ def hard_voxelize_async(points, voxel_size, point_cloud_range, max_points, max_v
         st = _raw_stream()
         L = lib()
         state = None
-        if max_points <= 16 and os.environ.get("OMNIHD_VOXELIZE_GRID", "1") != "0":
+        if max_points <= 16 and _env("OMNIHD_VOXELIZE_GRID", "1") != "0":
             # three launches on a persistent per-cell state (idle between calls), for grids of up to 4 M cells
             skey = (dev.index, st, tuple(h_vs), tuple(h_rg))
             ent = _VOXEL_STATE.get(skey)
@@ -883,7 +884,7 @@ def wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilatio
     wgrad_nhwc_bench.py, profiles/round5/wgrad_nhwc_vs_chain.txt), so the rule is: wherever it applies.  The staged chain
     (k_to_kmajor + k_wgrad_shift / k_wgrad_split3) stays for kernels larger than 4x4, operands of 2 GiB and more, and behind
     OMNIHD_WGRAD_NHWC=0."""
-    mode = os.environ.get("OMNIHD_WGRAD_NHWC", "auto")
+    mode = _env("OMNIHD_WGRAD_NHWC", "auto")
     if mode == "0" or k > 4:
         return False
     key = (B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation)
@@ -995,7 +996,7 @@ def _conv_out_hw(H, W, k, s, p, d):
 def conv_gen_supported(mode, x_shape, cout, k, stride, padding, dilation):
     """The general implicit-GEMM kernel (csrc/conv_gen.hip) takes this pass of conv2d(x (B,Cin,H,W), w (Cout,Cin,k,k), stride,
     padding, dilation): mode 0 = forward, mode 1 = data gradient (strided forms included; OMNIHD_CONV_GEN=0 turns it off)."""
-    if os.environ.get("OMNIHD_CONV_GEN", "1") == "0":
+    if _env("OMNIHD_CONV_GEN", "1") == "0":
         return False
     key = (int(mode), tuple(x_shape), int(cout), int(k), int(stride), int(padding), int(dilation))
     hit = _GEN_OK.get(key)
@@ -1045,7 +1046,7 @@ def deterministic():
     """OMNIHD_DETERMINISTIC=1: every convolution pass this library has a kernel for runs on it (no per-geometry race against the
     library kernels, whose fp32 solvers for strided layers and small weight gradients accumulate with atomics), so that a
     training step is run-to-run identical bit for bit (tests/test_determinism_gpu.py)."""
-    return os.environ.get("OMNIHD_DETERMINISTIC", "0") == "1"
+    return _env("OMNIHD_DETERMINISTIC", "0") == "1"
 
 
 # Which implementation computes the weight gradient of a given convolution geometry: the MFMA kernel chain of
@@ -1094,7 +1095,7 @@ def _tuplify(x):
 def _persisted_choices():
     if not _CHOICE_INFO["loaded"]:
         _CHOICE_INFO["loaded"] = True
-        path = os.environ.get("OMNIHD_CHOICE_TABLE")
+        path = _env("OMNIHD_CHOICE_TABLE")
         if path is None:
             path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kernel_choices", "gfx950.json")
         if path and path != "off" and os.path.exists(path):
@@ -1112,7 +1113,7 @@ def _persisted_choices():
             find_now = bool(torch.backends.cudnn.benchmark)
             mode_ok = bool(doc.get("miopen_find", True)) == find_now
             _CHOICE_INFO.update(arch=arch, table_arch=want_arch, miopen_find=find_now, table_miopen_find=bool(doc.get("miopen_find", True)))
-            if arch_ok and (mode_ok or os.environ.get("OMNIHD_CHOICE_TABLE_STRICT", "0") != "1"):
+            if arch_ok and (mode_ok or _env("OMNIHD_CHOICE_TABLE_STRICT", "0") != "1"):
                 for name in ("conv", "wgrad", "split"):
                     _PERSISTED[name] = {_tuplify(json.loads(k)): v for k, v in doc.get(name, {}).items()}
                 _CHOICE_INFO.update(path=path, sha256=hashlib.sha256(raw).hexdigest(), entries=sum(len(v) for v in _PERSISTED.values()))
@@ -1172,7 +1173,7 @@ def _miopen_wgrad(x, g, weight, stride, padding, dilation):
 
 
 def _tuned_wgrad(x, g, weight, stride, padding, dilation):
-    policy = "hip" if deterministic() else os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
+    policy = "hip" if deterministic() else _env("OMNIHD_WGRAD_POLICY", "tune")
     k = weight.shape[2]
     run_hip = lambda: conv_wgrad(x, g, k, stride[0], padding[0], dilation[0])
     if policy == "hip":
@@ -1191,7 +1192,7 @@ def _tuned_wgrad(x, g, weight, stride, padding, dilation):
 
 def wgrad_choice_for(x_shape, cout, k, stride, padding, dilation, device_index):
     """'hip' | 'miopen' | None (not measured yet) for a convolution geometry under the current policy."""
-    policy = "hip" if deterministic() else os.environ.get("OMNIHD_WGRAD_POLICY", "tune")
+    policy = "hip" if deterministic() else _env("OMNIHD_WGRAD_POLICY", "tune")
     if policy != "tune":
         return policy
     return _WGRAD_CHOICE.get((tuple(x_shape), cout, k, stride, padding, dilation, device_index))
@@ -1392,7 +1393,7 @@ _CONV_IMPLS = ("hip", "hip128x256", "miopen")
 
 
 def _conv_policy():
-    return "hip" if deterministic() else os.environ.get("OMNIHD_CONV_POLICY", "tune")
+    return "hip" if deterministic() else _env("OMNIHD_CONV_POLICY", "tune")
 
 
 def _conv_impl(direction, x, w_cl, stride, padding, dilation, run_miopen, bias=None, n_out=None, k=None, in_shape=None):
@@ -1516,7 +1517,7 @@ HANDOVER_STATS = {"taken": 0, "stale": 0, "asked": 0, "untagged": 0}
 
 
 def planes_wanted(key):
-    return key in _PLANES_WANTED and os.environ.get("OMNIHD_SPLIT_HANDOVER", "0") == "1"
+    return key in _PLANES_WANTED and _env("OMNIHD_SPLIT_HANDOVER", "0") == "1"
 
 
 def tag_planes(t, planes, key):
@@ -1541,7 +1542,7 @@ def take_planes(t):
         return None
     planes, version, key = tag
     if planes is None:
-        if os.environ.get("OMNIHD_SPLIT_HANDOVER", "0") == "1":
+        if _env("OMNIHD_SPLIT_HANDOVER", "0") == "1":
             _PLANES_WANTED.add(key)
         HANDOVER_STATS["asked"] += 1
         return None
@@ -1622,8 +1623,8 @@ def weight_images(records, dev):
     for the others."""
     if not records:
         return
-    cl = [r for r in records if r[2] == 1 and os.environ.get("OMNIHD_WEIGHT_IMAGES_CL", "1") != "0"]
-    rest = [r for r in records if not (r[2] == 1 and os.environ.get("OMNIHD_WEIGHT_IMAGES_CL", "1") != "0")]
+    cl = [r for r in records if r[2] == 1 and _env("OMNIHD_WEIGHT_IMAGES_CL", "1") != "0"]
+    rest = [r for r in records if not (r[2] == 1 and _env("OMNIHD_WEIGHT_IMAGES_CL", "1") != "0")]
     with _on(dev):
         if cl:
             table, blocks = _weight_image_table(cl, dev, per_tap=True)
@@ -1711,7 +1712,7 @@ def _clock(fn, dev, n=3, warm=1):
     """Milliseconds of ``n`` back-to-back calls after ``warm`` untimed ones; OMNIHD_TUNE_REPEATS > 1 (used when the persisted
     choice table is captured) repeats the measurement and keeps the minimum."""
     best = None
-    for _ in range(max(1, int(os.environ.get("OMNIHD_TUNE_REPEATS", "1")))):
+    for _ in range(max(1, int(_env("OMNIHD_TUNE_REPEATS", "1")))):
         for _ in range(warm):
             fn()
         torch.cuda.synchronize(dev)
@@ -1727,7 +1728,7 @@ def _clock(fn, dev, n=3, warm=1):
 
 
 def _fp32_policy():
-    return "split" if deterministic() else os.environ.get("OMNIHD_FP32_CONV", "tune")
+    return "split" if deterministic() else _env("OMNIHD_FP32_CONV", "tune")
 
 
 def _split_pick(key, run_split, run_miopen, dev):
@@ -2056,7 +2057,7 @@ def _wgrad_side_stream(dev, weight):
     has not run yet (OMNIHD_WGRAD_OVERLAP=all: every layer from the start of the pass).  The first use inside a backward pass queues
     ``wgrad_overlap_join`` as a final callback of the autograd engine, so whoever called ``backward`` finds the gradients
     complete on its stream — no caller has to know."""
-    mode = os.environ.get("OMNIHD_WGRAD_OVERLAP", "1")
+    mode = _env("OMNIHD_WGRAD_OVERLAP", "1")
     if mode == "0" or torch.is_grad_enabled() or not _WGRAD_ENGINE_OK:
         return None
     if not weight.is_leaf or weight.grad is not None or weight._backward_hooks or getattr(weight, "_post_accumulate_grad_hooks", None):
@@ -2118,7 +2119,7 @@ def wgrad_overlap_arm():
     OMNIHD_WGRAD_OVERLAP=all with OMNIHD_POOL_BWD_EXCLUSIVE=0) and never waits for one.  Measured alternatives, same box: all layers
     + a fence in front of the pooling backward 48.46 ms, recording the front layers' work and enqueueing it behind the pooling
     kernel 48.23 ms (but that kernel then 64 us), this 48.47 ms, no overlap 50.0 ms."""
-    if not _WGRAD_ENGINE_OK or torch._C._current_graph_task_id() < 0 or os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") == "0":
+    if not _WGRAD_ENGINE_OK or torch._C._current_graph_task_id() < 0 or _env("OMNIHD_WGRAD_OVERLAP", "1") == "0":
         return
     _wgrad_pass_begin()
     if not _WGRAD_ARMED:
@@ -2128,7 +2129,7 @@ def wgrad_overlap_arm():
 def wgrad_overlap_fence(dev):
     """Inside a backward pass: the current stream waits for the weight gradients enqueued so far (only OMNIHD_WGRAD_OVERLAP=all
     enqueues any in front of the pooling backward, which calls this)."""
-    if dev.index in _WGRAD_SIDE_USED and os.environ.get("OMNIHD_POOL_BWD_EXCLUSIVE", "1") != "0":
+    if dev.index in _WGRAD_SIDE_USED and _env("OMNIHD_POOL_BWD_EXCLUSIVE", "1") != "0":
         torch.cuda.current_stream(dev).wait_stream(_WGRAD_SIDE[dev.index])
 
 
@@ -2148,7 +2149,7 @@ def conv_grad_planes_ok(x_shape, weight, bias, stride, padding, dilation, device
     """May the backward of this fp32 convolution take its output gradient as hi / lo planes ONLY?  Yes when every consumer of
     that gradient inside ``_ConvSplit.backward`` is a split kernel: no bias (its gradient sums the fp32 tensor), data and weight
     gradient on the split kernels under the current policy / persisted choices (a geometry not measured yet: no)."""
-    if bias is not None or os.environ.get("OMNIHD_GRAD_PLANES_ONLY", "1") == "0":
+    if bias is not None or _env("OMNIHD_GRAD_PLANES_ONLY", "1") == "0":
         return False
     k = weight.shape[2]
     ok_f, ok_d, ok_w = conv_split_geometry(x_shape, weight.shape[0], k, stride, padding, dilation)
@@ -2645,7 +2646,7 @@ class _BnTrainAct(torch.autograd.Function):
         # forward's constants (OMNIHD_BN_MASK_FROM_X=1: one tensor less to read), but that measured SLOWER in the full
         # step (34.1-35.0 vs 32.5-33.3 ms, alternating blocks in one process): the per-element constant loads cost more
         # than the streamed read they save.
-        keep_y = relu and (res is not None or os.environ.get("OMNIHD_BN_MASK_FROM_X", "0") != "1")
+        keep_y = relu and (res is not None or _env("OMNIHD_BN_MASK_FROM_X", "0") != "1")
         ctx.save_for_backward(x, y if keep_y else None, gamma, consts)
         ctx.relu, ctx.group, ctx.ranks, ctx.param_dtypes = relu, group, ranks, (weight.dtype, bias.dtype)
         ctx.has_res = res is not None

@@ -13,6 +13,7 @@ for one of two row numberings: ``'bzyx'`` (the reference's (B,Z,Y,X,C) buffer) o
 ((B,Y,X,Z,C) memory = the channels-last layout of the s2c tensor (B, Z*C, Y, X)).
 """
 import os
+from ._env import env as _env
 from dataclasses import dataclass
 
 import torch
@@ -455,7 +456,7 @@ STREAM_DEFAULT = (8, 32, 256)   # (patch width, rows per stage, waves per XCD) o
 
 def stream_tables(plan, n_img, feat_hw2):
     """The stream backward's tables of ``plan``, built on first use and kept with it (None: does not fit, see above)."""
-    shape = os.environ.get("OMNIHD_POOL_BWD_STREAM_SHAPE", "")
+    shape = _env("OMNIHD_POOL_BWD_STREAM_SHAPE", "")
     pw, R, spx = (int(v) for v in shape.split(",")) if shape else STREAM_DEFAULT
     cache = plan.__dict__.setdefault("_stream", {})
     key = (pw, R, spx, n_img, tuple(feat_hw2))
@@ -523,14 +524,14 @@ def _lean_forward():
     """The one-table forward kernel (k_pool_fwd_lean) is the default when the plan knows its frustum geometry;
     OMNIHD_POOL_LEAN=0 selects the three-table kernel (bit-identical results, 43.2 vs 51.2 us at R1 in one run)."""
     import os
-    return os.environ.get("OMNIHD_POOL_LEAN", "1") != "0"
+    return _env("OMNIHD_POOL_LEAN", "1") != "0"
 
 
 def _direct_forward():
     """The direct forward (k_pool_fwd_direct, C = 64: lane groups walk their piece of the point list from global memory, no LDS
     record staging) is the default where it applies; OMNIHD_POOL_DIRECT=0 selects k_pool_fwd_lean2 (same tiles; rows cut by
     the in-tile split may differ in the last bit)."""
-    return os.environ.get("OMNIHD_POOL_DIRECT", "1") != "0"
+    return _env("OMNIHD_POOL_DIRECT", "1") != "0"
 
 
 def forward_tables(plan, channels=64):
@@ -546,7 +547,7 @@ def forward_tables(plan, channels=64):
 def _patch_backward():
     """The patch backward (k_pool_bwd_patch, C = 64) is the default; OMNIHD_POOL_BWD_PATCH=0 selects the scheduled kernel."""
     import os
-    return os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"
+    return _env("OMNIHD_POOL_BWD_PATCH", "1") != "0"
 
 
 # How often the optional fast paths of the pooling forward were actually taken in this process (bench.py reports them as
@@ -676,7 +677,7 @@ def _kept_output(plan, c, device):
                            "place; its buffer is zero-filled again (results stay right, the saving of the kept rows is lost for "
                            "this step).  Callers that write into the result must not pass keep_empty_rows.")
                 t.zero_()
-            elif os.environ.get("OMNIHD_POOL_VERIFY_ZEROS", "0") == "1":
+            elif _env("OMNIHD_POOL_VERIFY_ZEROS", "0") == "1":
                 idx = _empty_row_index(plan)
                 if idx.numel() and float(t.index_select(0, idx).abs().sum()) != 0.0:
                     _warn_once(("dirty", id(plan)), "omnihd_amd: OMNIHD_POOL_VERIFY_ZEROS found non-zero values in rows no frustum "
@@ -687,7 +688,7 @@ def _kept_output(plan, c, device):
     if len(kept) >= MAX_KEPT_OUTPUTS:
         return None
     nbytes = plan.n_rows * c * 4
-    if _KEPT_TOTAL[0] + nbytes > int(os.environ.get("OMNIHD_POOL_KEEP_MAX_MB", "2048")) * (1 << 20):
+    if _KEPT_TOTAL[0] + nbytes > int(_env("OMNIHD_POOL_KEEP_MAX_MB", "2048")) * (1 << 20):
         return None
     keeper = torch.zeros((plan.n_rows, c), dtype=torch.float32, device=device)          # zero-filled once
     base = _storage_users(keeper)
@@ -703,11 +704,11 @@ def _row_bin(plan):
     """(output row | depth bin << 24) per point in backward order, built once per plan on the device: the patch backward then
     reads ONE table word per point (the bin was ``(ranks_depth // (fH*fW)) % D``).  None when the fields do not fit or
     OMNIHD_POOL_BWD_PACKED=0."""
-    if plan.bp_row_bin is None and os.environ.get("OMNIHD_POOL_BWD_PACKED", "1") != "0":
+    if plan.bp_row_bin is None and _env("OMNIHD_POOL_BWD_PACKED", "1") != "0":
         if 0 < plan.depth_bins <= 127 and plan.n_rows < 0xffffff and plan.feat_hw > 0:
             d = torch.div(plan.bp_ranks_depth, plan.feat_hw, rounding_mode="floor") % plan.depth_bins
             plan.bp_row_bin = (plan.bp_ranks_row | (d << 24)).to(torch.int32).contiguous()
-    return plan.bp_row_bin if os.environ.get("OMNIHD_POOL_BWD_PACKED", "1") != "0" else None
+    return plan.bp_row_bin if _env("OMNIHD_POOL_BWD_PACKED", "1") != "0" else None
 
 
 class _PlannedPool(torch.autograd.Function):
@@ -723,7 +724,7 @@ class _PlannedPool(torch.autograd.Function):
         direct = (lean and feat.size(-1) == 64 and feat.numel() * 4 < 2 ** 31 and depth.numel() * 4 < 2 ** 32 - 8
                   and depth.numel() < 0x3fffffff and feat.data_ptr() % 16 == 0 and _direct_forward())
         # only the direct and the second-generation lean kernel know how to leave the empty rows alone
-        can_keep = direct or (lean and os.environ.get("OMNIHD_POOL_LEAN2", "1") != "0" and feat.numel() * 4 < 2 ** 31)
+        can_keep = direct or (lean and _env("OMNIHD_POOL_LEAN2", "1") != "0" and feat.numel() * 4 < 2 ** 31)
         keeper = _kept_output(plan, feat.size(-1), feat.device) if (keep_empty_rows and can_keep) else None
         FAST_PATHS["pool_fwd_calls"] += 1
         FAST_PATHS["kept_output"] += keeper is not None
@@ -757,7 +758,7 @@ class _PlannedPool(torch.autograd.Function):
         patch = (c == 64 and plan.patch_order is not None and plan.depth_bins > 0 and depth.dim() == 5
                  and plan.n_rows * 256 < 2 ** 32 and plan.n_rows < 0xffffff and plan.depth_bins <= 512
                  and feat.data_ptr() % 16 == 0 and _patch_backward())
-        if patch and out_grad.dtype != torch.float32 and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0":
+        if patch and out_grad.dtype != torch.float32 and _env("OMNIHD_POOL_PREFETCH", "1") != "0":
             # the forward's tensors and the backward tables have long left the Infinity Cache: read them ahead on the side
             # stream while the cast of the incoming gradient runs (bf16 step; in the fp32 step nothing precedes the kernel)
             packed = _row_bin(plan)
@@ -772,7 +773,7 @@ class _PlannedPool(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, out_grad, depth, feat, plan, c, patch):
-        if patch and os.environ.get("OMNIHD_POOL_BWD_STREAM", "0") == "1" and plan.depth_bins <= 64 and depth.numel() * 4 < 2 ** 32 - 256:
+        if patch and _env("OMNIHD_POOL_BWD_STREAM", "0") == "1" and plan.depth_bins <= 64 and depth.numel() * 4 < 2 ** 32 - 256:
             # opt-in: the stream form of the same arithmetic (rows of a patch gathered once; DESIGN 4.2: not faster, so not the default)
             st = stream_tables(plan, depth.size(0) * depth.size(1), (depth.size(3), depth.size(4)))
             if st is not None:

@@ -10,6 +10,7 @@ kernels; the pooled BEV tensor arrives channels-last and zero-copy; ``batch_size
 host (``len(img_metas)``) instead of the reference's device->host ``coors[-1, 0] + 1`` sync (:100);
 camera inverses are computed in one batched fp32 ``inverse`` on the host (:116-130 builds 12 tiny
 tensors per sample).  ``simple_test`` does not render debug figures (reference defect D7)."""
+from omnihd_amd._env import env as _env
 import os
 
 import numpy as np
@@ -173,7 +174,7 @@ class BEVFUSION_depth(MVXFasterRCNN):
         radar = None
         # default on for training on the GPU (33.2 -> 31.7 ms per step at R1); OMNIHD_DUAL_STREAM=0 turns it off
         if vox is not None and img is not None and img.is_cuda and self.training \
-                and os.environ.get("OMNIHD_DUAL_STREAM", "1") != "0" and self._side_thread_is_safe():
+                and _env("OMNIHD_DUAL_STREAM", "1") != "0" and self._side_thread_is_safe():
             radar = self._radar_branch_async(points, img_metas, vox)     # second host thread + second stream
         if img is not None and img.is_cuda and self.training:
             from omnihd_amd import ops as _ops
@@ -193,7 +194,7 @@ class BEVFUSION_depth(MVXFasterRCNN):
             # overlaps the image backbone and neck only; late: after it.  A/B in the bench, two runs each
             # (profiles/round5/radar_join_ab.txt): fp32 step 46.36 / 46.35 -> 46.01 / 46.01 ms, pooling forward in the step
             # 41.9 / 41.4 -> 41.2 / 40.2 us; the pooling BACKWARD meets the radar branch's backward instead (54.4 -> 59 us).
-            early = os.environ.get("OMNIHD_RADAR_JOIN", "early") != "late"
+            early = _env("OMNIHD_RADAR_JOIN", "early") != "late"
             if early:
                 pts_feats = radar()
             img_bev_feat, depth_dist = self.lift_splat_shot_vis(view, rots, trans, lidar2img_rt=None, img_metas=img_metas)

@@ -16,6 +16,7 @@ checkpoints load.  What is different underneath:
 Reference defects handled as documented in SURVEY.md 0.1: D3 (trunc) kept bit-exactly, D4 (empty
 frustum) returns an all-zero BEV, D12 only the 'kld' depth loss exists.
 """
+from omnihd_amd._env import env as _env
 import hashlib
 import os
 
@@ -156,7 +157,7 @@ class CamEncode(nn.Module):
         comes back fp32 and contiguous (the (B,N,D,fH,fW) tensor bev_pool_v2 gathers from, as bev_pool.py:20 casts it), the
         context as a (M,C,H,W)-shaped view of fp32 (M,H,W,C) rows (so that :290's permute + contiguous is a no-op), and the
         pixel-major copy of the distribution that the KL depth loss reads rides along as ``depth._omnihd_rows``."""
-        if x.is_cuda and os.environ.get("OMNIHD_DEPTH_HEAD", "1") != "0":
+        if x.is_cuda and _env("OMNIHD_DEPTH_HEAD", "1") != "0":
             logits, context = self.depthnet.heads(x)
             if _ops.depth_head_supported(logits, context):
                 if self.before_epilogue is not None:
@@ -301,7 +302,7 @@ class LiftSplatShoot_Depth(nn.Module):
     def voxel_pooling_v2(self, coor, depth, feat, plan=None):
         """(B,N,D,H,W) depth x (B,N,C,H,W) features -> (B, C, Z, Y, X) (logical shape)."""
         if (plan is not None and feat.is_cuda and getattr(plan, "tile_desc", None) is not None and not self._tables_read_ahead
-                and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0"):
+                and _env("OMNIHD_POOL_PREFETCH", "1") != "0"):
             # the plan's tables were last read a whole step ago: stream them into the caches on a side stream (the pooling
             # kernel is a chain of dependent reads per tile; 62 us with cold tables inside the step vs 45 us with resident
             # ones).  With the fused depth-head epilogue this has already happened in front of that kernel (get_voxels).
@@ -316,7 +317,7 @@ class LiftSplatShoot_Depth(nn.Module):
             return feat.new_zeros(B, self.camC, int(self.nx[2]), int(self.nx[1]), int(self.nx[0]))
         # the pooled tensor goes straight into the BEV encoder's first convolution (read-only): its empty rows can be kept
         # from the previous forward of this plan instead of being zero-filled again
-        return planned_pool(depth, feat, plan, keep_empty_rows=os.environ.get("OMNIHD_POOL_KEEP_ZEROS", "1") != "0")
+        return planned_pool(depth, feat, plan, keep_empty_rows=_env("OMNIHD_POOL_KEEP_ZEROS", "1") != "0")
 
     def get_voxels(self, x, rots=None, trans=None, post_rots=None, post_trans=None, extra_rots=None,
                    extra_trans=None, plan_key=None):
@@ -326,7 +327,7 @@ class LiftSplatShoot_Depth(nn.Module):
             # on the side stream, ordered behind DepthNet's last convolution: runs while the epilogue kernel writes depth / feat
             # and is finished when the pooling kernel starts (nothing else streams through the caches in between)
             if (x.is_cuda and getattr(plan, "tile_desc", None) is not None and plan.n_points > 0
-                    and os.environ.get("OMNIHD_POOL_PREFETCH", "1") != "0"):
+                    and _env("OMNIHD_POOL_PREFETCH", "1") != "0"):
                 _ops.prefetch(forward_tables(plan, self.camC))
                 self._tables_read_ahead = True
 

@@ -58,17 +58,24 @@ CONV_POLICIES = ["miopen", "split"]
 
 
 def _grads_agree(gpu, cpu, names, policy):
-    """Gradients of the named parameters of the TINY detector.  With the dense convolutions on MIOpen's fp32 kernels (whose outputs
-    agree with the CPU's to ~1e-6, so that no ReLU mask of these tiny maps flips) every entry is held to 5e-3 of the largest
-    (measured ~1e-6).  With the fp32-grade split kernels (5e-6 per convolution) single masks flip and a whole-tensor comparison
-    measures the number of flips, not the kernels (round 3 needed 3e-2 here): the gradient bound for that policy is
-    tests/test_stage_gradients_gpu.py — every dense stage at FULL size on identical inputs, 1e-3, both policies — and
+    """Gradients of the named parameters of the TINY detector, GPU (HIP operators) vs CPU (oracle operators).
+    miopen: the dense convolutions on MIOpen's fp32 kernels agree with the CPU's to ~1e-6, no ReLU mask of these tiny maps flips,
+    and every entry is held to 5e-3 of the largest (measured: worst 2.7e-3, 192 of 194 tensors below 1e-3).
+    split: the fp32-grade kernels differ from an fp32 convolution by ~5e-6 per layer; on feature maps of a few pixels that flips
+    single ReLU masks, and one flipped mask moves single ENTRIES of the gradients upstream by percents (measured over all 194
+    tensors, profiles/round5/tiny_grads_split.txt: worst entry 4.2e-2, worst relative L2 7.5e-3, both in the image backbone; 142
+    tensors below 1e-3 entry-wise).  What is asserted for this policy is therefore the tensor as a whole — relative L2 error
+    <= 2e-2 and cosine >= 0.9995 — and the entry-wise 1e-3 bound lives where masks cannot flip the comparison:
+    tests/test_stage_gradients_gpu.py (every dense stage at FULL size on identical inputs, both policies) and
     tests/test_conv_split_gpu.py (1e-4 per kernel)."""
-    if policy != "miopen":
-        return
     for n in names:
         a, b = gpu["grads"][n].double(), cpu["grads"][n].double()
-        assert _close(a, b, 5e-3), n
+        if policy == "miopen":
+            assert _close(a, b, 5e-3), n
+        else:
+            l2 = float((a - b).norm()) / max(float(b.norm()), 1e-30)
+            cos = float((a * b).sum()) / max(float(a.norm()) * float(b.norm()), 1e-30)
+            assert l2 <= 2e-2 and cos >= 0.9995, (n, l2, cos)
 
 
 @pytest.mark.parametrize("policy", CONV_POLICIES)
