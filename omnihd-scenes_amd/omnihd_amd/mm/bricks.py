@@ -345,6 +345,12 @@ class BilinearResize(nn.Module):
         if key not in self._cache:
             self._cache[key] = (self._matrix(self.size[0], H, x.device, x.dtype), self._matrix(self.size[1], W, x.device, x.dtype))
         rh, rw = self._cache[key]
+        if (x.dim() == 4 and x.is_cuda and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+                and _env("OMNIHD_RESIZE_CL", "1") != "0"):
+            # channels_last in, channels_last out (round 5): the NCHW product left a contiguous NCHW tensor in front of the NHWC
+            # convolution kernels — a layout copy forward and mixed-layout gradient sums backward per pyramid level
+            y = torch.einsum("ih,bhwc,jw->bijc", rh, x.permute(0, 2, 3, 1), rw)
+            return y.permute(0, 3, 1, 2)
         return torch.einsum("ih,bchw,jw->bcij", rh, x, rw)
 
 

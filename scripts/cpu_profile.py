@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "omnihd-scenes_amd")]
 import torch
 from omnihd_amd.harness import FusionTrainStep
-st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype="bf16", miopen_find=True)
+st = FusionTrainStep(res="r1", batch=1, radar_dims=7, dtype=(sys.argv[1] if len(sys.argv) > 1 else "bf16"), miopen_find=True)
 for _ in range(5):
     st.step()
 torch.cuda.synchronize()
