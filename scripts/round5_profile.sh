@@ -7,7 +7,7 @@
 #   5. the fp32 bench line under OMNIHD_DETERMINISTIC=1
 export TMPDIR=/tmp; out=gpurun_out/r5p_final; mkdir -p $out
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-rocprofv3 --output-format csv --kernel-trace --stats -d $out/prof -o bench -- python3 bench.py --no-cpu-baseline > $out/bench_prof.json 2> $out/bench_prof.err
+OMNIHD_BENCH_CHILD=1 rocprofv3 --output-format csv --kernel-trace --stats -d $out/prof -o bench -- python3 bench.py --no-cpu-baseline > $out/bench_prof.json 2> $out/bench_prof.err
 cp $(find $out/prof -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats.csv
 python3 - <<PY
 import csv, glob
