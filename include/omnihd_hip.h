@@ -507,11 +507,15 @@ int omnihd_conv_wgrad_split(const void* x_hi, const void* x_lo, const void* g_hi
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient straight from the NHWC operands (round 5, csrc/conv_wgrad_nhwc.hip): no pixel-major staging pass — the
- * [pixel][channel] tiles are read transposed from LDS (ds_read_b64_tr_b16); one 128x128 (Cout, Cin) tile per workgroup and tap,
- * split-K over the output pixels into fp32 slabs summed in a fixed order (deterministic).  Any stride / padding / dilation, square
- * kernels up to 4x4, channel counts multiples of 8, operands below 2 GiB.  x_lo / g_lo NULL: bf16 operands; both non-NULL: the
- * fp32-grade split form.  dw (cout,k,k,cin) F32.  Two launches (one when the pixels are not split).  For the small and
- * middle-sized layers (ResNet-50 bottlenecks, FPN, DepthNet, SECOND, the head): reference layers bevfusion.py:62-85,96-123.        */
+ * [pixel][channel] tiles are read transposed from LDS (ds_read_b64_tr_b16); a workgroup computes a 128x128 (Cout, Cin) tile for
+ * one tap — or, for 3x3 / stride 1 / pad 1 / dilation 1, for the three taps of a kernel row over a padded raster — with split-K
+ * over the pixels into fp32 slabs summed in a fixed order (deterministic).  The launch is persistent (one or two workgroups per
+ * CU walk the tile list).  Any stride / padding / dilation, square kernels up to 4x4, channel counts multiples of 8, operands
+ * below 2 GiB.  x_lo / g_lo NULL: bf16 operands; both non-NULL: the fp32-grade split form.  dw (cout,k,k,cin) F32.  Two launches
+ * (one when the pixels are not split); the workspace holds the slabs (up to 256 MB: 1024->1024 3x3 takes 4 x 38 MB).  Replaces
+ * the weight-gradient half of cuDNN's convolution backward for every Conv2d of the detector it applies to: ResNet-50, FPN / FPNC,
+ * DepthNet, the BEV encoder (cam_stream_lss_bevpoolv2_depthnet.py:201-214), SECOND / SECONDFPN, the anchor head — reference
+ * layers bevfusion.py:62-85,96-123.                                                                                             */
 size_t omnihd_conv_wgrad_nhwc_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout, int ksize, int stride,
                                               int pad, int dil);
 int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const void* g_hi, const void* g_lo, float* dw, int batch, int h,
