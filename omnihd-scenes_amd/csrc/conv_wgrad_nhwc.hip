@@ -573,12 +573,13 @@ extern "C" int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const 
   hipStream_t st = (hipStream_t)stream;
   const bool split = x_lo != nullptr;
   float* slab = a.n_split > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + 256) : dw;
-  // persistent launch: one workgroup per CU for the three-taps form (192 accumulator registers: one wave per SIMD), two otherwise
-  const int resident_per_xcd = (kCUs / 8) * (a.three ? 1 : 2);
+  // persistent launch: one workgroup per CU for the three-taps form (192 accumulator registers: one wave per SIMD) and for the
+  // three-stage one-tap split form (96 KB of LDS), two otherwise
+  static const int one_tap_stages = env_int("OMNIHD_WGRAD_NHWC_STAGES", 2);
+  const int resident_per_xcd = (kCUs / 8) * ((a.three || (one_tap_stages == 3 && split)) ? 1 : 2);
   const int blocks = 8 * (a.per_xcd < resident_per_xcd ? a.per_xcd : resident_per_xcd);
   const unsigned short *G = static_cast<const unsigned short*>(g_hi), *G2 = static_cast<const unsigned short*>(g_lo);
   const unsigned short *X = static_cast<const unsigned short*>(x_hi), *X2 = static_cast<const unsigned short*>(x_lo);
-  static const int one_tap_stages = env_int("OMNIHD_WGRAD_NHWC_STAGES", 2);
   static const char* trace_path = getenv("OMNIHD_WGRAD_NHWC_TRACE");        // lab only: synchronises and dumps every launch
   if (trace_path) {
     if (hipMalloc((void**)&a.trace, (size_t)blocks * 32) != hipSuccess) a.trace = nullptr;
