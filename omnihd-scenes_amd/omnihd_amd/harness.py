@@ -381,7 +381,8 @@ class FusionTrainStep:
                 nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, [n for n, _ in named])
             self.model = nn.parallel.DistributedDataParallel(
                 model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
-                broadcast_buffers=False, bucket_cap_mb=25, gradient_as_bucket_view=True)
+                broadcast_buffers=False, bucket_cap_mb=int(os.environ.get("OMNIHD_DDP_BUCKET_MB", "25")), gradient_as_bucket_view=True,
+                static_graph=os.environ.get("OMNIHD_DDP_STATIC", "0") == "1")
             if os.environ.get("OMNIHD_DDP_HOOK", "1") != "0":
                 from . import ops
                 # bucket all-reduces on a stream that also waits for the weight-gradient side stream; side-stream weight

@@ -13,11 +13,11 @@ if mode == "ddp":
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29731")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 st = FusionTrainStep(res="r1", batch=1, radar_dims=7, device="cuda:0", seed=1234, dtype="fp32", ddp=mode == "ddp", miopen_find=True)
-for _ in range(8):
+for _ in range(12):
     st.step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 12
+n = 30
 for _ in range(n):
     st.step()
 torch.cuda.synchronize()
