@@ -881,6 +881,7 @@ def main():
             _phase(f"training step, {dt}: warm-up + timed steps")
             runs[dt] = timed(wl)
             fast[dt] = ops_mod_.fast_paths_report()      # live counters of the timed steps (+ warm-up), not the switches
+            _phase(f"training step, {dt}: counting the step's FLOPs (one eval-mode forward)")
             # every rank counts (one eval-mode forward: no collective, no BatchNorm statistics touched): the ranks' control flow
             # stays identical, whatever a module of a future config does in its forward
             from omnihd_amd.harness import count_step_flops
