@@ -43,3 +43,29 @@ def test_bench_guard_does_not_restart_a_child_that_exits_by_itself():
     assert out.returncode != 0 and out.stdout.strip() == ""
     assert out.stderr.count("bench.py needs a GPU") == 1, out.stderr[-800:]
     assert "attempt 1 ended with exit code 1" in out.stderr and "starting it once more" not in out.stderr
+
+
+def test_nhwc_weight_gradient_plan_fills_the_chip_and_is_not_clamped_by_the_slab_budget():
+    """Host side of csrc/conv_wgrad_nhwc.hip (no GPU work): the split-K plan behind the workspace size.  Round 5's first version
+    capped the slabs at 64 MB and silently ran 1024 -> 1024 3x3 at 160 x 240 with ONE split (192 workgroups on 256 CUs) and
+    640 -> 384 with 7 ragged ones; the cap is 256 MB now."""
+    from omnihd_amd._lib import lib
+    L = lib()
+    ws = L.omnihd_conv_wgrad_nhwc_workspace_bytes
+
+    def splits(B, H, W, cin, cout, k, s, p, d):
+        Ho, Wo = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+        n = ws(B, H, W, cin, Ho, Wo, cout, k, s, p, d)
+        assert n >= 256
+        return round((n - 256) / (cout * k * k * cin * 4))
+
+    # three-taps form, one workgroup per CU: (Cout tiles x Cin tiles x 3 kernel rows) x splits is a whole number of rounds of 256
+    assert splits(1, 160, 240, 1024, 1024, 3, 1, 1, 1) == 4          # 192 groups x 4 = 768 = 3 rounds
+    assert splits(1, 160, 240, 640, 384, 3, 1, 1, 1) == 11           # 45 groups x 11 = 495
+    assert splits(6, 64, 176, 256, 256, 3, 1, 1, 1) == 21            # 12 groups x 21 = 252
+    # one split: no slab at all
+    assert ws(1, 2, 3, 8, 2, 3, 8, 3, 1, 1, 1) == 256
+    # not taken: 5x5, channel counts that are not multiples of 8, inconsistent output size
+    assert ws(1, 64, 64, 64, 64, 64, 64, 5, 1, 2, 1) == 0
+    assert ws(1, 64, 64, 60, 64, 64, 64, 3, 1, 1, 1) == 0
+    assert ws(1, 64, 64, 64, 63, 64, 64, 3, 1, 1, 1) == 0
