@@ -451,6 +451,10 @@ def run_guarded():
     env = dict(os.environ, OMNIHD_BENCH_CHILD="1")
     rc = 1
     for attempt in (1, 2):
+        if attempt == 2:
+            # the fault of round 5 lives in the library's bf16 kernels (profiles/round5/bf16_fault_hunt.txt; the fp32 step never
+            # faulted): the second attempt measures the headline precision only and says so in its line
+            env["OMNIHD_BENCH_SAFE"] = "1"
         p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
         out = p.stdout.decode(errors="replace")
         rc = p.returncode
@@ -759,6 +763,9 @@ def main():
         print(json.dumps(cpu_baseline_fusion(sys.argv[2], int(sys.argv[3]))), flush=True)
         return
     a = parse()
+    safe_rerun = os.environ.get("OMNIHD_BENCH_SAFE") == "1" and a.dtype == "both"
+    if safe_rerun:
+        a.dtype = "fp32"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a.gpus))          # before anything in this process touches the GPU
     profiled = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_TOOL", "ROCPROF")) for k in os.environ)
@@ -1026,6 +1033,10 @@ def main():
                                      "note": "dense convolutions under bf16 autocast (our implicit-GEMM MFMA kernels for forward / data / weight gradient or MIOpen, measured per geometry), "
                                              "pooling / voxelisation / losses fp32; deviation from the fp32 step bounded in "
                                              "tests/test_detector_gpu.py::test_bf16_step_deviation_from_the_fp32_step"}
+        if safe_rerun:
+            line["bf16_autocast"] = {"value": None, "note": "not measured: the first attempt of this bench died of a signal (GPU memory fault; "
+                                     "seen only in the library's bf16 kernels, profiles/round5/bf16_fault_hunt.txt) and this second attempt "
+                                     "measures the headline precision only"}
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would sit in the
             if a.workload == "fusion":                # closing barrier for minutes while the host cores are busy
                 line["cpu_baseline"] = run_cpu_baseline_child(a.res, radar_dims)
