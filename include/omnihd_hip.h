@@ -128,6 +128,44 @@ int omnihd_bev_pool_v2_fwd_direct(const float* depth, const float* feat, const i
                                   const int* desc32, int n_slots, const int* row_ptr, float* out, int c, int n_rows,
                                   int n_points, int d_bins, int fhw, int n_feat_rows, int empty_rows_kept, void* stream);
 
+/* The same kernel on a plan that was built on the device (omnihd_pool_plan_build below): the number of schedule slots is not
+ * known to the host.  hdr (device, int[32]): hdr[3] = slots per XCD.  launch_slots = 8*k workgroups are launched, k >= hdr[3]
+ * (the plan's capacity, or the exact value once the host has learned it); surplus workgroups leave at once.
+ * ivl_capacity: ints allocated behind ivl_rel.  empty_rows_mode: 0 = zero-fill every empty row; 1 = `out` was filled by the
+ * SAME tables last (empty rows are zero already); 2 = `out` was filled last by tables whose row CSR is prev_row_ptr: a row
+ * that is empty now is zero-filled only if it was not empty then (per-frame calibrations: a handful of rows per launch).
+ * ref: replaces ops/bev_pool_v2/src/bev_pool_cuda.cu:21-48 + bev_pool.py:27,91 for tables rebuilt every forward
+ * (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:283-300). */
+int omnihd_bev_pool_v2_fwd_direct_dev(const float* depth, const float* feat, const int* pt, const int* ivl_rel,
+                                      long long ivl_capacity, const int* desc32, const int* hdr, int launch_slots,
+                                      const int* row_ptr, const int* prev_row_ptr, float* out, int c, int n_rows, int d_bins,
+                                      int fhw, int n_feat_rows, int empty_rows_mode, void* stream);
+
+/* Pooling plan for a NEW camera calibration, built entirely on the device: no host read-back, no synchronisation; every
+ * launch goes to `stream`.  ref: voxel_pooling_prepare_v2 (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:302-362,
+ * called per forward at :283-300) + the re-sort of QuickCumsumCuda.backward (ops/bev_pool_v2/bev_pool.py:47-57) + the
+ * host-side scheduling of omnihd_amd/plan.py (tiles, XCD runs, patch order).
+ *   geometry: either geom (B,N,D,fH,fW,3) fp32, or geom == NULL and rots (B*N,3,3), trans (B*N,3), xs (fW), ys (fH), ds (D)
+ *             (device): the frustum point is formed in the kernel with the rounding steps of get_geometry (:235-264);
+ *   h_off3 = bx - dx/2, h_dx3, h_nx3: host triples of gen_dx_bx (:80-85); layout_yxz: output row = ((b*Y+y)*X+x)*Z+z
+ *             (else ((b*Z+z)*Y+y)*X+x);
+ *   walk / wblock (device, n_patch ints each): the static walk of the patch backward over the 16-pixel patches of the
+ *             frustum shape and the 4-row band of every walk position (omnihd_amd/pool_plan.py: patch_walk);
+ *   outputs (device; capacities from omnihd_pool_plan_sizes, n_total = B*N*D*fH*fW, n_rows = B*X*Y*Z):
+ *     pt [n_total], ivl_rel [n_rows], desc32 [tiles_cap*32] (16-byte aligned), row_ptr [n_rows+1]: the tables of
+ *     omnihd_bev_pool_v2_fwd_direct_dev; row_bin [n_total], pix_ptr [B*N*fH*fW+1], patch_order [8*patch_per]: the tables of
+ *     omnihd_bev_pool_v2_bwd_patch (packed form); hdr int[32] = {points, non-empty rows, tiles, tiles per XCD, longest
+ *     patch run, status (0 = ok), ...}; rows_sorted / ranks_depth_sorted [n_total]: the sorted (row, point index) pairs
+ *     = ranks_bev (in the chosen numbering) / ranks_depth of the reference, valid for the first hdr[0] entries.
+ * omnihd_pool_plan_sizes: out4 = {workspace bytes, tiles_cap, n_patch, patch_per}. */
+int omnihd_pool_plan_sizes(long long n_total, int n_rows, int n_pix, int fhw, int tile_items, int long_len, long long* out4);
+int omnihd_pool_plan_build(const float* geom, const float* rots, const float* trans, const float* xs, const float* ys,
+                           const float* ds, int B, int N, int D, int fH, int fW, const float* h_off3, const float* h_dx3,
+                           const int* h_nx3, int layout_yxz, const int* walk, const int* wblock, int tile_items, int long_len,
+                           int* pt, int* ivl_rel, int* desc32, int* row_ptr, int* row_bin, int* pix_ptr, int* patch_order,
+                           int* hdr, uint32_t* rows_sorted, int* ranks_depth_sorted, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* Schedule descriptors for the call above from a tile table (omnihd_csr_tiles) and an optional
  * tile order (8*ceil(n_tiles/8) ints, -1 = idle slot, NULL = tiles in index order).          */
 int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const int* tile_order,

@@ -1548,19 +1548,14 @@ __device__ __forceinline__ void direct_batch8(const __amdgpu_buffer_rsrc_t feat_
   direct_point<J0 + 7>(a7, ck, out_rsrc, lane_off, acc, pend, s_head, s_head_row, tid, grp, sub);
 }
 
-__global__ __launch_bounds__(kBlock) void k_pool_fwd_direct(
+// One tile of the direct forward.  `prev_row_ptr` (device-built plans, empty_rows_kept == 2): the CSR of the tables that filled
+// `out` last — a row that is empty now is zero-filled only if it was NOT empty then.
+__device__ __forceinline__ void direct_tile(
     const float* __restrict__ depth, unsigned depth_bytes, const float* __restrict__ feat, unsigned feat_bytes,
-    const int* __restrict__ pt, const int* __restrict__ ivl_rel, unsigned ivl_bytes, const int* __restrict__ desc32,
-    const int* __restrict__ row_ptr, float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw,
-    float inv_dfhw, int empty_rows_kept) {
+    const int* __restrict__ pt, const int* __restrict__ ivl_rel, unsigned ivl_bytes, const int* __restrict__ dsc,
+    const int* __restrict__ row_ptr, const int* __restrict__ prev_row_ptr, float* __restrict__ out, int fhw, int dfhw,
+    float inv_fhw, float inv_dfhw, int empty_rows_kept, float4* s_tail, float4* s_head, int* s_head_row, int* s_tail_flags) {
   constexpr int C4 = 16, G = kBlock / C4, GPW = 64 / C4;
-  __shared__ float4 s_tail[kBlock];
-  __shared__ float4 s_head[kBlock];
-  __shared__ int s_head_row[G];
-  __shared__ int s_tail_flags[G];
-
-  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
-  const int* dsc = desc32 + ((size_t)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)) * 32;
   const int Ra = dsc[0], nrows = dsc[1], Pa = dsc[2], npts = dsc[3];
   if (nrows <= 0) return;
   const int tid = threadIdx.x;
@@ -1584,12 +1579,15 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_direct(
   }
 
   // ---- zero-fill the rows no point falls into (unless the caller's buffer holds those zeros already) -----------
-  if (!empty_rows_kept && !(nrows == 1 && npts > 0)) {
+  if (empty_rows_kept != 1 && !(nrows == 1 && npts > 0)) {
     const int gw = lane / C4;
     for (int base = 0; base < nrows; base += kBlock) {
       const int i = base + tid;
       bool empty = false;
-      if (i < nrows) empty = row_ptr[Ra + i + 1] == row_ptr[Ra + i];
+      if (i < nrows) {
+        empty = row_ptr[Ra + i + 1] == row_ptr[Ra + i];
+        if (empty_rows_kept == 2 && empty) empty = prev_row_ptr[Ra + i + 1] != prev_row_ptr[Ra + i];
+      }
       const unsigned long long m = __ballot(empty);
       if (m == 0ull) continue;
       const int wave_row0 = Ra + base + (tid & ~63);
@@ -1664,6 +1662,28 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd_direct(
     const u32x4t o = {__float_as_uint(tsum.x), __float_as_uint(tsum.y), __float_as_uint(tsum.z), __float_as_uint(tsum.w)};
     __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)s_head_row[grp] << 8) | lane_off, 0, 2);
   }
+}
+
+// DEV = false: the schedule has n_slots = 8 * tiles_per_xcd descriptors known to the host, one workgroup each.
+// DEV = true (plans built by csrc/pool_plan.hip): the number of slots per XCD is hdr[3] ON THE DEVICE; the host launches 8 * k
+// workgroups with k >= hdr[3] (the plan's capacity, or the exact count once it has travelled to the host) and the workgroups
+// of slots beyond hdr[3] leave at once.  (A form that lets a workgroup walk several slots was tried: the loop costs 40 VGPRs.)
+template <bool DEV>
+__global__ __launch_bounds__(kBlock) void k_pool_fwd_direct(
+    const float* __restrict__ depth, unsigned depth_bytes, const float* __restrict__ feat, unsigned feat_bytes,
+    const int* __restrict__ pt, const int* __restrict__ ivl_rel, unsigned ivl_bytes, const int* __restrict__ desc32,
+    const int* __restrict__ row_ptr, float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw,
+    float inv_dfhw, int empty_rows_kept, const int* __restrict__ hdr, const int* __restrict__ prev_row_ptr) {
+  constexpr int G = kBlock / 16;
+  __shared__ float4 s_tail[kBlock];
+  __shared__ float4 s_head[kBlock];
+  __shared__ int s_head_row[G];
+  __shared__ int s_tail_flags[G];
+  const int per = DEV ? hdr[3] : tiles_per_xcd;
+  if ((int)(blockIdx.x >> 3) >= per) return;
+  const int* dsc = desc32 + ((size_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3)) * 32;
+  direct_tile(depth, depth_bytes, feat, feat_bytes, pt, ivl_rel, ivl_bytes, dsc, row_ptr, DEV ? prev_row_ptr : nullptr, out, fhw,
+              dfhw, inv_fhw, inv_dfhw, empty_rows_kept, s_tail, s_head, s_head_row, s_tail_flags);
 }
 
 __global__ __launch_bounds__(kBlock) void k_pool_bwd_generic(
@@ -1860,10 +1880,34 @@ extern "C" int omnihd_bev_pool_v2_fwd_direct(const float* depth, const float* fe
                  "feature table below 2 GiB and depth tensor below 4 GiB (32-bit gather offsets)");
   OMNIHD_REQUIRE((long long)d_bins * fhw < (1ll << 30), "D * fH * fW too large");
   const int dfhw = d_bins * fhw;
-  hipLaunchKernelGGL(k_pool_fwd_direct, dim3(n_slots), dim3(kBlock), 0, (hipStream_t)stream, depth, (unsigned)depth_bytes, feat,
+  hipLaunchKernelGGL(k_pool_fwd_direct<false>, dim3(n_slots), dim3(kBlock), 0, (hipStream_t)stream, depth, (unsigned)depth_bytes, feat,
                      (unsigned)feat_bytes, pt, ivl_rel, (unsigned)((long long)n_intervals * 4), desc32, row_ptr, out, n_slots / 8, fhw,
-                     dfhw, 1.0f / (float)fhw, 1.0f / (float)dfhw, empty_rows_kept);
+                     dfhw, 1.0f / (float)fhw, 1.0f / (float)dfhw, empty_rows_kept ? 1 : 0, (const int*)nullptr, (const int*)nullptr);
   return check_launch("bev_pool_v2_fwd_direct");
+}
+
+extern "C" int omnihd_bev_pool_v2_fwd_direct_dev(const float* depth, const float* feat, const int* pt, const int* ivl_rel,
+                                                 long long ivl_capacity, const int* desc32, const int* hdr, int launch_slots,
+                                                 const int* row_ptr, const int* prev_row_ptr, float* out, int c, int n_rows,
+                                                 int d_bins, int fhw, int n_feat_rows, int empty_rows_mode, void* stream) {
+  OMNIHD_REQUIRE(c == 64, "the direct forward is written for C = 64");
+  OMNIHD_REQUIRE(n_rows > 0 && launch_slots > 0 && launch_slots % 8 == 0 && ivl_capacity > 0 && d_bins > 0 && fhw > 0 &&
+                     n_feat_rows > 0, "sizes");
+  OMNIHD_REQUIRE(depth && feat && out && desc32 && hdr && pt && ivl_rel && row_ptr, "null pointer");
+  OMNIHD_REQUIRE(empty_rows_mode == 0 || empty_rows_mode == 1 || (empty_rows_mode == 2 && prev_row_ptr),
+                 "empty_rows_mode: 0 fill, 1 kept, 2 kept relative to prev_row_ptr");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(desc32)) & 15u) == 0,
+                 "16-byte aligned feat / out / desc32");
+  const long long feat_bytes = (long long)n_feat_rows * c * 4;
+  const long long depth_bytes = (long long)n_feat_rows * d_bins * 4;
+  OMNIHD_REQUIRE(feat_bytes < (1ll << 31) && depth_bytes < (1ll << 32) - 8 && (long long)n_feat_rows * d_bins < kPtSentinel,
+                 "feature table below 2 GiB and depth tensor below 4 GiB (32-bit gather offsets)");
+  OMNIHD_REQUIRE((long long)d_bins * fhw < (1ll << 30) && ivl_capacity * 4 < (1ll << 32) - 8, "D * fH * fW / interval table too large");
+  const int dfhw = d_bins * fhw;
+  hipLaunchKernelGGL(k_pool_fwd_direct<true>, dim3(launch_slots), dim3(kBlock), 0, (hipStream_t)stream, depth, (unsigned)depth_bytes,
+                     feat, (unsigned)feat_bytes, pt, ivl_rel, (unsigned)(ivl_capacity * 4), desc32, row_ptr, out, 0, fhw, dfhw,
+                     1.0f / (float)fhw, 1.0f / (float)dfhw, empty_rows_mode, hdr, prev_row_ptr);
+  return check_launch("bev_pool_v2_fwd_direct_dev");
 }
 
 extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,

@@ -8,3 +8,4 @@ missing.
 from ._lib import lib, library_path, require_gpu  # noqa: F401
 from . import ops  # noqa: F401
 from .plan import BevPoolPlan, build_plan, plan_from_tables  # noqa: F401
+from .pool_plan import DevicePoolPlan, build_device_plan  # noqa: F401

@@ -538,6 +538,8 @@ def forward_tables(plan, channels=64):
     """The static tables the forward kernel of ``plan`` will read for ``channels`` feature channels (what the LSS module streams
     into the caches ahead of the launch, ``ops.prefetch``): the direct kernel's point words, row ids and 32-int descriptors, or
     the lean kernels' tile descriptors, CSR and rank table."""
+    if hasattr(plan, "launch_slots"):                     # pool_plan.DevicePoolPlan: valid prefixes once its counts are known
+        return plan.forward_tables() or []
     if channels == 64 and plan.depth_bins > 0 and _lean_forward() and _direct_forward():
         pt, ivl_rel, desc32 = direct_tables(plan)
         return [desc32, ivl_rel, pt]
@@ -807,6 +809,9 @@ def planned_pool(depth, feat, plan, keep_empty_rows=False):
     zero-copy view over (B,Y,X,Z,C) memory, so ``cat(unbind(dim=2), 1)`` (s2c) is a reshape.
     ``keep_empty_rows``: reuse an output buffer of the same plan whose empty rows are zero already (see ``_kept_output``);
     only for callers that never write into the result in place."""
+    if hasattr(plan, "launch_slots"):                     # a plan built on the device (omnihd_amd/pool_plan.py)
+        from .pool_plan import device_planned_pool
+        return device_planned_pool(depth, feat, plan, keep_empty_rows)
     B, Z, Y, X = plan.grid
     C = feat.size(-1)
     # fp32 like the reference (bev_pool.py:20-21); the casts are autograd ops so bf16 callers get bf16 grads

@@ -30,11 +30,18 @@ from omnihd_amd import ops as _ops
 from omnihd_amd.mm import build_conv_layer, build_norm_layer
 from omnihd_amd.mm.bricks import bn_act, conv_bn_act, run_fused
 from omnihd_amd.mm.resnet import BasicBlock
+from omnihd_amd import pool_plan as _pool_plan
 from omnihd_amd.plan import forward_tables, planned_pool
 from projects.mmdet3d_plugin.ops.bev_pool_v2.bev_pool import bev_pool_v2  # noqa: F401  (API parity)
 from projects.mmdet3d_plugin.utils.gaussian import generate_guassian_depth_target
 
 __all__ = ["LiftSplatShoot_Depth", "CamEncode", "DepthNet", "ASPP", "gen_dx_bx"]
+
+
+def _has_tables(plan):
+    """The plan carries device tables that a read-ahead can stream (host-built: tile descriptors; device-built: always —
+    ``forward_tables`` returns nothing while its counts have not reached the host)."""
+    return isinstance(plan, _pool_plan.DevicePoolPlan) or (getattr(plan, "tile_desc", None) is not None and plan.n_points > 0)
 
 
 def gen_dx_bx(xbound, ybound, zbound):
@@ -290,18 +297,45 @@ class LiftSplatShoot_Depth(nn.Module):
         plan = self._plans.get(key)
         if plan is None:
             with torch.no_grad():
-                geom = self.get_geometry(rots, trans, *extra).contiguous().float()
-                origin = trans[..., :2].float().mean(dim=(0, 1)).cpu().tolist()     # centroid of the camera positions
-                plan = omnihd_amd.build_plan(geom, self.dx.numpy(), self.bx.numpy(), self.nx.numpy(),
-                                             layout=self.pool_layout, origin_xy=origin)
+                plan = self._new_plan(rots, trans, extra)
             if len(self._plans) >= self._max_plans:
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = plan
         return plan
 
+    def _frustum_axes(self, device):
+        """(xs (fW), ys (fH), ds (D)) of ``self.frustum`` on ``device``: what the device-side plan builder forms the frustum
+        points from (the values of the parameter, not a recomputation)."""
+        got = getattr(self, "_axes", None)
+        if got is None or got[0].device != device or got[3] != self.frustum._version:
+            fr = self.frustum.detach().to(device)
+            got = self._axes = (fr[0, 0, :, 0].contiguous(), fr[0, :, 0, 1].contiguous(), fr[:, 0, 0, 2].contiguous(),
+                                self.frustum._version)
+        return got[:3]
+
+    def _new_plan(self, rots, trans, extra):
+        """Plan of a calibration that is not in the cache.  On the device (the product path): built by ONE library call that
+        enqueues its launches and returns — no host read-back, no synchronisation (omnihd_amd/pool_plan.py): the reference's
+        ``lidar2img`` differs from frame to frame (datasets/newscenes_dataset.py:203-216), so this runs every forward there.
+        Frustum shapes the device builder does not cover, OMNIHD_POOL_DEVICE_PLAN=0 and CPU tensors (the oracle shim of the
+        CPU tests) take ``omnihd_amd.build_plan``."""
+        B, N = trans.shape[:2]
+        nx = self.nx.numpy()
+        if (rots.is_cuda and _pool_plan.device_plans_enabled()
+                and _pool_plan.device_plan_supported(B, N, self.D, self.fH, self.fW, nx, self.camC)):
+            if all(e is None for e in extra):
+                return _pool_plan.build_device_plan(self.dx.numpy(), self.bx.numpy(), nx, layout=self.pool_layout, rots=rots,
+                                                    trans=trans, axes=self._frustum_axes(rots.device))
+            geom = self.get_geometry(rots, trans, *extra).contiguous().float()
+            return _pool_plan.build_device_plan(self.dx.numpy(), self.bx.numpy(), nx, layout=self.pool_layout, geom=geom)
+        geom = self.get_geometry(rots, trans, *extra).contiguous().float()
+        origin = trans[..., :2].float().mean(dim=(0, 1)).cpu().tolist()             # centroid of the camera positions
+        return omnihd_amd.build_plan(geom, self.dx.numpy(), self.bx.numpy(), self.nx.numpy(), layout=self.pool_layout,
+                                     origin_xy=origin)
+
     def voxel_pooling_v2(self, coor, depth, feat, plan=None):
         """(B,N,D,H,W) depth x (B,N,C,H,W) features -> (B, C, Z, Y, X) (logical shape)."""
-        if (plan is not None and feat.is_cuda and getattr(plan, "tile_desc", None) is not None and not self._tables_read_ahead
+        if (plan is not None and feat.is_cuda and _has_tables(plan) and not self._tables_read_ahead
                 and _env("OMNIHD_POOL_PREFETCH", "1") != "0"):
             # the plan's tables were last read a whole step ago: stream them into the caches on a side stream (the pooling
             # kernel is a chain of dependent reads per tile; 62 us with cold tables inside the step vs 45 us with resident
@@ -312,7 +346,9 @@ class LiftSplatShoot_Depth(nn.Module):
         if plan is None:
             plan = omnihd_amd.build_plan(coor.contiguous().float(), self.dx.numpy(), self.bx.numpy(),
                                          self.nx.numpy(), layout=self.pool_layout)
-        if plan.n_points == 0:   # defect D4: the reference would crash; defined here as all-zero BEV
+        if not isinstance(plan, _pool_plan.DevicePoolPlan) and plan.n_points == 0:
+            # defect D4: the reference would crash; defined here as all-zero BEV (a device-built plan yields the same zeros
+            # from its kernels: it cannot know its point count without a synchronisation)
             B = depth.shape[0]
             return feat.new_zeros(B, self.camC, int(self.nx[2]), int(self.nx[1]), int(self.nx[0]))
         # the pooled tensor goes straight into the BEV encoder's first convolution (read-only): its empty rows can be kept
@@ -326,8 +362,7 @@ class LiftSplatShoot_Depth(nn.Module):
         def read_tables_ahead():
             # on the side stream, ordered behind DepthNet's last convolution: runs while the epilogue kernel writes depth / feat
             # and is finished when the pooling kernel starts (nothing else streams through the caches in between)
-            if (x.is_cuda and getattr(plan, "tile_desc", None) is not None and plan.n_points > 0
-                    and _env("OMNIHD_POOL_PREFETCH", "1") != "0"):
+            if x.is_cuda and _has_tables(plan) and _env("OMNIHD_POOL_PREFETCH", "1") != "0":
                 _ops.prefetch(forward_tables(plan, self.camC))
                 self._tables_read_ahead = True
 

@@ -53,3 +53,12 @@ def test_cpu_tensors_are_rejected_loudly():
     r = torch.zeros(4, dtype=torch.int32)
     with pytest.raises(RuntimeError, match="no CPU path"):
         bev_pool_v2(depth, feat, r, r, r, (1, 1, 2, 2, 2), r[:1], r[:1])
+
+
+def test_device_plan_builder_has_no_synchronising_call():
+    """csrc/pool_plan.hip answers a new calibration inside the training step (the reference rebuilds its tables every
+    forward): it may enqueue work and nothing else — no stream / device synchronisation, no copy to the host."""
+    src = open(os.path.join(ROOT, "omnihd-scenes_amd", "csrc", "pool_plan.hip")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    for banned in ("hipStreamSynchronize", "hipDeviceSynchronize", "hipMemcpy", "hipEventSynchronize", "hipMalloc", "hipFree"):
+        assert banned not in code, banned

@@ -379,3 +379,16 @@ def test_stream_dealing_keeps_the_walk_order_and_balances_the_waves():
                 assert all(p in pos for p in l) and [pos[p] for p in l] == sorted(pos[p] for p in l)   # same XCD, walk order kept
         load = np.array([float(cost[l].sum()) for l in lists])
         assert load.max() / load.mean() < 1.15
+
+
+@pytest.mark.parametrize("n_img,fH,fW", [(6, 64, 176), (12, 136, 240), (2, 5, 24), (3, 7, 16)])
+def test_static_patch_walk_of_the_device_plan_is_the_walk_of_the_host_schedule(n_img, fH, fW):
+    """omnihd_amd.pool_plan.patch_walk (what csrc/pool_plan.hip cuts into XCD runs on the device) lists every patch once, band by
+    band, and without per-pixel costs the host's patch_schedule is exactly this walk cut into 8 equal runs."""
+    from omnihd_amd import plan as P, pool_plan
+    walk, band = pool_plan.patch_walk(n_img, fH, fW)
+    ppi = (fH * fW + 15) // 16
+    assert sorted(walk.tolist()) == list(range(n_img * ppi))
+    assert bool((band[1:] >= band[:-1]).all()), "bands in ascending order"
+    flat = P.patch_schedule(n_img, (fH, fW)).view(8, -1)
+    assert [p for run in flat.tolist() for p in run if p >= 0] == walk.tolist()
