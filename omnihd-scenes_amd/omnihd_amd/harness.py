@@ -383,6 +383,7 @@ class FusionTrainStep:
                 model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 broadcast_buffers=False, bucket_cap_mb=int(os.environ.get("OMNIHD_DDP_BUCKET_MB", "25")), gradient_as_bucket_view=True,
                 static_graph=os.environ.get("OMNIHD_DDP_STATIC", "0") == "1")
+            _broadcast_small(self.small_params, self.model.process_group)
             if os.environ.get("OMNIHD_DDP_HOOK", "1") != "0":
                 from . import ops
                 # bucket all-reduces on a stream that also waits for the weight-gradient side stream; side-stream weight
@@ -404,6 +405,11 @@ class FusionTrainStep:
         self.i = 0
         self.last_losses = None
         self.ddp = bool(ddp)
+        # A new camera calibration every step, as on the reference's own frames: its lidar2img is composed per sample through
+        # the ego poses of the camera and of the LiDAR sweep (datasets/newscenes_dataset.py:203-216,
+        # newscenes_devkit/newscenes_converter_final.py:346-383).  Off: the static rig of SURVEY 8(d).
+        self.jitter_calibration = False
+        self._jitter_rng = np.random.default_rng(seed + 77)
 
     def _reduce_small_params(self):
         import torch.distributed as dist
@@ -430,9 +436,21 @@ class FusionTrainStep:
         finally:
             epoch_end()
 
+    def _jittered(self, lidar2img):
+        """The rig seen from an ego pose that moved by up to 1 degree of yaw and 0.5 m (0.05 m vertically) since the sweep."""
+        a = math.radians(self._jitter_rng.uniform(-1.0, 1.0))
+        T = np.eye(4)
+        T[:2, :2] = [[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]]
+        T[:3, 3] = self._jitter_rng.uniform(-0.5, 0.5, 3) * [1.0, 1.0, 0.1]
+        return [np.asarray(m, dtype=np.float64) @ T for m in lidar2img]
+
     def _step(self):
         b = self.batches[self.i % len(self.batches)]
         self.i += 1
+        if self.jitter_calibration:
+            b = dict(b)
+            if isinstance(b.get("img_metas"), list) and b["img_metas"] and isinstance(b["img_metas"][0], dict):
+                b["img_metas"] = [dict(m, lidar2img=self._jittered(m["lidar2img"])) for m in b["img_metas"]]
         self.opt.zero_grad(set_to_none=True)
         with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.autocast):
             losses = self.model(return_loss=True, **b)
@@ -452,18 +470,62 @@ class FusionTrainStep:
 
 def _reduce_small(params, group=None):
     """Mean over the ranks of the gradients of ``params`` through ONE flat all-reduce (cat -> all_reduce -> multi-tensor copy
-    back): what the reducer would do with one copy launch per parameter."""
+    back): what the reducer would do with one copy launch per parameter.
+
+    The flat buffer has a FIXED layout — every parameter of the list in list order, zeros where this rank holds no gradient,
+    followed by one "has a gradient" flag per parameter — so ranks that disagree on which parameters received a gradient (a
+    data-dependent branch) still exchange buffers of one size and meaning (sizing it from ``grad is not None``
+    hangs or corrupts).  A parameter without a gradient here that got one on another rank receives the mean like everybody else
+    (what DistributedDataParallel does for its own parameters); one without a gradient on every rank keeps ``None``."""
     import torch.distributed as dist
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    if not params:
         return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    dev, dt = params[0].device, params[0].dtype
+    sizes = [p.numel() for p in params]
+    have = [p.grad is not None for p in params]
+    if not any(have) and dist.get_world_size(group) == 1:
+        return 0
+    zeros = {}
+    parts = []
+    for p, h, n in zip(params, have, sizes):
+        if h:
+            parts.append(p.grad.reshape(-1))
+        else:
+            if n not in zeros:
+                zeros[n] = torch.zeros(n, dtype=dt, device=dev)
+            parts.append(zeros[n])
+    parts.append(torch.tensor([1.0 if h else 0.0 for h in have], dtype=dt, device=dev))
+    flat = torch.cat(parts)
     world = dist.get_world_size(group)
+    n_grad = sum(sizes)
     if world > 1:
-        flat.mul_(1.0 / world)
+        flat[:n_grad].mul_(1.0 / world)
     dist.all_reduce(flat, group=group)
-    torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    chunks = flat[:n_grad].split(sizes)
+    if all(have):
+        torch._foreach_copy_([p.grad for p in params], [c.view_as(p.grad) for c, p in zip(chunks, params)])
+    else:
+        anywhere = (flat[n_grad:] > 0).tolist()              # (a host read: only on the rare path where a gradient is missing)
+        dst, src = [], []
+        for p, h, c, a in zip(params, have, chunks, anywhere):
+            if h:
+                dst.append(p.grad); src.append(c.view_as(p.grad))
+            elif a:
+                p.grad = c.clone().view_as(p)
+        if dst:
+            torch._foreach_copy_(dst, src)
     return flat.numel()
+
+
+def _broadcast_small(params, group=None, src=0):
+    """The parameters kept outside the reducer are not covered by its construction-time broadcast: one flat broadcast instead."""
+    import torch.distributed as dist
+    if not params or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        dist.broadcast(flat, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+        torch._foreach_copy_([p.data for p in params], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in params]), params)])
 
 
 def count_step_flops(step):

@@ -1862,6 +1862,8 @@ class _ConvSplit(torch.autograd.Function):
                 if tns is not None:
                     tns.record_stream(side)              # allocated on the main stream, read on the side stream
             view = _ddp_bucket_view(weight)
+            if view is not None:
+                _VIEW_WRITTEN.add(id(weight))        # a second convolution on this weight must not write the view again
             with torch.cuda.stream(side):
                 gw = weight_gradient(view if _view_writable(view, weight) else None)
                 if view is not None:
@@ -1895,8 +1897,18 @@ class _ConvSplit(torch.autograd.Function):
             _SPLIT_CHOICE.setdefault(("dgrad",) + geo, "miopen")          # never asked for: nothing to measure
         if ctx.needs_input_grad[1] and side is None:
             # in line; under a hooked reducer still straight into the bucket view (the reducer then has nothing to copy)
-            view = _ddp_bucket_view(weight) if (weight.is_leaf and weight.grad is None and not torch.is_grad_enabled()) else None
-            if _view_writable(view, weight) and want_w_split:
+            view = None
+            if weight.is_leaf and weight.grad is None and not torch.is_grad_enabled() and _WGRAD_ENGINE_OK and want_w_split:
+                _wgrad_pass_begin()                  # (the per-pass sets below belong to THIS backward pass)
+                # A weight that feeds several convolutions of one pass: ``weight.grad`` stays None until autograd
+                # has summed ALL its gradients, so the first use's alias of the bucket view is still pending when the second use
+                # arrives.  Writing the view again would overwrite the first gradient (autograd would then sum two aliases of
+                # one buffer: 2*g2 instead of g1 + g2) — from the second sighting on the gradient goes into a fresh tensor and
+                # autograd sums, the reducer copies.
+                if id(weight) not in _VIEW_WRITTEN:
+                    view = _ddp_bucket_view(weight)
+            if _view_writable(view, weight):
+                _VIEW_WRITTEN.add(id(weight))
                 gw = into_view(view, weight_gradient(view))
             else:
                 gw = weight_gradient()
@@ -1924,6 +1936,7 @@ def fast_paths_report():
             "wgrad_overlap": {"active": FAST_PATHS["wgrad_side_stream"] > 0, "share_of_split_weight_gradients": round(FAST_PATHS["wgrad_side_stream"] / max(1, wg), 3),
                               "private_hooks_ok": bool(_WGRAD_ENGINE_OK), "ddp": ddp_overlap_info()},
             "dual_stream": {"active": FAST_PATHS["dual_stream_forward"] > 0, "share_of_forwards": round(FAST_PATHS["dual_stream_forward"] / max(1, fw), 3)},
+            "device_plans_built": int(__import__("omnihd_amd.pool_plan", fromlist=["BUILDS"]).BUILDS["device_plans"]),
             "choice_table_misses": int(_CHOICE_INFO["misses"])}
 
 
@@ -1937,6 +1950,7 @@ def fast_paths_reset():
 _WGRAD_SIDE = {}
 _WGRAD_SIDE_USED = set()
 _WGRAD_SEEN = set()         # ids of the weights whose gradient went to the side stream in this backward pass
+_VIEW_WRITTEN = set()       # ids of the weights whose gradient was written into the reducer's bucket view in this backward pass
 _WGRAD_ARMED = []           # non-empty: the pooling backward of this backward pass has been launched (see wgrad_overlap_arm)
 _WGRAD_PASS = [None]        # autograd graph-task id of the backward pass the two above belong to
 # the two private hooks of the autograd engine this rests on; a torch without them keeps the in-line path
@@ -2077,7 +2091,7 @@ def _wgrad_side_stream(dev, weight):
     # A weight that feeds SEVERAL convolutions of one pass: the engine sums their gradients on the caller's stream as soon as the
     # last one has arrived — from the second sighting on, the caller's stream first waits for what the side stream holds and the
     # layer stays in line (tests/test_conv_split_gpu.py::test_shared_weight...)
-    if id(weight) in _WGRAD_SEEN:
+    if id(weight) in _WGRAD_SEEN or id(weight) in _VIEW_WRITTEN:
         if dev.index in _WGRAD_SIDE_USED:
             torch.cuda.current_stream(dev).wait_stream(_WGRAD_SIDE[dev.index])
         return None
@@ -2101,6 +2115,7 @@ def _wgrad_pass_begin():
             wgrad_overlap_join()
         _WGRAD_ARMED.clear()
         _WGRAD_SEEN.clear()
+        _VIEW_WRITTEN.clear()
         _WGRAD_PASS[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(wgrad_overlap_join)
 
@@ -2112,6 +2127,7 @@ def wgrad_overlap_join():
     _WGRAD_SIDE_USED.clear()
     _WGRAD_ARMED.clear()
     _WGRAD_SEEN.clear()
+    _VIEW_WRITTEN.clear()
     _WGRAD_PASS[0] = None
 
 

@@ -13,6 +13,7 @@ The tables are the ones ``omnihd_amd.plan`` documents (direct forward, packed pa
 host-built plan of the same calibration (tests/test_device_plan_gpu.py).
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -114,6 +115,7 @@ class DevicePoolPlan:
                     raise RuntimeError(f"device pooling plan reported status {self._counts['status']} "
                                        "(tile capacity exceeded: a bug in omnihd_pool_plan_sizes)")
                 self._hdr_host = self._hdr_event = None
+                _LAST_COUNTS[self._shape_key()] = self._counts
         return self._counts
 
     @property
@@ -125,9 +127,26 @@ class DevicePoolPlan:
         c = self.counts()
         return 8 * max(1, c["tiles_per_xcd"]) if c is not None else self.tiles_cap
 
-    def forward_tables(self):
-        """The valid prefixes of the forward tables (for read-ahead), or None while the counts are unknown."""
+    def _shape_key(self):
+        return (str(self.device), self.layout, self.grid, self.n_img, self.depth_bins, self.fH, self.fW)
+
+    def size_hint(self):
+        """This plan's counts, or — while they are still on their way — those of the last plan of the same shape whose counts
+        have arrived, 5 % up (a calibration that moved by a frame's ego motion keeps its counts to a fraction of a percent).
+        Good for READ-AHEAD sizes only: nothing whose correctness depends on a count may use a hint."""
         c = self.counts()
+        if c is not None:
+            return c
+        _poll_pending()
+        h = _LAST_COUNTS.get(self._shape_key())
+        if h is None:
+            return None
+        return dict(points=min(self.n_total, int(h["points"] * 1.05)), rows=min(self.n_rows, int(h["rows"] * 1.05)),
+                    tiles_per_xcd=min(self.tiles_cap // 8, int(h["tiles_per_xcd"] * 1.05) + 1))
+
+    def forward_tables(self):
+        """The (approximately) valid prefixes of the forward tables, for read-ahead; None while nothing is known of their size."""
+        c = self.size_hint()
         if c is None or c["points"] == 0:
             return None
         return [self.desc32[:8 * c["tiles_per_xcd"]], self.ivl_rel[:c["rows"]], self.pt[:c["points"]]]
@@ -140,6 +159,20 @@ class DevicePoolPlan:
         n = self.n_points
         rd = self.ranks_depth_sorted[:n]
         return self.rows_sorted[:n], rd, ops.ranks_feat_from_depth(rd.contiguous(), self.depth_bins, self.feat_hw)
+
+
+_LAST_COUNTS = {}       # shape key -> counts of the most recent plan of that shape whose counts reached the host
+_PENDING = []           # weak references to plans whose counts are still in flight
+
+
+def _poll_pending():
+    """Collect the counts that have arrived since the last look (event queries, no waiting)."""
+    alive = []
+    for ref in _PENDING:
+        p = ref()
+        if p is not None and p.counts() is None:
+            alive.append(ref)
+    _PENDING[:] = alive[-8:]
 
 
 def device_plan_supported(B, N, D, fH, fW, nx, channels=64):
@@ -197,13 +230,12 @@ def build_device_plan(dx, bx, nx, layout="byxz", geom=None, rots=None, trans=Non
     h_nx = (ctypes.c_int * 3)(X, Y, Z)
     with ops._on(dev):
         ws = ops._workspace(plan.workspace_bytes, dev)
-        check(lib().omnihd_pool_plan_build(_ptr(geom), _ptr(rots_), _ptr(trans_), _ptr(xs), _ptr(ys), _ptr(ds), B, N, D, fH, fW,
-                                           ctypes.cast(h_off, ctypes.c_void_p), ctypes.cast(h_dx, ctypes.c_void_p),
-                                           ctypes.cast(h_nx, ctypes.c_void_p), 1 if layout == "byxz" else 0, _ptr(walk), _ptr(band),
-                                           _plan.TILE_ITEMS, _plan.LONG_LEN, _ptr(plan.pt), _ptr(plan.ivl_rel), _ptr(plan.desc32),
-                                           _ptr(plan.row_ptr), _ptr(plan.row_bin), _ptr(plan.pix_ptr), _ptr(plan.patch_order),
-                                           _ptr(plan.hdr), _ptr(rows_sorted), _ptr(rd_sorted), _ptr(ws), ws.numel(), ops._stream()),
-              "omnihd_pool_plan_build")
+        _plan._timed("plan", lambda: check(lib().omnihd_pool_plan_build(
+            _ptr(geom), _ptr(rots_), _ptr(trans_), _ptr(xs), _ptr(ys), _ptr(ds), B, N, D, fH, fW, ctypes.cast(h_off, ctypes.c_void_p),
+            ctypes.cast(h_dx, ctypes.c_void_p), ctypes.cast(h_nx, ctypes.c_void_p), 1 if layout == "byxz" else 0, _ptr(walk),
+            _ptr(band), _plan.TILE_ITEMS, _plan.LONG_LEN, _ptr(plan.pt), _ptr(plan.ivl_rel), _ptr(plan.desc32), _ptr(plan.row_ptr),
+            _ptr(plan.row_bin), _ptr(plan.pix_ptr), _ptr(plan.patch_order), _ptr(plan.hdr), _ptr(rows_sorted), _ptr(rd_sorted),
+            _ptr(ws), ws.numel(), ops._stream()), "omnihd_pool_plan_build"))
         # the counts follow the build to pinned host memory; nobody waits for them (see DevicePoolPlan.counts)
         plan._hdr_host = torch.empty(32, dtype=torch.int32, pin_memory=True)
         plan._hdr_host.copy_(plan.hdr, non_blocking=True)
@@ -211,6 +243,8 @@ def build_device_plan(dx, bx, nx, layout="byxz", geom=None, rots=None, trans=Non
         plan._hdr_event.record()
     if keep_sorted:
         plan.rows_sorted, plan.ranks_depth_sorted = rows_sorted, rd_sorted
+    _poll_pending()
+    _PENDING.append(weakref.ref(plan))
     BUILDS["device_plans"] += 1
     return plan
 
@@ -311,7 +345,7 @@ class _DevicePlannedPool(torch.autograd.Function):
         depth, feat = ctx.saved_tensors
         plan = ctx.plan
         if out_grad.dtype != torch.float32 and _env("OMNIHD_POOL_PREFETCH", "1") != "0":
-            c = plan.counts()
+            c = plan.size_hint()
             ops.prefetch([plan.row_bin[:c["points"]] if c is not None else None, depth, feat])
         out_grad = out_grad.contiguous().float()
         ops.wgrad_overlap_fence(out_grad.device)

@@ -160,7 +160,16 @@ class BEVFUSION_depth(MVXFasterRCNN):
         hit = cls._inverse_cache.get(key)
         if hit is None:
             inv = torch.Tensor(arr).inverse()
-            hit = (inv[..., :3, :3].to(device), inv[..., :3, 3].to(device))
+            if torch.device(device).type == "cuda":
+                # a new calibration every frame on the reference's own data (datasets/newscenes_dataset.py:203-216): ONE
+                # asynchronous upload from pinned memory — a pageable-memory copy would make the host wait for the stream
+                host = torch.empty(inv.shape[:-2] + (12,), dtype=torch.float32, pin_memory=True)
+                host[..., :9] = inv[..., :3, :3].reshape(inv.shape[:-2] + (9,))
+                host[..., 9:] = inv[..., :3, 3]
+                both = host.to(device, non_blocking=True)
+                hit = (both[..., :9].reshape(inv.shape[:-2] + (3, 3)), both[..., 9:].contiguous())
+            else:
+                hit = (inv[..., :3, :3].to(device), inv[..., :3, 3].to(device))
             if len(cls._inverse_cache) >= 64:
                 cls._inverse_cache.clear()
             cls._inverse_cache[key] = hit

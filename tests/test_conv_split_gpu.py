@@ -407,3 +407,80 @@ print("DDP_OVERLAP_OK", worst, info)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DDP_OVERLAP_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("overlap", ["all", "1", "0"])
+def test_shared_weight_under_ddp_bucket_views_sums_both_uses(cuda, overlap):
+    """ONE weight used by TWO convolutions of a backward pass under the hooked reducer.  Both uses used
+    to write their gradient into the reducer's bucket view of that weight (``weight.grad`` is still None while the first alias is
+    pending), so autograd summed two aliases of one buffer: 2*g2 instead of g1 + g2 — and with the first use in line and the second
+    on the side stream also a cross-stream race.  Now the second sighting computes into a fresh tensor.  Gradients must equal the
+    plain in-line run's for side stream on all layers / behind the pooling backward only / off."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import copy, os, sys, torch, torch.distributed as dist
+from torch import nn
+sys.path[:0] = [%r, %r]
+os.environ["OMNIHD_FP32_CONV"] = "split"
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+from omnihd_amd import ops
+from omnihd_amd.mm.bricks import use_bev_conv
+torch.manual_seed(9)
+
+class Twice(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Conv2d(64, 128, 3, padding=1, bias=False)
+        self.shared = nn.Conv2d(128, 128, 3, padding=1, bias=False)
+        self.b = nn.Conv2d(128, 64, 3, padding=1, bias=False)
+    def forward(self, x):
+        y = torch.relu(self.a(x))
+        y = torch.relu(self.shared(y))
+        y = torch.relu(self.shared(y) * 0.5 + y)          # the second use sees another input and another gradient
+        return self.b(y)
+
+net = Twice().to(dev).to(memory_format=torch.channels_last)
+use_bev_conv(net)
+ref = copy.deepcopy(net)
+xs = [torch.randn(2, 64, 64, 96, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(5)]
+
+def grads_of(model, x):
+    for p in model.parameters():
+        p.grad = None
+    y = model(x)
+    (y * y).mean().backward()
+    torch.cuda.synchronize()
+    return [p.grad.clone() for p in model.parameters()]
+
+os.environ["OMNIHD_WGRAD_OVERLAP"] = "0"
+want = [grads_of(ref, x) for x in xs]
+os.environ["OMNIHD_WGRAD_OVERLAP"] = %r
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=False, bucket_cap_mb=1, gradient_as_bucket_view=True)
+assert ops.ddp_wgrad_overlap(ddp)
+rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+worst = 0.0
+for it, x in enumerate(xs):
+    for p in ddp.parameters():
+        p.grad = None
+    if 0 in ops._WGRAD_SIDE:
+        with torch.cuda.stream(ops._WGRAD_SIDE[0]):
+            torch.cuda._sleep(20_000_000)
+    y = ddp(x)
+    (y * y).mean().backward()
+    got = [p.grad.clone() for p in net.parameters()]
+    torch.cuda.synchronize()
+    for g, w in zip(got, want[it]):
+        assert torch.isfinite(g).all()
+        worst = max(worst, rel(g, w))
+info = ops.ddp_overlap_info()
+assert info["hooked"] and info["settled"] and info["direct_writes"] >= 3 * 2, info
+assert worst <= 1e-6, worst
+dist.destroy_process_group()
+print("DDP_SHARED_OK", worst, info)
+''' % (root, os.path.join(root, "omnihd-scenes_amd"), overlap)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DDP_SHARED_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

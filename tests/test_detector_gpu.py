@@ -304,8 +304,10 @@ def test_full_size_r2_training_step_runs_and_is_finite(cuda, dtype):
     assert len(lss._plans) == 1
     plan = next(iter(lss._plans.values()))
     assert plan.n_points == 4503872 and plan.feat_hw == 136 * 240 and plan.layout == "byxz"
-    assert kinds.count("fwd") == 2 and kinds.count("bwd") == 2              # lean / direct forward and patch backward ran
-    assert getattr(plan, "_direct", None) is not None                        # ... the forward on k_pool_fwd_direct
+    assert kinds.count("fwd") == 2 and kinds.count("bwd") == 2              # direct forward and patch backward ran
+    assert kinds.count("plan") == 1                                          # ... on ONE plan, built on the device (round 6)
+    from omnihd_amd.pool_plan import DevicePoolPlan
+    assert isinstance(plan, DevicePoolPlan) and plan.counts()["tiles"] > 6000
 
 
 def test_full_size_detector_bf16_step_runs_and_is_finite(cuda):
@@ -324,12 +326,18 @@ def test_full_size_detector_bf16_step_runs_and_is_finite(cuda):
     assert set(st.last_losses) == {"loss_cls", "loss_bbox", "loss_dir", "img_depth_loss"}
 
 
-def test_occupancy_variant_tiny_parity_and_full_size_step(cuda):
+@pytest.mark.parametrize("policy", CONV_POLICIES)
+def test_occupancy_variant_tiny_parity_and_full_size_step(cuda, policy, monkeypatch):
     """BEVF_FasterRCNN_MTL with the occupancy head — tiny model GPU (HIP ops) vs CPU (oracle ops)
-    in fp32, then one full-size bf16 step of the reference's occupancy configuration."""
+    in fp32, then one full-size bf16 step of the reference's occupancy configuration.
+    The convolution policy is PINNED like in the sibling tests (round 6): under the default measured choice the kernel of a
+    geometry seen for the first time is picked by a timing race, so the last bits — and with them single ReLU masks of these
+    few-pixel maps, see ``_grads_agree`` — followed the box's timing (the test failed 2 of 7 runs once the plan of a new
+    calibration no longer synchronised the device: profiles/round6/occ_flaky.txt)."""
     import contextlib
     from omnihd_amd.harness import FusionTrainStep
     from oracle.torch_shim import oracle_ops
+    monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
 
     def run(device, use_oracle):
         with (oracle_ops() if use_oracle else contextlib.nullcontext()):
@@ -349,7 +357,9 @@ def test_occupancy_variant_tiny_parity_and_full_size_step(cuda):
     assert set(gl) == {"loss_ssc", "loss_occ", "occ_sum", "img_depth_loss"}
     for k in cl:
         assert abs(gl[k] - cl[k]) <= 1e-3 * max(abs(cl[k]), 1e-3), (k, gl[k], cl[k])
-    assert _close(gg, cg, 5e-3)
+    _grads_agree({"grads": {"g": gg}}, {"grads": {"g": cg}}, ["g"], policy)
+    if policy != "split":
+        return                                   # the full-size step once
     st = FusionTrainStep(res="r1", batch=1, radar_dims=7, device="cuda:0", dtype="bf16", task="occ")
     l0 = float(st.step().detach())
     l1 = float(st.step().detach())
@@ -400,9 +410,9 @@ def test_bf16_step_deviation_from_the_fp32_step(cuda):
             cls, reg, dirc = m.pts_bbox_head(fd["pts_feats"])
             losses = m.pts_bbox_head.loss(cls, reg, dirc, b["gt_bboxes_3d"], b["gt_labels_3d"], b["img_metas"])
             depth_loss, _ = m.lift_splat_shot_vis.get_depth_loss(b["img_depth"], fd["depth_dist"], "kld")
-        plan = next(iter(m.lift_splat_shot_vis._plans.values()))
+        plan = next(iter(m.lift_splat_shot_vis._plans.values()))     # built on the device: point words (ranks_depth | closing) + row CSR
         outs[dt] = dict(bev=fd["pts_feats"][0].float().cpu(), reg=reg[0].float().cpu(), cls=cls[0].float().cpu(),
-                        depth=fd["depth_dist"].float().cpu(), ranks=plan.ranks_depth.cpu(), rows=plan.ranks_row.cpu(),
+                        depth=fd["depth_dist"].float().cpu(), ranks=plan.pt[:plan.n_points].cpu(), rows=plan.row_ptr.cpu(),
                         losses={k: float(v[0]) for k, v in losses.items()}, depth_loss=float(depth_loss))
         del st, m
         torch.cuda.empty_cache()
