@@ -146,13 +146,7 @@ class BevOps:
         omnihd_amd.require_gpu()
         self.ops, self.omnihd = ops, omnihd_amd
         self.dev, self.batch = dev, batch
-        self.tiled = True
-        self.lean = os.environ.get("OMNIHD_POOL_LEAN", "1") != "0"      # one-table forward kernel (default)
-        self.sched_bwd = True
-        self.patch_bwd = os.environ.get("OMNIHD_POOL_BWD_PATCH", "1") != "0"   # k_pool_bwd_patch (C = 64), the default
-        self.scheduled = True
         self.keep_empty = os.environ.get("OMNIHD_POOL_KEEP_ZEROS", "1") != "0"
-        self.direct = os.environ.get("OMNIHD_POOL_DIRECT", "1") != "0"      # k_pool_fwd_direct (C = 64), the default
         H, W, _ = RES[res]
         self.fH, self.fW, self.D, self.C, self.N = H // 4, W // 4, 59, 64, 6
         dx, bx, nx, frustum = lss_constants(res)
@@ -162,7 +156,7 @@ class BevOps:
         self.plan = omnihd_amd.build_plan(geom, dx, bx, nx, layout="byxz")
         from omnihd_amd.plan import _row_bin, direct_tables
         self.row_bin = _row_bin(self.plan)
-        self.direct_tabs = direct_tables(self.plan) if self.direct else None
+        self.direct_tabs = direct_tables(self.plan)
         del geom
         g = torch.Generator(device=dev).manual_seed(seed)
         self.sets = []
@@ -171,13 +165,10 @@ class BevOps:
             feat = torch.randn(batch, self.N, self.fH, self.fW, self.C, device=dev, generator=g)
             og = torch.randn(self.plan.n_rows, self.C, device=dev, generator=g)
             out = torch.zeros(self.plan.n_rows, self.C, device=dev)
-            # private copies of the tables too, so that nothing is served from the Infinity Cache
-            tabs = [x.clone() for x in (self.plan.ranks_depth, self.plan.ranks_feat, self.plan.row_ptr,
-                                        self.plan.bp_ranks_depth, self.plan.bp_ranks_feat, self.plan.bp_ranks_row,
-                                        self.plan.bp_starts, self.plan.bp_lengths, self.plan.tile_desc, self.plan.ranks_row,
-                                        self.plan.pix_desc, self.plan.pix_ptr, self.plan.patch_order)]
-            tabs.append(None if self.row_bin is None else self.row_bin.clone())
-            tabs.append([t.clone() for t in self.direct_tabs] if self.direct else None)       # tb[14]: pt, ivl_rel, desc32
+            # private copies of the tables too, so that nothing is served from the Infinity Cache:
+            # tb = (row_ptr, pix_ptr, patch_order, packed backward table, (pt, ivl_rel, desc32))
+            tabs = [self.plan.row_ptr.clone(), self.plan.pix_ptr.clone(), self.plan.patch_order.clone(), self.row_bin.clone(),
+                    [t.clone() for t in self.direct_tabs]]
             self.sets.append((depth, feat, og, out, torch.empty_like(depth), torch.empty_like(feat), tabs))
         rng = np.random.default_rng(seed)
         self.points = [torch.from_numpy(radar_points(rng, int(rng.integers(8000, 20001)))).to(dev) for _ in range(batch)]
@@ -185,31 +176,15 @@ class BevOps:
 
     def pool_fwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
-        if self.tiled and self.lean and self.direct:
-            # as the product launches it: the empty rows of `out` are zero already (same plan, nobody wrote to it) and are kept
-            pt, ivl_rel, desc32 = tb[14]
-            self.ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, tb[2], out, self.D, self.fH * self.fW,
-                                                empty_rows_kept=self.keep_empty)
-        elif self.tiled and self.lean:
-            self.ops.bev_pool_v2_forward_lean(depth, feat, tb[0], tb[2], tb[8], out, self.D, self.fH * self.fW,
-                                              empty_rows_kept=self.keep_empty)
-        else:
-            self.ops.bev_pool_v2_forward_csr(depth, feat, tb[0], tb[1], tb[2], out, tb[9], tb[8] if self.tiled else None)
+        # as the product launches it: the empty rows of `out` are zero already (same plan, nobody wrote to it) and are kept
+        pt, ivl_rel, desc32 = tb[4]
+        self.ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, tb[0], out, self.D, self.fH * self.fW,
+                                            empty_rows_kept=self.keep_empty)
 
     def pool_bwd(self, s):
         depth, feat, og, out, dg, fg, tb = self.sets[s]
-        if self.patch_bwd:
-            if tb[13] is not None:       # one packed table (row | depth bin << 24), as the plan's autograd function does
-                self.ops.bev_pool_v2_backward_patch(og, depth, feat, None, tb[13], tb[11], tb[12], dg, fg)
-            else:
-                self.ops.bev_pool_v2_backward_patch(og, depth, feat, tb[3], tb[5], tb[11], tb[12], dg, fg)
-            return
-        dg.zero_()
-        if self.sched_bwd:
-            self.ops.bev_pool_v2_backward_sched(og, depth, feat, tb[3], tb[5], tb[10], dg, fg)
-        else:
-            fg.zero_()
-            self.ops.bev_pool_v2_backward(og.view(1, 1, 1, -1, self.C), dg, fg, depth, feat, tb[3], tb[4], tb[5], tb[7], tb[6])
+        # one packed table (row | depth bin << 24), as the plan's autograd function does
+        self.ops.bev_pool_v2_backward_patch(og, depth, feat, None, tb[3], tb[1], tb[2], dg, fg)
 
     def radar(self):
         vox, coors, nums = [], [], []
@@ -313,14 +288,10 @@ class BevOps:
         self.radar()
 
     def fwd_kernel_name(self):
-        if self.tiled and self.lean and self.direct:
-            return "k_pool_fwd_direct"
-        if self.tiled and self.lean:
-            return "k_pool_fwd_lean2<16,4>" if os.environ.get("OMNIHD_POOL_LEAN2", "1") != "0" else "k_pool_fwd_lean<16,4>"
-        return "k_pool_fwd_tiles<16,4>" if self.tiled else "k_pool_fwd<16,true>"
+        return "k_pool_fwd_direct"
 
     def bwd_kernel_name(self):
-        return "k_pool_bwd_patch" if self.patch_bwd else ("k_pool_bwd_sched<16,4> + memset" if self.sched_bwd else "k_pool_bwd<16> + 2 memsets")
+        return "k_pool_bwd_patch"
 
     def bwd_algorithmic_bytes(self):
         """3 per-point tables + backward interval tables + depth gather + feature rows + touched out_grad rows
@@ -473,31 +444,24 @@ def _phase(name):
 
 
 def run_guarded():
-    """N = 1: the measurement runs in a CHILD process of this one and its stdout (the one JSON line) is passed through.  If the
-    child dies without a line — in round 5 one of ~15 otherwise identical runs on fresh boxes ended in `Memory access fault by GPU
-    ... address (nil)` half a minute after start, never reproduced — it is started once more; the second child's outcome stands.
-    Nothing is averaged or selected: a run either prints its line or it does not."""
+    """N = 1: the measurement runs in a CHILD process of this one (the parent never touches the GPU) and its stdout — the one JSON
+    line — is passed through.  A child that dies is a failed run: its exit code is this run's exit code (a signal becomes
+    128 + signal), nothing is retried.  (Rounds 4-5 restarted a child that died of `Memory access fault by GPU`; the cause was
+    found and removed in round 6, profiles/round6/fault_root_cause.txt.)"""
     import subprocess
     env = dict(os.environ, OMNIHD_BENCH_CHILD="1")
-    rc = 1
-    for attempt in (1, 2):
-        if attempt == 2:
-            # the fault of round 5 lives in the library's bf16 kernels (profiles/round5/bf16_fault_hunt.txt; the fp32 step never
-            # faulted): the second attempt measures the headline precision only and says so in its line
-            env["OMNIHD_BENCH_SAFE"] = "1"
-        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
-        out = p.stdout.decode(errors="replace")
-        rc = p.returncode
-        if rc == 0 and any(ln.lstrip().startswith("{") for ln in out.splitlines()):
-            sys.stdout.write(out)
-            sys.stdout.flush()
-            return 0
-        killed = rc < 0 or rc >= 128                   # died of a signal (a GPU memory fault ends in abort()), not of its own exit
-        print(f"bench.py: attempt {attempt} ended with exit code {rc} and no result line" +
-              ("; starting it once more" if attempt == 1 and killed else ""), file=sys.stderr, flush=True)
-        if not killed:
-            break
-    return rc or 1
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE)
+    out = p.stdout.decode(errors="replace")
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    rc = p.returncode
+    if rc == 0 and not any(ln.lstrip().startswith("{") for ln in out.splitlines()):
+        print("bench.py: the measurement process ended without a result line", file=sys.stderr, flush=True)
+        return 1
+    if rc != 0:
+        print(f"bench.py: the measurement process ended with exit code {rc}", file=sys.stderr, flush=True)
+        return 128 - rc if rc < 0 else rc
+    return 0
 
 
 def launch_ranks(n):
@@ -793,9 +757,6 @@ def main():
         print(json.dumps(cpu_baseline_fusion(sys.argv[2], int(sys.argv[3]))), flush=True)
         return
     a = parse()
-    safe_rerun = os.environ.get("OMNIHD_BENCH_SAFE") == "1" and a.dtype == "both"
-    if safe_rerun:
-        a.dtype = "fp32"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a.gpus))          # before anything in this process touches the GPU
     profiled = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_TOOL", "ROCPROF")) for k in os.environ)
@@ -1015,12 +976,13 @@ def main():
                                      if (main_dt != "bf16" and a.workload == "fusion") else
                                      "bf16 autocast for the dense convolutions, everything else fp32" if a.workload == "fusion" else "fp32 operators"),
                        "frames_per_gpu": a.batch, "n_points": n_points, "n_intervals": n_intervals,
-                       "streams": ("radar branch of the forward on a second stream (OMNIHD_DUAL_STREAM=%s); weight gradients of the split "
-                                   "convolutions behind the pooling backward on a side stream, joined at the end of backward "
-                                   "(OMNIHD_WGRAD_OVERLAP=%s, one rank and fp32 only: %s) — kernels measured inside the step run 3-5 %% above their "
+                       "streams": ("radar branch in line on the step's stream (OMNIHD_DUAL_STREAM=%s; the second stream of rounds 3-5 was the "
+                                   "trigger of the intermittent GPU memory fault, profiles/round6/fault_root_cause.txt); weight gradients of the "
+                                   "split convolutions behind the pooling backward on a side stream, joined at the end of backward "
+                                   "(OMNIHD_WGRAD_OVERLAP=%s, fp32 only: %s) — kernels measured inside the step run 3-5 %% above their "
                                    "isolated durations" % (
-                                       os.environ.get("OMNIHD_DUAL_STREAM", "1"), os.environ.get("OMNIHD_WGRAD_OVERLAP", "1"),
-                                       "active" if (world == 1 and main_dt != "bf16" and os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") != "0"
+                                       os.environ.get("OMNIHD_DUAL_STREAM", "0"), os.environ.get("OMNIHD_WGRAD_OVERLAP", "1"),
+                                       "active" if (main_dt != "bf16" and os.environ.get("OMNIHD_WGRAD_OVERLAP", "1") != "0"
                                                     and os.environ.get("OMNIHD_FP32_CONV", "tune") != "miopen") else "inactive")
                                    if a.workload == "fusion" else "one stream"),
                        "parallelism": (f"dp{world}: one rank per GPU, DDP gradient all-reduce over RCCL (25 MB buckets, "
@@ -1087,10 +1049,6 @@ def main():
                                      "note": "dense convolutions under bf16 autocast (our implicit-GEMM MFMA kernels for forward / data / weight gradient or MIOpen, measured per geometry), "
                                              "pooling / voxelisation / losses fp32; deviation from the fp32 step bounded in "
                                              "tests/test_detector_gpu.py::test_bf16_step_deviation_from_the_fp32_step"}
-        if safe_rerun:
-            line["bf16_autocast"] = {"value": None, "note": "not measured: the first attempt of this bench died of a signal (GPU memory fault; "
-                                     "seen only in the library's bf16 kernels, profiles/round5/bf16_fault_hunt.txt) and this second attempt "
-                                     "measures the headline precision only"}
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only: at N>1 the other ranks would sit in the
             if a.workload == "fusion":                # closing barrier for minutes while the host cores are busy
                 line["cpu_baseline"] = run_cpu_baseline_child(a.res, radar_dims)

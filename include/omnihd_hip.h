@@ -77,53 +77,31 @@ int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth, const floa
                            float* depth_grad, float* feat_grad, int c, int n_intervals,
                            void* stream);
 
-/* Fused dense forward used by our own LSS module (no reference counterpart: it removes the
- * reference's zero-fill (bev_pool.py:27), permute copy (:91) and s2c concat copy
- * (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:374-376)).
- * The points are grouped by OUTPUT ROW in CSR form: row r owns points
- * [row_ptr[r], row_ptr[r+1]) of ranks_depth/ranks_feat.  Every one of the n_rows rows is
- * written (zeros for empty rows), so `out` needs no initialisation.  The row numbering is
- * whatever the plan builder chose (reference (b,z,y,x) order, or (b,y,x,z) = channels-last
- * of the s2c tensor).
- *   ranks_row[p]  (n_points ints) output row of point p (the sorted keys of omnihd_sort_ranks);
- *   tile_desc     (8*ceil(n_tiles/8) x 4 ints, 16-byte aligned, from omnihd_tile_desc) launch
- *                 schedule: entry [x*ceil(n_tiles/8)+i] = {first row, #rows, first point, #points}
- *                 of the i-th tile worked on by XCD x (#rows = 0: idle slot).  Tiles must be runs
- *                 of whole rows covering every row exactly once; their ORDER only affects speed
- *                 (L2 locality), never results.
- * With ranks_row and tile_desc the load-balanced tiled kernel runs (rows cut by the in-tile work
- * split are combined in a fixed order: a row's sum may be associated differently from table
- * order, run-to-run deterministic).  With either NULL a simple row-per-lane-group kernel runs. */
-int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
-                               const int* ranks_depth, const int* ranks_feat,
-                               const int* ranks_row, const int* row_ptr,
-                               const int* tile_desc, int n_tiles, float* out, int c,
-                               int n_rows, int n_points, void* stream);
+/* Dense forward for ANY channel count (no reference counterpart: it removes the reference's zero-fill (bev_pool.py:27),
+ * permute copy (:91) and s2c concat copy (bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:374-376)).
+ * The points are grouped by OUTPUT ROW in CSR form: row r owns points [row_ptr[r], row_ptr[r+1]) of ranks_depth / ranks_feat.
+ * Every one of the n_rows rows is written (zeros for empty rows), so `out` needs no initialisation.  The row numbering is
+ * whatever the plan builder chose (reference (b,z,y,x) order, or (b,y,x,z) = channels-last of the s2c tensor).  One group
+ * of C/4 lanes per row, long rows split over the workgroup (the kernel of omnihd_bev_pool_v2_fwd); C = 64 — every
+ * configuration of the reference — runs omnihd_bev_pool_v2_fwd_direct instead.  (The LDS-staged tiled kernels of rounds 2-4
+ * behind this entry point and omnihd_bev_pool_v2_fwd_lean were superseded: scripts/lab/patches/pool_superseded_kernels.patch.) */
+int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat, const int* ranks_depth, const int* ranks_feat,
+                               const int* row_ptr, float* out, int c, int n_rows, int n_points, void* stream);
 
-/* The same dense forward reading ONE per-point table: the pixel row is derived from the depth index
- * (rf = (rd / (d_bins*fhw)) * fhw + rd % fhw, i.e. depth (B,N,D,fH,fW) and feat (B,N,fH,fW,C) of the same frames)
- * and the closing point of every output row comes from row_ptr.  tile_desc: 8*k slots as above (required).
- * n_feat_rows = B*N*fH*fW, the number of rows of `feat` (the kernel gathers them with range-checked buffer loads:
- * n_feat_rows*c*4 must stay below 2 GiB; 0 = unknown selects the first-generation kernel with 64-bit addressing).
- * empty_rows_kept != 0: `out` is the buffer of an earlier launch with the SAME tables (or a zero-filled one) that nobody
- * has written to since — its empty rows (no point falls into them: a property of the tables) are zero already and are
- * not stored again; only the rows that collect points are written (at R1: 94 MB instead of 157 MB per launch).  The
- * result in `out` is the same dense tensor either way.  Needs n_feat_rows > 0. */
-int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int* ranks_depth, const int* row_ptr,
-                                const int* tile_desc, int n_tiles, float* out, int c, int n_rows, int n_points,
-                                int d_bins, int fhw, int n_feat_rows, int empty_rows_kept, void* stream);
-
-/* The same dense forward for C = 64 without LDS staging of the point records (round 4): every group of 16 lanes walks its
- * own piece of the tile's point list straight from global memory (csrc/bev_pool_v2.hip, k_pool_fwd_direct).
+/* The dense forward of the product, C = 64 (round 4): the row sequence is cut into TILES of ~768 rows + points (runs of whole
+ * rows, a row of more than 512 points alone: omnihd_csr_tiles) scheduled per XCD (omnihd_tile_desc); every group of 16 lanes
+ * walks its own piece of the tile's point list straight from global memory (csrc/bev_pool_v2.hip, k_pool_fwd_direct).
+ * empty_rows_kept != 0: `out` is the buffer of an earlier launch with the SAME tables (or a zero-filled one) that nobody has
+ * written to since — its empty rows are zero already and are not stored again.
  *   pt        (n_points ints)   ranks_depth | closing << 31, closing = the point is the last one of its output row;
  *   ivl_rel   (n_intervals ints) output row of the k-th non-empty row of the launch, relative to the first row of its tile;
- *   desc32    (n_slots x 32 ints, n_slots = 8*k, 16-byte aligned) launch schedule as in omnihd_bev_pool_v2_fwd_csr:
+ *   desc32    (n_slots x 32 ints, n_slots = 8*k, 16-byte aligned) launch schedule, entry [x*k + i] = the i-th tile of XCD x:
  *             {first row, #rows, first point, #points, 0, 0, 0, 0, g[16], 0 x 8} with g[j] = number of non-empty rows of the
  *             launch that close before point first_point + min(j*w, #points), w = ceil(#points/16), | 1<<31 when that
  *             point continues the row of the point in front of it inside the same tile;
  *   row_ptr   CSR over all rows (only read to zero-fill empty rows: may be NULL when empty_rows_kept != 0).
- * Same tiles, same result contract as omnihd_bev_pool_v2_fwd_lean (rows cut by the in-tile split are combined in a fixed
- * order; run-to-run identical; no atomics).  ref: replaces ops/bev_pool_v2/src/bev_pool_cuda.cu:21-48 + bev_pool.py:27,91. */
+ * Rows cut by the in-tile split are combined in a fixed order (a row's sum may be associated differently from table order;
+ * run-to-run identical; no atomics); tile ORDER only affects speed.  ref: replaces ops/bev_pool_v2/src/bev_pool_cuda.cu:21-48 + bev_pool.py:27,91. */
 int omnihd_bev_pool_v2_fwd_direct(const float* depth, const float* feat, const int* pt, const int* ivl_rel, int n_intervals,
                                   const int* desc32, int n_slots, const int* row_ptr, float* out, int c, int n_rows,
                                   int n_points, int d_bins, int fhw, int n_feat_rows, int empty_rows_kept, void* stream);
@@ -185,50 +163,6 @@ int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* depth, cons
                                  const int* ranks_depth, const int* ranks_row, const int* pix_ptr,
                                  const int* patch_order, int n_slots, int n_img, int d_bins, int fhw,
                                  long long n_rows, float* depth_grad, float* feat_grad, int c, void* stream);
-
-/* Stream backward, C = 64 (round 4, opt-in): the arithmetic of omnihd_bev_pool_v2_bwd_patch — replaces the reference's
- * bev_pool_grad_kernel (ops/bev_pool_v2/src/bev_pool_cuda.cu:67-121) + the re-sort in front of it (ops/bev_pool_v2/bev_pool.py:47-57) —
- * with every out_grad row that the 16 pixels of a patch share gathered from global memory once and handed on through LDS.
- * ONE WAVEFRONT per stream of stages (no workgroup barrier; the loads of a stage are in flight while earlier stages are
- * consumed, across patch boundaries), 4 lanes per pixel.  feat_grad bit-identical to omnihd_bev_pool_v2_bwd_patch's (the
- * reference's fma chain per channel); depth_grad a fixed-order channel sum (run-to-run identical; differs from the reference's
- * serial loop by fp32 rounding).  Both written densely.
- * Patches are patch_w x (16/patch_w) pixel blocks of the (fh, fw) feature image, patch_w in {16, 8, 4}; patch id =
- * (image * ceil(fh / (16/patch_w)) + patch row) * ceil(fw / patch_w) + patch column; pixel g of a patch = row g / patch_w,
- * column g % patch_w of the block.
- *   uniq_rows   per patch: the sorted distinct output rows its points touch, cut into stages of rows_per_stage rows
- *               (rows_per_stage in {32, 48, 64});
- *   pt_word[i]  (backward order: points sorted by pixel, inside a pixel by output row) = 256 * (index of the point's row
- *               inside its stage) | depth bin << 24   (d_bins <= 64);
- *   px_off      (#offset rows + 1) x 16 ints: row r, column g = index into pt_word of pixel g's first point of the stage that
- *               row stands for; the row behind a patch's last stage holds the ends of the 16 lists; a patch without points
- *               has one (empty) stage;
- *   stream      n_entries x 4 ints, 16-byte aligned; wave w walks entries [stream_ptr[w], stream_ptr[w+1]): two more than
- *               it has stages.  Entry e of a wave (e = 0, 1, ..): {x, y, z, w} =
- *                 x: patch of stage e-2 | 1<<30 if that stage is the first of its patch | 1<<29 if the last | 1<<28 (0 for e < 2),
- *                 y: first entry of stage e in uniq_rows, z: px_off row of stage e | #rows of stage e << 24 (0, 0 past the end),
- *                 w: the patch whose FIRST stage is stage e-1, else -1;
- *   n_streams   a multiple of 8; wave (blockIdx & 7) * n_streams/8 + blockIdx / 8 walks one stream: consecutive streams of
- *               one eighth share an XCD.  Every stage of every patch must appear in exactly one stream, in order.       */
-int omnihd_bev_pool_v2_bwd_stream(const float* out_grad, const float* depth, const float* feat, const int* pt_word,
-                                  long long n_points, const int* uniq_rows, long long n_uniq, const int* px_off, long long n_off,
-                                  const int* stream, long long n_entries, const int* stream_ptr, int n_streams, int n_img,
-                                  int d_bins, int fh, int fw, int patch_w, int rows_per_stage, long long n_rows,
-                                  float* depth_grad, float* feat_grad, int c, void* stream_handle);
-/* dynamic LDS bytes one wavefront of the kernel above asks for */
-int omnihd_bev_pool_v2_bwd_stream_lds_bytes(int rows_per_stage, int d_bins);
-
-/* Scheduled backward used by our own LSS module (same arithmetic as omnihd_bev_pool_v2_bwd).
- * pix_desc: 8 * groups_per_xcd descriptors of 4 ints {pixel row f, first point, #points, 0},
- * 16-byte aligned; entry [x*groups_per_xcd + i] is the i-th pixel handled on XCD x; f = -1 marks
- * an idle slot.  Points [first, first+#points) of ranks_depth / ranks_row (the backward tables:
- * sorted by pixel) belong to pixel f.  EVERY pixel should be listed exactly once (also pixels
- * without points): feat_grad is then written densely and needs no zero-fill.  depth_grad is
- * only written at the listed points (the caller zero-fills it).  C in {4,8,16,32,64}.        */
-int omnihd_bev_pool_v2_bwd_sched(const float* out_grad, const float* depth, const float* feat,
-                                 const int* ranks_depth, const int* ranks_row,
-                                 const int* pix_desc, int groups_per_xcd, float* depth_grad,
-                                 float* feat_grad, int c, void* stream);
 
 /* Work partition for the tiled forward: tile_row[0..n_tiles] (capacity n_rows+1 ints) with
  * tile k = rows [tile_row[k], tile_row[k+1]).  A tile closes when rows+points reach a multiple

@@ -173,699 +173,25 @@ __global__ __launch_bounds__(kBlock) void k_pool_fwd(
 
 
 // ---------------------------------------------------------------------------------------------
-// Tiled dense forward.
-//
-// A TILE is a run of whole output rows that holds at most kCap points, or one single row of any
-// length; the plan builds tiles of ~tile_items points+rows so every workgroup gets the same
-// amount of work although 40 % of the BEV rows are empty and a few near-ego rows hold thousands
-// of points.  The launch schedule is an array of 16-byte descriptors {first row, #rows, first
-// point, #points}, one per (XCD, slot): workgroup b runs on XCD b % 8 (observed dispatch rule,
-// used for locality only), and the plan orders the schedule so that one XCD works on tiles that
-// gather from the same image columns — its 4 MiB L2 then holds the feature rows it needs
-// (measured: 24 TB/s of 256-byte row gathers from an L2-resident table vs 9 TB/s from the
-// Infinity Cache).  One workgroup per tile, phases:
-//   L  ALL 256 lanes read the tile's rank tables coalesced and gather the depth values 256-wide;
-//      they land in LDS as { pixel-row index | last-point-of-row flag, depth, output row };
-//   Z  meanwhile the empty rows of the tile are zero-filled (row_ptr read coalesced);
-//   P  the points are cut into G equal pieces, one per group of C4 lanes.  A group reads one
-//      record (broadcast LDS read), gathers the 16 B x C4 feature row (U gathers in flight),
-//      accumulates, and on a last-point flag stores the finished row (256 B for C=64).
-//      A row cut by a piece boundary leaves partials in LDS which are added in piece order after
-//      one barrier.
-// 19 KiB of LDS and <= 64 VGPRs: 8 workgroups (32 waves) per CU hide the dependent latencies.
-// No atomics, no dependence on dispatch order: results are run-to-run identical.
+// Tiles.  A TILE is a run of whole output rows of ~tile_items points + rows, or one single row of any length (the plan cuts
+// them so that every workgroup gets the same amount of work although 40 % of the BEV rows are empty and a few near-ego rows hold
+// thousands of points).  The launch schedule is an array of descriptors, one per (XCD, slot): workgroup b runs on XCD b % 8
+// (observed dispatch rule, used for locality only), and the plan orders the schedule so that one XCD works on tiles that gather from
+// the same image columns.  The kernels that staged a tile's point records in LDS (k_pool_fwd_tiles, k_pool_fwd_lean,
+// k_pool_fwd_lean2: rounds 2-4) were superseded by k_pool_fwd_direct below and live on as scripts/lab/patches/pool_superseded_kernels.patch.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCap = 1280;   // LDS point records per workgroup
-
 __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
 
-template <int C4, int U>
-__global__ __launch_bounds__(kBlock) void k_pool_fwd_tiles(
-    const float* __restrict__ depth, const float4* __restrict__ feat4,
-    const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
-    const int* __restrict__ ranks_row, const int* __restrict__ row_ptr,
-    const int4* __restrict__ tile_desc, float4* __restrict__ out4, int tiles_per_xcd,
-    int n_points_total) {
-  constexpr int G = kBlock / C4;
-  constexpr int GPW = 64 / C4;   // groups per wavefront
-  constexpr int kRecInts = kCap * 3;
-  // s_mem: [0, 2*kCap) int2 {rf|last, depth}; [2*kCap, 3*kCap) output row; the tail partials
-  // (kBlock float4 = 1024 ints) reuse the front of the record area after a barrier.
-  __shared__ int s_mem[kRecInts > kBlock * 4 ? kRecInts : kBlock * 4];
-  __shared__ float4 s_head[kBlock];
-  __shared__ int s_head_row[G];
-  __shared__ int s_tail_row[G];
-  int2* s_rfd = reinterpret_cast<int2*>(s_mem);
-  int* s_row = s_mem + 2 * kCap;
-  float4* s_tail = reinterpret_cast<float4*>(s_mem);
-
-  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
-  const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
-  const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
-  if (nrows <= 0) return;
-
-  const int tid = threadIdx.x;
-  const int sub = tid % C4;
-  const int grp = tid / C4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool long_row = (nrows == 1 && npts > kCap);
-  const bool staged = (npts > 0 && npts <= kCap);
-
-  // ---- phase L (issue): rank tables -> registers ------------------------------------------------
-  constexpr int kPer = (kCap + kBlock - 1) / kBlock;   // records per lane
-  int l_rf[kPer], l_rd[kPer], l_row[kPer], l_nxt[kPer];
-  if (staged) {
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int i = tid + k * kBlock;
-      if (i < npts) {
-        const int q = Pa + i;
-        l_rf[k] = ranks_feat[q];
-        l_rd[k] = ranks_depth[q];
-        l_row[k] = ranks_row[q];
-        l_nxt[k] = (q + 1 < n_points_total) ? ranks_row[q + 1] : -1;
-      }
-    }
-  }
-
-  // ---- phase Z: zero-fill the empty rows (stores only; overlaps the loads above) ---------------
-  if (!(nrows == 1 && npts > 0)) {
-    const int lane = tid & 63;
-    const int gw = lane / C4;
-    for (int base = 0; base < nrows; base += kBlock) {
-      const int i = base + tid;
-      bool empty = false;
-      if (i < nrows) empty = row_ptr[Ra + i + 1] == row_ptr[Ra + i];
-      const unsigned long long m = __ballot(empty);
-      if (m == 0ull) continue;
-      const int wave_row0 = Ra + base + (tid & ~63);
-      for (int k = 0; k < 64; k += GPW) {
-        const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
-        if (window == 0ull) continue;
-        if ((m >> (k + gw)) & 1ull)
-          store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
-      }
-    }
-  }
-  if (npts == 0) return;
-
-  float4 acc = zero4;
-
-  // ---- a single long row: windows of kCap points, every group accumulates, one combine --------
-  if (long_row) {
-    for (int base = 0; base < npts; base += kCap) {
-      const int n = min(kCap, npts - base);
-      for (int i = tid; i < n; i += kBlock) {
-        const int q = Pa + base + i;
-        s_rfd[i] = make_int2(ranks_feat[q], __float_as_int(depth[ranks_depth[q]]));
-      }
-      __syncthreads();
-      const int cw = (n + G - 1) / G;
-      const int j0 = min(grp * cw, n), j1 = min(j0 + cw, n);
-      for (int j = j0; j < j1; j += U) {
-        float4 v[U];
-        float d[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int2 rc = s_rfd[min(j + u, j1 - 1)];
-          d[u] = (j + u < j1) ? __int_as_float(rc.y) : 0.f;
-          v[u] = feat4[(size_t)rc.x * C4 + sub];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc = fma4(d[u], v[u], acc);
-      }
-      __syncthreads();
-    }
-    s_tail[tid] = acc;
-    __syncthreads();
-    if (grp == 0) {
-      float4 tsum = s_tail[sub];
-      for (int g = 1; g < G; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-      store_row(out4 + (size_t)Ra * C4 + sub, tsum, true);
-    }
-    return;
-  }
-
-  // ---- a tile that does not fit the LDS window (only for foreign tile tables): row by row -----
-  if (!staged) {
-    for (int r = Ra + grp; r < Ra + nrows; r += G) {
-      const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
-      if (len > 0)
-        store_row(out4 + (size_t)r * C4 + sub,
-                  pool_range<C4>(depth, feat4, ranks_depth, ranks_feat, s0, len, sub), true);
-    }
-    return;
-  }
-
-  // ---- phase L (finish): depth gather, records -> LDS -------------------------------------------
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int i = tid + k * kBlock;
-    if (i < npts) {
-      const float dv = depth[l_rd[k]];
-      const int last = (l_row[k] != l_nxt[k]) ? (int)0x80000000 : 0;
-      s_rfd[i] = make_int2(l_rf[k] | last, __float_as_int(dv));
-      s_row[i] = l_row[k];
-    }
-  }
-  if (tid < G) s_head_row[tid] = -1;
-  __syncthreads();
-
-  // ---- phase P: equal pieces of the point list, one per group ----------------------------------
-  const int w = (npts + G - 1) / G;
-  const int i0 = min(grp * w, npts);
-  const int i1 = min(i0 + w, npts);
-  // my first point continues a row that an earlier piece started
-  bool head_pending = (i0 > 0) && (i0 < i1) && (s_rfd[i0 - 1].x >= 0);
-  for (int i = i0; i < i1; i += U) {
-    float4 v[U];
-    float d[U];
-    int fl[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int2 rc = s_rfd[min(i + u, i1 - 1)];
-      d[u] = __int_as_float(rc.y);
-      fl[u] = rc.x;
-      v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (i + u < i1) {
-        acc = fma4(d[u], v[u], acc);
-        if (fl[u] < 0) {   // this point closes its output row
-          const int row = s_row[i + u];
-          if (head_pending) {
-            s_head[tid] = acc;
-            if (sub == 0) s_head_row[grp] = row;
-            head_pending = false;
-          } else {
-            store_row(out4 + (size_t)row * C4 + sub, acc, true);
-          }
-          acc = zero4;
-        }
-      }
-    }
-  }
-  const int tail_row = (i1 > i0 && s_rfd[i1 - 1].x >= 0) ? s_row[i1 - 1] : -2;
-  __syncthreads();   // every group is done with the records: their LDS is reused for the tails
-  s_tail[tid] = acc;
-  if (sub == 0) s_tail_row[grp] = tail_row;
-  __syncthreads();
-
-  const int hr = s_head_row[grp];
-  if (hr >= 0) {
-    int g0 = grp;
-    while (g0 > 0 && s_tail_row[g0 - 1] == hr) --g0;
-    float4 tsum = zero4;
-    for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-    tsum = add4(tsum, s_head[tid]);
-    store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// "Two-table" variant of the tiled forward: reads ONE per-point table (ranks_depth) instead of three.
-//   * the pixel row of a point is a function of its depth index: rf = (rd / (D*fHW)) * fHW + rd % fHW
-//     (two divisions by launch constants, done in fp32 with an exact fix-up);
-//   * which point closes which output row comes from the CSR boundaries the zero-fill phase reads anyway:
-//     row r closes at point row_ptr[r+1]-1, so the lane that looks at row r sets the flag (and the row id)
-//     of that one record after the records are in LDS (one extra barrier).
-// Per launch at R1 that is 16 MB less table traffic (225 -> 209 MB) and one load stream instead of four in phase L.
-// Partials of rows cut by a piece boundary are combined by adjacency (piece g's open tail belongs to the row that a
-// later piece closes first), so no per-point row id is needed at all.
-// ---------------------------------------------------------------------------------------------
+// x / d for a launch constant d (fp32 reciprocal with an exact fix-up)
 __device__ __forceinline__ int div_const(int x, int d, float inv) {
   int q = (int)((float)x * inv);
   int r = x - q * d;
   if (r < 0) { --q; r += d; }
   if (r >= d) { ++q; }
   return q;
-}
-
-template <int C4, int U>
-__global__ __launch_bounds__(kBlock) void k_pool_fwd_lean(
-    const float* __restrict__ depth, const float4* __restrict__ feat4, const int* __restrict__ ranks_depth,
-    const int* __restrict__ row_ptr, const int4* __restrict__ tile_desc, float4* __restrict__ out4,
-    int tiles_per_xcd, int fhw, int dfhw, float inv_fhw, float inv_dfhw) {
-  constexpr int G = kBlock / C4;
-  constexpr int GPW = 64 / C4;
-  constexpr int kRecInts = kCap * 3;
-  constexpr int kRowsPerLane = 3;                  // a staged tile holds <= 768 rows
-  __shared__ int s_mem[kRecInts > kBlock * 4 ? kRecInts : kBlock * 4];
-  __shared__ float4 s_head[kBlock];
-  __shared__ int s_head_row[G];
-  __shared__ int s_tail_flags[G];                  // bit0: piece ends inside a row, bit1: piece closes no row
-  int2* s_rfd = reinterpret_cast<int2*>(s_mem);
-  int* s_row = s_mem + 2 * kCap;
-  float4* s_tail = reinterpret_cast<float4*>(s_mem);
-
-  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
-  const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
-  const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
-  if (nrows <= 0) return;
-
-  const int tid = threadIdx.x;
-  const int sub = tid % C4;
-  const int grp = tid / C4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool long_row = (nrows == 1 && npts > kCap);
-  const bool staged = (npts > 0 && npts <= kCap && nrows <= kRowsPerLane * kBlock);
-
-  auto pixel_row = [&](int rd) {
-    const int n = div_const(rd, dfhw, inv_dfhw);
-    const int q = div_const(rd, fhw, inv_fhw);
-    return n * fhw + (rd - q * fhw);
-  };
-
-  // ---- phase L (issue): ONE rank table -> registers -------------------------------------------
-  constexpr int kPer = (kCap + kBlock - 1) / kBlock;
-  int l_rd[kPer];
-  if (staged) {
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int i = tid + k * kBlock;
-      if (i < npts) l_rd[k] = ranks_depth[Pa + i];
-    }
-  }
-
-  // ---- phase Z: zero-fill the empty rows; remember where the non-empty rows of this lane close --
-  int l_close[kRowsPerLane], l_crow[kRowsPerLane];
-#pragma unroll
-  for (int j = 0; j < kRowsPerLane; ++j) l_close[j] = -1;
-  if (!(nrows == 1 && npts > 0)) {
-    const int lane = tid & 63;
-    const int gw = lane / C4;
-    int j = 0;
-    for (int base = 0; base < nrows; base += kBlock, ++j) {
-      const int i = base + tid;
-      bool empty = false;
-      if (i < nrows) {
-        const int s0 = row_ptr[Ra + i], e0 = row_ptr[Ra + i + 1];
-        empty = e0 == s0;
-        if (!empty && j < kRowsPerLane) {
-          l_close[j] = e0 - 1 - Pa;
-          l_crow[j] = Ra + i;
-        }
-      }
-      const unsigned long long m = __ballot(empty);
-      if (m == 0ull) continue;
-      const int wave_row0 = Ra + base + (tid & ~63);
-      for (int k = 0; k < 64; k += GPW) {
-        const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
-        if (window == 0ull) continue;
-        if ((m >> (k + gw)) & 1ull)
-          store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
-      }
-    }
-  } else if (tid == 0) {
-    l_close[0] = npts - 1;                         // the single row of the tile closes at its last point
-    l_crow[0] = Ra;
-  }
-  if (npts == 0) return;
-
-  float4 acc = zero4;
-
-  // ---- a single long row: windows of kCap points, every group accumulates, one combine --------
-  if (long_row) {
-    for (int base = 0; base < npts; base += kCap) {
-      const int n = min(kCap, npts - base);
-      for (int i = tid; i < n; i += kBlock) {
-        const int rd = ranks_depth[Pa + base + i];
-        s_rfd[i] = make_int2(pixel_row(rd), __float_as_int(depth[rd]));
-      }
-      __syncthreads();
-      const int cw = (n + G - 1) / G;
-      const int j0 = min(grp * cw, n), j1 = min(j0 + cw, n);
-      for (int j = j0; j < j1; j += U) {
-        float4 v[U];
-        float d[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int2 rc = s_rfd[min(j + u, j1 - 1)];
-          d[u] = (j + u < j1) ? __int_as_float(rc.y) : 0.f;
-          v[u] = feat4[(size_t)rc.x * C4 + sub];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc = fma4(d[u], v[u], acc);
-      }
-      __syncthreads();
-    }
-    s_tail[tid] = acc;
-    __syncthreads();
-    if (grp == 0) {
-      float4 tsum = s_tail[sub];
-      for (int g = 1; g < G; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-      store_row(out4 + (size_t)Ra * C4 + sub, tsum, true);
-    }
-    return;
-  }
-
-  // ---- a tile that does not fit the LDS window (only for foreign tile tables): row by row -----
-  if (!staged) {
-    for (int r = Ra + grp; r < Ra + nrows; r += G) {
-      const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
-      if (len <= 0) continue;
-      float4 a4 = zero4;
-      for (int q = s0; q < s0 + len; ++q) {
-        const int rd = ranks_depth[q];
-        a4 = fma4(depth[rd], feat4[(size_t)pixel_row(rd) * C4 + sub], a4);
-      }
-      store_row(out4 + (size_t)r * C4 + sub, a4, true);
-    }
-    return;
-  }
-
-  // ---- phase L (finish): pixel row, depth gather, records -> LDS --------------------------------
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int i = tid + k * kBlock;
-    if (i < npts) {
-      s_rfd[i] = make_int2(pixel_row(l_rd[k]), __float_as_int(depth[l_rd[k]]));
-    }
-  }
-  if (tid < G) s_head_row[tid] = -1;
-  __syncthreads();
-  // ---- closing flags + row ids from the CSR boundaries (each closing record has exactly one owner) ----
-#pragma unroll
-  for (int j = 0; j < kRowsPerLane; ++j)
-    if (l_close[j] >= 0) {
-      s_rfd[l_close[j]].x |= (int)0x80000000;
-      s_row[l_close[j]] = l_crow[j];
-    }
-  __syncthreads();
-
-  // ---- phase P: equal pieces of the point list, one per group ----------------------------------
-  const int w = (npts + G - 1) / G;
-  const int i0 = min(grp * w, npts);
-  const int i1 = min(i0 + w, npts);
-  bool head_pending = (i0 > 0) && (i0 < i1) && (s_rfd[i0 - 1].x >= 0);
-  bool closed_any = false;
-  for (int i = i0; i < i1; i += U) {
-    float4 v[U];
-    float d[U];
-    int fl[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int2 rc = s_rfd[min(i + u, i1 - 1)];
-      d[u] = __int_as_float(rc.y);
-      fl[u] = rc.x;
-      v[u] = feat4[(size_t)(rc.x & 0x7fffffff) * C4 + sub];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (i + u < i1) {
-        acc = fma4(d[u], v[u], acc);
-        if (fl[u] < 0) {   // this point closes its output row
-          const int row = s_row[i + u];
-          closed_any = true;
-          if (head_pending) {
-            s_head[tid] = acc;
-            if (sub == 0) s_head_row[grp] = row;
-            head_pending = false;
-          } else {
-            store_row(out4 + (size_t)row * C4 + sub, acc, true);
-          }
-          acc = zero4;
-        }
-      }
-    }
-  }
-  // piece ends inside a row (or is empty: then it is "inside" whatever row surrounds it, with a zero partial)
-  const bool open_end = (i1 <= i0) || (s_rfd[i1 - 1].x >= 0);
-  __syncthreads();
-  s_tail[tid] = acc;
-  if (sub == 0) s_tail_flags[grp] = (open_end ? 1 : 0) | (closed_any ? 0 : 2);
-  __syncthreads();
-
-  const int hr = s_head_row[grp];
-  if (hr >= 0) {
-    // the row I close first started in earlier pieces: add their open tails, walking back through pieces that lie
-    // entirely inside the row and stopping after the first one that closed a row of its own
-    int g0 = grp;
-    while (g0 > 0) {
-      const int f = s_tail_flags[g0 - 1];
-      if (!(f & 1)) break;
-      --g0;
-      if (!(f & 2)) break;
-    }
-    float4 tsum = zero4;                             // point order, like the three-table kernel
-    for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-    tsum = add4(tsum, s_head[tid]);
-    store_row(out4 + (size_t)hr * C4 + sub, tsum, true);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_pool_fwd_lean2: the same tiles, plan and one-table phase L as k_pool_fwd_lean, with the point loop rewritten for
-// ISSUE cost.  Phase timelines of k_pool_fwd_lean (scripts/lab/pool_trace.py, wall_clock64 stamps per workgroup) showed the
-// point loop taking 10.6 of a workgroup's 20.2 us — and still 6.0 us with every feature gather AND every store compiled
-// out: the loop was bound by instruction issue (about 40 wave-instructions per step of 4 points, most of them exec-mask
-// bookkeeping for bounds checks and the three-way "first close of a continued row / later close / no close" branch), not
-// by memory.  Changes:
-//   * every group runs the SAME number of full steps: the record list is padded to G * Wp entries whose pixel offset lies
-//     outside the feature buffer — a raw buffer load returns zeros there (hardware range check), so a pad point adds
-//     0 * 0 and no bounds test exists in the loop; the trip count is a scalar;
-//   * gathers are `buffer_load_dwordx4 ... offen` with a 32-bit offset (pixel << 8 | lane*16: ONE v_lshl_or_b32, the
-//     closing flag in bit 31 shifts out) instead of 64-bit address arithmetic;
-//   * the closing flag and the output row travel together in ONE LDS word (s_row[i] = row | 1<<31, zero otherwise), read
-//     four at a time with one ds_read_b128; two ds_read_b128 fetch four {pixel, depth} records;
-//   * the head partial of a row continued from an earlier piece stays in registers (no LDS head slots);
-//   * the closing words are written by the lanes that look at row_ptr in the zero-fill phase BEFORE the depth gather
-//     returns (the LDS row words are zeroed behind an early barrier), so the second barrier of the old kernel and its
-//     phase are gone.
-// Results: same tiles, same per-piece fma order, pieces of Wp = roundup(ceil(n/G), U) points (the old kernel: ceil(n/G)),
-// so rows cut by a piece boundary may differ from k_pool_fwd_lean in the last bit; run-to-run identical, no atomics.
-// ---------------------------------------------------------------------------------------------
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-
-template <int C4, int U>
-__global__ __launch_bounds__(kBlock) void k_pool_fwd_lean2(
-    const float* __restrict__ depth, const float* __restrict__ feat, unsigned feat_bytes,
-    const int* __restrict__ ranks_depth, const int* __restrict__ row_ptr, const int4* __restrict__ tile_desc,
-    float* __restrict__ out, int tiles_per_xcd, int fhw, int dfhw, float inv_fhw, float inv_dfhw, int empty_rows_kept) {
-  static_assert(U == 4, "the record reads below are written for 4 points per step");
-  constexpr int G = kBlock / C4;
-  constexpr int GPW = 64 / C4;
-  constexpr int SH = (C4 == 1 ? 4 : C4 == 2 ? 5 : C4 == 4 ? 6 : C4 == 8 ? 7 : C4 == 16 ? 8 : C4 == 32 ? 9 : 10);  // log2(row bytes)
-  constexpr int kPad = G * U;
-  constexpr int kRec = kCap + kPad;
-  constexpr int kRowsPerLane = 3;
-  constexpr int kMemInts = (kRec * 3 > kBlock * 4) ? kRec * 3 : kBlock * 4;
-  __shared__ __attribute__((aligned(16))) int s_mem[kMemInts];   // [0, 2*kRec) records {pixel, depth}; [2*kRec, 3*kRec) row words
-  __shared__ int s_tail_flags[G];
-  __shared__ float4 s_head[kBlock];                               // head partials (rare path), outside the aliased area
-  __shared__ int s_head_row[G];
-  int2* s_rec = reinterpret_cast<int2*>(s_mem);
-  int* s_row = s_mem + 2 * kRec;
-  float4* s_tail = reinterpret_cast<float4*>(s_mem);              // after the point loop
-
-  if ((int)(blockIdx.x >> 3) >= tiles_per_xcd) return;
-  const int4 desc = tile_desc[(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)];
-  const int Ra = desc.x, nrows = desc.y, Pa = desc.z, npts = desc.w;
-  const int tid = threadIdx.x;
-  if (nrows <= 0) return;
-
-  const int sub = tid % C4;
-  const int grp = tid / C4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4* out4 = reinterpret_cast<float4*>(out);
-  const float4* feat4 = reinterpret_cast<const float4*>(feat);
-  const bool long_row = (nrows == 1 && npts > kCap);
-  const bool staged = (npts > 0 && npts <= kCap && nrows <= kRowsPerLane * kBlock);
-
-  auto pixel_row = [&](int rd) {
-    const int n = div_const(rd, dfhw, inv_dfhw);
-    const int q = div_const(rd, fhw, inv_fhw);
-    return n * fhw + (rd - q * fhw);
-  };
-
-  // ---- phase L (issue): the one rank table -> registers -----------------------------------------
-  constexpr int kPer = (kCap + kBlock - 1) / kBlock;
-  int l_rd[kPer];
-  if (staged) {
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int i = tid + k * kBlock;
-      if (i < npts) l_rd[k] = ranks_depth[Pa + i];
-    }
-    // row words of this tile start at zero (a closing record overwrites its word below)
-    for (int i = tid; i < kRec; i += kBlock) s_row[i] = 0;
-    __syncthreads();
-  }
-
-  // ---- phase Z: zero-fill the empty rows; the lane that sees a non-empty row marks its closing record --------
-  if (!(nrows == 1 && npts > 0)) {
-    const int lane = tid & 63;
-    const int gw = lane / C4;
-    for (int base = 0; base < nrows; base += kBlock) {
-      const int i = base + tid;
-      bool empty = false;
-      if (i < nrows) {
-        const int s0 = row_ptr[Ra + i], e0 = row_ptr[Ra + i + 1];
-        empty = e0 == s0;
-        if (!empty && staged) s_row[e0 - 1 - Pa] = i | (int)0x80000000;   // row offset inside the tile
-      }
-      // empty_rows_kept: the caller hands in a buffer whose empty rows (a property of the plan) are zero already — the
-      // buffer of an earlier launch of the SAME plan, which only ever wrote the non-empty rows — so they are not stored again
-      const unsigned long long m = empty_rows_kept ? 0ull : __ballot(empty);
-      if (m == 0ull) continue;
-      const int wave_row0 = Ra + base + (tid & ~63);
-      for (int k = 0; k < 64; k += GPW) {
-        const unsigned long long window = (GPW >= 64) ? m : ((m >> k) & ((1ull << GPW) - 1ull));
-        if (window == 0ull) continue;
-        if ((m >> (k + gw)) & 1ull)
-          store_row(out4 + (size_t)(wave_row0 + k + gw) * C4 + sub, zero4, true);
-      }
-    }
-  } else if (tid == 0 && staged) {
-    s_row[npts - 1] = (int)0x80000000;             // the single row of the tile (offset 0) closes at its last point
-  }
-  if (npts == 0) return;
-
-  float4 acc = zero4;
-
-  // ---- a single long row: windows of kCap points, every group accumulates, one combine --------
-  if (long_row) {
-    for (int base = 0; base < npts; base += kCap) {
-      const int n = min(kCap, npts - base);
-      for (int i = tid; i < n; i += kBlock) {
-        const int rd = ranks_depth[Pa + base + i];
-        s_rec[i] = make_int2(pixel_row(rd), __float_as_int(depth[rd]));
-      }
-      __syncthreads();
-      const int cw = (n + G - 1) / G;
-      const int j0 = min(grp * cw, n), j1 = min(j0 + cw, n);
-      for (int j = j0; j < j1; j += U) {
-        float4 v[U];
-        float d[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int2 rc = s_rec[min(j + u, j1 - 1)];
-          d[u] = (j + u < j1) ? __int_as_float(rc.y) : 0.f;
-          v[u] = feat4[(size_t)rc.x * C4 + sub];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc = fma4(d[u], v[u], acc);
-      }
-      __syncthreads();
-    }
-    s_tail[tid] = acc;
-    __syncthreads();
-    if (grp == 0) {
-      float4 tsum = s_tail[sub];
-      for (int g = 1; g < G; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-      store_row(out4 + (size_t)Ra * C4 + sub, tsum, true);
-    }
-    return;
-  }
-
-  // ---- a tile that does not fit the LDS window (only for foreign tile tables): row by row -----
-  if (!staged) {
-    for (int r = Ra + grp; r < Ra + nrows; r += G) {
-      const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0;
-      if (len <= 0) continue;
-      float4 a4 = zero4;
-      for (int q = s0; q < s0 + len; ++q) {
-        const int rd = ranks_depth[q];
-        a4 = fma4(depth[rd], feat4[(size_t)pixel_row(rd) * C4 + sub], a4);
-      }
-      store_row(out4 + (size_t)r * C4 + sub, a4, true);
-    }
-    return;
-  }
-
-  // ---- phase L (finish): pixel row, depth gather, records -> LDS; pad records gather zeros ---------
-  const int w = (npts + G - 1) / G;
-  const int Wp = (w + U - 1) / U * U;              // points per group, the same for every group
-  const int n_rec = G * Wp;                        // <= npts + G*U - 1 < kRec
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int i = tid + k * kBlock;
-    if (i < npts) {
-      s_rec[i] = make_int2(pixel_row(l_rd[k]), __float_as_int(depth[l_rd[k]]));
-    }
-  }
-  for (int i = npts + tid; i < n_rec; i += kBlock) s_rec[i] = make_int2(0x7fffffff, 0);   // offset beyond the buffer
-  __syncthreads();
-
-  // ---- phase P: Wp points per group, U per step, no bounds tests -------------------------------
-  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
-  // output window of this tile: rows [Ra, Ra + nrows); the row words hold offsets relative to Ra
-  const __amdgpu_buffer_rsrc_t out_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)Ra * (C4 * 4)), 0, nrows << SH, 0x00020000);
-  const unsigned lane_off = (unsigned)sub << 4;
-  const int i0 = grp * Wp;
-  // `pend`: the wave's mask of lanes whose first point continues a row that an earlier piece started; the first row such a
-  // group closes holds only a HEAD partial, kept in LDS and completed with the earlier pieces' tails after the loop.
-  const bool was_pending = (i0 > 0 && i0 < npts && s_row[i0 - 1] >= 0);
-  unsigned long long pend = __builtin_amdgcn_ballot_w64(was_pending);
-  const int lane = tid & 63;
-  const int4* rec4 = reinterpret_cast<const int4*>(s_rec + i0);      // 2 records per int4 (i0 is a multiple of U)
-  const int4* row4 = reinterpret_cast<const int4*>(s_row + i0);
-  const int steps = Wp / U;
-
-  // (A variant that issued the gathers of step b+1 before the stores of step b — so that the in-order vmcnt wait for a
-  // step's last gather would not cover that step's own stores — needed 72-78 VGPRs and measured the same: 41.7-43.0 us
-  // against 42.3-42.6 us in alternating runs; the simple loop is kept.)
-  for (int b = 0; b < steps; ++b) {
-    const int4 ra = rec4[2 * b], rb = rec4[2 * b + 1];
-    const int4 rw = row4[b];
-    const int px[U] = {ra.x, ra.z, rb.x, rb.z};
-    const float d[U] = {__int_as_float(ra.y), __int_as_float(ra.w), __int_as_float(rb.y), __int_as_float(rb.w)};
-    const int cl[U] = {rw.x, rw.y, rw.z, rw.w};
-    float4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const u32x4v raw = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, ((unsigned)px[u] << SH) | lane_off, 0, 0);
-      v[u] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc = fma4(d[u], v[u], acc);
-      const bool closing = cl[u] < 0;                    // this point closes its output row
-      const unsigned long long cm = __builtin_amdgcn_ballot_w64(closing);
-      if (closing) {
-        if ((pend >> lane) & 1ull) {                     // head partial of a continued row: completed after the loop
-          s_head[tid] = acc;
-          if (sub == 0) s_head_row[grp] = cl[u];
-        } else {
-          const u32x4v o = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
-          __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)cl[u] << SH) | lane_off, 0, 2 /* nt */);
-        }
-        acc = zero4;
-      }
-      pend &= ~cm;
-    }
-  }
-  const bool pending = ((pend >> lane) & 1ull) != 0ull;   // started inside a row and never closed it
-  // piece ends inside a row (or is empty: then it lies "inside" whatever row surrounds it, with a zero partial)
-  const int i1 = min(i0 + Wp, npts);
-  const bool open_end = (i1 <= i0) || (s_row[i1 - 1] >= 0);
-  __syncthreads();   // every group is done with the records: their LDS is reused for the tails
-  s_tail[tid] = acc;
-  // bit0: the piece ends inside a row; bit1: the piece lies entirely inside one row that started before it
-  if (sub == 0) s_tail_flags[grp] = (open_end ? 1 : 0) | ((pending || i1 <= i0) ? 2 : 0);
-  __syncthreads();
-
-  if (was_pending && !pending) {
-    // the row I closed first started in earlier pieces: add their open tails, walking back through pieces that lie
-    // entirely inside the row and stopping after the first one that started a row of its own
-    int g0 = grp;
-    while (g0 > 0) {
-      const int f = s_tail_flags[g0 - 1];
-      if (!(f & 1)) break;
-      --g0;
-      if (!(f & 2)) break;
-    }
-    float4 tsum = zero4;                             // point order
-    for (int g = g0; g < grp; ++g) tsum = add4(tsum, s_tail[g * C4 + sub]);
-    tsum = add4(tsum, s_head[tid]);
-    const u32x4v o = {__float_as_uint(tsum.x), __float_as_uint(tsum.y), __float_as_uint(tsum.z), __float_as_uint(tsum.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ((unsigned)s_head_row[grp] << SH) | lane_off, 0, 2);
-  }
 }
 
 // schedule slot -> {first row, #rows, first point, #points}; idle slots get #rows = 0
@@ -963,90 +289,6 @@ __global__ __launch_bounds__(kBlock) void k_pool_bwd(
     }
     feat_grad4[(size_t)ranks_feat[s] * C4 + sub] = fg;
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Scheduled backward: one group of C4 lanes per image-feature pixel, pixels taken from a plan-made
-// schedule of 16-byte descriptors {pixel row, first point, #points, -}.
-//   * the schedule lists EVERY pixel (also those without points), so feat_grad is written densely
-//     and needs no zero-fill; it walks the image in 4x4 pixel patches and gives each XCD one
-//     contiguous run of patches: neighbouring pixels hit the same BEV rows (a voxel collects its
-//     points from adjacent pixels), so an out_grad row fetched once is reused from L1/L2;
-//   * per chunk of C4 points the three tables are read coalesced, depth is gathered C4-wide,
-//     U out_grad rows (16 B x C4 lanes) are in flight per group;
-//   * depth_grad needs a dot product over the C channels for every point: each lane keeps its
-//     4-channel partial for the C4 points of the chunk and ONE log2(C4)-stage butterfly
-//     (C4-1 exchanges instead of C4*log2(C4)) leaves lane j with the sum of point j, which
-//     it then scatters to depth_grad.
-// feat_grad: fg += depth * g in table order (same fma chain as the reference kernel).
-// ---------------------------------------------------------------------------------------------
-template <int C4, int U>
-__global__ __launch_bounds__(kBlock) void k_pool_bwd_sched(
-    const float4* __restrict__ og4, const float* __restrict__ depth,
-    const float4* __restrict__ feat4, const int* __restrict__ ranks_depth,
-    const int* __restrict__ ranks_row, const int4* __restrict__ pix_desc,
-    float* __restrict__ depth_grad, float4* __restrict__ feat_grad4, int groups_per_xcd) {
-  static_assert(U >= 1 && U <= C4 && (C4 % U) == 0 && (U & (U - 1)) == 0, "U: power of two dividing C4");
-  constexpr int G = kBlock / C4;
-  const int sub = threadIdx.x % C4;
-  const int grp = threadIdx.x / C4;
-  const int gi = (int)(blockIdx.x >> 3) * G + grp;     // group slot inside this XCD's run
-  if (gi >= groups_per_xcd) return;
-  const int4 desc = pix_desc[(size_t)(blockIdx.x & 7) * groups_per_xcd + gi];
-  const int f = desc.x, s = desc.y, len = desc.z;
-  if (f < 0) return;
-  float4 fg = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (len > 0) {
-    const float4 x = feat4[(size_t)f * C4 + sub];
-    for (int cb = 0; cb < len; cb += C4) {
-      const int n = min(C4, len - cb);
-      int my_rb = 0, my_rd = 0;
-      float my_d = 0.f;
-      if (sub < n) {
-        my_rb = ranks_row[s + cb + sub];
-        my_rd = ranks_depth[s + cb + sub];
-        my_d = depth[my_rd];
-      }
-      for (int j = 0; j < n; j += U) {
-        float4 g[U];
-        float d[U];
-        float part[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int jj = min(j + u, n - 1);
-          const int v = __shfl(my_rb, jj, C4);
-          d[u] = (j + u < n) ? __shfl(my_d, jj, C4) : 0.f;
-          g[u] = og4[(size_t)v * C4 + sub];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          part[u] = fmaf(g[u].w, x.w, fmaf(g[u].z, x.z, fmaf(g[u].y, x.y, g[u].x * x.x)));
-          fg = fma4(d[u], g[u], fg);
-        }
-        // Channel sums of the U points: log2(U) halving stages over the TOP lane bits (a lane keeps
-        // the partials whose index matches its bits), then a plain xor-reduction over the remaining
-        // low bits.  Afterwards every lane with (sub / (C4/U)) == u holds the full dot of point j+u.
-        int m = C4 / 2;
-#pragma unroll
-        for (int h = U / 2; h >= 1; h >>= 1, m >>= 1) {
-          const bool hi = (sub & m) != 0;
-#pragma unroll
-          for (int k = 0; k < h; ++k) {
-            const float send = hi ? part[k] : part[k + h];
-            const float keep = hi ? part[k + h] : part[k];
-            part[k] = keep + __shfl_xor(send, m, C4);
-          }
-        }
-#pragma unroll
-        for (; m >= 1; m >>= 1) part[0] += __shfl_xor(part[0], m, C4);
-        constexpr int kLanesPerPoint = C4 / U;
-        const int u_mine = sub / kLanesPerPoint;
-        const int rd_mine = __shfl(my_rd, min(j + u_mine, n - 1), C4);
-        if ((sub % kLanesPerPoint) == 0 && j + u_mine < n) depth_grad[rd_mine] = part[0];
-      }
-    }
-  }
-  feat_grad4[(size_t)f * C4 + sub] = fg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1188,277 +430,6 @@ __global__ __launch_bounds__(kBlock, 8) void k_pool_bwd_patch(
   for (int i = tid; i < n_cell; i += kBlock) {
     const int d = i / kPatch, px = i % kPatch;
     if (px < npx) depth_grad[img_base + (size_t)d * fhw + px] = s_dg[i];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Stream backward (round 4, C = 64; OPT-IN, OMNIHD_POOL_BWD_STREAM=1 — measured slower than k_pool_bwd_patch at 256x704 and equal at
-// 544x960): every out_grad row that the 16 pixels of a patch share is fetched from global memory ONCE and handed
-// on through LDS.  Why it was built: k_pool_bwd_patch issues one 256-byte row gather per frustum point and neighbouring pixels ask
-// for the same rows — points per DISTINCT row inside a 16-pixel patch: 2.3 (16x1 run) / 2.9 (8x2) / 3.2 (4x4) at 256x704, 3.1 / 4.3 /
-// 4.8 at 544x960 (profiles/round4/pool_bwd_row_reuse.txt); the L1 serves the repeats, but each still occupies the vector-memory path.
-// The plan lists, per patch, the distinct output rows its points touch (sorted: `uniq`) and cuts that list into STAGES of R rows; a
-// pixel's points are sorted by output row (the backward tables are a stable sort of the row-sorted forward tables by pixel), so its
-// points of one stage are a contiguous piece of its list.  A first form with one workgroup per patch and a barrier per stage
-// (scripts/lab/records/pool_bwd_shared_workgroup.inc.txt) paid 5-7 us of dependent loads in front of every workgroup's first stage;
-// this form removes that and halves the VALU work per point:
-//   * ONE WAVEFRONT walks a STREAM of stages (the stages of the patches the plan dealt to it, one after the other): no
-//     workgroup barrier anywhere, and the loads of a stage are issued while earlier stages are consumed, across patch
-//     boundaries.  In iteration t the wave stores the rows of stage t-2 (registers -> LDS) and consumes that stage, gathers
-//     the rows and the first table words of stage t-1, and reads the row ids and per-pixel offsets of stage t and the stream
-//     entry t+1.  Every load is unconditional (range-checked buffer loads: a missing row / word / entry is an address beyond
-//     the buffer and returns zeros), so no register that a pending load writes is copied before the point loop: the only
-//     place the wave waits for memory is the top of an iteration.
-//   * 4 lanes per pixel (16 channels each) instead of 16: one wave = the 16 pixels of a patch, one point-loop step = one point of
-//     every pixel: 16 packed FMAs for feat_grad + 9 packed ops and 2 quad exchanges for the depth gradient per 16 points (the
-//     16-lane version: 17 VALU per 4 points).  The four 16-byte slots a lane owns of a row are rotated by the pixel's position
-//     inside its ds_read_b128 lane group, so the 16 lanes of a group hit 16 distinct 16-byte bank slots whatever rows they read.
-// feat_grad: fg += depth * g per channel in table order (the reference's fma chain, bit-exact); depth_grad: a fixed-order
-// channel sum (16 in-lane packed FMAs, then two quad exchanges): run-to-run identical, differs from the reference's serial
-// channel loop by fp32 rounding.
-//   stream[e]   = {patch | flags of stage e-2 (bit 30: first stage of its patch, 29: last, 28: entry has a stage to consume),
-//                  first uniq entry of stage e, (row of stage e in px_off) | #rows << 24, patch whose first stage is e-1 or -1}
-//   px_off      = per stage 16 ints (+ the 16 of the next row): index into pt_word of pixel g's first point of the stage
-// ---------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int kStreamFirst = 1 << 30, kStreamLast = 1 << 29, kStreamValid = 1 << 28;
-constexpr int kStreamCellRegs = 16;       // D * 16 cells of a patch over 64 lanes, D <= 64
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_quad_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);             // quad_perm
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-
-// One point-loop step = point t of every pixel's piece, in two halves so that the LDS reads of step t+1 are in flight while step
-// t is accumulated (with two waves per SIMD nothing else hides the LDS latency).
-struct StreamStep {
-  float4 g0, g1, g2, g3;      // my 16 channels of the point's out_grad row
-  float dv;                   // its depth value
-  int cell;                   // (depth bin * 16 + pixel): where its depth gradient goes
-  bool act;                   // the pixel's piece has a point t
-};
-
-// J = t % 4: lane q of a quad holds the table word of step 4*(t/4) + q in `wblk`
-template <int J, int R>
-__device__ __forceinline__ StreamStep stream_load(const char* s_rows, const float* s_dv, int wblk, int t, int cnt, int p, const int (&o)[4]) {
-  StreamStep st;
-  const int w = dpp_quad_i<J * 0x55>(wblk);
-  st.act = t < cnt;
-  const int off = st.act ? (w & 0x00ffffff) : R * 256;                         // past the piece: the zero row
-  st.cell = (int)(((unsigned)w >> 24) << 4) | p;
-  st.dv = s_dv[st.act ? st.cell : p];
-  st.g0 = *reinterpret_cast<const float4*>(s_rows + off + o[0]);
-  st.g1 = *reinterpret_cast<const float4*>(s_rows + off + o[1]);
-  st.g2 = *reinterpret_cast<const float4*>(s_rows + off + o[2]);
-  st.g3 = *reinterpret_cast<const float4*>(s_rows + off + o[3]);
-  return st;
-}
-
-__device__ __forceinline__ void stream_math(const StreamStep& st, float* s_dg, int q, const f32x2 (&x)[8], f32x2 (&fg)[8]) {
-  const float dv = st.act ? st.dv : 0.f;
-  // {dv, dv} as a REAL register pair: the compiler's own form is a packed op that broadcasts the low register and leaves the high
-  // one of the pair to whatever lives there — here the destination of a pending load, which the point loop then waited for
-  float dv_hi;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(dv_hi) : "v"(dv));
-  const f32x2 d2 = {dv, dv_hi};
-  const f32x2 ga[8] = {{st.g0.x, st.g0.y}, {st.g0.z, st.g0.w}, {st.g1.x, st.g1.y}, {st.g1.z, st.g1.w},
-                       {st.g2.x, st.g2.y}, {st.g2.z, st.g2.w}, {st.g3.x, st.g3.y}, {st.g3.z, st.g3.w}};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) fg[i] = __builtin_elementwise_fma(d2, ga[i], fg[i]);
-  f32x2 acc = ga[0] * x[0];
-#pragma unroll
-  for (int i = 1; i < 8; ++i) acc = __builtin_elementwise_fma(ga[i], x[i], acc);
-  float sum = acc.x + acc.y;
-  sum += dpp_quad_f<0xB1>(sum);                                                // lanes 1,0,3,2
-  sum += dpp_quad_f<0x4E>(sum);                                                // lanes 2,3,0,1
-  if (st.act && q == 0) s_dg[st.cell] = sum;
-}
-
-template <int RQ>          // RQ = rows per stage / 4 = row gathers per lane and stage
-__global__ __launch_bounds__(64, 2) void k_pool_bwd_stream(
-    const float* __restrict__ og, unsigned og_bytes, const float* __restrict__ depth, unsigned depth_bytes,
-    const float* __restrict__ feat, unsigned feat_bytes, const int* __restrict__ pt_word, unsigned word_bytes,
-    const int* __restrict__ uniq, unsigned uniq_bytes, const int* __restrict__ px_off, unsigned off_bytes,
-    const int4* __restrict__ stream, unsigned stream_bytes, const int* __restrict__ stream_ptr, int streams_per_xcd,
-    int fh, int fw, int pw_shift, int d_bins, float* __restrict__ depth_grad, float4* __restrict__ feat_grad4) {
-  constexpr int R = RQ * 4;
-  extern __shared__ float s_dyn[];                 // [(R+1) rows x 64][64*16 depth values][64*16 depth gradients]
-  char* s_rows = reinterpret_cast<char*>(s_dyn);
-  float* s_dv = s_dyn + (R + 1) * 64;
-  float* s_dg = s_dv + 64 * kPatch;
-  const int lane = threadIdx.x;
-  const int p = lane >> 2, q = lane & 3;           // point loop: pixel of the patch, quarter of its channels
-  const int gq = lane & 15, gr = lane >> 4;        // row gathers and depth cells: 16-byte slot / pixel, row of a 4-row group
-  const int sid = (int)(blockIdx.x & 7) * streams_per_xcd + (int)(blockIdx.x >> 3);
-  const int sbeg = stream_ptr[sid], send = stream_ptr[sid + 1];
-  if (sbeg >= send) return;
-  if (lane < 16) reinterpret_cast<float4*>(s_rows)[R * 16 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  const __amdgpu_buffer_rsrc_t og_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)og_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t depth_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)depth, 0, (int)depth_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t feat_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t word_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pt_word, 0, (int)word_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t uniq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)uniq, 0, (int)uniq_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t off_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)px_off, 0, (int)off_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t stream_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, (int)stream_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t dgrad_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)depth_grad, 0, (int)depth_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t fgrad_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat_grad4, 0, (int)feat_bytes, 0x00020000);
-  constexpr unsigned kBeyond = 0xfffffff0u;        // an offset no buffer reaches: the load returns zeros, the store is dropped
-
-  const int fhw = fh * fw;
-  const int plane4 = 16 * fhw;                     // bytes of four depth planes
-  const int pw = 1 << pw_shift, ph = kPatch >> pw_shift;
-  const int pcols = (fw + pw - 1) >> pw_shift, prows = (fh + ph - 1) / ph;
-  int o[4], slot[4];                               // my four 16-byte slots of a 256-byte row, rotated by the pixel's place in its lane group
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    slot[j] = 4 * ((((p >> 1) & 3) + j) & 3) + q;
-    o[j] = 16 * slot[j];
-  }
-
-  // ---- state carried from iteration to iteration ---------------------------------------------------------------
-  u32x4t pre[RQ];                                  // rows of the stage consumed NEXT iteration
-#pragma unroll
-  for (int m = 0; m < RQ; ++m) pre[m] = u32x4t{0u, 0u, 0u, 0u};
-  int w_next[4] = {0, 0, 0, 0};                    // first 16 table words of my pixel's piece of that stage
-  int ids_prev = 0, nrows_prev = 0;                // row ids of the stage whose rows are gathered this iteration
-  int oa1 = 0, ob1 = 0, oa2 = 0, ob2 = 0;          // my pixel's piece [oa, ob) of pt_word: stage t-1, stage t-2
-  f32x2 x[8], fg[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) x[i] = fg[i] = f32x2{0.f, 0.f};
-  u32x4t xn[4];                                    // feature row of my pixel in the NEXT patch, its depth cells
-  unsigned cn[kStreamCellRegs];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) xn[j] = u32x4t{0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int it = 0; it < kStreamCellRegs; ++it) cn[it] = 0u;
-  int f_cur = -1, f_next = -1;                     // my pixel's feature row (-1: outside the image)
-  int cell_cur = -1, cell_next = -1;               // index of (image, d = 0, pixel gq of the patch) in depth / depth_grad (-1: outside)
-
-  int ex, ey, ez, ew;
-  {
-    const u32x4t e = __builtin_amdgcn_raw_buffer_load_b128(stream_rsrc, (unsigned)sbeg << 4, 0, 0);
-    ex = __builtin_amdgcn_readfirstlane((int)e.x); ey = __builtin_amdgcn_readfirstlane((int)e.y);
-    ez = __builtin_amdgcn_readfirstlane((int)e.z); ew = __builtin_amdgcn_readfirstlane((int)e.w);
-  }
-  for (int j = sbeg; j < send; ++j) {
-    // ---- (1) what the previous iteration requested has arrived: rows of stage t-2 -> LDS, a new patch's pixel data ----
-#pragma unroll
-    for (int m = 0; m < RQ; ++m) reinterpret_cast<u32x4t*>(s_rows)[(4 * m + gr) * 16 + gq] = pre[m];
-    if (ex & kStreamFirst) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        x[2 * i] = f32x2{__uint_as_float(xn[i].x), __uint_as_float(xn[i].y)};
-        x[2 * i + 1] = f32x2{__uint_as_float(xn[i].z), __uint_as_float(xn[i].w)};
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fg[i] = f32x2{0.f, 0.f};
-      f_cur = f_next;
-      cell_cur = cell_next;
-#pragma unroll
-      for (int it = 0; it < kStreamCellRegs; ++it) {       // (64 bins are laid out: cells past d_bins hold the zeros their loads returned)
-        s_dv[(gr + 4 * it) * kPatch + gq] = __uint_as_float(cn[it]);
-        s_dg[(gr + 4 * it) * kPatch + gq] = 0.f;
-      }
-    }
-    int wq[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) wq[c] = w_next[c];
-
-    // ---- (2) requests: entry t+1, ids + offsets of stage t, pixel data of a patch that starts at t-1, rows + words of t-1 ----
-    const u32x4t e_n = __builtin_amdgcn_raw_buffer_load_b128(stream_rsrc, (unsigned)(j + 1) << 4, 0, 0);
-    const int ids_n = (int)__builtin_amdgcn_raw_buffer_load_b32(uniq_rsrc, (unsigned)(ey + lane) << 2, 0, 0);
-    const int so = ez & 0x00ffffff;
-    const int oa_n = (int)__builtin_amdgcn_raw_buffer_load_b32(off_rsrc, (unsigned)(so * kPatch + p) << 2, 0, 0);
-    const int ob_n = (int)__builtin_amdgcn_raw_buffer_load_b32(off_rsrc, (unsigned)((so + 1) * kPatch + p) << 2, 0, 0);
-    if (ew >= 0) {
-      const int img = ew / (pcols * prows);
-      const int pr = (ew - img * pcols * prows) / pcols, pc = ew - (img * prows + pr) * pcols;
-      const int h0 = pr * ph, w0 = pc << pw_shift;
-      const int hh = h0 + (p >> pw_shift), ww = w0 + (p & (pw - 1));
-      f_next = (hh < fh && ww < fw) ? img * fhw + hh * fw + ww : -1;
-      const int hc = h0 + (gq >> pw_shift), wc = w0 + (gq & (pw - 1));
-      cell_next = (hc < fh && wc < fw) ? img * d_bins * fhw + hc * fw + wc : -1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        xn[i] = __builtin_amdgcn_raw_buffer_load_b128(feat_rsrc, f_next >= 0 ? ((unsigned)f_next << 8) | (unsigned)o[i] : kBeyond, 0, 0);
-      // cell (d = gr + 4*it, pixel gq): the lane part of the address in the VGPR offset, 4*it depth planes in the scalar offset
-      const unsigned c_off = (unsigned)(cell_next + gr * fhw) << 2;
-#pragma unroll
-      for (int it = 0; it < kStreamCellRegs; ++it)
-        cn[it] = __builtin_amdgcn_raw_buffer_load_b32(depth_rsrc, (cell_next >= 0 && gr + 4 * it < d_bins) ? c_off : kBeyond, it * plane4, 0);
-    }
-    {
-      const int id_use = (lane < nrows_prev) ? ids_prev : 0x00ffffff;          // a row beyond out_grad: the gather returns zeros
-#pragma unroll
-      for (int m = 0; m < RQ; ++m) {
-        const int r = __builtin_amdgcn_ds_bpermute((4 * m + gr) << 2, id_use);
-        pre[m] = __builtin_amdgcn_raw_buffer_load_b128(og_rsrc, ((unsigned)r << 8) | ((unsigned)gq << 4), 0, 0);
-      }
-      const int cnt1 = ob1 - oa1;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        w_next[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(word_rsrc, (4 * c + q < cnt1) ? (unsigned)(oa1 + 4 * c + q) << 2 : kBeyond, 0, 0);
-    }
-
-    // ---- (3) the points of stage t-2 ------------------------------------------------------------------------------
-    if (ex & kStreamValid) {
-      const int cnt = ob2 - oa2;
-      int ml = cnt;
-      ml = max(ml, __shfl_xor(ml, 4));
-      ml = max(ml, __shfl_xor(ml, 8));
-      ml = max(ml, __shfl_xor(ml, 16));
-      ml = max(ml, __shfl_xor(ml, 32));
-      const int trip = __builtin_amdgcn_readfirstlane(ml);
-      StreamStep sa = stream_load<0, R>(s_rows, s_dv, wq[0], 0, cnt, p, o), sb;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (4 * c < trip) {
-          sb = stream_load<1, R>(s_rows, s_dv, wq[c], 4 * c + 1, cnt, p, o);
-          stream_math(sa, s_dg, q, x, fg);
-          sa = stream_load<2, R>(s_rows, s_dv, wq[c], 4 * c + 2, cnt, p, o);
-          stream_math(sb, s_dg, q, x, fg);
-          sb = stream_load<3, R>(s_rows, s_dv, wq[c], 4 * c + 3, cnt, p, o);
-          stream_math(sa, s_dg, q, x, fg);
-          if (c < 3) sa = stream_load<0, R>(s_rows, s_dv, wq[c < 3 ? c + 1 : 3], 4 * c + 4, cnt, p, o);
-          stream_math(sb, s_dg, q, x, fg);
-        }
-      }
-      for (int c = 4; 4 * c < trip; ++c) {           // a piece longer than 16 points: its further words are read here
-        const int wl = (int)__builtin_amdgcn_raw_buffer_load_b32(word_rsrc, (4 * c + q < cnt) ? (unsigned)(oa2 + 4 * c + q) << 2 : kBeyond, 0, 0);
-        sa = stream_load<0, R>(s_rows, s_dv, wl, 4 * c + 0, cnt, p, o);
-        sb = stream_load<1, R>(s_rows, s_dv, wl, 4 * c + 1, cnt, p, o);
-        stream_math(sa, s_dg, q, x, fg);
-        sa = stream_load<2, R>(s_rows, s_dv, wl, 4 * c + 2, cnt, p, o);
-        stream_math(sb, s_dg, q, x, fg);
-        sb = stream_load<3, R>(s_rows, s_dv, wl, 4 * c + 3, cnt, p, o);
-        stream_math(sa, s_dg, q, x, fg);
-        stream_math(sb, s_dg, q, x, fg);
-      }
-      if (ex & kStreamLast) {                        // the patch is complete: its feature gradient rows, its D x 16 block of depth gradients
-#pragma unroll
-        for (int i = 0; i < 4; ++i)                  // a store beyond the buffer is dropped
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4t{__float_as_uint(fg[2 * i].x), __float_as_uint(fg[2 * i].y), __float_as_uint(fg[2 * i + 1].x),
-                                                        __float_as_uint(fg[2 * i + 1].y)},
-                                                 fgrad_rsrc, f_cur >= 0 ? ((unsigned)f_cur << 8) | (unsigned)o[i] : kBeyond, 0, 0);
-        const unsigned c_off = (unsigned)(cell_cur + gr * fhw) << 2;
-#pragma unroll
-        for (int it = 0; it < kStreamCellRegs; ++it)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_dg[(gr + 4 * it) * kPatch + gq]), dgrad_rsrc,
-                                                (cell_cur >= 0 && gr + 4 * it < d_bins) ? c_off : kBeyond, it * plane4, 0);
-      }
-    }
-
-    // ---- (4) rotate (the only copies of registers that pending loads write: after the point loop) -------------------
-    oa2 = oa1; ob2 = ob1; oa1 = oa_n; ob1 = ob_n;
-    ids_prev = ids_n;
-    nrows_prev = (int)((unsigned)ez >> 24);
-    ex = __builtin_amdgcn_readfirstlane((int)e_n.x); ey = __builtin_amdgcn_readfirstlane((int)e_n.y);
-    ez = __builtin_amdgcn_readfirstlane((int)e_n.z); ew = __builtin_amdgcn_readfirstlane((int)e_n.w);
   }
 }
 
@@ -1795,73 +766,6 @@ extern "C" int omnihd_tile_desc(const int* row_ptr, const int* tile_row, const i
   return check_launch("tile_desc");
 }
 
-extern "C" int omnihd_bev_pool_v2_fwd_lean(const float* depth, const float* feat, const int* ranks_depth,
-                                           const int* row_ptr, const int* tile_desc, int n_tiles, float* out, int c,
-                                           int n_rows, int n_points, int d_bins, int fhw, int n_feat_rows,
-                                           int empty_rows_kept, void* stream) {
-  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles > 0 && n_points >= 0 && d_bins > 0 && fhw > 0 && n_feat_rows >= 0, "sizes");
-  if (n_rows == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(depth && feat && row_ptr && out && tile_desc && (n_points == 0 || ranks_depth), "null pointer");
-  OMNIHD_REQUIRE(vec_ok(c, feat, out) && (reinterpret_cast<uintptr_t>(tile_desc) & 15u) == 0 && n_tiles % 8 == 0,
-                 "C % 4 == 0, 16-byte aligned pointers, 8*k schedule slots");
-  OMNIHD_REQUIRE((long long)d_bins * fhw < (1ll << 30), "D * fH * fW too large");
-  hipStream_t st = (hipStream_t)stream;
-  const int tiles_per_xcd = n_tiles / 8;
-  const dim3 grid(n_tiles);
-  const float4* f4 = reinterpret_cast<const float4*>(feat);
-  const int4* td = reinterpret_cast<const int4*>(tile_desc);
-  float4* o4 = reinterpret_cast<float4*>(out);
-  const int dfhw = d_bins * fhw;
-  // k_pool_fwd_lean2 (issue-lean point loop) is the default; OMNIHD_POOL_LEAN2=0 selects the first lean kernel.  It needs
-  // 32-bit byte offsets into the feature table (buffer loads): the caller's feature table ends at the last pixel a rank
-  // names, and the wrapper passes its size in rows through n_feat_rows (0: unknown -> first lean kernel).
-  static const bool lean2 = [] { const char* e = getenv("OMNIHD_POOL_LEAN2"); return !(e && e[0] == '0'); }();
-  const long long feat_bytes = (long long)n_feat_rows * c * 4;
-  OMNIHD_REQUIRE(!empty_rows_kept || (lean2 && n_feat_rows > 0 && feat_bytes < (1ll << 31)),
-                 "empty_rows_kept needs the second-generation kernel (n_feat_rows given, feature table below 2 GiB)");
-  if (lean2 && n_feat_rows > 0 && feat_bytes < (1ll << 31)) {
-#define OMNIHD_LEAN2_CASE(C4)                                                                                     \
-  case C4:                                                                                                        \
-    hipLaunchKernelGGL((k_pool_fwd_lean2<C4, 4>), grid, dim3(kBlock), 0, st, depth, feat, (unsigned)feat_bytes,   \
-                       ranks_depth, row_ptr, td, out, tiles_per_xcd, fhw, dfhw, 1.0f / (float)fhw,               \
-                       1.0f / (float)dfhw, empty_rows_kept);                                                      \
-    break;
-    switch (c / 4) {
-      OMNIHD_LEAN2_CASE(1)
-      OMNIHD_LEAN2_CASE(2)
-      OMNIHD_LEAN2_CASE(4)
-      OMNIHD_LEAN2_CASE(8)
-      OMNIHD_LEAN2_CASE(16)
-      OMNIHD_LEAN2_CASE(32)
-      OMNIHD_LEAN2_CASE(64)
-      default:
-        set_error("bev_pool_v2_fwd_lean: C/4 must be a power of two <= 64");
-        return OMNIHD_ERR_ARG;
-    }
-#undef OMNIHD_LEAN2_CASE
-    return check_launch("bev_pool_v2_fwd_lean(2)");
-  }
-#define OMNIHD_LEAN_CASE(C4)                                                                                     \
-  case C4:                                                                                                       \
-    hipLaunchKernelGGL((k_pool_fwd_lean<C4, 4>), grid, dim3(kBlock), 0, st, depth, f4, ranks_depth, row_ptr, td, \
-                       o4, tiles_per_xcd, fhw, dfhw, 1.0f / (float)fhw, 1.0f / (float)dfhw);                     \
-    break;
-  switch (c / 4) {
-    OMNIHD_LEAN_CASE(1)
-    OMNIHD_LEAN_CASE(2)
-    OMNIHD_LEAN_CASE(4)
-    OMNIHD_LEAN_CASE(8)
-    OMNIHD_LEAN_CASE(16)
-    OMNIHD_LEAN_CASE(32)
-    OMNIHD_LEAN_CASE(64)
-    default:
-      set_error("bev_pool_v2_fwd_lean: C/4 must be a power of two <= 64");
-      return OMNIHD_ERR_ARG;
-  }
-#undef OMNIHD_LEAN_CASE
-  return check_launch("bev_pool_v2_fwd_lean");
-}
-
 extern "C" int omnihd_bev_pool_v2_fwd_direct(const float* depth, const float* feat, const int* pt, const int* ivl_rel,
                                              int n_intervals, const int* desc32, int n_slots, const int* row_ptr, float* out,
                                              int c, int n_rows, int n_points, int d_bins, int fhw, int n_feat_rows,
@@ -1910,52 +814,12 @@ extern "C" int omnihd_bev_pool_v2_fwd_direct_dev(const float* depth, const float
   return check_launch("bev_pool_v2_fwd_direct_dev");
 }
 
-extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat,
-                                          const int* ranks_depth, const int* ranks_feat,
-                                          const int* ranks_row, const int* row_ptr,
-                                          const int* tile_desc, int n_tiles, float* out, int c,
-                                          int n_rows, int n_points, void* stream) {
-  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_tiles >= 0 && n_points >= 0, "sizes");
+extern "C" int omnihd_bev_pool_v2_fwd_csr(const float* depth, const float* feat, const int* ranks_depth, const int* ranks_feat,
+                                          const int* row_ptr, float* out, int c, int n_rows, int n_points, void* stream) {
+  OMNIHD_REQUIRE(c > 0 && n_rows >= 0 && n_points >= 0, "sizes");
   if (n_rows == 0) return OMNIHD_OK;
-  // ranks_* may be null when the plan holds no point at all (every row is then written as zeros)
-  OMNIHD_REQUIRE(depth && feat && row_ptr && out, "null pointer");
-  hipStream_t st = (hipStream_t)stream;
-  if (tile_desc != nullptr && ranks_row != nullptr && n_tiles > 0 && vec_ok(c, feat, out) &&
-      (reinterpret_cast<uintptr_t>(tile_desc) & 15u) == 0) {
-    const int tiles_per_xcd = (n_tiles + 7) / 8;
-    const dim3 grid(tiles_per_xcd * 8);
-    const float4* f4 = reinterpret_cast<const float4*>(feat);
-    const int4* td = reinterpret_cast<const int4*>(tile_desc);
-    float4* o4 = reinterpret_cast<float4*>(out);
-    static const int unroll = [] { const char* e = getenv("OMNIHD_FWD_UNROLL"); const int u = e ? atoi(e) : 4; return (u == 8) ? 8 : 4; }();
-#define OMNIHD_TILE_CASE(C4)                                                                   \
-  case C4:                                                                                     \
-    if (unroll == 8)                                                                           \
-      hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 8>), grid, dim3(kBlock), 0, st, depth, f4,      \
-                         ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
-                         n_points);                                                            \
-    else                                                                                       \
-      hipLaunchKernelGGL((k_pool_fwd_tiles<C4, 4>), grid, dim3(kBlock), 0, st, depth, f4,      \
-                         ranks_depth, ranks_feat, ranks_row, row_ptr, td, o4, tiles_per_xcd,   \
-                         n_points);                                                            \
-    break;
-    switch (c / 4) {
-      OMNIHD_TILE_CASE(1)
-      OMNIHD_TILE_CASE(2)
-      OMNIHD_TILE_CASE(4)
-      OMNIHD_TILE_CASE(8)
-      OMNIHD_TILE_CASE(16)
-      OMNIHD_TILE_CASE(32)
-      OMNIHD_TILE_CASE(64)
-      default:
-        set_error("unreachable c4=%d", c / 4);
-        return OMNIHD_ERR_ARG;
-    }
-#undef OMNIHD_TILE_CASE
-    return check_launch("bev_pool_v2_fwd_csr(tiles)");
-  }
-  return launch_fwd<true>(depth, feat, ranks_depth, ranks_feat, nullptr, nullptr, row_ptr, out, c,
-                          n_rows, st);
+  OMNIHD_REQUIRE(depth && feat && row_ptr && out && (n_points == 0 || (ranks_depth && ranks_feat)), "null pointer");
+  return launch_fwd<true>(depth, feat, ranks_depth, ranks_feat, nullptr, nullptr, row_ptr, out, c, n_rows, (hipStream_t)stream);
 }
 
 extern "C" int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth,
@@ -2005,44 +869,6 @@ extern "C" int omnihd_bev_pool_v2_bwd(const float* out_grad, const float* depth,
   return check_launch("bev_pool_v2_bwd");
 }
 
-extern "C" int omnihd_bev_pool_v2_bwd_sched(const float* out_grad, const float* depth,
-                                            const float* feat, const int* ranks_depth,
-                                            const int* ranks_row, const int* pix_desc,
-                                            int groups_per_xcd, float* depth_grad,
-                                            float* feat_grad, int c, void* stream) {
-  OMNIHD_REQUIRE(c > 0 && groups_per_xcd >= 0, "sizes");
-  if (groups_per_xcd == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(out_grad && depth && feat && pix_desc && depth_grad && feat_grad, "null pointer");
-  OMNIHD_REQUIRE(c % 4 == 0 && (c / 4 == 16 || c / 4 == 8 || c / 4 == 4 || c / 4 == 2 || c / 4 == 1),
-                 "scheduled backward supports C in {4,8,16,32,64}");
-  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(out_grad) | reinterpret_cast<uintptr_t>(feat) |
-                   reinterpret_cast<uintptr_t>(feat_grad) | reinterpret_cast<uintptr_t>(pix_desc)) & 15u) == 0,
-                 "16-byte alignment");
-  hipStream_t st = (hipStream_t)stream;
-  const float4* og4 = reinterpret_cast<const float4*>(out_grad);
-  const float4* f4 = reinterpret_cast<const float4*>(feat);
-  float4* fg4 = reinterpret_cast<float4*>(feat_grad);
-  const int4* pd = reinterpret_cast<const int4*>(pix_desc);
-#define OMNIHD_BWDS_CASE(C4, U)                                                                 \
-  case C4: {                                                                                    \
-    const int G = kBlock / C4;                                                                  \
-    const dim3 grid(8 * ((groups_per_xcd + G - 1) / G));                                        \
-    hipLaunchKernelGGL((k_pool_bwd_sched<C4, U>), grid, dim3(kBlock), 0, st, og4, depth, f4,    \
-                       ranks_depth, ranks_row, pd, depth_grad, fg4, groups_per_xcd);            \
-  } break;
-  switch (c / 4) {
-    OMNIHD_BWDS_CASE(1, 1)
-    OMNIHD_BWDS_CASE(2, 2)
-    OMNIHD_BWDS_CASE(4, 4)
-    OMNIHD_BWDS_CASE(8, 4)
-    OMNIHD_BWDS_CASE(16, 4)
-    default:
-      return OMNIHD_ERR_ARG;
-  }
-#undef OMNIHD_BWDS_CASE
-  return check_launch("bev_pool_v2_bwd_sched");
-}
-
 extern "C" int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* depth, const float* feat,
                                             const int* ranks_depth, const int* ranks_row, const int* pix_ptr,
                                             const int* patch_order, int n_slots, int n_img, int d_bins, int fhw,
@@ -2069,50 +895,4 @@ extern "C" int omnihd_bev_pool_v2_bwd_patch(const float* out_grad, const float* 
                        reinterpret_cast<const float4*>(feat), ranks_depth, ranks_row, pix_ptr, patch_order, n_slots / 8,
                        patches_per_img, fhw, d_bins, 1.0f / (float)fhw, depth_grad, reinterpret_cast<float4*>(feat_grad));
   return check_launch("bev_pool_v2_bwd_patch");
-}
-
-extern "C" int omnihd_bev_pool_v2_bwd_stream_lds_bytes(int rows_per_stage, int d_bins) {
-  (void)d_bins;                                    // both depth blocks are laid out for 64 bins (16 cells per lane)
-  return (rows_per_stage + 1) * 256 + 2 * 64 * kPatch * (int)sizeof(float);
-}
-
-extern "C" int omnihd_bev_pool_v2_bwd_stream(const float* out_grad, const float* depth, const float* feat, const int* pt_word,
-                                             long long n_points, const int* uniq_rows, long long n_uniq, const int* px_off,
-                                             long long n_off, const int* stream, long long n_entries, const int* stream_ptr,
-                                             int n_streams, int n_img, int d_bins, int fh, int fw, int patch_w,
-                                             int rows_per_stage, long long n_rows, float* depth_grad, float* feat_grad, int c,
-                                             void* stream_handle) {
-  OMNIHD_REQUIRE(c == 64, "the stream backward is written for C = 64 (use omnihd_bev_pool_v2_bwd_sched otherwise)");
-  OMNIHD_REQUIRE(n_streams >= 0 && n_streams % 8 == 0 && n_img > 0 && d_bins > 0 && fh > 0 && fw > 0 && n_rows > 0, "sizes");
-  OMNIHD_REQUIRE(patch_w == 16 || patch_w == 8 || patch_w == 4, "patch width must be 16, 8 or 4 pixels");
-  OMNIHD_REQUIRE(rows_per_stage == 32 || rows_per_stage == 48 || rows_per_stage == 64, "rows per stage: 32, 48 or 64");
-  if (n_streams == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(out_grad && depth && feat && pt_word && uniq_rows && px_off && stream && stream_ptr && depth_grad && feat_grad,
-                 "null pointer");
-  OMNIHD_REQUIRE(d_bins <= 64, "the depth cells of a patch are held as 16 registers x 64 lanes: at most 64 depth bins");
-  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(out_grad) | reinterpret_cast<uintptr_t>(feat) |
-                   reinterpret_cast<uintptr_t>(feat_grad) | reinterpret_cast<uintptr_t>(stream)) & 15u) == 0, "16-byte alignment");
-  const long long n_px = (long long)n_img * fh * fw;
-  OMNIHD_REQUIRE(n_rows * 256 < (1ll << 32) - 256 && n_rows < 0x00ffffff, "out_grad must stay below 4 GiB (32-bit gather offsets)");
-  OMNIHD_REQUIRE(n_px * d_bins * 4 < (1ll << 32) - 256 && n_px * 256 < (1ll << 32) - 256, "depth / feat must stay below 4 GiB");
-  OMNIHD_REQUIRE(n_points * 4 < (1ll << 31) && n_uniq * 4 < (1ll << 31) && n_off * 4 < (1ll << 31) && n_entries * 16 < (1ll << 31),
-                 "tables must stay below 2 GiB");
-  const size_t lds = (size_t)omnihd_bev_pool_v2_bwd_stream_lds_bytes(rows_per_stage, d_bins);
-  hipStream_t st = (hipStream_t)stream_handle;
-  const int pw_shift = patch_w == 16 ? 4 : (patch_w == 8 ? 3 : 2);
-#define OMNIHD_STREAM_CASE(RQ)                                                                                             \
-  case RQ:                                                                                                                 \
-    hipLaunchKernelGGL(k_pool_bwd_stream<RQ>, dim3(n_streams), dim3(64), lds, st, out_grad, (unsigned)(n_rows * 256), depth, \
-                       (unsigned)(n_px * d_bins * 4), feat, (unsigned)(n_px * 256), pt_word, (unsigned)(n_points * 4),      \
-                       uniq_rows, (unsigned)(n_uniq * 4), px_off, (unsigned)(n_off * 4), reinterpret_cast<const int4*>(stream), \
-                       (unsigned)(n_entries * 16), stream_ptr, n_streams / 8, fh, fw, pw_shift, d_bins, depth_grad,          \
-                       reinterpret_cast<float4*>(feat_grad));                                                              \
-    break;
-  switch (rows_per_stage / 4) {
-    OMNIHD_STREAM_CASE(8) OMNIHD_STREAM_CASE(12) OMNIHD_STREAM_CASE(16)
-    default:
-      return OMNIHD_ERR_ARG;
-  }
-#undef OMNIHD_STREAM_CASE
-  return check_launch("bev_pool_v2_bwd_stream");
 }

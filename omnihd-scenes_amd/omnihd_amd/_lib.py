@@ -15,20 +15,15 @@ PROTOTYPES = {
     "omnihd_prefetch": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "omnihd_bev_pool_v2_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
-    "omnihd_bev_pool_v2_fwd_csr": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "omnihd_bev_pool_v2_fwd_lean": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "omnihd_bev_pool_v2_fwd_csr": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
     "omnihd_bev_pool_v2_fwd_direct": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "omnihd_bev_pool_v2_fwd_direct_dev": (c_int, [c_void_p] * 4 + [c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
                                           + [c_int] * 6 + [c_void_p]),
     "omnihd_pool_plan_sizes": (c_int, [c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "omnihd_pool_plan_build": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_int, c_void_p, c_void_p, c_int, c_int]
                                + [c_void_p] * 11 + [c_size_t, c_void_p]),
-    "omnihd_bev_pool_v2_bwd_sched": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "omnihd_column_sums_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "omnihd_column_sums": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "omnihd_bev_pool_v2_bwd_stream": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
-                                      + [c_int] * 7 + [c_int64, c_void_p, c_void_p, c_int, c_void_p]),
-    "omnihd_bev_pool_v2_bwd_stream_lds_bytes": (c_int, [c_int, c_int]),
     "omnihd_bev_pool_v2_bwd_patch": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "omnihd_tile_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "omnihd_csr_tiles_workspace_bytes": (c_size_t, [c_int]),

@@ -451,15 +451,22 @@ class FusionTrainStep:
             b = dict(b)
             if isinstance(b.get("img_metas"), list) and b["img_metas"] and isinstance(b["img_metas"][0], dict):
                 b["img_metas"] = [dict(m, lidar2img=self._jittered(m["lidar2img"])) for m in b["img_metas"]]
+        dbg = os.environ.get("OMNIHD_DEBUG_SYNC", "")      # lab switch (fault hunt, profiles/round6/fault_root_cause.txt): device syncs at phase borders
         self.opt.zero_grad(set_to_none=True)
         with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.autocast):
             losses = self.model(return_loss=True, **b)
         total = sum(v if torch.is_tensor(v) else sum(v) for v in losses.values())
+        if "post_fwd" in dbg:
+            torch.cuda.synchronize()
         total.backward()          # (ends with ops.wgrad_overlap_join: the weight gradients computed on the side stream are joined)
+        if "post_bwd" in dbg:
+            torch.cuda.synchronize()
         if self.small_params:
             self._reduce_small_params()
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=35, norm_type=2)
         self.opt.step()
+        if "post_opt" in dbg:
+            torch.cuda.synchronize()
         if self.device.type == "cuda":
             from . import ops
             ops.refresh_bf16_shadows()            # one fused fp32 -> bf16 copy of all convolution weights

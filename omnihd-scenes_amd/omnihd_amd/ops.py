@@ -105,9 +105,9 @@ def bev_pool_v2_backward(out_grad, depth_grad, feat_grad, depth, feat, ranks_dep
               "omnihd_bev_pool_v2_bwd")
 
 
-def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, ranks_row=None, tile_desc=None):
-    """Dense forward: every row of ``out`` (n_rows = row_ptr.numel()-1, C = feat.size(-1)) is written.
-    With ``ranks_row`` + ``tile_desc`` (from :func:`tile_descriptors`) the load-balanced tiled kernel runs."""
+def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out):
+    """Dense forward for any channel count: every row of ``out`` (n_rows = row_ptr.numel()-1, C = feat.size(-1)) is written (see
+    include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_csr).  C = 64 runs :func:`bev_pool_v2_forward_direct` instead."""
     _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
     _want(ranks_depth, torch.int32, "ranks_depth"); _want(ranks_feat, torch.int32, "ranks_feat")
     _want(row_ptr, torch.int32, "row_ptr")
@@ -115,20 +115,11 @@ def bev_pool_v2_forward_csr(depth, feat, ranks_depth, ranks_feat, row_ptr, out, 
     n_rows = row_ptr.numel() - 1
     if out.numel() != n_rows * c:
         raise ValueError(f"out has {out.numel()} elements, expected {n_rows}*{c}")
-    n_tiles = 0
-    if tile_desc is not None and ranks_row is not None:
-        _want(tile_desc, torch.int32, "tile_desc"); _want(ranks_row, torch.int32, "ranks_row")
-        if tile_desc.dim() != 2 or tile_desc.size(1) != 4 or tile_desc.size(0) % 8:
-            raise ValueError("tile_desc must be (8*k, 4) int32")
-        n_tiles = tile_desc.size(0)      # number of schedule slots; idle slots carry #rows = 0
-    else:
-        tile_desc = ranks_row = None
     dev = _same_device(depth, feat, out, ranks_depth, ranks_feat, row_ptr)
     with _on(dev):
-        check(lib().omnihd_bev_pool_v2_fwd_csr(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat),
-                                               _ptr(ranks_row), _ptr(row_ptr), _ptr(tile_desc), n_tiles, _ptr(out),
-                                               c, n_rows, ranks_depth.numel(), _stream()),
-              "omnihd_bev_pool_v2_fwd_csr")
+        check(lib().omnihd_bev_pool_v2_fwd_csr(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(ranks_feat), _ptr(row_ptr), _ptr(out),
+                                               c, n_rows, ranks_depth.numel(), _stream()), "omnihd_bev_pool_v2_fwd_csr")
+
 
 
 _PREFETCH_STREAMS = {}
@@ -154,29 +145,6 @@ def prefetch(tensors):
                                     ctypes.c_void_p(side.cuda_stream)), "omnihd_prefetch")
 
 
-def bev_pool_v2_forward_lean(depth, feat, ranks_depth, row_ptr, tile_desc, out, depth_bins, feat_hw, gen=2, empty_rows_kept=False):
-    """Dense tiled forward reading one per-point table (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_lean).
-    ``gen=1`` asks for the first-generation kernel (64-bit addressing; bit-identical to the three-table kernel).
-    ``empty_rows_kept``: ``out`` already holds zeros in every row no point falls into (an earlier result of the same tables
-    or a zero-filled buffer): those rows are not written again."""
-    _want(depth, torch.float32, "depth"); _want(feat, torch.float32, "feat"); _want(out, torch.float32, "out")
-    _want(ranks_depth, torch.int32, "ranks_depth"); _want(row_ptr, torch.int32, "row_ptr")
-    _want(tile_desc, torch.int32, "tile_desc")
-    c = feat.size(-1)
-    n_rows = row_ptr.numel() - 1
-    if out.numel() != n_rows * c:
-        raise ValueError(f"out has {out.numel()} elements, expected {n_rows}*{c}")
-    if depth.numel() != (feat.numel() // c) * int(depth_bins) or (feat.numel() // c) % int(feat_hw):
-        raise ValueError(f"depth ({depth.numel()} values) must hold depth_bins={depth_bins} values per pixel row of feat "
-                         f"({feat.numel() // c} rows, feat_hw={feat_hw})")
-    dev = _same_device(depth, feat, out, ranks_depth, row_ptr, tile_desc)
-    with _on(dev):
-        check(lib().omnihd_bev_pool_v2_fwd_lean(_ptr(depth), _ptr(feat), _ptr(ranks_depth), _ptr(row_ptr), _ptr(tile_desc),
-                                                tile_desc.size(0), _ptr(out), c, n_rows, ranks_depth.numel(), int(depth_bins),
-                                                int(feat_hw), feat.numel() // c if gen != 1 else 0, 1 if empty_rows_kept else 0,
-                                                _stream()), "omnihd_bev_pool_v2_fwd_lean")
-
-
 def bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, row_ptr, out, depth_bins, feat_hw, empty_rows_kept=False):
     """Dense tiled forward for C = 64 whose lane groups walk their piece of the point list straight from global memory
     (see include/omnihd_hip.h: omnihd_bev_pool_v2_fwd_direct; tables from ``plan.direct_tables``)."""
@@ -198,23 +166,6 @@ def bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, row_ptr, out, d
                                                   desc32.size(0), _ptr(row_ptr), _ptr(out), c, n_rows, pt.numel(), int(depth_bins),
                                                   int(feat_hw), feat.numel() // c, 1 if empty_rows_kept else 0, _stream()),
               "omnihd_bev_pool_v2_fwd_direct")
-
-
-def bev_pool_v2_backward_sched(out_grad, depth, feat, ranks_depth, ranks_row, pix_desc, depth_grad, feat_grad):
-    """Scheduled backward (see include/omnihd_hip.h): ``pix_desc`` (8*k, 4) int32 lists every pixel once."""
-    for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad),
-                 ("feat_grad", feat_grad)):
-        _want(t, torch.float32, n)
-    _want(ranks_depth, torch.int32, "ranks_depth"); _want(ranks_row, torch.int32, "ranks_row")
-    _want(pix_desc, torch.int32, "pix_desc")
-    if pix_desc.dim() != 2 or pix_desc.size(1) != 4 or pix_desc.size(0) % 8:
-        raise ValueError("pix_desc must be (8*k, 4) int32")
-    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, ranks_depth, ranks_row, pix_desc)
-    with _on(dev):
-        check(lib().omnihd_bev_pool_v2_bwd_sched(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(ranks_depth),
-                                                 _ptr(ranks_row), _ptr(pix_desc), pix_desc.size(0) // 8,
-                                                 _ptr(depth_grad), _ptr(feat_grad), feat.size(-1), _stream()),
-              "omnihd_bev_pool_v2_bwd_sched")
 
 
 def bev_pool_v2_backward_patch(out_grad, depth, feat, ranks_depth, ranks_row, pix_ptr, patch_order, depth_grad, feat_grad):
@@ -240,30 +191,6 @@ def bev_pool_v2_backward_patch(out_grad, depth, feat, ranks_depth, ranks_row, pi
                                                  _ptr(pix_ptr), _ptr(patch_order), patch_order.numel(), n_img, D, fhw,
                                                  out_grad.numel() // 64, _ptr(depth_grad), _ptr(feat_grad), 64, _stream()),
               "omnihd_bev_pool_v2_bwd_patch")
-
-
-def bev_pool_v2_backward_stream(out_grad, depth, feat, tables, depth_grad, feat_grad):
-    """Stream backward for C = 64 (see include/omnihd_hip.h): one wave per stream of stages, the distinct out_grad rows of a
-    16-pixel patch gathered once and shared through LDS; writes BOTH gradients densely.  ``tables``: plan.StreamBackwardTables."""
-    for n, t in (("out_grad", out_grad), ("depth", depth), ("feat", feat), ("depth_grad", depth_grad), ("feat_grad", feat_grad)):
-        _want(t, torch.float32, n)
-    for n, t in (("pt_word", tables.pt_word), ("uniq_rows", tables.uniq_rows), ("px_off", tables.px_off), ("stream", tables.stream),
-                 ("stream_ptr", tables.stream_ptr)):
-        _want(t, torch.int32, n)
-    if depth.dim() != 5 or feat.dim() != 5 or feat.size(-1) != 64:
-        raise ValueError("depth must be (B,N,D,H,W) and feat (B,N,H,W,64)")
-    B, N, D, H, W = depth.shape
-    if tables.stream_ptr.numel() != tables.n_streams + 1 or tables.n_streams % 8:
-        raise ValueError("stream_ptr must have n_streams + 1 entries, n_streams a multiple of 8")
-    dev = _same_device(out_grad, depth, feat, depth_grad, feat_grad, tables.pt_word, tables.uniq_rows, tables.px_off, tables.stream,
-                       tables.stream_ptr)
-    with _on(dev):
-        check(lib().omnihd_bev_pool_v2_bwd_stream(_ptr(out_grad), _ptr(depth), _ptr(feat), _ptr(tables.pt_word), tables.pt_word.numel(),
-                                                  _ptr(tables.uniq_rows), tables.uniq_rows.numel(), _ptr(tables.px_off),
-                                                  tables.px_off.numel(), _ptr(tables.stream), tables.stream.size(0),
-                                                  _ptr(tables.stream_ptr), tables.n_streams, B * N, D, H, W, tables.patch_w,
-                                                  tables.rows_per_stage, out_grad.numel() // 64, _ptr(depth_grad), _ptr(feat_grad),
-                                                  64, _stream()), "omnihd_bev_pool_v2_bwd_stream")
 
 
 def tile_descriptors(row_ptr, tile_row, tile_order=None):

@@ -43,7 +43,6 @@ class BevPoolPlan:
     bp_ranks_feat: torch.Tensor
     bp_starts: torch.Tensor
     bp_lengths: torch.Tensor
-    pix_desc: torch.Tensor = None   # int32 [8*k, 4] schedule of the scheduled backward (every pixel once)
     pix_ptr: torch.Tensor = None    # int32 [n_feat_rows+1] CSR of the backward tables over image-feature pixels
     patch_order: torch.Tensor = None  # int32 [8*k] schedule of the patch backward (16-pixel patches, -1 idle)
     bp_row_bin: torch.Tensor = None   # int32 [Npts] (output row | depth bin << 24) in backward order: the patch backward's one table
@@ -116,38 +115,6 @@ def tile_schedule(row_ptr, tile_row, ranks_feat, feat_hw=None, n_xcd=8, grid=Non
         flat[free] = extra
     assert int((flat >= 0).sum()) == n_tiles
     return flat.int().contiguous()
-
-
-def pixel_schedule(bp_ranks_feat, bp_starts, bp_lengths, n_feat_rows, feat_hw=None, n_xcd=8):
-    """Schedule of the scheduled backward: one descriptor {pixel row, first point, #points, 0} per
-    image-feature pixel (pixels without points included, so feat_grad is written densely), walked
-    in 4x4 pixel patches (neighbouring pixels hit the same BEV rows -> out_grad rows are reused from
-    L1/L2) and cut into ``n_xcd`` contiguous runs, one per XCD.  Host-side planning, once per
-    calibration; only the ORDER is a performance choice."""
-    dev = bp_ranks_feat.device
-    start = torch.zeros(n_feat_rows, dtype=torch.int32, device=dev)
-    length = torch.zeros(n_feat_rows, dtype=torch.int32, device=dev)
-    if bp_starts.numel():
-        pix = bp_ranks_feat[bp_starts.long()].long()
-        start[pix] = bp_starts
-        length[pix] = bp_lengths
-    f = torch.arange(n_feat_rows, device=dev)
-    if feat_hw is not None:
-        fH, fW = feat_hw
-        img, h, w = f // (fH * fW), (f // fW) % fH, f % fW
-        key = ((img * ((fH + 3) // 4) + h // 4) * ((fW + 3) // 4) + w // 4) * 16 + (h % 4) * 4 + (w % 4)
-        f = f[torch.argsort(key, stable=True)]
-    per = (n_feat_rows + n_xcd - 1) // n_xcd
-    desc = torch.zeros((n_xcd * per, 4), dtype=torch.int32, device=dev)
-    desc[:, 0] = -1
-    # equal pixel counts per XCD; run k of the walk -> rows [k*per, k*per + count)
-    bounds = [(n_feat_rows * k) // n_xcd for k in range(n_xcd + 1)]
-    for k in range(n_xcd):
-        run = f[bounds[k]:bounds[k + 1]]
-        desc[k * per:k * per + run.numel(), 0] = run.int()
-        desc[k * per:k * per + run.numel(), 1] = start[run]
-        desc[k * per:k * per + run.numel(), 2] = length[run]
-    return desc.contiguous()
 
 
 PATCH = 16   # pixels per patch of the patch backward (one 64-byte segment of depth / depth_grad per depth bin)
@@ -257,214 +224,6 @@ def direct_tables(plan):
     return got
 
 
-def _patch_geometry(n_img, feat_hw, patch_w):
-    fH, fW = feat_hw
-    pw, ph = patch_w, PATCH // patch_w
-    pcols, prows = (fW + pw - 1) // pw, (fH + ph - 1) // ph
-    return pw, ph, pcols, prows, n_img * pcols * prows
-
-
-def shared_schedule(n_img, feat_hw, patch_w, cost, n_xcd=8):
-    """Order of the patches of the stream (shared-row) backward: image by image in bands of 4 image rows, left to right inside a band
-    (vertically adjacent patches touch the same output rows: what one fetched is in L2 for the next), cut into ``n_xcd``
-    contiguous runs of equal COST (``cost`` per patch, points + a fixed cost), heaviest bands first inside a run (see
-    ``patch_schedule``).  Returns a list of ``n_xcd`` int64 tensors of patch ids; every patch appears exactly once."""
-    pw, ph, pcols, prows, n_patch = _patch_geometry(n_img, feat_hw, patch_w)
-    p = torch.arange(n_patch)
-    img, pr, pc = p // (pcols * prows), (p // pcols) % prows, p % pcols
-    band_rows = max(1, 4 // ph)
-    nb = (prows + band_rows - 1) // band_rows
-    band = img * nb + pr // band_rows
-    col_block = (pc * pw) // PATCH                                  # 16 image columns at a time
-    key = (band * ((pcols * pw + PATCH - 1) // PATCH + 1) + col_block) * (band_rows * (PATCH // pw)) + (pr % band_rows) * (PATCH // pw) + pc % (PATCH // pw)
-    order = p[torch.argsort(key, stable=True)]
-    c = cost[order].double()
-    cum = torch.cumsum(c, 0)
-    targets = cum[-1] * torch.arange(1, n_xcd, dtype=torch.float64) / n_xcd
-    cuts = [0] + torch.searchsorted(cum, targets).tolist() + [n_patch]
-    bands = band[order]
-    runs = []
-    for k_ in range(n_xcd):
-        run, rb, rc = order[cuts[k_]:cuts[k_ + 1]], bands[cuts[k_]:cuts[k_ + 1]], c[cuts[k_]:cuts[k_ + 1]]
-        if run.numel():
-            ids, inv = torch.unique(rb, return_inverse=True)
-            tot = torch.zeros(ids.numel(), dtype=torch.float64).index_add_(0, inv, rc)
-            cnt = torch.zeros(ids.numel(), dtype=torch.float64).index_add_(0, inv, torch.ones_like(rc))
-            rank = torch.argsort(torch.argsort(-(tot / cnt), stable=True), stable=True)       # heaviest band first
-            run = run[torch.argsort(rank[inv], stable=True)]
-        runs.append(run)
-    return runs
-
-
-def _patch_rows(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w, R):
-    """What the shared-row (stream) backward needs of the backward tables (points sorted by pixel, inside a pixel by output row):
-    per patch the sorted distinct rows (``uniq_rows`` with CSR ``u_ptr``), per point the stage-relative word, per patch and stage
-    the 16 pixels' offsets into their point lists.  None when a pixel's list is not sorted by row."""
-    dev = bp_ranks_row.device
-    fH, fW = feat_hw
-    fhw = fH * fW
-    pw, ph, pcols, prows, n_patch = _patch_geometry(n_img, feat_hw, patch_w)
-    n = int(bp_ranks_row.numel())
-    pp = pix_ptr.long()
-    lens = pp[1:] - pp[:-1]
-    f = torch.repeat_interleave(torch.arange(n_img * fhw, device=dev), lens)            # pixel of every point
-    rows = bp_ranks_row.long()
-    if n > 1 and bool(((rows[1:] < rows[:-1]) & (f[1:] == f[:-1])).any()):
-        return None                                                                     # a pixel's points must be sorted by row
-    img, h, w = f // fhw, (f % fhw) // fW, f % fW
-    patch = (img * prows + h // ph) * pcols + w // pw
-    g = (h % ph) * pw + w % pw                                                          # the pixel's lane group inside its patch
-    key = patch * (1 << 24) + rows
-    uk, inv = torch.unique(key, return_inverse=True)                                    # sorted: by patch, then by row
-    nu = torch.bincount(uk >> 24, minlength=n_patch)
-    u_ptr = torch.zeros(n_patch + 1, dtype=torch.int64, device=dev)
-    u_ptr[1:] = nu.cumsum(0)
-    n_stage = (nu + R - 1) // R
-    idx = inv - u_ptr[patch]                                                            # index of the point's row among its patch's rows
-    stage = idx // R
-    dbin = torch.div(bp_ranks_depth.long(), fhw, rounding_mode="floor") % depth_bins
-    pt_word = (((idx % R) << 8) | (dbin << 24)).to(torch.int32).contiguous()
-    rows_p = torch.clamp(n_stage, min=1) + 1                                            # offset rows of a patch: one per stage + the end (a patch without points: one empty stage)
-    so_ptr = torch.zeros(n_patch + 1, dtype=torch.int64, device=dev)                    # first px_stage_off row of every patch
-    so_ptr[1:] = rows_p.cumsum(0)
-    total = int(so_ptr[-1].item())
-    cnt = torch.zeros(total * PATCH, dtype=torch.int64, device=dev)
-    if n:
-        cnt.index_add_(0, (so_ptr[patch] + stage + 1) * PATCH + g, torch.ones(n, dtype=torch.int64, device=dev))
-    cs = cnt.view(total, PATCH).cumsum(0)                                               # points of lane group g in all stages before this row
-    first = torch.repeat_interleave(so_ptr[:-1], rows_p)
-    rel = cs - cs[first]                                                                # [total, 16] offsets inside the pixel's list
-    pts = torch.bincount(patch, minlength=n_patch) if n else torch.zeros(n_patch, dtype=torch.int64, device=dev)
-    # first point (index into the backward tables) of pixel g of every patch; pixels outside the image: 0 (they have no points)
-    pid = torch.arange(n_patch, device=dev)
-    p_img, p_r, p_c = pid // (pcols * prows), (pid // pcols) % prows, pid % pcols
-    gg = torch.arange(PATCH, device=dev)
-    hh, ww = p_r[:, None] * ph + gg[None, :] // pw, p_c[:, None] * pw + gg[None, :] % pw
-    inside = (hh < fH) & (ww < fW)
-    fpix = (p_img[:, None] * fhw + hh * fW + ww).clamp(max=n_img * fhw - 1)
-    px_start = torch.where(inside, pp[fpix], torch.zeros_like(fpix))
-    return dict(n_patch=n_patch, uniq=(uk & 0xffffff).to(torch.int32).contiguous(), u_ptr=u_ptr, nu=nu, n_stage=n_stage,
-                pt_word=pt_word, so_ptr=so_ptr, rel=rel, pts=pts, px_start=px_start, reuse=float(n) / max(1, int(uk.numel())))
-
-
-STREAM_FIRST, STREAM_LAST, STREAM_VALID = 1 << 30, 1 << 29, 1 << 28     # flags of a stream entry (csrc/bev_pool_v2.hip: kStream*)
-STREAM_STAGE_COST = 48        # cost model of the dealing: a stage costs as much as this many points, a patch as PATCH_FIXED_COST/4
-
-
-@dataclass
-class StreamBackwardTables:
-    """Tables of the stream backward (include/omnihd_hip.h: omnihd_bev_pool_v2_bwd_stream)."""
-    patch_w: int
-    rows_per_stage: int
-    pt_word: torch.Tensor       # int32 [Npts]: 256 * (index of the point's row inside its stage) | depth bin << 24
-    uniq_rows: torch.Tensor     # int32: per patch, the sorted distinct output rows its points touch
-    px_off: torch.Tensor        # int32 [(rows + 1) * 16]: per patch and stage, the index into pt_word of pixel g's first point of the stage
-    stream: torch.Tensor        # int32 [n_entries, 4]
-    stream_ptr: torch.Tensor    # int32 [n_streams + 1] entries of wave w: [ptr[w], ptr[w+1])
-    n_streams: int
-    reuse: float
-    balance: float              # heaviest stream / mean stream (cost model)
-
-
-def stream_deal(runs, cost, streams_per_xcd):
-    """Deal the patches of every XCD run (in walk order) to ``streams_per_xcd`` waves: the next patch goes to the wave with the
-    least cost so far, so that the waves of an XCD move through the walk together and finish together.  Returns one list of
-    patch ids per stream (XCD-major)."""
-    import heapq
-    out = []
-    c = cost.tolist()
-    for run in runs:
-        heap = [(0.0, w) for w in range(streams_per_xcd)]
-        lists = [[] for _ in range(streams_per_xcd)]
-        for pid in run.tolist():
-            load, w = heapq.heappop(heap)
-            lists[w].append(pid)
-            heapq.heappush(heap, (load + c[pid], w))
-        out += lists
-    return out
-
-
-def stream_tables_from(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w=8, rows_per_stage=64,
-                       streams_per_xcd=192):
-    """Tables of the stream backward: the stages of ``_patch_rows`` laid out as one stream per wave (see the kernel's header
-    comment for the entry format).  Pure torch + a host heap for the dealing; None when the tables do not fit the kernel."""
-    if patch_w not in (16, 8, 4) or rows_per_stage not in (32, 48, 64) or not 0 < depth_bins <= 64:
-        return None
-    R = rows_per_stage
-    t = _patch_rows(bp_ranks_row, bp_ranks_depth, pix_ptr, n_img, depth_bins, feat_hw, patch_w, R)
-    if t is None or t["n_patch"] >= (1 << 28) or int(t["so_ptr"][-1]) >= (1 << 24):
-        return None                                             # the entry fields: 28 bits of patch id, 24 bits of offset row
-    dev = bp_ranks_row.device
-    n_stage = t["n_stage"].cpu()
-    n_ent = torch.clamp(n_stage, min=1)                         # a patch without points still has one (empty) stage: its gradients are zeros
-    cost = (t["pts"].cpu() + STREAM_STAGE_COST * n_ent + PATCH_FIXED_COST // 4).double()
-    runs = shared_schedule(n_img, feat_hw, patch_w, cost)
-    lists = stream_deal(runs, cost, streams_per_xcd)
-    n_streams = len(lists)
-    order = torch.tensor([pid for l in lists for pid in l], dtype=torch.int64)          # patches in stream order
-    per_stream = torch.tensor([len(l) for l in lists], dtype=torch.int64)
-    sid_of_patch = torch.repeat_interleave(torch.arange(n_streams), per_stream)
-    # global stage list G: stream-major, inside a stream patch by patch, stage by stage
-    ne = n_ent[order]
-    g_patch = torch.repeat_interleave(order, ne)
-    g_sid = torch.repeat_interleave(sid_of_patch, ne)
-    g_first_idx = torch.zeros(order.numel() + 1, dtype=torch.int64)
-    g_first_idx[1:] = ne.cumsum(0)
-    g_k = torch.arange(int(g_first_idx[-1])) - torch.repeat_interleave(g_first_idx[:-1], ne)
-    nu, u_ptr, so_ptr = t["nu"].cpu(), t["u_ptr"].cpu(), t["so_ptr"].cpu()
-    g_first = g_k == 0
-    g_last = g_k == ne[torch.repeat_interleave(torch.arange(order.numel()), ne)] - 1
-    g_ustart = u_ptr[g_patch] + g_k * R
-    g_nrows = torch.clamp(nu[g_patch] - g_k * R, min=0, max=R)
-    g_so = so_ptr[g_patch] + g_k
-    n_g = g_patch.numel()
-    stages_per_stream = torch.bincount(g_sid, minlength=n_streams)
-    gs = torch.zeros(n_streams + 1, dtype=torch.int64)
-    gs[1:] = stages_per_stream.cumsum(0)
-    es = gs + 2 * torch.arange(n_streams + 1)                   # entries: two more than stages per stream
-    n_entries = int(es[-1])
-    e_sid = torch.repeat_interleave(torch.arange(n_streams), stages_per_stream + 2)
-    e_j = torch.arange(n_entries) - es[e_sid]
-    ent = torch.zeros((n_entries, 4), dtype=torch.int64)
-    ent[:, 3] = -1
-    # x: the stage consumed in this iteration (entry j consumes stage j - 2 of its stream)
-    has = e_j >= 2
-    gi = (gs[e_sid] + e_j - 2)[has]
-    ent[has, 0] = g_patch[gi] | STREAM_VALID | torch.where(g_first[gi], STREAM_FIRST, 0) | torch.where(g_last[gi], STREAM_LAST, 0)
-    # y, z: the stage whose row ids / offsets are requested (stage j)
-    has = e_j < stages_per_stream[e_sid]
-    gi = (gs[e_sid] + e_j)[has]
-    ent[has, 1] = g_ustart[gi]
-    ent[has, 2] = g_so[gi] | (g_nrows[gi] << 24)
-    # w: the patch whose first stage is stage j - 1 (its pixel data are requested one iteration ahead)
-    has = (e_j >= 1) & (e_j <= stages_per_stream[e_sid])
-    gi = (gs[e_sid] + e_j - 1)[has]
-    ent[has, 3] = torch.where(g_first[gi], g_patch[gi], torch.full_like(gi, -1))
-    # absolute offsets into pt_word (+ one row of padding: the kernel reads the row behind a patch's last one)
-    rel, px_start = t["rel"], t["px_start"]
-    patch_of_row = torch.repeat_interleave(torch.arange(t["n_patch"], device=dev), torch.clamp(t["n_stage"], min=1) + 1)
-    px_off = rel + px_start[patch_of_row]
-    px_off = torch.cat([px_off, px_off.new_zeros(1, PATCH)]).to(torch.int32).contiguous().view(-1)
-    load = torch.zeros(n_streams, dtype=torch.float64).index_add_(0, sid_of_patch, cost[order])
-    return StreamBackwardTables(patch_w, R, t["pt_word"], t["uniq"], px_off, ent.to(torch.int32).contiguous().to(dev),
-                                es.to(torch.int32).contiguous().to(dev), n_streams, t["reuse"],
-                                float(load.max() / load.mean().clamp(min=1e-9)))
-
-
-STREAM_DEFAULT = (8, 32, 256)   # (patch width, rows per stage, waves per XCD) of the stream backward unless OMNIHD_POOL_BWD_STREAM_SHAPE="w,R,waves"
-
-
-def stream_tables(plan, n_img, feat_hw2):
-    """The stream backward's tables of ``plan``, built on first use and kept with it (None: does not fit, see above)."""
-    shape = _env("OMNIHD_POOL_BWD_STREAM_SHAPE", "")
-    pw, R, spx = (int(v) for v in shape.split(",")) if shape else STREAM_DEFAULT
-    cache = plan.__dict__.setdefault("_stream", {})
-    key = (pw, R, spx, n_img, tuple(feat_hw2))
-    if key not in cache:
-        cache[key] = stream_tables_from(plan.bp_ranks_row, plan.bp_ranks_depth, plan.pix_ptr, n_img, plan.depth_bins, feat_hw2, pw, R, spx)
-    return cache[key]
-
-
 def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=None, origin_cell=None):
     B, Z, Y, X = grid
     n_rows = B * Z * Y * X
@@ -473,9 +232,8 @@ def _finish(layout, grid, rows, rd, rf, starts, lengths, n_feat_rows, feat_hw=No
     tile_order = tile_schedule(row_ptr, tile_row, rf, feat_hw, grid=grid, layout=layout, origin_cell=origin_cell)
     tile_desc = ops.tile_descriptors(row_ptr, tile_row, tile_order)
     bp = ops.backward_tables(rows, rd, rf, n_feat_rows)
-    pix_desc = pixel_schedule(bp[2], bp[3], bp[4], n_feat_rows, feat_hw)
     plan = BevPoolPlan(layout, grid, n_rows, int(rows.numel()), rows, rd, rf, row_ptr, tile_row, tile_order,
-                       tile_desc, starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4], pix_desc)
+                       tile_desc, starts, lengths, bp[0], bp[1], bp[2], bp[3], bp[4])
     if feat_hw is not None and n_feat_rows % (feat_hw[0] * feat_hw[1]) == 0:
         plan.pix_ptr = ops.csr_from_sorted_keys(bp[2], n_feat_rows)
         plan.patch_order = patch_schedule(n_feat_rows // (feat_hw[0] * feat_hw[1]), feat_hw, pix_ptr=plan.pix_ptr).to(rows.device)
@@ -520,36 +278,21 @@ def plan_from_tables(ranks_bev, ranks_depth, ranks_feat, grid, n_feat_rows, layo
                    lengths.contiguous(), n_feat_rows, feat_hw=feat_hw)
 
 
-def _lean_forward():
-    """The one-table forward kernel (k_pool_fwd_lean) is the default when the plan knows its frustum geometry;
-    OMNIHD_POOL_LEAN=0 selects the three-table kernel (bit-identical results, 43.2 vs 51.2 us at R1 in one run)."""
-    import os
-    return _env("OMNIHD_POOL_LEAN", "1") != "0"
-
-
-def _direct_forward():
-    """The direct forward (k_pool_fwd_direct, C = 64: lane groups walk their piece of the point list from global memory, no LDS
-    record staging) is the default where it applies; OMNIHD_POOL_DIRECT=0 selects k_pool_fwd_lean2 (same tiles; rows cut by
-    the in-tile split may differ in the last bit)."""
-    return _env("OMNIHD_POOL_DIRECT", "1") != "0"
+def _direct_ok(plan, channels):
+    """The product's forward kernel (k_pool_fwd_direct) takes C = 64 and a plan that knows its frustum geometry."""
+    return channels == 64 and plan.depth_bins > 0 and plan.tile_desc is not None
 
 
 def forward_tables(plan, channels=64):
     """The static tables the forward kernel of ``plan`` will read for ``channels`` feature channels (what the LSS module streams
-    into the caches ahead of the launch, ``ops.prefetch``): the direct kernel's point words, row ids and 32-int descriptors, or
-    the lean kernels' tile descriptors, CSR and rank table."""
+    into the caches ahead of the launch, ``ops.prefetch``): the direct kernel's descriptors, row ids and point words, or the
+    CSR and rank tables of the any-channel kernel."""
     if hasattr(plan, "launch_slots"):                     # pool_plan.DevicePoolPlan: valid prefixes once its counts are known
         return plan.forward_tables() or []
-    if channels == 64 and plan.depth_bins > 0 and _lean_forward() and _direct_forward():
+    if _direct_ok(plan, channels):
         pt, ivl_rel, desc32 = direct_tables(plan)
         return [desc32, ivl_rel, pt]
-    return [plan.tile_desc, plan.row_ptr, plan.ranks_depth]
-
-
-def _patch_backward():
-    """The patch backward (k_pool_bwd_patch, C = 64) is the default; OMNIHD_POOL_BWD_PATCH=0 selects the scheduled kernel."""
-    import os
-    return _env("OMNIHD_POOL_BWD_PATCH", "1") != "0"
+    return [plan.row_ptr, plan.ranks_depth, plan.ranks_feat]
 
 
 # How often the optional fast paths of the pooling forward were actually taken in this process (bench.py reports them as
@@ -714,20 +457,20 @@ def _row_bin(plan):
 
 
 class _PlannedPool(torch.autograd.Function):
-    """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order."""
+    """depth (B,N,D,H,W), feat (B,N,H,W,C) -> dense rows (n_rows, C) in the plan's row order.
+
+    C = 64 (every configuration of the reference): k_pool_fwd_direct / k_pool_bwd_patch.  Any other channel count: the
+    any-channel dense kernel forward and the reference-format backward kernel on the plan's backward tables."""
 
     @staticmethod
     def forward(ctx, depth, feat, plan, keep_empty_rows=False):
         depth = depth.contiguous().float()
         feat = feat.contiguous().float()
         _check_plan_matches(plan, depth, feat)
-        lean = plan.depth_bins > 0 and plan.tile_desc is not None and plan.n_points > 0 and _lean_forward()
         # the limits of omnihd_bev_pool_v2_fwd_direct (csrc/bev_pool_v2.hip): C = 64, 32-bit gather offsets into feat / depth
-        direct = (lean and feat.size(-1) == 64 and feat.numel() * 4 < 2 ** 31 and depth.numel() * 4 < 2 ** 32 - 8
-                  and depth.numel() < 0x3fffffff and feat.data_ptr() % 16 == 0 and _direct_forward())
-        # only the direct and the second-generation lean kernel know how to leave the empty rows alone
-        can_keep = direct or (lean and _env("OMNIHD_POOL_LEAN2", "1") != "0" and feat.numel() * 4 < 2 ** 31)
-        keeper = _kept_output(plan, feat.size(-1), feat.device) if (keep_empty_rows and can_keep) else None
+        direct = (_direct_ok(plan, feat.size(-1)) and plan.n_points > 0 and feat.numel() * 4 < 2 ** 31
+                  and depth.numel() * 4 < 2 ** 32 - 8 and depth.numel() < 0x3fffffff and feat.data_ptr() % 16 == 0)
+        keeper = _kept_output(plan, feat.size(-1), feat.device) if (keep_empty_rows and direct) else None
         FAST_PATHS["pool_fwd_calls"] += 1
         FAST_PATHS["kept_output"] += keeper is not None
         FAST_PATHS["direct_fwd"] += bool(direct)
@@ -739,12 +482,8 @@ class _PlannedPool(torch.autograd.Function):
             pt, ivl_rel, desc32 = direct_tables(plan)
             _timed("fwd", lambda: ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, plan.row_ptr, out, plan.depth_bins,
                                                                  plan.feat_hw, empty_rows_kept=keeper is not None))
-        elif lean:
-            _timed("fwd", lambda: ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, out,
-                                                               plan.depth_bins, plan.feat_hw, empty_rows_kept=keeper is not None))
         else:
-            ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out,
-                                        plan.ranks_row, plan.tile_desc)
+            ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, out)
         ctx.save_for_backward(depth, feat)
         ctx.plan = plan
         return out
@@ -755,11 +494,10 @@ class _PlannedPool(torch.autograd.Function):
         plan = ctx.plan
         c = feat.size(-1)
         # the limits of omnihd_bev_pool_v2_bwd_patch (csrc/bev_pool_v2.hip): C = 64, 32-bit gather offsets into out_grad and a
-        # 24-bit row field, both D x 16 LDS blocks within 64 KiB, 16-byte aligned row tensors; anything else takes the
-        # scheduled kernel
+        # 24-bit row field, both D x 16 LDS blocks within 64 KiB, 16-byte aligned row tensors
         patch = (c == 64 and plan.patch_order is not None and plan.depth_bins > 0 and depth.dim() == 5
                  and plan.n_rows * 256 < 2 ** 32 and plan.n_rows < 0xffffff and plan.depth_bins <= 512
-                 and feat.data_ptr() % 16 == 0 and _patch_backward())
+                 and feat.data_ptr() % 16 == 0)
         if patch and out_grad.dtype != torch.float32 and _env("OMNIHD_POOL_PREFETCH", "1") != "0":
             # the forward's tensors and the backward tables have long left the Infinity Cache: read them ahead on the side
             # stream while the cast of the incoming gradient runs (bf16 step; in the fp32 step nothing precedes the kernel)
@@ -768,39 +506,22 @@ class _PlannedPool(torch.autograd.Function):
         out_grad = out_grad.contiguous().float()
         ops.wgrad_overlap_fence(out_grad.device)       # (a no-op unless OMNIHD_WGRAD_OVERLAP=all put weight gradients in flight)
         try:
-            return _PlannedPool._backward(ctx, out_grad, depth, feat, plan, c, patch)
+            if patch:
+                depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)   # both written densely
+                packed = _row_bin(plan)
+                _timed("bwd", lambda: ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat,
+                                                                     None if packed is not None else plan.bp_ranks_depth,
+                                                                     packed if packed is not None else plan.bp_ranks_row, plan.pix_ptr,
+                                                                     plan.patch_order, depth_grad, feat_grad))
+            else:
+                depth_grad, feat_grad = torch.zeros_like(depth), torch.zeros_like(feat)
+                og5 = out_grad.view(1, 1, 1, plan.n_rows, c)
+                ops.bev_pool_v2_backward(og5, depth_grad, feat_grad, depth, feat, plan.bp_ranks_depth, plan.bp_ranks_feat,
+                                         plan.bp_ranks_row, plan.bp_lengths, plan.bp_starts)
+            return depth_grad, feat_grad, None, None
         finally:
             if depth.is_cuda and not torch.is_grad_enabled():
                 ops.wgrad_overlap_arm()                # the convolutions behind this point overlap their weight gradients
-
-    @staticmethod
-    def _backward(ctx, out_grad, depth, feat, plan, c, patch):
-        if patch and _env("OMNIHD_POOL_BWD_STREAM", "0") == "1" and plan.depth_bins <= 64 and depth.numel() * 4 < 2 ** 32 - 256:
-            # opt-in: the stream form of the same arithmetic (rows of a patch gathered once; DESIGN 4.2: not faster, so not the default)
-            st = stream_tables(plan, depth.size(0) * depth.size(1), (depth.size(3), depth.size(4)))
-            if st is not None:
-                depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
-                _timed("bwd", lambda: ops.bev_pool_v2_backward_stream(out_grad.view(plan.n_rows, c), depth, feat, st, depth_grad, feat_grad))
-                return depth_grad, feat_grad, None, None
-        if patch:
-            depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)   # both written densely
-            packed = _row_bin(plan)
-            _timed("bwd", lambda: ops.bev_pool_v2_backward_patch(out_grad.view(plan.n_rows, c), depth, feat,
-                                                                 None if packed is not None else plan.bp_ranks_depth,
-                                                                 packed if packed is not None else plan.bp_ranks_row, plan.pix_ptr,
-                                                                 plan.patch_order, depth_grad, feat_grad))
-            return depth_grad, feat_grad, None, None
-        depth_grad = torch.zeros_like(depth)
-        if plan.pix_desc is not None and c in (4, 8, 16, 32, 64):
-            feat_grad = torch.empty_like(feat)          # written densely by the scheduled kernel
-            ops.bev_pool_v2_backward_sched(out_grad.view(plan.n_rows, c), depth, feat, plan.bp_ranks_depth,
-                                           plan.bp_ranks_row, plan.pix_desc, depth_grad, feat_grad)
-        else:
-            feat_grad = torch.zeros_like(feat)
-            og5 = out_grad.view(1, 1, 1, plan.n_rows, c)
-            ops.bev_pool_v2_backward(og5, depth_grad, feat_grad, depth, feat, plan.bp_ranks_depth,
-                                     plan.bp_ranks_feat, plan.bp_ranks_row, plan.bp_lengths, plan.bp_starts)
-        return depth_grad, feat_grad, None, None
 
 
 def planned_pool(depth, feat, plan, keep_empty_rows=False):

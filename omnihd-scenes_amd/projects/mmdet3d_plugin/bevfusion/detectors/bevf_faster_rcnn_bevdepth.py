@@ -119,10 +119,22 @@ class BEVFUSION_depth(MVXFasterRCNN):
         GPU, and the radar kernels are too small to fill the chip on their own.  Returns a join function."""
         import threading
         main = torch.cuda.current_stream()
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream()
-        side = self._side_stream
-        side.wait_stream(main)
+        mode = _env("OMNIHD_DUAL_STREAM", "0")
+        if mode == "thread":
+            # second host thread, SAME stream (round 6): the two threads' kernels interleave on the caller's stream in FIFO order
+            # (every thread's own order is kept), the backward pass runs on one stream, no tensor ever crosses streams
+            side = main
+        else:
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(main)
+        # what the side stream reads but the main stream allocated: the allocator must not hand these blocks to a main-stream
+        # allocation while the side stream may still be reading them (they are dropped by the main thread's frames)
+        if side is not main:
+            for t in list(points) + [x for h in vox for x in (getattr(h, "voxels", None), getattr(h, "coors", None), getattr(h, "num_points", None))]:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)
         state = dict(grad=torch.is_grad_enabled(), amp=torch.is_autocast_enabled(),
                      amp_dtype=torch.get_autocast_dtype("cuda"), device=torch.cuda.current_device())
         box = {}
@@ -136,16 +148,23 @@ class BEVFUSION_depth(MVXFasterRCNN):
             except BaseException as e:      # re-raised on the calling thread
                 box["err"] = e
 
-        th = threading.Thread(target=work)
-        th.start()
+        if mode == "stream":
+            # (lab switch, profiles/round6/fault_root_cause.txt: the second STREAM without the second host thread)
+            work()
+            th = None
+        else:
+            th = threading.Thread(target=work)
+            th.start()
 
         def join():
-            th.join()
+            if th is not None:
+                th.join()
             if "err" in box:
                 raise box["err"]
-            main.wait_stream(side)
-            for t in box["out"]:
-                t.record_stream(main)
+            if side is not main:
+                main.wait_stream(side)
+                for t in box["out"]:
+                    t.record_stream(main)
             return box["out"]
         return join
 
@@ -181,10 +200,14 @@ class BEVFUSION_depth(MVXFasterRCNN):
         # of the GPU across step boundaries (7 ms of stall per step before).
         vox = self.voxelize_begin(points) if self.with_pts_backbone and points is not None else None
         radar = None
-        # default on for training on the GPU (33.2 -> 31.7 ms per step at R1); OMNIHD_DUAL_STREAM=0 turns it off
+        # OMNIHD_DUAL_STREAM: "0" (default since round 6) = the radar branch runs in line, on the caller's stream; "1" = second host
+        # thread + second stream (the default of rounds 3-5 — and the trigger of the intermittent GPU memory fault: a race in the
+        # BACKWARD pass between nodes of the two streams, profiles/round6/fault_root_cause.txt; 2 % of the fp32 step); "thread" = second
+        # host thread on the caller's stream (no fault in 2 000 steps, but the two threads fight over the GIL: slower than "0" in the
+        # host-bound bf16 step); "stream" = second stream without the thread (lab)
         if vox is not None and img is not None and img.is_cuda and self.training \
-                and _env("OMNIHD_DUAL_STREAM", "1") != "0" and self._side_thread_is_safe():
-            radar = self._radar_branch_async(points, img_metas, vox)     # second host thread + second stream
+                and _env("OMNIHD_DUAL_STREAM", "0") != "0" and self._side_thread_is_safe():
+            radar = self._radar_branch_async(points, img_metas, vox)
         if img is not None and img.is_cuda and self.training:
             from omnihd_amd import ops as _ops
             _ops.FAST_PATHS["dual_stream_forward" if radar is not None else "single_stream_forward"] += 1

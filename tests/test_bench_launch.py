@@ -64,7 +64,8 @@ def test_fp32_bench_line_carries_the_one_rank_ddp_block_and_the_live_fast_paths(
     assert out.returncode == 0, out.stderr[-3000:]
     line = _json_line(out)
     fp = line["fast_paths"]
-    assert fp["kept_output"]["active"] and fp["direct_fwd"]["active"] and fp["dual_stream"]["active"], fp
+    assert fp["kept_output"]["active"] and fp["direct_fwd"]["active"], fp
+    assert not fp["dual_stream"]["active"], "the radar branch runs in line since round 6 (profiles/round6/fault_root_cause.txt)"
     assert fp["wgrad_overlap"]["active"] and fp["wgrad_overlap"]["private_hooks_ok"] and fp["choice_table_misses"] == 0, fp
     d = line["ddp_1rank"]
     assert d["backend"] == "nccl" and d["world_size"] == 1 and d["ms_per_step"] > 0 and d["plain_ms_per_step"] == line["ms_per_step"]

@@ -168,9 +168,10 @@ def test_csr_dense_forward_and_planned_autograd(cuda, golden):
 @pytest.mark.parametrize("tile_items", [64, 200, 512, 1000])
 @pytest.mark.parametrize("c", [64, 8])
 def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
-    """Tiled (workgroup merge-path) dense kernel: rows far longer than a tile, long runs of empty
-    rows, rows cut at every piece boundary.  Checked against the oracle (which only writes named
-    rows into a zero buffer) and against the untiled dense kernel; run-to-run identical."""
+    """Tile tables (csr_tiles, tile_schedule, tile_descriptors: what the direct forward's schedule is made of) on rows far longer
+    than a tile and long runs of empty rows, and the any-channel dense kernel on the same rows against the oracle (which only
+    writes named rows into a zero buffer); run-to-run identical.  (The C = 64 kernel of the product on such rows:
+    test_direct_forward_on_heavy_tailed_rows.)"""
     from omnihd_amd import ops
     rng = np.random.default_rng(tile_items + c)
     n_rows, n_pix, D = 3000, 600, 20
@@ -200,20 +201,16 @@ def test_tiled_dense_forward_heavy_tail_and_empty_rows(cuda, tile_items, c):
     assert np.array_equal(np.sort(o[o >= 0]), np.arange(tiles.numel() - 1))     # every tile exactly once
     o2 = tile_schedule(row_ptr, tiles, t(rf, cuda), (20, 30), grid=(1, 10, 20, 15), layout="byxz").cpu().numpy()
     assert np.array_equal(np.sort(o2[o2 >= 0]), np.arange(tiles.numel() - 1))
-    outs = []
-    d_plain = ops.tile_descriptors(row_ptr, tiles)
     d_sched = ops.tile_descriptors(row_ptr, tiles, order)
     dn = d_sched.cpu().numpy()
     assert dn[:, 1].sum() == n_rows and dn[:, 3].sum() == npts
-    for desc in (d_plain, None, d_plain, d_sched):
+    outs = []
+    for _ in range(2):
         out = torch.full((n_rows, c), float("nan"), device=cuda)        # every row must be written
-        ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out,
-                                    t(rows, cuda), desc)
+        ops.bev_pool_v2_forward_csr(t(depth, cuda), t(feat, cuda), t(rd, cuda), t(rf, cuda), row_ptr, out)
         outs.append(out.cpu().numpy())
     np.testing.assert_allclose(outs[0], want, rtol=1e-5, atol=2e-4)
-    np.testing.assert_allclose(outs[1], want, rtol=1e-5, atol=2e-4)
-    assert np.array_equal(outs[0], outs[2])          # run-to-run identical
-    assert np.array_equal(outs[0], outs[3])          # the schedule never changes results
+    assert np.array_equal(outs[0], outs[1])          # run-to-run identical
 
 
 def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
@@ -223,8 +220,7 @@ def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
     e = torch.empty(0, dtype=torch.int32, device=cuda)
     row_ptr = ops.csr_from_sorted_keys(e, 1000)
     out = torch.full((1000, 64), 3.0, device=cuda)
-    ops.bev_pool_v2_forward_csr(depth, feat, e, e, row_ptr, out, e,
-                                ops.tile_descriptors(row_ptr, ops.csr_tiles(row_ptr, 128, 64)))
+    ops.bev_pool_v2_forward_csr(depth, feat, e, e, row_ptr, out)
     assert out.abs().sum() == 0
     rows = torch.zeros(5000, dtype=torch.int32, device=cuda)             # one row holds everything
     g = torch.Generator(device="cpu").manual_seed(11)
@@ -232,8 +228,7 @@ def test_tiled_dense_forward_all_rows_empty_and_single_row(cuda):
     rf = torch.randint(0, 4, (5000,), dtype=torch.int32, generator=g).to(cuda)
     row_ptr = ops.csr_from_sorted_keys(rows, 1)
     out = torch.empty(1, 64, device=cuda)
-    ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out, rows,
-                                ops.tile_descriptors(row_ptr, ops.csr_tiles(row_ptr, 256, 256)))
+    ops.bev_pool_v2_forward_csr(depth, feat, rd, rf, row_ptr, out)
     terms = depth.view(-1)[rd.long()][:, None].double() * feat.view(4, 64)[rf.long()].double()
     want = terms.sum(0)
     # 5000 fp32 products summed in the kernel's split order: error bound relative to the sum of magnitudes
@@ -290,78 +285,12 @@ def test_v1_pool_matches_oracle(cuda):
     assert np.array_equal(x.grad.cpu().numpy(), want_xg)
 
 
-@pytest.mark.parametrize("tile_items,long_len", [(64, 64), (200, 256), (768, 512)])
-@pytest.mark.parametrize("c,B", [(64, 1), (8, 2)])
-def test_one_table_forward_is_bit_identical_to_three_table_forward(cuda, tile_items, long_len, c, B):
-    """k_pool_fwd_lean derives the pixel row from the depth index and the closing points from row_ptr: same bits as
-    k_pool_fwd_tiles on heavy-tailed rows (rows longer than a tile, empty runs, rows cut at piece boundaries)."""
-    from omnihd_amd import ops
-    from omnihd_amd.plan import tile_schedule
-    rng = np.random.default_rng(tile_items + c + B)
-    N, D, fH, fW = 2, 7, 5, 12
-    fhw, n_rows = fH * fW, 2500
-    rows = np.concatenate([np.full(4000, 3), np.full(1300, 4), np.full(2600, 1200), np.full(600, n_rows - 1),
-                           rng.choice(n_rows, 500, replace=False).repeat(rng.integers(1, 12, 500))])
-    rows = np.sort(rows).astype(np.int32)
-    rd = rng.integers(0, B * N * D * fhw, rows.size).astype(np.int32)
-    rf = ((rd // (D * fhw)) * fhw + rd % fhw).astype(np.int32)            # what the kernel must derive
-    depth = t(rng.random((B, N, D, fH, fW), dtype=np.float32), cuda)
-    feat = t(rng.standard_normal((B, N, fH, fW, c), dtype=np.float32), cuda)
-    row_ptr = ops.csr_from_sorted_keys(t(rows, cuda), n_rows)
-    tiles = ops.csr_tiles(row_ptr, tile_items, long_len)
-    for order in (None, tile_schedule(row_ptr, tiles, t(rf, cuda), (fH, fW))):
-        desc = ops.tile_descriptors(row_ptr, tiles, order)
-        a = torch.full((n_rows, c), float("nan"), device=cuda)
-        b = torch.full((n_rows, c), float("nan"), device=cuda)
-        b2 = torch.full((n_rows, c), float("nan"), device=cuda)
-        ops.bev_pool_v2_forward_csr(depth, feat, t(rd, cuda), t(rf, cuda), row_ptr, a, t(rows, cuda), desc)
-        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b, D, fhw, gen=1)
-        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b2, D, fhw)
-        assert not torch.isnan(b).any() and not torch.isnan(b2).any()
-        assert torch.equal(a, b)
-        # the second-generation kernel (the default) cuts a tile's points into pieces of a different length: rows cut by a
-        # piece boundary associate their partial sums differently (last bit), every other row is bit-identical
-        assert float((a - b2).abs().max()) <= 2e-6 * float(a.abs().max())
-        b3 = torch.full((n_rows, c), float("nan"), device=cuda)
-        ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b3, D, fhw)
-        assert torch.equal(b2, b3)                                                        # run-to-run identical
-    st, ln = O.run_length(rows)
-    want = OC.bev_pool_v2_fwd(depth.cpu().numpy(), feat.cpu().numpy(), rd, rf, rows, (1, 1, 1, n_rows, c), st, ln)
-    np.testing.assert_allclose(b.cpu().numpy(), want.reshape(n_rows, c), rtol=1e-5, atol=2e-4)
-    np.testing.assert_allclose(b2.cpu().numpy(), want.reshape(n_rows, c), rtol=1e-5, atol=2e-4)
-    # rows of one point have no summation order at all: both kernels must reproduce the oracle's single product exactly
-    one = np.bincount(rows, minlength=n_rows) == 1
-    assert np.array_equal(b2.cpu().numpy()[one], want.reshape(n_rows, c)[one])
-
-
-def test_one_table_forward_full_size_plan(cuda):
-    """R1 frame geometry: the planned pool (one-table kernel by default) against the three-table kernel."""
-    from omnihd_amd import build_plan, ops
-    geom, dx, bx, nx = full_size_geometry("r1")
-    plan = build_plan(t(geom, cuda), dx, bx, nx, layout="byxz")
-    assert plan.depth_bins == 59 and plan.feat_hw == 64 * 176
-    g = torch.Generator(device="cpu").manual_seed(0)
-    depth = torch.rand(1, 6, 59, 64, 176, generator=g).softmax(2).to(cuda)
-    feat = torch.randn(1, 6, 64, 176, 64, generator=g).to(cuda)
-    a = torch.empty(plan.n_rows, 64, device=cuda)
-    b = torch.full((plan.n_rows, 64), float("nan"), device=cuda)
-    ops.bev_pool_v2_forward_csr(depth, feat, plan.ranks_depth, plan.ranks_feat, plan.row_ptr, a, plan.ranks_row, plan.tile_desc)
-    ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, b, plan.depth_bins, plan.feat_hw,
-                                 gen=1)
-    assert torch.equal(a, b)
-    b2 = torch.full((plan.n_rows, 64), float("nan"), device=cuda)
-    ops.bev_pool_v2_forward_lean(depth, feat, plan.ranks_depth, plan.row_ptr, plan.tile_desc, b2, plan.depth_bins, plan.feat_hw)
-    assert not torch.isnan(b2).any() and float((a - b2).abs().max()) <= 2e-6 * float(a.abs().max())
-    assert torch.equal((a == 0).all(1), (b2 == 0).all(1))                 # the same rows are empty
-
-
 FULL = {"r1": (64, 176, 2025022), "r2": (136, 240, 4503872)}      # fH, fW, points the reference keeps (SURVEY 8d)
 
 
 @pytest.mark.parametrize("res", ["r1", "r2"])
-def test_default_dense_forward_full_size_against_the_oracle(cuda, golden, res, monkeypatch):
-    """The headline kernel (what ``planned_pool`` launches: k_pool_fwd_direct, and k_pool_fwd_lean2 behind
-    OMNIHD_POOL_DIRECT=0) at the BASELINE frame size R1 and at the repo's own resolution R2 (544x960) against the CPU
+def test_default_dense_forward_full_size_against_the_oracle(cuda, golden, res):
+    """The headline kernel (what ``planned_pool`` launches: k_pool_fwd_direct) at the BASELINE frame size R1 and at the repo's own resolution R2 (544x960) against the CPU
     restatement of the reference kernel on the reference-format tables of the same geometry: every output row, 1e-5 relative
     (summation order of rows cut inside a tile differs; north_star allows 1e-3), empty rows exactly zero, rows with a single
     point bit-exact; the kept-buffer path (rows without points keep their zeros) gives the same bits on its second use."""
@@ -380,21 +309,16 @@ def test_default_dense_forward_full_size_against_the_oracle(cuda, golden, res, m
     scale = float(np.abs(want).max())
     single = np.zeros(16 * 160 * 240, dtype=bool)
     single[rb[st[ln == 1]]] = True
-    results = {}
-    for direct in ("1", "0"):
-        monkeypatch.setenv("OMNIHD_POOL_DIRECT", direct)
-        got = planned_pool(t(depth, cuda), t(feat, cuda), plan)               # logical (B,C,Z,Y,X)
-        got = got.permute(0, 2, 3, 4, 1).contiguous().cpu().numpy()
-        assert got.shape == want.shape
-        assert float(np.abs(got - want).max()) <= 1e-5 * scale
-        assert np.array_equal((got == 0).all(-1), (want == 0).all(-1))
-        assert np.array_equal(got.reshape(-1, 64)[single], want.reshape(-1, 64)[single])
-        results[direct] = got
-    monkeypatch.setenv("OMNIHD_POOL_DIRECT", "1")
+    got = planned_pool(t(depth, cuda), t(feat, cuda), plan)               # logical (B,C,Z,Y,X)
+    got = got.permute(0, 2, 3, 4, 1).contiguous().cpu().numpy()
+    assert got.shape == want.shape
+    assert float(np.abs(got - want).max()) <= 1e-5 * scale
+    assert np.array_equal((got == 0).all(-1), (want == 0).all(-1))
+    assert np.array_equal(got.reshape(-1, 64)[single], want.reshape(-1, 64)[single])
     for _ in range(3):                                                        # kept buffers: fresh, reused, reused
         again = planned_pool(t(depth, cuda), t(feat, cuda), plan, keep_empty_rows=True)
         again = again.permute(0, 2, 3, 4, 1).contiguous().cpu().numpy()
-        assert np.array_equal(again, results["1"])
+        assert np.array_equal(again, got)
         del again
 
 
@@ -403,7 +327,7 @@ def test_default_dense_forward_full_size_against_the_oracle(cuda, golden, res, m
 def test_direct_forward_on_heavy_tailed_rows(cuda, tile_items, long_len, B):
     """k_pool_fwd_direct (C = 64) on rows longer than a tile, single-row tiles, empty runs, tiles with fewer than 16 points and
     rows cut at every piece boundary, written into NaN-filled buffers: equals the oracle to 1e-5 (rows of one point bit-exact),
-    agrees with k_pool_fwd_lean2 to the last-bit association difference, is run-to-run identical, does not depend on the
+    agrees with the any-channel kernel to the last-bit association difference, is run-to-run identical, does not depend on the
     schedule order, and with ``empty_rows_kept`` leaves exactly the empty rows untouched."""
     from omnihd_amd import ops
     from omnihd_amd.plan import direct_tables_from, tile_schedule
@@ -442,10 +366,9 @@ def test_direct_forward_on_heavy_tailed_rows(cuda, tile_items, long_len, B):
         ops.bev_pool_v2_forward_direct(depth, feat, pt, ivl_rel, desc32, row_ptr, k, D, fhw, empty_rows_kept=True)
         kk = k.cpu().numpy()
         assert np.isnan(kk[empty]).all() and np.array_equal(kk[~empty], a.cpu().numpy()[~empty])
-        if tile_items <= 768:                                                  # the LDS record window of k_pool_fwd_lean2
-            b = torch.full((n_rows, c), float("nan"), device=cuda)
-            ops.bev_pool_v2_forward_lean(depth, feat, t(rd, cuda), row_ptr, desc, b, D, fhw)
-            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+        b = torch.full((n_rows, c), float("nan"), device=cuda)                 # the any-channel kernel: row sums in table order
+        ops.bev_pool_v2_forward_csr(depth, feat, t(rd, cuda), t(rf, cuda), row_ptr, b)
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
 @pytest.mark.parametrize("fH,fW,B", [(5, 12, 1), (8, 12, 2), (4, 44, 1), (3, 7, 2)])
@@ -548,72 +471,6 @@ def test_patch_backward_full_size_r1_directly_against_the_oracle(cuda):
     assert np.array_equal(got_fg, want_fg)
     assert float(np.abs(got_dg - want_dg).max()) <= 1e-5 * float(np.abs(want_dg).max())
     assert np.array_equal(got_dg == 0, want_dg == 0)
-
-
-@pytest.mark.parametrize("fH,fW,B,D,n_rows,pw,R,spx", [(5, 12, 1, 7, 3000, 8, 32, 1), (8, 12, 2, 7, 3000, 4, 32, 2), (4, 44, 1, 7, 3000, 16, 48, 1),
-                                                        (3, 7, 2, 7, 3000, 8, 64, 1), (6, 16, 1, 40, 50, 8, 64, 1), (6, 16, 1, 40, 700, 4, 32, 3)])
-def test_stream_backward_matches_oracle(cuda, fH, fW, B, D, n_rows, pw, R, spx):
-    """k_pool_bwd_stream (C = 64, opt-in): one wave per stream of stages, the distinct out_grad rows of a 16-pixel patch staged in
-    LDS.  Against the CPU restatement of the reference kernel: feat_grad bit-exact (same fma chain per channel), depth_grad 1e-5
-    (fixed-order channel sum), untouched entries exactly zero; patches cut by the image edge for every patch shape, pixels and depth
-    bins without points, streams of several patches (1-3 waves per XCD), patches of several stages (up to 112 distinct rows at 32
-    per stage) and pieces longer than the 16 table words read ahead (40 bins onto 50 rows: one stage holds a pixel's whole ray)."""
-    from omnihd_amd import ops
-    from omnihd_amd.plan import stream_tables_from
-    rng = np.random.default_rng(fH * 100 + fW + B + D)
-    N, c = 2, 64
-    fhw = fH * fW
-    n_depth = B * N * D * fhw
-    rd = np.sort(rng.permutation(n_depth)[:int(0.6 * n_depth)]).astype(np.int32)        # every frustum point at most once
-    rd = rd[(rd // fhw) % D != 3]                                                       # one depth bin never used
-    rd = rd[rd % fhw != 5]                                                              # one pixel column never used
-    rf = ((rd // (D * fhw)) * fhw + rd % fhw).astype(np.int32)
-    rows = rng.integers(0, n_rows, rd.size).astype(np.int32)
-    order = np.lexsort((rd, rows))
-    brb, brd, brf, bst, bln = O.backward_tables(rows[order], rd[order], rf[order])
-    depth = rng.random((B, N, D, fH, fW), dtype=np.float32)
-    feat = rng.standard_normal((B, N, fH, fW, c), dtype=np.float32)
-    og = rng.standard_normal((1, 1, 1, n_rows, c), dtype=np.float32)
-    want_dg, want_fg = OC.bev_pool_v2_bwd(og, depth, feat, brd, brf, brb, bst, bln)
-    pix_ptr = ops.csr_from_sorted_keys(t(brf, cuda), B * N * fhw)
-    tb = stream_tables_from(t(brb, cuda), t(brd, cuda), pix_ptr, B * N, D, (fH, fW), pw, R, spx)
-    assert tb is not None and tb.n_streams == 8 * spx
-    dg = torch.full((B, N, D, fH, fW), float("nan"), device=cuda)
-    fg = torch.full((B, N, fH, fW, c), float("nan"), device=cuda)
-    ops.bev_pool_v2_backward_stream(t(og.reshape(n_rows, c), cuda), t(depth, cuda), t(feat, cuda), tb, dg, fg)
-    assert not torch.isnan(dg).any() and not torch.isnan(fg).any()
-    assert np.array_equal(fg.cpu().numpy(), want_fg)
-    np.testing.assert_allclose(dg.cpu().numpy(), want_dg, rtol=1e-5, atol=1e-5)
-    assert np.array_equal(dg.cpu().numpy() == 0, want_dg == 0)
-    dg2, fg2 = torch.empty_like(dg), torch.empty_like(fg)
-    ops.bev_pool_v2_backward_stream(t(og.reshape(n_rows, c), cuda), t(depth, cuda), t(feat, cuda), tb, dg2, fg2)
-    assert torch.equal(dg, dg2) and torch.equal(fg, fg2)                                # run-to-run identical
-
-
-@pytest.mark.parametrize("res", ["r1", "r2"])
-def test_stream_backward_full_size_equals_the_patch_backward(cuda, res, monkeypatch):
-    """R1 and R2 frame geometry through ``planned_pool``'s autograd path with OMNIHD_POOL_BWD_STREAM=1 against the default (patch)
-    backward of the same plan: feat_grad the same bits, depth_grad within 1e-5 of its largest entry, the same zeros."""
-    from omnihd_amd import build_plan
-    from omnihd_amd import plan as P
-    fH, fW, _ = FULL[res]
-    geom, dx, bx, nx = full_size_geometry(res)
-    plan = build_plan(t(geom, cuda), dx, bx, nx, layout="byxz")
-    g = torch.Generator(device="cpu").manual_seed(5)
-    depth0 = torch.rand(1, 6, 59, fH, fW, generator=g).softmax(2).to(cuda)
-    feat0 = torch.randn(1, 6, fH, fW, 64, generator=g).to(cuda)
-    og = torch.randn(plan.n_rows, 64, generator=g).to(cuda).view(1, 160, 240, 16, 64).permute(0, 4, 3, 1, 2)
-    grads = []
-    for stream in ("0", "1"):
-        monkeypatch.setenv("OMNIHD_POOL_BWD_STREAM", stream)
-        depth, feat = depth0.clone().requires_grad_(), feat0.clone().requires_grad_()
-        P.planned_pool(depth, feat, plan).backward(og)
-        grads.append((depth.grad, feat.grad))
-    assert getattr(plan, "_stream", None), "the stream tables were not built: the opt-in path did not run"
-    (dg0, fg0), (dg1, fg1) = grads
-    assert torch.equal(fg0, fg1)
-    assert float((dg0 - dg1).abs().max()) <= 1e-5 * float(dg0.abs().max())
-    assert torch.equal(dg0 == 0, dg1 == 0)
 
 
 def test_kept_output_buffers_survive_consumers_that_write_in_place(cuda, monkeypatch):

@@ -334,7 +334,8 @@ def test_shared_weight_of_two_convolutions_with_the_side_stream(cuda, monkeypatc
     assert not ops._WGRAD_SIDE_USED and not ops._WGRAD_SEEN
 
 
-def test_side_stream_weight_gradients_under_ddp_go_straight_into_the_bucket_views(cuda):
+@pytest.mark.parametrize("bucket_mb", [1, 25, 100])
+def test_side_stream_weight_gradients_under_ddp_go_straight_into_the_bucket_views(cuda, bucket_mb):
     """the N > 1 step must be the N = 1 step.  A chain of split convolutions under DistributedDataParallel
     (one-rank RCCL group, several buckets) with `ops.ddp_wgrad_overlap`: once the reducer has re-bucketed, the weight gradients
     are computed on the side stream INTO the reducer's bucket views, autograd keeps an alias as `.grad` (no copy on the caller's
@@ -373,7 +374,7 @@ os.environ["OMNIHD_WGRAD_OVERLAP"] = "0"
 want = [grads_of(ref, x) for x in xs]
 os.environ["OMNIHD_WGRAD_OVERLAP"] = "all"
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=False, bucket_cap_mb=1, gradient_as_bucket_view=True)
+ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=False, bucket_cap_mb=%d, gradient_as_bucket_view=True)
 assert ops.ddp_wgrad_overlap(ddp)
 rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
 worst = 0.0
@@ -403,7 +404,7 @@ with ddp.no_sync():                                    # no synchronisation this
     assert all(ops._ddp_bucket_view(p) is None for p in net.parameters())
 dist.destroy_process_group()
 print("DDP_OVERLAP_OK", worst, info)
-''' % (root, os.path.join(root, "omnihd-scenes_amd"))
+''' % (root, os.path.join(root, "omnihd-scenes_amd"), bucket_mb)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DDP_OVERLAP_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -68,33 +68,6 @@ def test_tile_schedule_spills_when_one_run_holds_too_many_tiles():
     assert sorted(flat[flat >= 0].tolist()) == list(range(n_tiles)) and int((flat < 0).sum()) == flat.numel() - n_tiles
 
 
-def test_pixel_schedule_lists_every_pixel_once_with_its_points():
-    from omnihd_amd.plan import pixel_schedule
-    rb, rd, rf, st, ln, _, _ = _tables()
-    bp = O.backward_tables(rb, rd, rf)                     # (ranks_bev, ranks_depth, ranks_feat, starts, lengths) sorted by pixel
-    n_pix = 4 * 8 * 12
-    desc = pixel_schedule(torch.from_numpy(bp[2]), torch.from_numpy(bp[3]), torch.from_numpy(bp[4]), n_pix, feat_hw=(8, 12))
-    per = (n_pix + 7) // 8
-    assert desc.shape == (8 * per, 4) and desc.dtype == torch.int32
-    rows = desc[desc[:, 0] >= 0]
-    assert sorted(rows[:, 0].tolist()) == list(range(n_pix))                 # pixels without points are listed too
-    starts, lengths = bp[3], bp[4]
-    for pix, s, n, z in rows.tolist():
-        assert z == 0
-        if n:
-            assert np.all(bp[2][s:s + n] == pix)                              # its run of the pixel-sorted tables
-        else:
-            assert s == 0
-    assert int(rows[:, 2].sum()) == len(rb)
-    # 4x4 patches: the first 16 descriptors of a run cover one 4x4 block of one image
-    first = rows[:16, 0].numpy()
-    h, w = (first // 12) % 8, first % 12
-    assert len({int(v) for v in first // 96}) == 1 and h.max() - h.min() <= 3 and w.max() - w.min() <= 3
-    empty = pixel_schedule(torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32),
-                           10, feat_hw=None)
-    assert sorted(empty[empty[:, 0] >= 0][:, 0].tolist()) == list(range(10)) and int(empty[:, 2].sum()) == 0
-
-
 def test_patch_schedule_lists_every_patch_once():
     from omnihd_amd.plan import patch_schedule
     for n_img, hw in ((6, (64, 176)), (3, (8, 12)), (2, (5, 12)), (1, (3, 7))):
@@ -241,144 +214,6 @@ def test_direct_forward_tables_walk_every_point_once_and_close_every_row(tile_ro
     nonempty = np.diff(row_ptr) > 0
     assert np.array_equal(written > 0, nonempty) and written.max() == 1      # every non-empty row written exactly once
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
-
-
-def _walk_stream_tables(out_grad, depth, feat, tb, d_bins, fh, fw):
-    """Host emulation of k_pool_bwd_stream's walk (csrc/bev_pool_v2.hip), iteration by iteration as the kernel does it: entry t
-    names the stage consumed now (t-2), the stage whose rows are fetched now was named by entry t-1, the stage whose ids / offsets
-    are read now is entry t's own; the pixel data of a patch are fetched one iteration before its first stage."""
-    C = feat.shape[-1]
-    og = out_grad.reshape(-1, C).astype(np.float64)
-    dflat = depth.reshape(-1).astype(np.float64)
-    frows = feat.reshape(-1, C).astype(np.float64)
-    dg = np.full(dflat.shape, np.nan)
-    fg = np.full(frows.shape, np.nan)
-    pw, R = tb.patch_w, tb.rows_per_stage
-    ph = 16 // pw
-    pcols, prows = -(-fw // pw), -(-fh // ph)
-    fhw = fh * fw
-    stream, sptr = tb.stream.numpy().astype(np.int64), tb.stream_ptr.numpy()
-    uniq, off, word = tb.uniq_rows.numpy(), tb.px_off.numpy().reshape(-1, 16), tb.pt_word.numpy()
-    consumed = []
-
-    def geometry(patch):
-        img, pr, pc = patch // (pcols * prows), (patch // pcols) % prows, patch % pcols
-        return [(img, (pr * ph + g // pw) * fw + pc * pw + g % pw) if (pr * ph + g // pw < fh and pc * pw + g % pw < fw) else None
-                for g in range(16)]
-
-    for w in range(tb.n_streams):
-        ids_prev, nrows_prev, o1, o2, rows_lds, rows_regs, geo_next, geo, acc = None, 0, None, None, None, None, None, None, None
-        for e in range(sptr[w], sptr[w + 1]):
-            ex, ey, ez, ew = (int(v) for v in stream[e])
-            rows_lds = rows_regs                                            # (1) the rows requested last iteration -> LDS
-            if ex & (1 << 30):
-                geo = geo_next
-                acc = {g: np.zeros(C) for g in range(16) if geo[g] is not None}
-                for g, px in enumerate(geo):
-                    if px is not None:
-                        dg[(px[0] * d_bins + np.arange(d_bins)) * fhw + px[1]] = 0.0
-            ids_n = uniq[ey:ey + 64]                                        # (2) requests
-            so, nrows = ez & 0xffffff, (ez >> 24) & 0xff
-            o_n = (off[so].copy(), off[so + 1].copy())
-            if ew >= 0:
-                geo_next = geometry(ew)
-            rows_regs = None if ids_prev is None else [ids_prev[r] if r < nrows_prev else None for r in range(R)]
-            if ex & (1 << 28):                                              # (3) the points of stage t-2
-                assert (ex & 0x0fffffff) >= 0 and geo is not None
-                consumed.append((ex & 0x0fffffff, bool(ex & (1 << 30)), bool(ex & (1 << 29))))
-                a, b = o2
-                for g, px in enumerate(geo):
-                    if px is None:
-                        assert a[g] == b[g]
-                        continue
-                    assert 0 <= b[g] - a[g] <= 64
-                    f = px[0] * fhw + px[1]
-                    for q in range(a[g], b[g]):
-                        wd = int(word[q])
-                        lid, dk = (wd & 0xffffff) >> 8, (wd >> 24) & 0xff
-                        row = og[rows_lds[lid]]
-                        rd = (px[0] * d_bins + dk) * fhw + px[1]
-                        acc[g] = acc[g] + dflat[rd] * row
-                        dg[rd] = float(row @ frows[f])
-                if ex & (1 << 29):
-                    for g, px in enumerate(geo):
-                        if px is not None:
-                            fg[px[0] * fhw + px[1]] = acc[g]
-            o2, o1 = o1, o_n                                                # (4) rotate
-            ids_prev, nrows_prev = ids_n, nrows
-    return dg, fg, consumed
-
-
-@pytest.mark.parametrize("patch_w,rows_per_stage,streams_per_xcd", [(16, 32, 1), (8, 32, 2), (4, 32, 1), (8, 64, 3)])
-def test_stream_backward_tables_walk_every_stage_once(patch_w, rows_per_stage, streams_per_xcd):
-    """plan.stream_tables_from: the per-wave streams (two entries more than stages, every entry naming the stage consumed, the
-    stage whose rows are on their way and the stage whose ids are read) drive a walk that equals the pooling oracle's backward;
-    every patch's stages appear once, in order, first/last flagged; patches without points still write their zeros."""
-    from omnihd_amd.plan import stream_tables_from
-    from oracle import cpu as OC
-    rb, rd, rf, st, ln, (X, Y, Z), rng = _tables()
-    N, D, H, W, C = 4, 8, 8, 12, 8
-    n_rows = Z * Y * X
-    keep = (rf // (H * W) != 2) | ((rf % (H * W)) // W >= 4)       # no points in the upper half of image 2: patches without a stage
-    rb, rd, rf = rb[keep], rd[keep], rf[keep]
-    order = np.lexsort((rb, rf))
-    brb, brd, brf = rb[order].astype(np.int32), rd[order].astype(np.int32), rf[order].astype(np.int32)
-    pix_ptr = np.concatenate([[0], np.cumsum(np.bincount(brf, minlength=N * H * W))]).astype(np.int32)
-    tb = stream_tables_from(torch.from_numpy(brb), torch.from_numpy(brd), torch.from_numpy(pix_ptr), N, D, (H, W), patch_w, rows_per_stage,
-                            streams_per_xcd)
-    assert tb is not None and tb.n_streams == 8 * streams_per_xcd and tb.stream.shape[1] == 4 and tb.balance >= 1.0
-    depth = rng.random((1, N, D, H, W), dtype=np.float32)
-    feat = rng.standard_normal((1, N, H, W, C), dtype=np.float32)
-    out_grad = rng.standard_normal((n_rows, C), dtype=np.float32)
-    dg, fg, consumed = _walk_stream_tables(out_grad, depth, feat, tb, D, H, W)
-    n_patch = N * -(-W // patch_w) * -(-H // (16 // patch_w))
-    firsts = [p for p, first, last in consumed if first]
-    lasts = [p for p, first, last in consumed if last]
-    assert sorted(firsts) == list(range(n_patch)) and sorted(lasts) == list(range(n_patch))      # every patch opened and closed once
-    assert not np.isnan(dg).any() and not np.isnan(fg).any()
-    bst = np.flatnonzero(np.r_[True, brf[1:] != brf[:-1]]).astype(np.int32)
-    bln = np.diff(np.r_[bst, len(brf)]).astype(np.int32)
-    want_dg, want_fg = OC.bev_pool_v2_bwd(out_grad.reshape(1, Z, Y, X, C), depth, feat, brd, brf, brb, bst, bln)
-    np.testing.assert_allclose(dg.reshape(want_dg.shape), want_dg, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(fg.reshape(want_fg.shape), want_fg, rtol=1e-5, atol=1e-6)
-
-
-def test_stream_backward_tables_refuse_what_the_kernel_cannot_walk():
-    from omnihd_amd.plan import stream_tables_from
-    rows = torch.tensor([5, 3], dtype=torch.int32)                # one pixel whose two points are NOT sorted by row
-    rd = torch.tensor([0, 16], dtype=torch.int32)
-    pix_ptr = torch.zeros(17, dtype=torch.int32); pix_ptr[1:] = 2
-    assert stream_tables_from(rows, rd, pix_ptr, 1, 2, (4, 4), 4, 32, 1) is None
-    ok = stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 4, 32, 1)
-    assert ok is not None and ok.uniq_rows.tolist() == [3, 5] and ok.stream.shape == (2 * 8 + 1, 4)        # one stage + two entries per wave
-    assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 65, (4, 4), 4, 32, 1) is None     # > 64 depth bins
-    assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 5, 32, 1) is None      # patch width
-    assert stream_tables_from(torch.tensor([3, 5], dtype=torch.int32), rd, pix_ptr, 1, 2, (4, 4), 4, 40, 1) is None      # rows per stage
-
-
-
-def test_stream_dealing_keeps_the_walk_order_and_balances_the_waves():
-    """plan.shared_schedule + plan.stream_deal: every patch of every patch shape lands in exactly one stream, a stream's patches
-    keep the walk order of their XCD run (neighbouring patches close in time), and the dealt cost per wave is even (each next
-    patch goes to the least loaded wave) although patch costs vary by 10x."""
-    from omnihd_amd.plan import shared_schedule, stream_deal
-    rng = np.random.default_rng(5)
-    n_img, feat_hw = 6, (64, 176)
-    for patch_w in (16, 8, 4):
-        n_patch = n_img * -(-feat_hw[1] // patch_w) * -(-feat_hw[0] // (16 // patch_w))
-        cost = torch.from_numpy(rng.integers(100, 1000, n_patch)).double()
-        runs = shared_schedule(n_img, feat_hw, patch_w, cost)
-        assert len(runs) == 8 and sorted(torch.cat(runs).tolist()) == list(range(n_patch))
-        run_cost = [float(cost[r].sum()) for r in runs]
-        assert max(run_cost) / min(run_cost) < 1.02                                      # XCD runs cut by cost
-        lists = stream_deal(runs, cost, 24)
-        assert len(lists) == 8 * 24 and sorted(p for l in lists for p in l) == list(range(n_patch))
-        for x, run in enumerate(runs):
-            pos = {int(p): i for i, p in enumerate(run.tolist())}
-            for l in lists[x * 24:(x + 1) * 24]:
-                assert all(p in pos for p in l) and [pos[p] for p in l] == sorted(pos[p] for p in l)   # same XCD, walk order kept
-        load = np.array([float(cost[l].sum()) for l in lists])
-        assert load.max() / load.mean() < 1.15
 
 
 @pytest.mark.parametrize("n_img,fH,fW", [(6, 64, 176), (12, 136, 240), (2, 5, 24), (3, 7, 16)])

@@ -1,5 +1,5 @@
 """Size-independent properties of bev_pool_v2 at the full frame sizes R1 (256x704) and R2 (544x960), through the path the model
-runs (``planned_pool``: k_pool_fwd_direct, k_pool_bwd_patch; and the opt-in k_pool_bwd_stream).  They need no oracle run at
+runs (``planned_pool``: k_pool_fwd_direct, k_pool_bwd_patch).  They need no oracle run at
 2-4.5 M points and hold for ANY correct implementation of the reference's operator (ops/bev_pool_v2/bev_pool.py:9-57):
   * checksum:  sum over rows of out = sum over points of depth * feat   (per channel; an independent torch gather-sum);
   * adjoint:   <out, og> = <depth, depth_grad> = <feat, feat_grad>        (out is bilinear in (depth, feat));
@@ -51,11 +51,9 @@ def test_checksum_of_the_pooled_rows(cuda, res):
     assert not bool(rows[~touched].any())
 
 
-@pytest.mark.parametrize("stream", ["0", "1"], ids=["patch", "stream"])
 @pytest.mark.parametrize("res", ["r1", "r2"])
-def test_forward_and_backward_are_adjoint(cuda, res, stream, monkeypatch):
+def test_forward_and_backward_are_adjoint(cuda, res):
     from omnihd_amd.plan import planned_pool
-    monkeypatch.setenv("OMNIHD_POOL_BWD_STREAM", stream)
     plan, depth, feat, og = _setup(cuda, res, 22)
     depth.requires_grad_(); feat.requires_grad_()
     out = planned_pool(depth, feat, plan)
