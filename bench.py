@@ -510,22 +510,27 @@ def pool_source_hash():
 
 
 def pmc_traffic(res, fwd_kernel):
-    """HBM-side bytes per launch of the pooling forward from the committed rocprofv3 PMC passes (profiles/round4/pmc_pool_<res>.json:
-    FETCH_SIZE x the factor calibrated on a 128 MiB copy + WRITE_SIZE, separate --pmc passes, scripts/lab/pmc_bwd.sh) — a pointer to
-    a measurement of THIS kernel, not a counter read in this run: null unless the file names the kernel that ran AND was taken from
-    the same csrc/bev_pool_v2.hip (sha256 recorded in the file)."""
-    pmc = os.path.join(ROOT, "profiles", "round4", f"pmc_pool_{res}.json")
-    if not os.path.exists(pmc):
-        return None, None
-    rec = json.load(open(pmc))
-    k = rec.get("fwd_lean", {})
-    if not (fwd_kernel.startswith(rec.get("fwd_kernel", "?")) and "read_bytes_corrected" in k and "write_bytes" in k):
-        return None, None
-    if rec.get("pool_source_sha256") != pool_source_hash():
-        return None, f"profiles/round4/pmc_pool_{res}.json is stale: csrc/bev_pool_v2.hip changed since the counters were taken"
-    return round(k["read_bytes_corrected"] + k["write_bytes"]), (
-        f"profiles/round4/pmc_pool_{res}.json (rocprofv3 --pmc passes of scripts/lab/pmc_bwd.sh on {rec.get('fwd_kernel')}, "
-        f"same csrc/bev_pool_v2.hip: sha256 {rec.get('pool_source_sha256', '?')[:12]})")
+    """HBM-side bytes per launch of the pooling forward from the committed rocprofv3 PMC passes (profiles/round6/pmc_pool_<res>.json,
+    else the round-4 file: FETCH_SIZE x the factor calibrated on a 128 MiB copy + WRITE_SIZE, separate --pmc passes,
+    scripts/lab/pmc_bwd.sh) — a pointer to a measurement of THIS kernel, not a counter read in this run: null unless the file names the
+    kernel that ran AND was taken from the same csrc/bev_pool_v2.hip (sha256 recorded in the file)."""
+    stale = None
+    for rnd in ("round6", "round4"):
+        rel = f"profiles/{rnd}/pmc_pool_{res}.json"
+        pmc = os.path.join(ROOT, rel)
+        if not os.path.exists(pmc):
+            continue
+        rec = json.load(open(pmc))
+        k = rec.get("fwd_lean", {})
+        if not (fwd_kernel.startswith(rec.get("fwd_kernel", "?")) and "read_bytes_corrected" in k and "write_bytes" in k):
+            continue
+        if rec.get("pool_source_sha256") != pool_source_hash():
+            stale = stale or f"{rel} is stale: csrc/bev_pool_v2.hip changed since the counters were taken"
+            continue
+        return round(k["read_bytes_corrected"] + k["write_bytes"]), (
+            f"{rel} (rocprofv3 --pmc passes of scripts/lab/pmc_bwd.sh on {rec.get('fwd_kernel')}, "
+            f"same csrc/bev_pool_v2.hip: sha256 {rec.get('pool_source_sha256', '?')[:12]})")
+    return None, stale
 
 
 def pooling_at_r2(dev, launches):

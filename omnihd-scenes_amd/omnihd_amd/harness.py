@@ -475,6 +475,9 @@ class FusionTrainStep:
         return total
 
 
+_SMALL_FLAGS = {}
+
+
 def _reduce_small(params, group=None):
     """Mean over the ranks of the gradients of ``params`` through ONE flat all-reduce (cat -> all_reduce -> multi-tensor copy
     back): what the reducer would do with one copy launch per parameter.
@@ -501,7 +504,15 @@ def _reduce_small(params, group=None):
             if n not in zeros:
                 zeros[n] = torch.zeros(n, dtype=dt, device=dev)
             parts.append(zeros[n])
-    parts.append(torch.tensor([1.0 if h else 0.0 for h in have], dtype=dt, device=dev))
+    if all(have):
+        # the common case must not cost a host-to-device copy per step (a pageable-memory upload makes the host wait for the stream)
+        key = (str(dev), dt, len(params))
+        ones = _SMALL_FLAGS.get(key)
+        if ones is None:
+            ones = _SMALL_FLAGS[key] = torch.ones(len(params), dtype=dt, device=dev)
+        parts.append(ones)
+    else:
+        parts.append(torch.tensor([1.0 if h else 0.0 for h in have], dtype=dt, device=dev))
     flat = torch.cat(parts)
     world = dist.get_world_size(group)
     n_grad = sum(sizes)
@@ -681,4 +692,4 @@ def syncbn_exchange_probe(step, iters=20):
     dt = (time.perf_counter() - t0) / iters
     return {"exchanges_per_step": len(bufs), "total_us_per_step": round(dt * 1e6, 1), "per_call_us": round(dt * 1e6 / len(bufs), 2),
             "message_floats": [2 * c for c in sorted(set(chans))],
-            "note": "all-reduces issued back to back by one thread; in the step the radar branch's exchanges run on the second stream"}
+            "note": "all-reduces issued back to back by one thread, as in the step (the radar branch runs in line since round 6)"}
