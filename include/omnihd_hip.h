@@ -344,38 +344,6 @@ int omnihd_pfn_bwd_final(const float* sums, const float* ab_all_ranks, const dou
                          const float* gamma, const float* consts, int k, long long n_rows, int n_ranks, float* dweight,
                          float* dgamma, float* dbeta, void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * Dense BEV convolutions (matrix cores)
- * ---------------------------------------------------------------------------------------- */
-
-/* Weight gradient of a dense 2-D convolution, bf16 inputs, fp32 accumulate/output.
- * ref: the backward of the nn.Conv2d / ConvModule layers on the path (e.g. LiftSplatShoot_Depth.bevencode,
- * bevfusion/detectors/cam_stream_lss_bevpoolv2_depthnet.py:201-214; reduc_conv,
- * bevf_faster_rcnn_bevdepth.py:61-72; ASPP :491-561; SECOND / FPN / ResNet through mmcv), which the
- * reference leaves to cuDNN.
- *   x_nhwc    [batch, h, w, cin]    bf16 (channels-last activations of the forward pass)
- *   gout_nhwc [batch, ho, wo, cout] bf16 (gradient of the conv output)
- *   dw        [cout, kh, kw, cin]   fp32 (= the memory of a channels-last (cout,cin,kh,kw) weight)
- * kh == kw in {1, 3}; stride, dilation >= 1 (same in both directions), pad >= 0; cin, cout multiples of 8
- * (padded to 128 internally); ho, wo must be the convolution's output size.  groups == 1.
- * Deterministic (fixed split-K order).  The workspace query returns 0 for an unsupported geometry.   */
-size_t omnihd_conv_wgrad_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout,
-                                         int kh, int kw, int stride, int pad, int dil);
-int omnihd_conv_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw, int batch, int h, int w,
-                           int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad, int dil,
-                           void* workspace, size_t workspace_bytes, void* stream);
-
-/* The common 3x3 / stride 1 / pad 1 case under its original name.                                     */
-size_t omnihd_conv3x3_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout);
-int omnihd_conv3x3_wgrad_bf16(const void* x_nhwc, const void* gout_nhwc, float* dw,
-                              int batch, int h, int w, int cin, int cout,
-                              void* workspace, size_t workspace_bytes, void* stream);
-
-/* 1x1 / stride 1 case: dw [cout, cin] fp32 = gout^T x with x_rows [m, cin] and gout_rows [m, cout] bf16.   */
-size_t omnihd_conv1x1_wgrad_workspace_bytes(int m, int cin, int cout);
-int omnihd_conv1x1_wgrad_bf16(const void* x_rows, const void* gout_rows, float* dw, int m, int cin, int cout,
-                              void* workspace, size_t workspace_bytes, void* stream);
-
 /* Bilinear sampling ("deformable im2col") of the 3x3 deformable convolution of DepthNet, deform_groups = 1.
  * ref: build_conv_layer(dict(type='DCN', ...)) at cam_stream_lss_bevpoolv2_depthnet.py:587-595 (mmcv
  * DeformConv2dPack, un-vendored).  x [batch,h,w,c] bf16 channels-last; offset [batch,ho,wo,18] fp32 with
@@ -468,15 +436,6 @@ int omnihd_split_f32(const float* x, long long n, void* hi, void* lo, void* stre
 int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                           float* y_nhwc, int batch, int h, int w, int cin, int cout, int ksize, int dil, int tile,
                           void* stream);
-
-/* Weight gradient of the same convolutions from split operands (see omnihd_conv_wgrad_bf16 for the geometry arguments):
- * dW = G_hi*X_hi + G_hi*X_lo + G_lo*X_hi with fp32 accumulation — the four planes are staged once and one GEMM launch runs
- * its pixel loop three times into the same tiles.  dw (cout,kh,kw,cin) f32.                                               */
-size_t omnihd_conv_wgrad_split_workspace_bytes(int batch, int h, int w, int cin, int ho, int wo, int cout, int kh, int kw,
-                                               int stride, int pad, int dil);
-int omnihd_conv_wgrad_split(const void* x_hi, const void* x_lo, const void* g_hi, const void* g_lo, float* dw, int batch, int h,
-                            int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad, int dil,
-                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient straight from the NHWC operands (round 5, csrc/conv_wgrad_nhwc.hip): no pixel-major staging pass — the
  * [pixel][channel] tiles are read transposed from LDS (ds_read_b64_tr_b16); a workgroup computes a 128x128 (Cout, Cin) tile for

@@ -59,16 +59,8 @@ PROTOTYPES = {
     "omnihd_pfn_bwd_final": (c_int, [c_void_p] * 6 + [c_int, c_longlong, c_int] + [c_void_p] * 4),
     "omnihd_pillar_cell_map": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "omnihd_pillar_canvas": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "omnihd_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
-    "omnihd_conv3x3_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
-    "omnihd_conv_wgrad_workspace_bytes": (c_size_t, [c_int] * 12),
-    "omnihd_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
-    "omnihd_conv_wgrad_split_workspace_bytes": (c_size_t, [c_int] * 12),
-    "omnihd_conv_wgrad_split": (c_int, [c_void_p] * 5 + [c_int] * 12 + [c_void_p, c_size_t, c_void_p]),
     "omnihd_conv_wgrad_nhwc_workspace_bytes": (c_size_t, [c_int] * 11),
     "omnihd_conv_wgrad_nhwc": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
-    "omnihd_conv1x1_wgrad_workspace_bytes": (c_size_t, [c_int] * 3),
-    "omnihd_conv1x1_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
     "omnihd_conv_fwd_supported": (c_int, [c_int] * 7),
     "omnihd_conv_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
     "omnihd_split_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),

@@ -750,16 +750,8 @@ def conv_wgrad(x, grad_out, kernel_size, stride=1, padding=0, dilation=1):
             check(L.omnihd_conv_wgrad_nhwc(x.data_ptr(), None, grad_out.data_ptr(), None, dw.data_ptr(), *g11, ws.data_ptr(), ws.numel(),
                                            _raw_stream()), "omnihd_conv_wgrad_nhwc")
         return dw.permute(0, 3, 1, 2)
-    with _on(dev):
-        nbytes = _SIZE_CACHE.get(geo)
-        if nbytes is None:
-            nbytes = _SIZE_CACHE[geo] = L.omnihd_conv_wgrad_workspace_bytes(*geo)
-        if nbytes == 0:
-            raise ValueError(f"conv_wgrad: unsupported geometry {geo}")
-        ws = _wgrad_workspace(nbytes, dev)
-        check(L.omnihd_conv_wgrad_bf16(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(), *geo, ws.data_ptr(), ws.numel(),
-                                       _raw_stream()), "omnihd_conv_wgrad_bf16")
-    return dw.permute(0, 3, 1, 2)
+    raise ValueError(f"conv_wgrad: the NHWC weight-gradient kernel does not take geometry {geo} (square kernel <= 4x4, channels multiples "
+                     "of 8, operands below 2 GiB); the staged chain of rounds 2-4 left the library in round 6")
 
 
 def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1, out=None):
@@ -792,27 +784,16 @@ def conv_wgrad_split(xs, gs, kernel_size, stride=1, padding=0, dilation=1, out=N
             check(L.omnihd_conv_wgrad_nhwc(xs[0].data_ptr(), xs[1].data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), dw.data_ptr(), *g11,
                                            ws.data_ptr(), ws.numel(), _raw_stream()), "omnihd_conv_wgrad_nhwc")
         return dw.permute(0, 3, 1, 2)
-    with _on(dev):
-        nbytes = _SIZE_CACHE.get(("split",) + geo)
-        if nbytes is None:
-            nbytes = _SIZE_CACHE[("split",) + geo] = L.omnihd_conv_wgrad_split_workspace_bytes(*geo)
-        if nbytes == 0:
-            raise ValueError(f"conv_wgrad_split: unsupported geometry {geo}")
-        ws = _wgrad_workspace(nbytes, dev)
-        check(L.omnihd_conv_wgrad_split(xs[0].data_ptr(), xs[1].data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), dw.data_ptr(), *geo,
-                                        ws.data_ptr(), ws.numel(), _raw_stream()), "omnihd_conv_wgrad_split")
-    return dw.permute(0, 3, 1, 2)
+    raise ValueError(f"conv_wgrad_split: the NHWC weight-gradient kernel does not take geometry {geo}")
 
 
 def wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation):
-    """Which of this library's two weight-gradient forms takes a geometry?  A RULE, not a measurement, so that a run's kernels —
-    and the last bits of its gradients — never depend on timing noise.  Since the three-taps form and the XCD-aware work order
-    (csrc/conv_wgrad_nhwc.hip) the NHWC kernel is the faster one on every geometry of the detector it takes (scripts/lab/
-    wgrad_nhwc_bench.py, profiles/round5/wgrad_nhwc_vs_chain.txt), so the rule is: wherever it applies.  The staged chain
-    (k_to_kmajor + k_wgrad_shift / k_wgrad_split3) stays for kernels larger than 4x4, operands of 2 GiB and more, and behind
-    OMNIHD_WGRAD_NHWC=0."""
-    mode = _env("OMNIHD_WGRAD_NHWC", "auto")
-    if mode == "0" or k > 4:
+    """Does this library's weight-gradient kernel (csrc/conv_wgrad_nhwc.hip) take a geometry?  A RULE, not a measurement, so that a
+    run's kernels — and the last bits of its gradients — never depend on timing noise: square kernels up to 4x4, channel counts
+    multiples of 8, operands below 2 GiB.  (The staged chain of rounds 2-4 — k_to_kmajor + k_wgrad_shift / k_wgrad_split3,
+    csrc/conv_wgrad.hip — left the library in round 6: scripts/lab/records/conv_wgrad_staged_chain.hip.txt; what the kernel does not
+    take goes to MIOpen.)"""
+    if k > 4:
         return False
     key = (B, H, W, cin, Ho, Wo, cout, k, stride, padding, dilation)
     hit = _NHWC_OK.get(key)
@@ -850,7 +831,11 @@ def conv_wgrad_supported(x, weight, stride, padding, dilation=(1, 1)):
     s, p, d = _pair_same(stride), _pair_same(padding), _pair_same(dilation)
     if k not in ((1, 1), (3, 3)) or s is None or p is None or d is None:
         return False
-    return not (k == (3, 3) and s == 1 and p == d and d > 18) and s >= 1 and d >= 1
+    if not (s >= 1 and d >= 1):
+        return False
+    B, cin, H, W = x.shape
+    Ho, Wo = (H + 2 * p - d * (k[0] - 1) - 1) // s + 1, (W + 2 * p - d * (k[0] - 1) - 1) // s + 1
+    return Ho > 0 and Wo > 0 and wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, weight.shape[0], k[0], s, p, d)
 
 
 def conv3x3_wgrad_supported(x, weight):
@@ -1627,7 +1612,8 @@ def conv_split_geometry(x_shape, cout, k, stride, padding, dilation, groups=1):
         fwd = "gen"
     if not dgrad and cin % 8 == 0 and conv_gen_supported(1, x_shape, cout, k, s, p, d):
         dgrad = "gen"
-    wgrad = cin % 8 == 0 and cout % 8 == 0 and not (k == 3 and s == 1 and p == d and d > 18)
+    Ho, Wo = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+    wgrad = cin % 8 == 0 and cout % 8 == 0 and Ho > 0 and Wo > 0 and wgrad_nhwc_preferred(B, H, W, cin, Ho, Wo, cout, k, s, p, d)
     return fwd, dgrad, wgrad
 
 
@@ -2096,7 +2082,8 @@ def conv_grad_planes_ok(x_shape, weight, bias, stride, padding, dilation, device
     """May the backward of this fp32 convolution take its output gradient as hi / lo planes ONLY?  Yes when every consumer of
     that gradient inside ``_ConvSplit.backward`` is a split kernel: no bias (its gradient sums the fp32 tensor), data and weight
     gradient on the split kernels under the current policy / persisted choices (a geometry not measured yet: no)."""
-    if bias is not None or _env("OMNIHD_GRAD_PLANES_ONLY", "1") == "0":
+    if bias is not None or _env("OMNIHD_GRAD_PLANES_ONLY", "1") == "0" or torch.is_anomaly_enabled():
+        # (anomaly mode inspects every gradient tensor: the planes-only hand-over passes bf16 planes under an fp32 view — ADVICE round 5)
         return False
     k = weight.shape[2]
     ok_f, ok_d, ok_w = conv_split_geometry(x_shape, weight.shape[0], k, stride, padding, dilation)
@@ -2729,6 +2716,12 @@ class _AnchorLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up_cls, up_box, up_dir, _up_info):
+        if getattr(ctx, "consumed", False):
+            # the gradient maps are scaled IN PLACE below (raw pointers: autograd's version counters do not see it): a second
+            # backward over the same graph would scale them twice and return wrong gradients without an error
+            raise RuntimeError("omnihd anchor loss: a second backward pass over the same forward is not supported (the saved "
+                               "gradient maps are consumed in place); run the forward again, or set OMNIHD_ANCHOR_LOSS=0")
+        ctx.consumed = True
         g_cls, g_box, g_dir, out = ctx.saved_tensors
         dev = g_cls.device
         h_lw = (ctypes.c_float * 3)(*ctx.loss_weights)

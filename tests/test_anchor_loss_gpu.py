@@ -88,3 +88,22 @@ def test_fused_loss_under_bf16_maps_and_in_the_detector_step(cuda, monkeypatch):
         vals[fused] = {k: float(v[0] if isinstance(v, (list, tuple)) else v) for k, v in st.last_losses.items()}
     for k in vals["0"]:
         assert abs(vals["1"][k] - vals["0"][k]) <= 1e-4 * max(abs(vals["0"][k]), 1e-3), (k, vals)
+
+
+def test_a_second_backward_over_the_fused_loss_is_refused(cuda, monkeypatch):
+    """the backward scales the saved gradient maps in place through raw pointers (autograd's version counters do
+    not move), so a second backward over the same graph used to return gradients scaled twice without any error.  It raises now."""
+    head = _head(cuda)
+    rng = np.random.default_rng(4)
+    torch.manual_seed(5)
+    H, W = 40, 60
+    monkeypatch.setenv("OMNIHD_ANCHOR_LOSS", "1")
+    ms = [(torch.randn(1, c, H, W, device=cuda) * s).requires_grad_() for c, s in ((8 * 4, 2.0), (8 * 9, 0.5), (8 * 2, 1.0))]
+    bx, lb = _gts(rng, 6, cuda)
+    losses = head.loss([ms[0]], [ms[1]], [ms[2]], [bx], [lb], [{}])
+    total = losses["loss_cls"][0] + losses["loss_bbox"][0] + losses["loss_dir"][0]
+    total.backward(retain_graph=True)
+    first = [m.grad.clone() for m in ms]
+    with pytest.raises(RuntimeError, match="second backward"):
+        total.backward()
+    assert all(torch.equal(m.grad, g) for m, g in zip(ms, first))

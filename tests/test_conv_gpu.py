@@ -252,11 +252,9 @@ GEOMS = [  # B, H, W, cin, cout, k, stride, pad, dil
 ]
 
 
-@pytest.mark.parametrize("form", ["nhwc", "chain"])     # csrc/conv_wgrad_nhwc.hip (the default) and the staged chain of csrc/conv_wgrad.hip
 @pytest.mark.parametrize("B,H,W,cin,cout,k,stride,pad,dil", GEOMS)
-def test_generic_wgrad_matches_fp32_reference(cuda, B, H, W, cin, cout, k, stride, pad, dil, form, monkeypatch):
+def test_generic_wgrad_matches_fp32_reference(cuda, B, H, W, cin, cout, k, stride, pad, dil):
     from omnihd_amd import ops
-    monkeypatch.setenv("OMNIHD_WGRAD_NHWC", "1" if form == "nhwc" else "0")
     torch.manual_seed(H * W + cin + k)
     x = torch.randn(B, cin, H, W, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w0 = torch.zeros(cout, cin, k, k, device=cuda, requires_grad=True)

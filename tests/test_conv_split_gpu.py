@@ -126,13 +126,10 @@ def test_split_weight_gradient_of_a_bev_sized_layer(cuda, monkeypatch):
     (3, 33, 50, 384, 384),      # odd image height, three images
     (1, 160, 240, 640, 384),    # the fusion convolution of the detector
 ])
-@pytest.mark.parametrize("form", ["nhwc", "chain"])
-def test_split_weight_gradient_with_register_shifted_taps(cuda, B, H, W, cin, cout, form, monkeypatch):
-    """3x3 / dilation 1 weight gradient on split operands, every tap against the fp32 library gradient, 1e-4.  chain: the kernel
-    stages ONE copy of x and shifts fragments by one element for the outer taps (csrc/conv_wgrad.hip::k_wgrad_shift); nhwc: the
-    three-taps form of csrc/conv_wgrad_nhwc.hip (a 34-row X tile read at three pixel shifts, padded raster)."""
+def test_split_weight_gradient_with_register_shifted_taps(cuda, B, H, W, cin, cout):
+    """3x3 / dilation 1 weight gradient on split operands, every tap against the fp32 library gradient, 1e-4: the three-taps form of
+    csrc/conv_wgrad_nhwc.hip (a 34-row X tile read at three pixel shifts, padded raster)."""
     from omnihd_amd import ops
-    monkeypatch.setenv("OMNIHD_WGRAD_NHWC", "1" if form == "nhwc" else "0")
     torch.manual_seed(B * 1000 + W)
     x = torch.randn(B, cin, H, W, device=cuda).contiguous(memory_format=torch.channels_last)
     g = (torch.randn(B, cout, H, W, device=cuda) * 0.05).contiguous(memory_format=torch.channels_last)

@@ -1,7 +1,7 @@
 """GPU parity of the NHWC weight-gradient kernel (csrc/conv_wgrad_nhwc.hip: tiles read transposed from LDS, no staging pass) against
 torch's fp32 weight gradient: split form on fp32 operands 1e-4 of the largest entry, bf16 form on the bf16-rounded operands 2e-3;
 strides, paddings, dilations, ragged channel counts, pixel counts that are not multiples of the K-step, split-K and single-split
-launches; results run-to-run identical; agreement with the staged chain of csrc/conv_wgrad.hip.  Layers: ResNet-50 / FPN / DepthNet /
+launches; results run-to-run identical.  Layers: ResNet-50 / FPN / DepthNet /
 SECOND / head of the reference config (projects/configs/bevfusion_NewScenes/bevfusion.py:62-123)."""
 import pytest
 import torch
@@ -38,7 +38,6 @@ GEOMS = [  # B, H, W, cin, cout, k, stride, pad, dil
 @pytest.mark.parametrize("B,H,W,cin,cout,k,s,p,d", GEOMS)
 def test_split_and_bf16_forms_match_the_fp32_weight_gradient(cuda, B, H, W, cin, cout, k, s, p, d, monkeypatch):
     from omnihd_amd import ops
-    monkeypatch.setenv("OMNIHD_WGRAD_NHWC", "1")
     torch.manual_seed(B * 100 + H + cin + cout + k)
     x = torch.randn(B, cin, H, W, device=cuda).contiguous(memory_format=torch.channels_last)
     Ho, Wo = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
@@ -53,15 +52,10 @@ def test_split_and_bf16_forms_match_the_fp32_weight_gradient(cuda, B, H, W, cin,
     want_b = torch.nn.grad.conv2d_weight(xb.float(), (cout, cin, k, k), gb.float(), stride=s, padding=p, dilation=d)
     got_b = ops.conv_wgrad(xb, gb, k, s, p, d)
     assert _rel(got_b, want_b) <= 2e-3, _rel(got_b, want_b)
-    if k in (1, 3):                                                        # the staged chain on the same operands
-        monkeypatch.setenv("OMNIHD_WGRAD_NHWC", "0")
-        chain = ops.conv_wgrad_split(ops.split_f32(x), ops.split_f32(g), k, s, p, d)
-        assert _rel(got, chain) <= 1e-4
 
 
-def test_the_routing_rule_takes_every_detector_geometry_and_leaves_the_rest_to_the_chain(cuda, monkeypatch):
+def test_the_routing_rule_takes_every_detector_geometry_and_leaves_the_rest_to_the_library(cuda):
     from omnihd_amd import ops
-    monkeypatch.delenv("OMNIHD_WGRAD_NHWC", raising=False)
     assert ops.wgrad_nhwc_preferred(1, 160, 240, 1024, 160, 240, 1024, 3, 1, 1, 1)          # BEV encoder (three-taps form)
     assert ops.wgrad_nhwc_preferred(6, 64, 176, 256, 64, 176, 256, 3, 1, 1, 1)              # DepthNet 3x3 at 6 x 64 x 176
     assert ops.wgrad_nhwc_preferred(1, 160, 240, 64, 160, 240, 64, 3, 1, 1, 1)              # SECOND stage 0
@@ -69,5 +63,7 @@ def test_the_routing_rule_takes_every_detector_geometry_and_leaves_the_rest_to_t
     assert ops.wgrad_nhwc_preferred(6, 64, 176, 128, 32, 88, 128, 3, 2, 1, 1)               # strided
     assert not ops.wgrad_nhwc_preferred(1, 64, 64, 64, 64, 64, 64, 5, 1, 2, 1)              # 5x5: not taken
     assert not ops.wgrad_nhwc_preferred(1, 64, 64, 60, 64, 64, 64, 3, 1, 1, 1)              # channels not a multiple of 8
-    monkeypatch.setenv("OMNIHD_WGRAD_NHWC", "0")
-    assert not ops.wgrad_nhwc_preferred(6, 64, 176, 256, 64, 176, 64, 1, 1, 0, 1)
+    x = torch.zeros(1, 64, 64, 64, device=cuda, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(ValueError, match="does not take"):                                  # no silent second path: the caller routes to MIOpen
+        ops.conv_wgrad(x, x, 5, 1, 2, 1)
+    assert not ops.conv_split_geometry((1, 60, 64, 64), 64, 3, (1, 1), (1, 1), (1, 1))[2]
