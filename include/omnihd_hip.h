@@ -437,6 +437,29 @@ int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const void* w_hi, 
                           float* y_nhwc, int batch, int h, int w, int cin, int cout, int ksize, int dil, int tile,
                           void* stream);
 
+/* ---- TF32-grade form of the dense convolutions (round 6) ----------------------------------------------------------------------
+ * The reference trains with TF32 left on (tools/train.py:150-153): its cuDNN convolutions round both operands to 11 significant
+ * bits.  An IEEE half has the same 11 bits, and gfx950's half MFMA runs at the bf16 rate: ONE matrix product per fp32 product
+ * instead of the three of the fp32-grade split form.  Half has 5 exponent bits, so a GRADIENT tensor is converted with a
+ * power-of-two scale (exact) that brings its largest magnitude just below 2^15, and the consuming kernel multiplies by the inverse.
+ *   omnihd_cast_f16     out16[i] = half(x[i] * s) (round to nearest even).  scaled == 0: s = 1.  scaled != 0: s = 2^(15 - e) with
+ *                       max|x| in [2^(e-1), 2^e) found by a first pass; scratch2 (2 device words) receives the working maximum in
+ *                       [0] and 1 / s in [1] (what the consumers take as `alpha`).  No synchronisation.
+ *   omnihd_conv_fwd_f16 omnihd_conv_fwd_bf16's geometries and tile codes on half operands: x16 (batch,h,w,cin), w16 (cout,k,k,cin)
+ *                       -> y (batch,h,w,cout) F32 = alpha * conv + bias (alpha: device scalar or NULL = 1).  The data gradient is
+ *                       the same call on the scaled half output gradient with the mirrored weight image and alpha = its 1 / s.
+ *   omnihd_conv_wgrad_nhwc_f16  omnihd_conv_wgrad_nhwc on half operands, dw = alpha * sum (same split-K slabs, fixed order).
+ *   omnihd_weight_images / _cl  an entry with k < 0 asks for HALF images of a |k| x |k| kernel (f_hi / d_hi; the lo pointers unused).
+ * Parity contract: tests/test_conv_f16_gpu.py (per kernel: exact against an fp32 convolution of the half-rounded operands up to
+ * fp32 summation order; 2^-10-grade against the fp32 convolution).  ref: the cuDNN TF32 convolutions behind every nn.Conv2d of
+ * bevfusion.py:62-123 and cam_stream_lss_bevpoolv2_depthnet.py:201-214. */
+int omnihd_cast_f16(const float* x, long long n, int scaled, void* out16, float* scratch2, void* stream);
+int omnihd_conv_fwd_f16(const void* x16, const void* w16, const float* bias, float* y_nhwc, const float* alpha, int batch, int h,
+                        int w, int cin, int cout, int ksize, int dil, int tile, void* stream);
+int omnihd_conv_wgrad_nhwc_f16(const void* x16, const void* g16, float* dw, const float* alpha, int batch, int h, int w, int cin,
+                               int ho, int wo, int cout, int ksize, int stride, int pad, int dil, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* Weight gradient straight from the NHWC operands (round 5, csrc/conv_wgrad_nhwc.hip): no pixel-major staging pass — the
  * [pixel][channel] tiles are read transposed from LDS (ds_read_b64_tr_b16); a workgroup computes a 128x128 (Cout, Cin) tile for
  * one tap — or, for 3x3 / stride 1 / pad 1 / dilation 1, for the three taps of a kernel row over a padded raster — with split-K

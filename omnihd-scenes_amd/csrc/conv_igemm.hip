@@ -39,7 +39,16 @@ namespace omnihd {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// one 32x32x16 matrix product on 16-bit fragments: bf16 operands, or (F16: the TF32-grade form of round 6) IEEE half operands —
+// the same bits in the same registers, another instruction
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef __attribute__((address_space(1))) const void gbl_ptr_t;
 
@@ -51,12 +60,15 @@ __device__ __forceinline__ unsigned short f2bf_rn(float f) {
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int WM, int WN, int STAGES, bool SPREAD, bool SPLIT = false>
+// F16 (with SPLIT = false): operands are IEEE half planes, the output is fp32 = alpha * (x * w) + bias with alpha read from the
+// device (the inverse of the power-of-two scale a gradient plane was converted with; NULL = 1).
+template <int WM, int WN, int STAGES, bool SPREAD, bool SPLIT = false, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
     const float* __restrict__ bias, void* __restrict__ Yv, int M, int H, int W, int Cin, int Cout, int ksize,
     int dil, int tiles_m, int tiles_n, int tiles_per_xcd, const unsigned short* __restrict__ X2 = nullptr,
-    const unsigned short* __restrict__ Wt2 = nullptr) {
+    const unsigned short* __restrict__ Wt2 = nullptr, const float* __restrict__ alpha = nullptr) {
+  static_assert(!(SPLIT && F16), "the half form has one plane per operand");
   constexpr int kCS = SPLIT ? 32 : 64;            // channels per K-step
   constexpr int TM = 64 * WM, TN = 64 * WN, NW = WM * WN;
   constexpr int A_CALLS = TM / (8 * NW), B_CALLS = TN / (8 * NW);     // 8-row LDS-DMA calls per wavefront and stage
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[2 + j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<F16>(f[i], f[2 + j], acc[i][j]);
     }
   };
   auto wait_stage = [&]() {   // this wave's fills of the next K-step have landed: (STAGES-2) younger K-steps may be outstanding
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail loads before the epilogue stores
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31 (B row = output channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const float alpha_v = (F16 && alpha) ? *alpha : 1.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = nt * TN + wn * 64 + j * 32 + (lane & 31);
@@ -297,6 +310,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(
         const int m = mt * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < M && n < Cout) {
           if constexpr (SPLIT) static_cast<float*>(Yv)[(size_t)m * Cout + n] = acc[i][j][r] + bv;
+          else if constexpr (F16) static_cast<float*>(Yv)[(size_t)m * Cout + n] = acc[i][j][r] * alpha_v + bv;
           else static_cast<unsigned short*>(Yv)[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
         }
       }
@@ -324,12 +338,13 @@ constexpr int kHalo = 8;
 // exec-mask branch.  Now: all fragments of slice s+1 are requested before the MFMAs of slice s are issued (two register
 // sets, pinned with sched_barrier), the per-lane source pointers are precomputed and a fill call adds one scalar offset and
 // selects the zero page with two v_cndmask.
-template <bool SPREAD, bool SPLIT = false>
+template <bool SPREAD, bool SPLIT = false, bool F16 = false>
 __global__ __launch_bounds__(512) void k_conv_igemm_rs(
     const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wt, const unsigned short* __restrict__ zero_page,
     const float* __restrict__ bias, void* __restrict__ Yv, int M, int H, int W, int Cin, int Cout, int dil,
     int tiles_m, int tiles_n, int tiles_per_xcd, const unsigned short* __restrict__ X2 = nullptr,
-    const unsigned short* __restrict__ Wt2 = nullptr) {
+    const unsigned short* __restrict__ Wt2 = nullptr, const float* __restrict__ alpha = nullptr) {
+  static_assert(!(SPLIT && F16), "the half form has one plane per operand");
   constexpr int TM = 256, TN = 128, WN = 2;
   constexpr int kCS = SPLIT ? 32 : 64;                // channels per K-step (SPLIT: 32 of the hi plane + the same 32 of the lo plane)
   constexpr int NS = kCS / 16;                        // 16-deep slices per K-step
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[2 + j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<F16>(f[i], f[2 + j], acc[i][j]);
     }
   };
 
@@ -600,6 +615,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  const float alpha_v = (F16 && alpha) ? *alpha : 1.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = nt * TN + wn * 64 + j * 32 + (lane & 31);
@@ -611,6 +627,7 @@ __global__ __launch_bounds__(512) void k_conv_igemm_rs(
         const long long m = (long long)mt * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < M && n < Cout) {
           if constexpr (SPLIT) static_cast<float*>(Yv)[(size_t)m * Cout + n] = acc[i][j][r] + bv;
+          else if constexpr (F16) static_cast<float*>(Yv)[(size_t)m * Cout + n] = acc[i][j][r] * alpha_v + bv;
           else static_cast<unsigned short*>(Yv)[(size_t)m * Cout + n] = f2bf_rn(acc[i][j][r] + bv);
         }
       }
@@ -661,6 +678,56 @@ __global__ __launch_bounds__(256) void k_split_f32(const float* __restrict__ x, 
       hi[i] = h;
       lo[i] = ((h & 0x7f80) != 0x7f80) ? f2bf_rn(x[i] - __uint_as_float((unsigned)h << 16)) : (unsigned short)0;
     }
+  }
+}
+
+// ---- TF32-grade form (round 6): fp32 -> IEEE half planes -------------------------------------------------------------------------
+// A half has the 11 significant bits of TF32 (what the reference's cuDNN convolutions compute with: tools/train.py:150-153 leaves
+// allow_tf32 on) but 5 exponent bits: activations and weights fit as they are; a GRADIENT tensor is multiplied by a power of two that
+// brings its largest magnitude just below 2^15 (exact: no rounding is added), and the consuming kernel's epilogue multiplies by the
+// inverse.  k_amax_f32: the largest |x| as the bit pattern of a non-negative float (atomicMax: order-independent, deterministic).
+__global__ __launch_bounds__(256) void k_amax_f32(const float* __restrict__ x, long long n, unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fabsf(a.x)), fmaxf(fabsf(a.y), fmaxf(fabsf(a.z), fabsf(a.w))));
+  }
+  if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));
+}
+
+__device__ __forceinline__ unsigned short f2h_rn(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+
+// out = half(x * s), s = 2^(15 - e) for amax in [2^(e-1), 2^e) (amax_bits given) or 1; *inv_scale = 1 / s.  8 values per lane.
+__global__ __launch_bounds__(256) void k_cast_f16(const float* __restrict__ x, long long n, const unsigned* __restrict__ amax_bits,
+                                                  unsigned short* __restrict__ out, float* __restrict__ inv_scale) {
+  float s = 1.f, inv = 1.f;
+  if (amax_bits) {
+    const unsigned b = *amax_bits;
+    if (b != 0u && b < 0x7f800000u) {
+      const int e = (int)(b >> 23) - 126;                       // amax < 2^e
+      s = ldexpf(1.f, 15 - e);
+      inv = ldexpf(1.f, e - 15);
+    }
+  }
+  if (inv_scale && blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = inv;
+  const long long n8 = n / 8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned short h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = f2h_rn(v[k] * s);
+    uint4 ph;
+    ph.x = h[0] | ((unsigned)h[1] << 16); ph.y = h[2] | ((unsigned)h[3] << 16); ph.z = h[4] | ((unsigned)h[5] << 16); ph.w = h[6] | ((unsigned)h[7] << 16);
+    reinterpret_cast<uint4*>(out)[i] = ph;
+  }
+  if (blockIdx.x == 0) {
+    const long long i = n8 * 8 + threadIdx.x;
+    if (i < n) out[i] = f2h_rn(x[i] * s);
   }
 }
 
@@ -782,7 +849,9 @@ __global__ __launch_bounds__(256) void k_weight_images(const WeightImageEntry* _
     const int mid = (lo_e + hi_e + 1) >> 1;
     if (table[mid].first_block <= (int)blockIdx.x) lo_e = mid; else hi_e = mid - 1;
   }
-  const WeightImageEntry e = table[lo_e];
+  WeightImageEntry e = table[lo_e];
+  const bool f16 = e.k < 0;                          // round 6: k < 0 asks for IEEE half images (f_hi / d_hi only) of a |k| x |k| kernel
+  e.k = f16 ? -e.k : e.k;
   const int taps = e.k * e.k;
   const int tiles_i = (e.cin + 31) / 32;
   const int b = (int)blockIdx.x - e.first_block;
@@ -802,7 +871,8 @@ __global__ __launch_bounds__(256) void k_weight_images(const WeightImageEntry* _
     s[o][t][i] = v;
   }
   __syncthreads();
-  auto split = [](float v, unsigned short& h, unsigned short& l) {
+  auto split = [f16](float v, unsigned short& h, unsigned short& l) {
+    if (f16) { h = f2h_rn(v); l = 0; return; }
     h = f2bf_rn(v);
     const float hv = __uint_as_float((unsigned)h << 16);
     l = ((h & 0x7f80) != 0x7f80) ? f2bf_rn(v - hv) : (unsigned short)0;
@@ -844,7 +914,9 @@ __global__ __launch_bounds__(256) void k_weight_images_cl(const WeightImageEntry
     const int mid = (lo_e + hi_e + 1) >> 1;
     if (table[mid].first_block <= (int)blockIdx.x) lo_e = mid; else hi_e = mid - 1;
   }
-  const WeightImageEntry e = table[lo_e];
+  WeightImageEntry e = table[lo_e];
+  const bool f16 = e.k < 0;
+  e.k = f16 ? -e.k : e.k;
   const int taps = e.k * e.k;
   const int tiles_i = (e.cin + 63) / 64;
   int b = (int)blockIdx.x - e.first_block;
@@ -859,7 +931,8 @@ __global__ __launch_bounds__(256) void k_weight_images_cl(const WeightImageEntry
     s[o][i] = v;
   }
   __syncthreads();
-  auto split = [](float v, unsigned short& h, unsigned short& l) {
+  auto split = [f16](float v, unsigned short& h, unsigned short& l) {
+    if (f16) { h = f2h_rn(v); l = 0; return; }
     h = f2bf_rn(v);
     const float hv = __uint_as_float((unsigned)h << 16);
     l = ((h & 0x7f80) != 0x7f80) ? f2bf_rn(v - hv) : (unsigned short)0;
@@ -920,6 +993,65 @@ extern "C" int omnihd_split_f32(const float* x, long long n, void* hi, void* lo,
   hipLaunchKernelGGL(k_split_f32, dim3(grid_for(n / 8 + 1, 256 * 2)), dim3(256), 0, (hipStream_t)stream, x, n,
                      static_cast<unsigned short*>(hi), static_cast<unsigned short*>(lo));
   return check_launch("split_f32");
+}
+
+extern "C" int omnihd_cast_f16(const float* x, long long n, int scaled, void* out16, float* scratch2, void* stream) {
+  OMNIHD_REQUIRE(n >= 0 && (n == 0 || (x && out16)) && (!scaled || scratch2), "arguments");
+  if (n == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out16)) & 15u) == 0, "16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* amax = nullptr;
+  if (scaled) {                                   // scratch2[0]: amax bits (working value), scratch2[1]: the inverse scale (result)
+    amax = reinterpret_cast<unsigned*>(scratch2);
+    OMNIHD_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_amax_f32, dim3(grid_for(n / 4 + 1, 256 * 4)), dim3(256), 0, st, x, n, amax);
+  }
+  hipLaunchKernelGGL(k_cast_f16, dim3(grid_for(n / 8 + 1, 256 * 2)), dim3(256), 0, st, x, n, amax, static_cast<unsigned short*>(out16),
+                     scaled ? scratch2 + 1 : (float*)nullptr);
+  return check_launch("cast_f16");
+}
+
+extern "C" int omnihd_conv_fwd_f16(const void* x16, const void* w16, const float* bias, float* y_nhwc, const float* alpha, int batch,
+                                   int h, int w, int cin, int cout, int ksize, int dil, int tile, void* stream) {
+  OMNIHD_REQUIRE(omnihd_conv_fwd_supported(batch, h, w, cin, cout, ksize, dil),
+                 "conv_fwd_f16: square 1x1 / 3x3 kernel, stride 1, 'same' padding, Cin a multiple of 64, Cout of 8");
+  OMNIHD_REQUIRE(x16 && w16 && y_nhwc, "null pointer");
+  OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(x16) | reinterpret_cast<uintptr_t>(w16)) & 15u) == 0, "16-byte alignment");
+  const unsigned short* zero_page = igemm_zero_page();
+  OMNIHD_REQUIRE(zero_page != nullptr, "could not allocate the zero page");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = batch * h * w;
+  const unsigned short* X = static_cast<const unsigned short*>(x16);
+  const unsigned short* Wt = static_cast<const unsigned short*>(w16);
+  const unsigned short* nul = nullptr;
+  const long long big_tiles = (long long)((M + 255) / 256) * ((cout + 127) / 128);
+  const bool big = tile == 256 || (tile == 0 && big_tiles >= 2 * kCUs);
+  OMNIHD_REQUIRE(rs_addressable(X, nullptr, (size_t)M * cin * 2) && rs_addressable(Wt, nullptr, (size_t)cout * ksize * ksize * cin * 2),
+                 "operands of 2 GiB and more are not addressable (32-bit buffer offsets)");
+  const bool rs_ok = ksize == 3 && dil <= kHalo;
+  if (tile == 300 || (tile == 0 && rs_ok && big_tiles >= 2 * kCUs)) {
+    OMNIHD_REQUIRE(rs_ok, "the row-shift kernel takes 3x3 kernels with dilation <= 8");
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm_rs<true, false, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc, M, h, w,
+                       cin, cout, dil, tiles_m, tiles_n, per, nul, nul, alpha);
+  } else if (tile == 129 || (tile == 0 && !big && (long long)((M + 127) / 128) * ((cout + 127) / 128) >= kCUs)) {
+    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<2, 2, 2, true, false, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc,
+                       M, h, w, cin, cout, ksize, dil, tiles_m, tiles_n, per, nul, nul, alpha);
+  } else if (big) {
+    const int tiles_m = (M + 255) / 256, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<4, 2, 3, true, false, true>), dim3(8 * per), dim3(512), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc,
+                       M, h, w, cin, cout, ksize, dil, tiles_m, tiles_n, per, nul, nul, alpha);
+  } else {
+    const int tiles_m = (M + 127) / 128, tiles_n = (cout + 127) / 128;
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    hipLaunchKernelGGL((k_conv_igemm<2, 2, 4, true, false, true>), dim3(8 * per), dim3(256), 0, st, X, Wt, zero_page, bias, (void*)y_nhwc,
+                       M, h, w, cin, cout, ksize, dil, tiles_m, tiles_n, per, nul, nul, alpha);
+  }
+  return check_launch("conv_fwd_f16");
 }
 
 extern "C" int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,

@@ -42,6 +42,7 @@ namespace omnihd {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -60,6 +61,7 @@ struct WgNhwcArgs {
   int total, per_xcd;                             // work items; items per XCD run (launched: 8 * min(per_xcd, resident workgroups per XCD))
   unsigned long long* trace;                      // lab (OMNIHD_WGRAD_NHWC_TRACE): per workgroup {start, end} in 10 ns ticks, hardware id, XCC id
   int RW, RH;                                     // the raster the reduction runs over: (Wo, Ho), or (W + 1, H + 1) padded
+  const float* alpha;                             // F16 form: device scalar the result is multiplied by (NULL: 1)
 };
 
 template <class F, int... Is>
@@ -92,7 +94,10 @@ __device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | ((row >>
 
 struct RowPos { int cx, cy, cb; };
 
-template <bool SPLIT, bool T3, int STAGES>
+// F16 (round 6, with SPLIT = false): the operands are IEEE half planes (the TF32-grade form); the gradient plane carries a power-of-two
+// scale whose inverse `a.alpha` (device) multiplies the result — in this kernel's epilogue when the pixels are not split, in the slab sum
+// otherwise.
+template <bool SPLIT, bool T3, int STAGES, bool F16 = false>
 __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __restrict__ G, const unsigned short* __restrict__ G2,
                                                     const unsigned short* __restrict__ X, const unsigned short* __restrict__ X2,
                                                     float* __restrict__ dst, const WgNhwcArgs a) {
@@ -353,7 +358,8 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
         constexpr int i = IJ / 2, j = IJ % 2;
         const bf16x8 av = (SPLIT && TERM == 0) ? fa2[i] : fa[i];
         const bf16x8 bv = (SPLIT && TERM == 1) ? fb2[j] : fb[j];
-        acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[TP][i][j], 0, 0, 0);
+        if constexpr (F16) acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), acc[TP][i][j], 0, 0, 0);
+        else acc[TP][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[TP][i][j], 0, 0, 0);
         hook(std::integral_constant<int, TERM * 4 + IJ>{});
       });
     });
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31 (B row = input channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* out = dst + (size_t)sp * a.slab_stride;
+  const float alpha_v = (F16 && a.alpha) ? *a.alpha : 1.f;
 #pragma unroll
   for (int tp = 0; tp < NT; ++tp) {
     const int tap = T3 ? ky * 3 + tp : tg;
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
         for (int r = 0; r < 16; ++r) {
           const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           const int c = c0 + wn * 64 + j * 32 + (lane & 31);
-          if (n < a.Cout && c < a.Cin) out[((size_t)n * taps + tap) * a.Cin + c] = acc[tp][i][j][r];
+          if (n < a.Cout && c < a.Cin) out[((size_t)n * taps + tap) * a.Cin + c] = (F16 && a.n_split == 1) ? acc[tp][i][j][r] * alpha_v : acc[tp][i][j][r];
         }
   }
   __builtin_amdgcn_s_barrier();                  // the next item's first fills overwrite stages a slower wave may still be reading
@@ -478,11 +485,13 @@ __global__ __launch_bounds__(256) void k_wgrad_nhwc(const unsigned short* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void k_sum_slabs_nhwc(const float* __restrict__ slab, int n_split, size_t n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_sum_slabs_nhwc(const float* __restrict__ slab, int n_split, size_t n, float* __restrict__ out,
+                                                        const float* __restrict__ alpha) {
+  const float al = alpha ? *alpha : 1.f;                                       // (F16 form: the inverse of the gradient plane's scale)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float s = slab[i];
     for (int k = 1; k < n_split; ++k) s += slab[(size_t)k * n + i];           // fixed order: run-to-run identical
-    out[i] = s;
+    out[i] = alpha ? s * al : s;
   }
 }
 
@@ -543,6 +552,7 @@ bool nhwc_plan(int batch, int h, int w, int cin, int ho, int wo, int cout, int k
   a->px_per_split = steps_per * kKP;
   a->slab_stride = a->n_split > 1 ? slab_floats : 0;
   a->trace = nullptr;
+  a->alpha = nullptr;
   a->total = (int)(groups * a->n_split);
   a->per_xcd = (a->total + 7) / 8;
   return true;
@@ -560,9 +570,27 @@ extern "C" size_t omnihd_conv_wgrad_nhwc_workspace_bytes(int batch, int h, int w
   return 256 + (a.n_split > 1 ? align_up((size_t)a.n_split * cout * ksize * ksize * cin * sizeof(float), 256) : 0);
 }
 
+static int wgrad_nhwc_launch(const void* x_hi, const void* x_lo, const void* g_hi, const void* g_lo, float* dw, int batch, int h, int w,
+                             int cin, int ho, int wo, int cout, int ksize, int stride, int pad, int dil, void* workspace,
+                             size_t workspace_bytes, bool f16, const float* alpha, void* stream);
+
 extern "C" int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const void* g_hi, const void* g_lo, float* dw, int batch,
                                       int h, int w, int cin, int ho, int wo, int cout, int ksize, int stride, int pad, int dil,
                                       void* workspace, size_t workspace_bytes, void* stream) {
+  return wgrad_nhwc_launch(x_hi, x_lo, g_hi, g_lo, dw, batch, h, w, cin, ho, wo, cout, ksize, stride, pad, dil, workspace,
+                           workspace_bytes, false, nullptr, stream);
+}
+
+extern "C" int omnihd_conv_wgrad_nhwc_f16(const void* x16, const void* g16, float* dw, const float* alpha, int batch, int h, int w,
+                                          int cin, int ho, int wo, int cout, int ksize, int stride, int pad, int dil,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  return wgrad_nhwc_launch(x16, nullptr, g16, nullptr, dw, batch, h, w, cin, ho, wo, cout, ksize, stride, pad, dil, workspace,
+                           workspace_bytes, true, alpha, stream);
+}
+
+static int wgrad_nhwc_launch(const void* x_hi, const void* x_lo, const void* g_hi, const void* g_lo, float* dw, int batch, int h, int w,
+                             int cin, int ho, int wo, int cout, int ksize, int stride, int pad, int dil, void* workspace,
+                             size_t workspace_bytes, bool f16, const float* alpha, void* stream) {
   WgNhwcArgs a;
   OMNIHD_REQUIRE(nhwc_plan(batch, h, w, cin, ho, wo, cout, ksize, stride, pad, dil, &a),
                  "conv_wgrad_nhwc: square kernel <= 4x4, channels multiples of 8, consistent output size, operands below 2 GiB");
@@ -589,7 +617,13 @@ extern "C" int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const 
     if (hipMalloc((void**)&a.trace, (size_t)blocks * 32) != hipSuccess) a.trace = nullptr;
     else (void)hipMemsetAsync(a.trace, 0, (size_t)blocks * 32, st);
   }
-  if (a.three) {
+  a.alpha = f16 ? alpha : nullptr;
+  if (f16) {
+    OMNIHD_REQUIRE(!split, "the half form takes one plane per operand");
+    if (a.three) hipLaunchKernelGGL((k_wgrad_nhwc<false, true, 3, true>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+    else if (one_tap_stages == 3) hipLaunchKernelGGL((k_wgrad_nhwc<false, false, 3, true>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+    else hipLaunchKernelGGL((k_wgrad_nhwc<false, false, 2, true>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
+  } else if (a.three) {
     if (split) hipLaunchKernelGGL((k_wgrad_nhwc<true, true, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
     else hipLaunchKernelGGL((k_wgrad_nhwc<false, true, 3>), dim3(blocks), dim3(256), 0, st, G, G2, X, X2, slab, a);
   } else if (one_tap_stages == 3) {
@@ -614,7 +648,7 @@ extern "C" int omnihd_conv_wgrad_nhwc(const void* x_hi, const void* x_lo, const 
   }
   if (a.n_split > 1) {
     const size_t n = (size_t)cout * ksize * ksize * cin;
-    hipLaunchKernelGGL(k_sum_slabs_nhwc, dim3(grid_for((int64_t)n, 256 * 4)), dim3(256), 0, st, slab, a.n_split, n, dw);
+    hipLaunchKernelGGL(k_sum_slabs_nhwc, dim3(grid_for((int64_t)n, 256 * 4)), dim3(256), 0, st, slab, a.n_split, n, dw, a.alpha);
   }
   return check_launch("conv_wgrad_nhwc");
 }

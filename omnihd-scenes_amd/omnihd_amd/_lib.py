@@ -61,6 +61,9 @@ PROTOTYPES = {
     "omnihd_pillar_canvas": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "omnihd_conv_wgrad_nhwc_workspace_bytes": (c_size_t, [c_int] * 11),
     "omnihd_conv_wgrad_nhwc": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
+    "omnihd_conv_wgrad_nhwc_f16": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
+    "omnihd_cast_f16": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "omnihd_conv_fwd_f16": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
     "omnihd_conv_fwd_supported": (c_int, [c_int] * 7),
     "omnihd_conv_fwd_bf16": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
     "omnihd_split_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),

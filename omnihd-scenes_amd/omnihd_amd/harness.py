@@ -471,6 +471,7 @@ class FusionTrainStep:
             from . import ops
             ops.refresh_bf16_shadows()            # one fused fp32 -> bf16 copy of all convolution weights
             ops.refresh_split_shadows()           # fp32 step: forward + data-gradient planes of every split convolution, one launch
+            ops.refresh_f16_shadows()             # OMNIHD_FP32_CONV=f16: the half images of the layers on the TF32-grade form (none otherwise)
         self.last_losses = losses
         return total
 

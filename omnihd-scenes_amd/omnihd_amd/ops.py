@@ -1519,7 +1519,7 @@ def _weight_image_table(records, dev, per_tap=False):
         first = 0
         for n, r in enumerate(records):
             arr[n] = r + (first,)
-            if per_tap:
+            if per_tap:                                   # (k < 0: half images of a |k| x |k| kernel)
                 first += ((r[9] + 63) // 64) * ((r[10] + 63) // 64) * r[11] * r[11]
             else:
                 first += ((r[9] + 31) // 32) * ((r[10] + 31) // 32)
@@ -1646,7 +1646,7 @@ def _fp32_policy():
 
 def _split_pick(key, run_split, run_miopen, dev):
     policy = _fp32_policy()
-    if policy == "split":
+    if policy in ("split", "f16"):          # (f16: layers the half form does not take run on the split kernels, never on a timing race)
         return run_split()
     if policy == "miopen":
         return run_miopen()
@@ -2075,14 +2075,172 @@ def conv_split_supported(x, weight, stride, padding, dilation, groups=1):
 
 
 def conv_split(x, weight, bias, stride, padding, dilation=(1, 1), grad_planes_only=False):
+    if _fp32_policy() == "f16" and conv_f16_applies(x.shape, weight, stride, padding, dilation):
+        return _ConvF16.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation))
     return _ConvSplit.apply(x, weight, bias, tuple(stride), tuple(padding), tuple(dilation), bool(grad_planes_only))
+
+
+# ---------------------------------------------------------------------------------------------
+# TF32-grade form of the fp32 step's convolutions (round 6; OMNIHD_FP32_CONV=f16): ONE half MFMA product per fp32 product
+# ---------------------------------------------------------------------------------------------
+# The reference trains with TF32 left on (tools/train.py:150-153): 11 significant bits per operand.  An IEEE half has the same 11
+# bits; activations and weights are converted as they are, gradients with an exact power-of-two scale found per tensor (amax pass)
+# whose inverse the consuming kernel applies.  Layers the half kernels do not take (strided, transposed, narrow) stay on the
+# fp32-grade split kernels, so every layer of the step is at least TF32-grade.  Parity: tests/test_conv_f16_gpu.py.
+_F16_SHADOW = {}
+
+
+def cast_f16(t, scaled=False):
+    """fp32 tensor (dense in its memory format) -> (half tensor of the same shape and strides, inverse scale).  ``scaled``: the
+    values are multiplied by the power of two that brings the largest magnitude just below 2^15; the second result is a device
+    scalar holding the inverse (what the kernels take as ``alpha``); without ``scaled`` it is None."""
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise TypeError("cast_f16 takes an fp32 CUDA(HIP) tensor")
+    if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+        t = t.contiguous()
+    out = torch.empty_strided(t.shape, t.stride(), dtype=torch.float16, device=t.device)
+    scratch = torch.empty(2, dtype=torch.float32, device=t.device) if scaled else None
+    with _on(t.device):
+        check(lib().omnihd_cast_f16(t.data_ptr(), t.numel(), 1 if scaled else 0, out.data_ptr(), _ptr(scratch), _raw_stream()),
+              "omnihd_cast_f16")
+    return out, (scratch[1:2] if scaled else None)
+
+
+def f16_weight(weight, dgrad=False):
+    """Half image of an fp32 convolution weight in (Cout,k,k,Cin) memory — ``dgrad``: (Cin,k,k,Cout) with mirrored taps — cached
+    while the parameter's version is unchanged (``refresh_f16_shadows`` rebuilds all stale ones with one launch)."""
+    key = (id(weight), dgrad)
+    e = _F16_SHADOW.get(key)
+    if e is not None and e[0]() is weight and e[1] == _wver(weight) and e[2].device == weight.device:
+        return e[2]
+    cout, cin, k, _ = weight.shape
+    shape = (cin, cout, k, k) if dgrad else (cout, cin, k, k)
+    img = e[2] if (e is not None and e[0]() is weight and tuple(e[2].shape) == shape and e[2].device == weight.device) else \
+        torch.empty(shape, dtype=torch.float16, device=weight.device, memory_format=torch.channels_last)
+    w = weight.detach()
+    so, si, sy, sx = w.stride()
+    rec = (w.data_ptr(), so, si, sy, sx, 0 if dgrad else img.data_ptr(), 0, img.data_ptr() if dgrad else 0, 0, cout, cin, -k)
+    if dgrad:
+        # the kernel always writes the forward image too: give it the forward shadow (built here if need be)
+        fwd = f16_weight(weight)
+        rec = rec[:5] + (fwd.data_ptr(),) + rec[6:]
+    weight_images([rec], weight.device)
+    if len(_F16_SHADOW) > 4096:
+        for k_ in [k_ for k_, v in _F16_SHADOW.items() if v[0]() is None]:
+            del _F16_SHADOW[k_]
+    _F16_SHADOW[key] = (weakref.ref(weight), _wver(weight), img)
+    return img
+
+
+def refresh_f16_shadows():
+    """Bring every stale half image up to date with ONE launch (a training loop calls it behind the optimiser step)."""
+    per_dev, touched, layers = {}, [], {}
+    for (wid, dgrad), (ref, ver, img) in list(_F16_SHADOW.items()):
+        w = ref()
+        if w is None:
+            del _F16_SHADOW[(wid, dgrad)]
+            continue
+        if ver == _wver(w) or img.device != w.device or w.dtype != torch.float32:
+            continue
+        layers.setdefault(wid, [w, None, None])[2 if dgrad else 1] = img
+        touched.append((wid, dgrad, ref, w, img))
+    for wid, (w, fwd, dg) in layers.items():
+        if fwd is None:
+            touched = [t for t in touched if t[0] != wid]
+            continue
+        cout, cin, k, _ = w.shape
+        so, si, sy, sx = w.stride()
+        per_dev.setdefault(w.device, []).append((w.data_ptr(), so, si, sy, sx, fwd.data_ptr(), 0, 0 if dg is None else dg.data_ptr(), 0,
+                                                  cout, cin, -k))
+    for dev, recs in per_dev.items():
+        weight_images(recs, dev)
+    for wid, dgrad, ref, w, img in touched:
+        _F16_SHADOW[(wid, dgrad)] = (ref, _wver(w), img)
+    return len(layers)
+
+
+def conv_fwd_f16(x16, w16, bias=None, alpha=None, dilation=1, tile=0):
+    """y = alpha * conv2d(x16, w16, stride 1, padding = dilation*(k//2)) + bias on half operands (channels_last) -> fp32 channels_last."""
+    for t in (x16, w16):
+        if t.dtype != torch.float16 or t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise TypeError("conv_fwd_f16 takes 4-D half tensors in channels_last memory format")
+    B, cin, H, W = x16.shape
+    cout, k = w16.shape[0], w16.shape[2]
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x16.device, memory_format=torch.channels_last)
+    with _on(y.device):
+        _conv_timed("f16", (cin, cout, k, H, W), lambda: check(
+            lib().omnihd_conv_fwd_f16(x16.data_ptr(), w16.data_ptr(), None if bias is None else _f32c(bias).data_ptr(), y.data_ptr(),
+                                      _ptr(alpha), B, H, W, cin, cout, k, int(dilation), int(tile), _raw_stream()), "omnihd_conv_fwd_f16"))
+    return y
+
+
+def conv_wgrad_f16(x16, g16, alpha, kernel_size, stride=1, padding=0, dilation=1):
+    """dW (Cout,Cin,k,k) fp32 (channels_last memory) = alpha * weight gradient from half operands (omnihd_conv_wgrad_nhwc_f16)."""
+    B, cin, H, W = x16.shape
+    _, cout, Ho, Wo = g16.shape
+    k = int(kernel_size)
+    dev = x16.device
+    g11 = (B, H, W, cin, Ho, Wo, cout, k, int(stride), int(padding), int(dilation))
+    if not wgrad_nhwc_preferred(*g11):
+        raise ValueError(f"conv_wgrad_f16: the NHWC weight-gradient kernel does not take geometry {g11}")
+    dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
+    L = lib()
+    with _on(dev):
+        nbytes = _SIZE_CACHE.get(("nhwc",) + g11)
+        if nbytes is None:
+            nbytes = _SIZE_CACHE[("nhwc",) + g11] = L.omnihd_conv_wgrad_nhwc_workspace_bytes(*g11)
+        ws = _wgrad_workspace(nbytes, dev)
+        check(L.omnihd_conv_wgrad_nhwc_f16(x16.data_ptr(), g16.data_ptr(), dw.data_ptr(), _ptr(alpha), *g11, ws.data_ptr(), ws.numel(),
+                                           _raw_stream()), "omnihd_conv_wgrad_nhwc_f16")
+    return dw.permute(0, 3, 1, 2)
+
+
+def conv_f16_applies(x_shape, weight, stride, padding, dilation):
+    """The half kernels take the layer in all three directions: stride-1 'same' 1x1 / 3x3, Cin and Cout multiples of 64."""
+    if weight.dim() != 4 or weight.shape[2] != weight.shape[3] or weight.dtype != torch.float32:
+        return False
+    ok_f, ok_d, ok_w = conv_split_geometry(x_shape, weight.shape[0], weight.shape[2], stride, padding, dilation)
+    return ok_f == "igemm" and ok_d == "igemm" and bool(ok_w)
+
+
+class _ConvF16(torch.autograd.Function):
+    """fp32 convolution in the TF32-grade form: forward, data gradient (omnihd_conv_fwd_f16) and weight gradient
+    (omnihd_conv_wgrad_nhwc_f16) on half operands with fp32 accumulation; the input is saved as its half plane."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
+        x = x.contiguous(memory_format=torch.channels_last)
+        x16, _ = cast_f16(x)
+        ctx.save_for_backward(x16, weight)
+        ctx.conv = (stride, padding, dilation)
+        ctx.has_bias = bias is not None
+        ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
+        return conv_fwd_f16(x16, f16_weight(weight), None if bias is None else bias.detach(), None, dilation[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x16, weight = ctx.saved_tensors
+        stride, padding, dilation = ctx.conv
+        g = g.float().contiguous(memory_format=torch.channels_last)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g16, inv = cast_f16(g, scaled=True)
+            if ctx.needs_input_grad[0]:
+                gx = conv_fwd_f16(g16, f16_weight(weight, dgrad=True), None, inv, dilation[0])
+            if ctx.needs_input_grad[1]:
+                FAST_PATHS["wgrad_in_line"] += 1
+                gw = conv_wgrad_f16(x16, g16, inv, weight.shape[2], stride[0], padding[0], dilation[0]).to(ctx.param_dtypes[0])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            n, c, h, w = g.shape
+            gb = column_sums(g.permute(0, 2, 3, 1).reshape(n * h * w, c)).to(ctx.param_dtypes[1])
+        return gx, gw, gb, None, None, None
 
 
 def conv_grad_planes_ok(x_shape, weight, bias, stride, padding, dilation, device_index):
     """May the backward of this fp32 convolution take its output gradient as hi / lo planes ONLY?  Yes when every consumer of
     that gradient inside ``_ConvSplit.backward`` is a split kernel: no bias (its gradient sums the fp32 tensor), data and weight
     gradient on the split kernels under the current policy / persisted choices (a geometry not measured yet: no)."""
-    if bias is not None or _env("OMNIHD_GRAD_PLANES_ONLY", "1") == "0" or torch.is_anomaly_enabled():
+    if bias is not None or _env("OMNIHD_GRAD_PLANES_ONLY", "1") == "0" or torch.is_anomaly_enabled() or _fp32_policy() == "f16":
         # (anomaly mode inspects every gradient tensor: the planes-only hand-over passes bf16 planes under an fp32 view — ADVICE round 5)
         return False
     k = weight.shape[2]
