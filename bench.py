@@ -749,7 +749,8 @@ def dense_rooflines(a, world, runs, flops, main_dt):
     if "tf32_grade" in runs:
         e4, sp4, _ = runs["tf32_grade"]
         out["tf32_grade"] = {"value": round(a.batch * world * a.steps / e4, 3), "unit": "frames/s", "ms_per_step": round(e4 / a.steps * 1e3, 4),
-                             "step_ms": sp4, "dtype": "f32 tensors, f16 x f16 -> f32 MFMA (11 significant bits per operand, as TF32)",
+                             "step_ms": sp4, "precision": "f32 tensors; convolution operands rounded to IEEE half (11 significant bits, as "
+                                                          "TF32), f16 x f16 -> f32 MFMA, fp32 accumulation; gradients scaled per tensor by 2^n",
                              "note": "OMNIHD_FP32_CONV=f16: the stride-1 convolutions with 64-multiple channels as ONE IEEE-half MFMA "
                                      "product per fp32 product in all three directions (gradients scaled per tensor by an exact power of "
                                      "two), the precision the reference trains at (TF32 on: tools/train.py:150-153); the other layers "

@@ -444,7 +444,8 @@ int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const void* w_hi, 
  * power-of-two scale (exact) that brings its largest magnitude just below 2^15, and the consuming kernel multiplies by the inverse.
  *   omnihd_cast_f16     out16[i] = half(x[i] * s) (round to nearest even).  scaled == 0: s = 1.  scaled != 0: s = 2^(15 - e) with
  *                       max|x| in [2^(e-1), 2^e) found by a first pass; scratch2 (2 device words) receives the working maximum in
- *                       [0] and 1 / s in [1] (what the consumers take as `alpha`).  No synchronisation.
+ *                       [0] and 1 / s in [1] (what the consumers take as `alpha`).  scaled == 1: [0] is zeroed by the call (a
+ *                       memset node); scaled == 2: the caller passes it zeroed (one memset for many calls).  No synchronisation.
  *   omnihd_conv_fwd_f16 omnihd_conv_fwd_bf16's geometries and tile codes on half operands: x16 (batch,h,w,cin), w16 (cout,k,k,cin)
  *                       -> y (batch,h,w,cout) F32 = alpha * conv + bias (alpha: device scalar or NULL = 1).  The data gradient is
  *                       the same call on the scaled half output gradient with the mirrored weight image and alpha = its 1 / s.

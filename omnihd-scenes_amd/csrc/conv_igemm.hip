@@ -696,7 +696,16 @@ __global__ __launch_bounds__(256) void k_amax_f32(const float* __restrict__ x, l
   if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));
+  // ONE atomic per workgroup, and only where it can still raise the value: every wavefront of a 2048-workgroup grid on the same
+  // word was 40 us of serialised L2 atomics per call (profiles/round6/step_f16_first.txt: 3.75 ms per step in 81 calls)
+  __shared__ float wave_max[4];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    const unsigned bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, bits);
+  }
 }
 
 __device__ __forceinline__ unsigned short f2h_rn(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
@@ -1003,8 +1012,9 @@ extern "C" int omnihd_cast_f16(const float* x, long long n, int scaled, void* ou
   unsigned* amax = nullptr;
   if (scaled) {                                   // scratch2[0]: amax bits (working value), scratch2[1]: the inverse scale (result)
     amax = reinterpret_cast<unsigned*>(scratch2);
-    OMNIHD_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_amax_f32, dim3(grid_for(n / 4 + 1, 256 * 4)), dim3(256), 0, st, x, n, amax);
+    if (scaled != 2) OMNIHD_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));      // (2: the caller hands a zeroed word)
+    const int blocks = grid_for(n / 4 + 1, 256 * 4);
+    hipLaunchKernelGGL(k_amax_f32, dim3(blocks > 4 * kCUs ? 4 * kCUs : blocks), dim3(256), 0, st, x, n, amax);
   }
   hipLaunchKernelGGL(k_cast_f16, dim3(grid_for(n / 8 + 1, 256 * 2)), dim3(256), 0, st, x, n, amax, static_cast<unsigned short*>(out16),
                      scaled ? scratch2 + 1 : (float*)nullptr);

@@ -1503,6 +1503,7 @@ def split_weight(weight, dgrad=False):
 
 _WIMG_DTYPE = None
 _WIMG_TABLES = {}
+WIMG_STATS = {"hit": 0, "miss": 0}
 
 
 def _weight_image_table(records, dev, per_tap=False):
@@ -1514,6 +1515,7 @@ def _weight_image_table(records, dev, per_tap=False):
                                 ("d_hi", "<u8"), ("d_lo", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("k", "<i4"), ("first_block", "<i4")])
     key = (dev.index, bool(per_tap), tuple(records))
     hit = _WIMG_TABLES.get(key)
+    WIMG_STATS["hit" if hit is not None else "miss"] += 1        # (a miss is a BLOCKING host-to-device copy: fast_paths_report shows the count)
     if hit is None:
         arr = np.zeros(len(records), dtype=_WIMG_DTYPE)
         first = 0
@@ -1523,7 +1525,7 @@ def _weight_image_table(records, dev, per_tap=False):
                 first += ((r[9] + 63) // 64) * ((r[10] + 63) // 64) * r[11] * r[11]
             else:
                 first += ((r[9] + 31) // 32) * ((r[10] + 31) // 32)
-        if len(_WIMG_TABLES) > 8:
+        if len(_WIMG_TABLES) > 64:
             _WIMG_TABLES.clear()
         hit = _WIMG_TABLES[key] = (torch.from_numpy(arr.view(np.uint8).copy()).to(dev), first)
     return hit
@@ -1850,12 +1852,14 @@ def fast_paths_report():
                               "private_hooks_ok": bool(_WGRAD_ENGINE_OK), "ddp": ddp_overlap_info()},
             "dual_stream": {"active": FAST_PATHS["dual_stream_forward"] > 0, "share_of_forwards": round(FAST_PATHS["dual_stream_forward"] / max(1, fw), 3)},
             "device_plans_built": int(__import__("omnihd_amd.pool_plan", fromlist=["BUILDS"]).BUILDS["device_plans"]),
-            "choice_table_misses": int(_CHOICE_INFO["misses"])}
+            "choice_table_misses": int(_CHOICE_INFO["misses"]),
+            # uploads of a weight-image table (a BLOCKING host-to-device copy each): 0 in a steady step
+            "weight_table_uploads": int(WIMG_STATS["miss"])}
 
 
 def fast_paths_reset():
     from . import plan as _plan
-    for d in (FAST_PATHS, _plan.FAST_PATHS):
+    for d in (FAST_PATHS, _plan.FAST_PATHS, WIMG_STATS):
         for k in d:
             d[k] = 0
 
@@ -2099,16 +2103,46 @@ def cast_f16(t, scaled=False):
     if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
         t = t.contiguous()
     out = torch.empty_strided(t.shape, t.stride(), dtype=torch.float16, device=t.device)
-    scratch = torch.empty(2, dtype=torch.float32, device=t.device) if scaled else None
+    mode, scratch = 0, None
+    if scaled == "ring":
+        mode, scratch = 2, _amax_slot(t.device)
+    elif scaled:
+        mode, scratch = 1, torch.empty(2, dtype=torch.float32, device=t.device)
     with _on(t.device):
-        check(lib().omnihd_cast_f16(t.data_ptr(), t.numel(), 1 if scaled else 0, out.data_ptr(), _ptr(scratch), _raw_stream()),
-              "omnihd_cast_f16")
+        check(lib().omnihd_cast_f16(t.data_ptr(), t.numel(), mode, out.data_ptr(), _ptr(scratch), _raw_stream()), "omnihd_cast_f16")
     return out, (scratch[1:2] if scaled else None)
+
+
+_AMAX_RING = {}
+_AMAX_SLOTS = 2048
+
+
+def _amax_slot(dev):
+    """Two zeroed device words for a scaled cast whose scale is consumed by launches enqueued right behind it on the SAME stream
+    (the backward of _ConvF16): slots of a ring that one fill re-zeroes every _AMAX_SLOTS casts instead of a memset node per cast
+    (92 fills per step in the first profile of the form).  Stream order makes the re-zeroing safe: it is enqueued behind every
+    consumer of the slots it clears."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    e = _AMAX_RING.get(key)
+    if e is None:
+        e = _AMAX_RING[key] = [torch.zeros(2 * _AMAX_SLOTS, dtype=torch.float32, device=dev), 0]
+    if e[1] == _AMAX_SLOTS:
+        e[0].zero_()
+        e[1] = 0
+    slot = e[0][2 * e[1]:2 * e[1] + 2]
+    e[1] += 1
+    return slot
 
 
 def f16_weight(weight, dgrad=False):
     """Half image of an fp32 convolution weight in (Cout,k,k,Cin) memory — ``dgrad``: (Cin,k,k,Cout) with mirrored taps — cached
     while the parameter's version is unchanged (``refresh_f16_shadows`` rebuilds all stale ones with one launch)."""
+    if weight.grad_fn is not None:
+        # a temporary computed from a parameter (the block-diagonal matrix DCN rebuilds every forward): never seen again under this
+        # id — converted directly, no cache entry and no table upload (a table miss is a blocking host-to-device copy)
+        w = weight.detach().float()
+        w = w.flip(2, 3).transpose(0, 1) if dgrad else w
+        return cast_f16(w.contiguous(memory_format=torch.channels_last))[0]
     key = (id(weight), dgrad)
     e = _F16_SHADOW.get(key)
     if e is not None and e[0]() is weight and e[1] == _wver(weight) and e[2].device == weight.device:
@@ -2203,33 +2237,84 @@ def conv_f16_applies(x_shape, weight, stride, padding, dilation):
     return ok_f == "igemm" and ok_d == "igemm" and bool(ok_w)
 
 
+_CL = torch.channels_last
+
+
+def _f16_plane(t, mode, scratch, L, st):
+    """cast_f16 without its argument checks (the caller holds a dense fp32 device tensor): one allocation, one library call."""
+    out = torch.empty_like(t, dtype=torch.float16)              # preserve_format: a dense tensor keeps its strides
+    check(L.omnihd_cast_f16(t.data_ptr(), t.numel(), mode, out.data_ptr(), None if scratch is None else scratch.data_ptr(), st),
+          "omnihd_cast_f16")
+    return out
+
+
 class _ConvF16(torch.autograd.Function):
     """fp32 convolution in the TF32-grade form: forward, data gradient (omnihd_conv_fwd_f16) and weight gradient
-    (omnihd_conv_wgrad_nhwc_f16) on half operands with fp32 accumulation; the input is saved as its half plane."""
+    (omnihd_conv_wgrad_nhwc_f16) on half operands with fp32 accumulation; the input is saved as its half plane.
+    (The step is host-bound in this form — scripts/lab/host_profile.py — so the calls below go to the library directly: the
+    checked wrappers ``cast_f16`` / ``conv_fwd_f16`` / ``conv_wgrad_f16`` are the public faces of the same entry points.)"""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
-        x = x.contiguous(memory_format=torch.channels_last)
-        x16, _ = cast_f16(x)
+        if not x.is_contiguous(memory_format=_CL):
+            x = x.contiguous(memory_format=_CL)
+        dev = x.device
+        L = lib()
+        B, cin, H, W = x.shape
+        cout, _, k, _ = weight.shape
+        w16 = f16_weight(weight)
+        y = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev, memory_format=_CL)
+        with _on(dev):
+            st = _raw_stream()
+            x16 = _f16_plane(x, 0, None, L, st)
+            _conv_timed("f16", (cin, cout, k, H, W), lambda: check(
+                L.omnihd_conv_fwd_f16(x16.data_ptr(), w16.data_ptr(), None if bias is None else _f32c(bias.detach()).data_ptr(),
+                                      y.data_ptr(), None, B, H, W, cin, cout, k, dilation[0], 0, st), "omnihd_conv_fwd_f16"))
         ctx.save_for_backward(x16, weight)
-        ctx.conv = (stride, padding, dilation)
+        ctx.conv = (stride[0], padding[0], dilation[0])
         ctx.has_bias = bias is not None
         ctx.param_dtypes = (weight.dtype, None if bias is None else bias.dtype)
-        return conv_fwd_f16(x16, f16_weight(weight), None if bias is None else bias.detach(), None, dilation[0])
+        return y
 
     @staticmethod
     def backward(ctx, g):
         x16, weight = ctx.saved_tensors
-        stride, padding, dilation = ctx.conv
-        g = g.float().contiguous(memory_format=torch.channels_last)
+        s, p, d = ctx.conv
+        if g.dtype != torch.float32:
+            g = g.float()
+        if not g.is_contiguous(memory_format=_CL):
+            g = g.contiguous(memory_format=_CL)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            g16, inv = cast_f16(g, scaled=True)
-            if ctx.needs_input_grad[0]:
-                gx = conv_fwd_f16(g16, f16_weight(weight, dgrad=True), None, inv, dilation[0])
-            if ctx.needs_input_grad[1]:
-                FAST_PATHS["wgrad_in_line"] += 1
-                gw = conv_wgrad_f16(x16, g16, inv, weight.shape[2], stride[0], padding[0], dilation[0]).to(ctx.param_dtypes[0])
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_x or need_w:
+            dev = g.device
+            L = lib()
+            B, cin, H, W = x16.shape
+            cout, _, k, _ = weight.shape
+            wd = f16_weight(weight, dgrad=True) if need_x else None
+            with _on(dev):
+                st = _raw_stream()
+                slot = _amax_slot(dev)
+                g16 = _f16_plane(g, 2, slot, L, st)
+                inv = slot.data_ptr() + 4
+                if need_x:
+                    gx = torch.empty((B, cin, H, W), dtype=torch.float32, device=dev, memory_format=_CL)
+                    _conv_timed("f16", (cout, cin, k, H, W), lambda: check(
+                        L.omnihd_conv_fwd_f16(g16.data_ptr(), wd.data_ptr(), None, gx.data_ptr(), inv, B, H, W, cout, cin, k, d, 0, st),
+                        "omnihd_conv_fwd_f16"))
+                if need_w:
+                    FAST_PATHS["wgrad_in_line"] += 1
+                    g11 = (B, H, W, cin, H, W, cout, k, s, p, d)
+                    nbytes = _SIZE_CACHE.get(("nhwc",) + g11)
+                    if nbytes is None:
+                        nbytes = _SIZE_CACHE[("nhwc",) + g11] = L.omnihd_conv_wgrad_nhwc_workspace_bytes(*g11)
+                    ws = _wgrad_workspace(nbytes, dev)
+                    dw = torch.empty((cout, k, k, cin), dtype=torch.float32, device=dev)
+                    check(L.omnihd_conv_wgrad_nhwc_f16(x16.data_ptr(), g16.data_ptr(), dw.data_ptr(), inv, *g11, ws.data_ptr(), ws.numel(), st),
+                          "omnihd_conv_wgrad_nhwc_f16")
+                    gw = dw.permute(0, 3, 1, 2)
+                    if ctx.param_dtypes[0] != torch.float32:
+                        gw = gw.to(ctx.param_dtypes[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             n, c, h, w = g.shape
             gb = column_sums(g.permute(0, 2, 3, 1).reshape(n * h * w, c)).to(ctx.param_dtypes[1])

@@ -146,6 +146,25 @@ def test_module_path_under_the_policy(cuda, monkeypatch):
     assert "ConvF16" not in type(m(x).grad_fn).__name__
 
 
+def test_temporary_weights_are_converted_directly_without_a_table_upload(cuda, monkeypatch):
+    """A weight computed in the forward (the block-diagonal matrix DCN rebuilds every step) is never seen again under its id: it
+    is converted directly — a cached image would be rebuilt every step through a table whose upload is a blocking copy (2.4 ms per
+    step in the first host profile of the form, profiles/round6/host_f16.txt)."""
+    from omnihd_amd import ops
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "f16")
+    torch.manual_seed(6)
+    w = (torch.randn(64, 128, 3, 3, device=cuda) * 0.05).requires_grad_()
+    x = _cl(torch.randn(1, 128, 10, 14, device=cuda)).requires_grad_()
+    uploads = ops.WIMG_STATS["miss"]
+    y = ops.conv_split(x, w * 2.0, None, (1, 1), (1, 1))
+    assert "ConvF16" in type(y.grad_fn).__name__
+    y.square().mean().backward()
+    assert ops.WIMG_STATS["miss"] == uploads
+    x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    F.conv2d(x2, w2 * 2.0, None, padding=1).square().mean().backward()
+    assert _rel(x.grad, x2.grad) <= 1e-3 and _rel(w.grad, w2.grad) <= 1e-3, (_rel(x.grad, x2.grad), _rel(w.grad, w2.grad))
+
+
 def test_half_images_follow_the_optimiser_with_one_launch(cuda, monkeypatch):
     from omnihd_amd import ops
     monkeypatch.setenv("OMNIHD_FP32_CONV", "f16")
@@ -164,15 +183,34 @@ def test_half_images_follow_the_optimiser_with_one_launch(cuda, monkeypatch):
         assert torch.equal(ops.f16_weight(w, dgrad=True), _cl(w.detach().half().flip(2, 3).transpose(0, 1)))
 
 
-def test_full_size_forward_under_the_policy_stays_within_north_stars_bound_of_the_fp32_grade_run(cuda, monkeypatch):
-    """One fp32 forward of the reference config at R1 (6 x 256 x 704, BatchNorm in inference mode, seeded weights) under
-    OMNIHD_FP32_CONV=f16 against the same under the fp32-grade split kernels: the fused BEV feature and the head outputs in
-    relative L2 (printed; the bound below is what the form is documented at in DESIGN.md 4.13)."""
+def _round_tf32(t):
+    """fp32 -> nearest value with 10 explicit mantissa bits (ties to even), as an fp32 tensor: what a TF32 matrix unit reads."""
+    b = t.detach().clone().view(torch.int32)
+    b += 0xFFF + ((b >> 13) & 1)
+    b &= ~0x1FFF
+    return b.view(torch.float32)
+
+
+@pytest.mark.parametrize("res", ["r1", "r2"])
+def test_full_size_forward_deviates_from_the_fp32_grade_run_as_tf32_operand_rounding_does(cuda, res, monkeypatch):
+    """VERDICT round 5 #4 asked for tests/test_detector_gpu.py:131's gate (fused BEV feature and box regressions <= 1e-3 at R1 and
+    R2) under the TF32-grade form.  Measured, it is NOT met — and cannot be by ANY arithmetic with 11-bit operands: the same
+    forward with every convolution operand rounded to TF32 and the products then taken at fp32 grade (what the reference's cuDNN
+    does with allow_tf32, tools/train.py:150-153) deviates from the fp32-grade run by the same amount.  One forward of the reference
+    config (BatchNorm in inference mode, seeded weights) three times: fp32-grade split kernels, the half form, the TF32 emulation.
+    Asserted: the half form is within 1.5 x the TF32 emulation's deviation (relative L2, BEV feature and box regressions), and
+    both within 1e-2; printed: all numbers.  Measured (profiles/round6/pytest_f16_gates.txt), half form / TF32 emulation:
+    R1 BEV 2.78e-3 / 2.78e-3, box regressions 2.95e-3 / 2.97e-3; R2 BEV 6.02e-3 / 5.69e-3, box regressions 6.47e-3 / 6.11e-3."""
+    from omnihd_amd import ops
     from omnihd_amd.harness import FusionTrainStep
     out = {}
-    for policy in ("split", "f16"):
-        monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
-        st = FusionTrainStep(res="r1", batch=1, radar_dims=7, device="cuda:0", seed=5, dtype="fp32", channels_last=True, sets=1)
+    real_conv_split = ops.conv_split
+    for policy in ("split", "f16", "tf32emu"):
+        monkeypatch.setenv("OMNIHD_FP32_CONV", "split" if policy == "tf32emu" else policy)
+        if policy == "tf32emu":
+            monkeypatch.setattr(ops, "conv_split", lambda x, w, b, *a, **k: real_conv_split(_round_tf32(x), _round_tf32(w), b, *a, **k))
+        st = FusionTrainStep(res=res, batch=1, radar_dims=7 if res == "r1" else 8, device="cuda:0", seed=5, dtype="fp32",
+                             channels_last=True, sets=1)
         m, b = st.raw_model, st.batches[0]
         m.eval()
         with torch.no_grad():
@@ -181,10 +219,14 @@ def test_full_size_forward_under_the_policy_stays_within_north_stars_bound_of_th
         out[policy] = dict(bev=fd["pts_feats"][0].float(), cls=cls[0].float(), reg=reg[0].float())
         del st, m, fd
     rel = lambda a, b: float((a - b).norm() / b.norm())
-    report = {k: rel(out["f16"][k], out["split"][k]) for k in ("bev", "cls", "reg")}
-    print("f16 vs split, relative L2:", {k: "%.2e" % v for k, v in report.items()})
-    assert max(report.values()) <= 3e-3, report
-    assert min(report.values()) > 0.0, "the policy did not change a single convolution"
+    mx = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    report = {p: {k: rel(out[p][k], out["split"][k]) for k in ("bev", "cls", "reg")} for p in ("f16", "tf32emu")}
+    report_max = {p: {k: mx(out[p][k], out["split"][k]) for k in ("bev", "cls", "reg")} for p in ("f16", "tf32emu")}
+    print("\n", res, "relative L2 against the fp32-grade run:", {p: {k: "%.2e" % v for k, v in r.items()} for p, r in report.items()})
+    print(res, "max |diff| / max |ref|:", {p: {k: "%.2e" % v for k, v in r.items()} for p, r in report_max.items()})
+    for k in ("bev", "reg"):
+        assert 0.0 < report["f16"][k] <= 1.5 * report["tf32emu"][k], (k, report)
+        assert report["f16"][k] <= 1e-2 and report["tf32emu"][k] <= 1e-2, (k, report)
 
 
 def test_training_steps_under_the_policy_track_the_fp32_grade_steps(cuda, monkeypatch):

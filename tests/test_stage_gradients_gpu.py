@@ -86,10 +86,19 @@ def _run(model, make, shape, device):
     return dict(y=y.detach().float().cpu(), gx=x.grad.detach().float().cpu(), grads=grads)
 
 
+# x the fp32-grade gates for the TF32-grade form; measured (profiles/round6/pytest_f16_gates.txt): outputs, input gradients and
+# convolution weight gradients <= 5.3e-3; BatchNorm weight / bias gradients (sums with cancellation, see below) <= 1.9e-2
+F16_GRADE = 8.0
+F16_GRADE_BN = 16.0
+
+
 @pytest.mark.parametrize("relus", ["open", "real"])
-@pytest.mark.parametrize("policy", ["split", "miopen"])
+@pytest.mark.parametrize("policy", ["split", "miopen", "f16"])
 @pytest.mark.parametrize("stage", ["bev_encoder", "fusion_conv_se", "second_backbone", "fpnc_reduce", "depthnet_trunk"])
 def test_stage_gradients_match_the_cpu_on_identical_inputs(cuda, stage, policy, relus, monkeypatch):
+    """(``policy`` "f16", round 6: the TF32-grade half form.  Its gate is TF32's grade, not fp32's: GRADE below.)"""
+    if policy == "f16" and relus == "real":
+        pytest.skip("informational variant: run for the fp32-grade policies")
     monkeypatch.setenv("OMNIHD_FP32_CONV", policy)
     torch.backends.cudnn.allow_tf32 = False
     gpu, cpu = _models()
@@ -112,13 +121,16 @@ def test_stage_gradients_match_the_cpu_on_identical_inputs(cuda, stage, policy, 
         if float(want["grads"][n].norm()) > 1e-5 * biggest:     # (a bias in front of a BatchNorm has a zero gradient: noise on both sides)
             report[n] = rel(got["grads"][n], want["grads"][n])
     print("\nSTAGE", stage, policy, relus, "worst:", {k.split("vis.")[-1]: "%.1e" % v for k, v in sorted(report.items(), key=lambda kv: -kv[1])[:4]})
-    assert report["y"] <= 1e-3
+    # 11-bit operands: every product carries 2^-11-grade rounding of both factors; a stage of 3-10 layers measures <= F16_GRADE
+    grade = F16_GRADE if policy == "f16" else 1.0
+    assert report["y"] <= 1e-3 * grade
     if relus == "open":
         # BatchNorm weight / bias gradients are sums over ~10^5 rows in which terms of both signs nearly cancel: their RELATIVE
         # error carries that cancellation factor (measured up to 1.4e-3 with the split kernels, 4e-5 with MIOpen): 2e-3;
         # everything else — the output, the input gradient, every convolution weight gradient — 1e-3 (measured <= 2.5e-4)
         is_bn = lambda k: (".bn" in k or ".norm" in k or k.split(".")[-2].isdigit()) and k.split(".")[-1] in ("weight", "bias") and got["grads"][k].dim() == 1
-        bad = {k: v for k, v in report.items() if not v <= (2e-3 if k in got["grads"] and is_bn(k) else 1e-3)}
+        grade_bn = F16_GRADE_BN if policy == "f16" else 1.0
+        bad = {k: v for k, v in report.items() if not v <= (grade_bn * 2e-3 if k in got["grads"] and is_bn(k) else grade * 1e-3)}
         assert not bad, bad
     else:                                         # informational (see the module docstring): flips of real ReLUs, ~sqrt(p)
         assert max(report.values()) <= 5e-2
