@@ -711,6 +711,13 @@ __global__ __launch_bounds__(256) void k_amax_f32(const float* __restrict__ x, l
 __device__ __forceinline__ unsigned short f2h_rn(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
 
 // out = half(x * s), s = 2^(15 - e) for amax in [2^(e-1), 2^e) (amax_bits given) or 1; *inv_scale = 1 / s.  8 values per lane.
+// Without a scale, finite values beyond the half range SATURATE at +-65504 instead of becoming infinities (TF32 has fp32's
+// exponent range: an activation of 1e5 is not an overflow there); infinities and NaNs pass through.
+__device__ __forceinline__ float sat_half(float v) {
+  const float a = fabsf(v);
+  return (a > 65504.f && a < __builtin_huge_valf()) ? copysignf(65504.f, v) : v;
+}
+
 __global__ __launch_bounds__(256) void k_cast_f16(const float* __restrict__ x, long long n, const unsigned* __restrict__ amax_bits,
                                                   unsigned short* __restrict__ out, float* __restrict__ inv_scale) {
   float s = 1.f, inv = 1.f;
@@ -729,14 +736,14 @@ __global__ __launch_bounds__(256) void k_cast_f16(const float* __restrict__ x, l
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     unsigned short h[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) h[k] = f2h_rn(v[k] * s);
+    for (int k = 0; k < 8; ++k) h[k] = f2h_rn(amax_bits ? v[k] * s : sat_half(v[k]));
     uint4 ph;
     ph.x = h[0] | ((unsigned)h[1] << 16); ph.y = h[2] | ((unsigned)h[3] << 16); ph.z = h[4] | ((unsigned)h[5] << 16); ph.w = h[6] | ((unsigned)h[7] << 16);
     reinterpret_cast<uint4*>(out)[i] = ph;
   }
   if (blockIdx.x == 0) {
     const long long i = n8 * 8 + threadIdx.x;
-    if (i < n) out[i] = f2h_rn(x[i] * s);
+    if (i < n) out[i] = f2h_rn(amax_bits ? x[i] * s : sat_half(x[i]));
   }
 }
 

@@ -43,6 +43,19 @@ def test_cast_is_round_to_nearest_and_the_scale_is_an_exact_power_of_two(cuda, n
     assert float(inv) == 1.0 and not bool(z.any())
 
 
+def test_unscaled_cast_saturates_finite_values_beyond_the_half_range(cuda):
+    """TF32 keeps fp32's exponent range; the half form cannot — but a large finite activation must not turn into an infinity
+    (and then NaNs) silently: it saturates.  Scaled casts never come near the range."""
+    from omnihd_amd import ops
+    inf, nan = float("inf"), float("nan")
+    x = torch.tensor([7e4, -1e9, inf, -inf, nan, 65519.0, -65504.0, 1.0, 3e38, 0.0, -0.0, 6e-8, 1e-9], device=cuda)
+    h, _ = ops.cast_f16(x)
+    want = torch.tensor([65504.0, -65504.0, inf, -inf, nan, 65504.0, -65504.0, 1.0, 65504.0, 0.0, -0.0, 6e-8, 0.0]).half().to(cuda)
+    assert torch.equal(h[:4], want[:4]) and bool(torch.isnan(h[4])) and torch.equal(h[5:], want[5:]), h
+    g16, inv = ops.cast_f16(torch.tensor([3e38, -1e30, 1.0], device=cuda), scaled=True)
+    assert bool(torch.isfinite(g16).all()) and float(g16[0].float() * inv) == pytest.approx(3e38, rel=1e-3)
+
+
 def test_cast_keeps_the_memory_format(cuda):
     from omnihd_amd import ops
     x = _cl(torch.randn(2, 64, 6, 10, device=cuda))
