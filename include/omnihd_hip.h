@@ -445,7 +445,8 @@ int omnihd_conv_fwd_split(const void* x_hi, const void* x_lo, const void* w_hi, 
  *   omnihd_cast_f16     out16[i] = half(x[i] * s) (round to nearest even).  scaled == 0: s = 1.  scaled != 0: s = 2^(15 - e) with
  *                       max|x| in [2^(e-1), 2^e) found by a first pass; scratch2 (2 device words) receives the working maximum in
  *                       [0] and 1 / s in [1] (what the consumers take as `alpha`).  scaled == 1: [0] is zeroed by the call (a
- *                       memset node); scaled == 2: the caller passes it zeroed (one memset for many calls).  No synchronisation.
+ *                       memset node); scaled == 2: the caller passes it zeroed (one memset for many calls); scaled == 3: [0] already
+ *                       holds max|x| (accumulated by x's producer: omnihd_*_bwd_f32_amax) — no first pass.  No synchronisation.
  *   omnihd_conv_fwd_f16 omnihd_conv_fwd_bf16's geometries and tile codes on half operands: x16 (batch,h,w,cin), w16 (cout,k,k,cin)
  *                       -> y (batch,h,w,cout) F32 = alpha * conv + bias (alpha: device scalar or NULL = 1).  The data gradient is
  *                       the same call on the scaled half output gradient with the mirrored weight image and alpha = its 1 / s.
@@ -576,6 +577,12 @@ int omnihd_affine_act_fwd_f32_planes(const float* x, const float* scale, const f
                                      void* y_hi, void* y_lo, long long n_rows, int c, int relu, void* stream);
 int omnihd_affine_act_bwd_f32(const float* gy, const float* y, const float* scale, float* gx, float* gres,
                               long long n_rows, int c, int relu, void* stream);
+/* Round 6, for the TF32-grade convolutions next to these layers (omnihd_conv_fwd_f16): omnihd_affine_act_fwd_f32_planes with
+ * y_lo == NULL writes ONE plane to y_hi — the IEEE half of y (omnihd_cast_f16's unscaled output: saves that cast pass);
+ * omnihd_affine_act_bwd_f32_amax additionally accumulates max |gx| into *amax_bits (bit pattern of a float >= 0, zeroed by the caller;
+ * one atomic per workgroup), so that the cast of gx needs no pass of its own for the scale (omnihd_cast_f16 with scaled == 3). */
+int omnihd_affine_act_bwd_f32_amax(const float* gy, const float* y, const float* scale, float* gx, float* gres, void* amax_bits,
+                                   long long n_rows, int c, int relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training-mode BatchNorm (+ReLU) with the statistics exchange left to the caller ("naive" SyncBN:
@@ -646,6 +653,11 @@ int omnihd_bn_train_fwd_f32_planes(const float* x, const float* res, const float
 int omnihd_bn_train_bwd_f32_planes(const float* gy, const float* y_mask, int relu_from_x, const float* x, const float* gamma,
                                    const float* consts4c, float* gx, void* gx_hi, void* gx_lo, float* gres, float* sums2c,
                                    float* out5c, long long rows, int c, void* workspace, size_t workspace_bytes, void* stream);
+/* The TF32-grade neighbours (round 6): omnihd_bn_train_fwd_f32_planes with y_lo == NULL writes the IEEE-half plane of y to y_hi;
+ * omnihd_bn_train_bwd_f32_amax = omnihd_bn_train_bwd_f32 that also accumulates max |gx| into *amax_bits (see the affine form). */
+int omnihd_bn_train_bwd_f32_amax(const float* gy, const float* y_mask, int relu_from_x, const float* x, const float* gamma,
+                                 const float* consts4c, float* gx, void* amax_bits, float* gres, float* sums2c, float* out5c,
+                                 long long rows, int c, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Column sums of a row-major [rows][c] bf16 (is_f32 = 0) or fp32 matrix for ANY c, in fp32, two stages in a fixed order:
  * the bias gradient of a convolution whose channel count is not a multiple of 8 (sum over N, H, W of the NHWC output

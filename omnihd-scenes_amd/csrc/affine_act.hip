@@ -40,14 +40,18 @@ __global__ __launch_bounds__(256) void k_affine_fwd(const T* __restrict__ x, con
       out[k] = v;
     }
     store8(y, i, out);
-    if (y_hi) store_planes8(y_hi, y_lo, i, out);     // the next fp32-grade convolution reads these instead of a split pass over y
+    if (y_hi) {                                      // the next convolution reads these instead of a split / cast pass over y:
+      if (y_lo) store_planes8(y_hi, y_lo, i, out);   //   the two bf16 planes of the fp32-grade form,
+      else store_half8(y_hi, i, out);                //   or (y_lo NULL) the IEEE-half plane of the TF32-grade form
+    }
   }
 }
 
-template <typename T, bool RELU, bool RES>
+template <typename T, bool RELU, bool RES, bool AMAX = false>
 __global__ __launch_bounds__(256) void k_affine_bwd(const T* __restrict__ gy, const T* __restrict__ y,
                                                     const float* __restrict__ scale, T* __restrict__ gx,
-                                                    T* __restrict__ gres, int64_t n_vec, int c8) {
+                                                    T* __restrict__ gres, int64_t n_vec, int c8, unsigned* __restrict__ amax_bits = nullptr) {
+  float amax = 0.f;                                // max |gx| for the TF32-grade convolution in front of this layer (its cast needs the scale)
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % c8) * 8;
     float gv[8], yv[8], o1[8], o2[8];
@@ -61,10 +65,12 @@ __global__ __launch_bounds__(256) void k_affine_bwd(const T* __restrict__ gy, co
       const float g = pass ? gv[k] : 0.f;
       o2[k] = g;
       o1[k] = g * sc[k];
+      if (AMAX) amax = fmaxf(amax, fabsf(o1[k]));
     }
     store8(gx, i, o1);
     if (RES) store8(gres, i, o2);
   }
+  if (AMAX) block_amax_256(amax, amax_bits);
 }
 
 template <typename T>
@@ -83,15 +89,27 @@ int affine_fwd_t(const void* x, const float* scale, const float* shift, const vo
 
 template <typename T>
 int affine_bwd_t(const void* gy, const void* y, const float* scale, void* gx, void* gres, long long n_rows, int c, int relu,
-                 void* stream) {
+                 void* stream, unsigned* amax_bits = nullptr) {
   const int64_t n_vec = (int64_t)n_rows * (c / 8);
   const dim3 grid(grid_for(n_vec, 256 * 2)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const T *gv = (const T*)gy, *yv = (const T*)y;
-  if (relu && gres) hipLaunchKernelGGL((k_affine_bwd<T, true, true>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
-  else if (relu) hipLaunchKernelGGL((k_affine_bwd<T, true, false>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
-  else if (gres) hipLaunchKernelGGL((k_affine_bwd<T, false, true>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
-  else hipLaunchKernelGGL((k_affine_bwd<T, false, false>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8);
+#define OMNIHD_AFFINE_BWD(R, G, A)                                                                                          \
+  hipLaunchKernelGGL((k_affine_bwd<T, R, G, A>), grid, block, 0, st, gv, yv, scale, (T*)gx, (T*)gres, n_vec, c / 8, amax_bits)
+  if (amax_bits) {
+    if constexpr (sizeof(T) == 4) {
+      if (relu && gres) OMNIHD_AFFINE_BWD(true, true, true);
+      else if (relu) OMNIHD_AFFINE_BWD(true, false, true);
+      else if (gres) OMNIHD_AFFINE_BWD(false, true, true);
+      else OMNIHD_AFFINE_BWD(false, false, true);
+    } else {
+      OMNIHD_REQUIRE(false, "the amax form takes fp32 rows");
+    }
+  } else if (relu && gres) OMNIHD_AFFINE_BWD(true, true, false);
+  else if (relu) OMNIHD_AFFINE_BWD(true, false, false);
+  else if (gres) OMNIHD_AFFINE_BWD(false, true, false);
+  else OMNIHD_AFFINE_BWD(false, false, false);
+#undef OMNIHD_AFFINE_BWD
   return check_launch("affine_act_bwd");
 }
 
@@ -121,9 +139,19 @@ extern "C" int omnihd_affine_act_fwd_f32_planes(const float* x, const float* sca
                                                 void* y_hi, void* y_lo, long long n_rows, int c, int relu, void* stream) {
   OMNIHD_REQUIRE(n_rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
   if (n_rows == 0) return OMNIHD_OK;
-  OMNIHD_REQUIRE(x && scale && shift && y && y_hi && y_lo, "null pointer");
+  OMNIHD_REQUIRE(x && scale && shift && y && y_hi, "null pointer");          // (y_lo NULL: y_hi receives the IEEE-half plane)
   OMNIHD_REQUIRE(((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15u) == 0, "16-byte alignment");
   return affine_fwd_t<float>(x, scale, shift, res, y, n_rows, c, relu, stream, static_cast<bf16_t*>(y_hi), static_cast<bf16_t*>(y_lo));
+}
+
+/* omnihd_affine_act_bwd_f32 that ALSO accumulates max |gx| into *amax_bits (bit pattern of a float >= 0; the caller zeroes it): the
+ * scale of the half cast of gx for the TF32-grade convolution in front of this layer (omnihd_cast_f16, scaled == 3) */
+extern "C" int omnihd_affine_act_bwd_f32_amax(const float* gy, const float* y, const float* scale, float* gx, float* gres,
+                                              void* amax_bits, long long n_rows, int c, int relu, void* stream) {
+  OMNIHD_REQUIRE(n_rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
+  if (n_rows == 0) return OMNIHD_OK;
+  OMNIHD_REQUIRE(gy && scale && gx && (!relu || y) && amax_bits, "null pointer");
+  return affine_bwd_t<float>(gy, y, scale, gx, gres, n_rows, c, relu, stream, static_cast<unsigned*>(amax_bits));
 }
 
 extern "C" int omnihd_affine_act_bwd(const void* gy, const void* y, const float* scale, void* gx, void* gres,

@@ -205,13 +205,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_consts(const float* __restrict__
 // scale / shift (fss).  The per-channel coefficients are read as two 16-byte vectors per array (round 3's form read them one
 // float at a time inside a three-way conditional: 24 dependent 4-byte loads per 8 elements, 2.4 TB/s; this form 4.8 TB/s on
 // a 157 MB tensor, scripts/micro/bn_apply_bw.hip).
-template <typename T, int MASK>
+template <typename T, int MASK, bool AMAX = false>      // (AMAX: its own instantiation — two more registers would cost the plain form a wave of occupancy)
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ gy, const T* __restrict__ y,
                                                       const T* __restrict__ x, const float* __restrict__ coefA,
                                                       const float* __restrict__ coefB, const float* __restrict__ coefC,
                                                       const float* __restrict__ fss, T* __restrict__ gx,
                                                       T* __restrict__ gres, int64_t n_vec, int c8, bf16_t* __restrict__ gx_hi = nullptr,
-                                                      bf16_t* __restrict__ gx_lo = nullptr) {
+                                                      bf16_t* __restrict__ gx_lo = nullptr, unsigned* __restrict__ amax_bits = nullptr) {
+  float amax = 0.f;                                // max |gx| (amax_bits given: the TF32-grade convolution in front casts gx with that scale)
   auto vec8 = [](const float* p, float (&v)[8]) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -235,11 +236,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* __restrict__ gy, 
       const float g = pass ? gv[k] : 0.f;
       masked[k] = g;
       out[k] = fmaf(g, ca[k], fmaf(xv[k], cb[k], cc[k]));
+      if (AMAX) amax = fmaxf(amax, fabsf(out[k]));
     }
     if (gx) store8(gx, i, out);                      // (gx NULL: the convolution behind this layer takes the planes ONLY)
     if (gx_hi) store_planes8(gx_hi, gx_lo, i, out);  // the convolution behind this layer reads these instead of a split pass over gx
     if (gres) store8(gres, i, masked);             // gradient of a residual added before the ReLU
   }
+  if (AMAX) block_amax_256(amax, amax_bits);
 }
 
 int plan_blocks(long long rows, int c8, long long* rows_per_block) {
@@ -384,18 +387,26 @@ int channel_sums_t(const void* a, const void* b, const void* mask, const float* 
 template <typename T>
 int bwd_apply_t(const void* gy, const void* y_mask, const float* fwd_scale_shift, const void* x, const float* coef_a,
                 const float* coef_b, const float* coef_c, void* gx, void* gres, long long rows, int c, void* stream,
-                bf16_t* gx_hi = nullptr, bf16_t* gx_lo = nullptr) {
+                bf16_t* gx_hi = nullptr, bf16_t* gx_lo = nullptr, unsigned* amax_bits = nullptr) {
   OMNIHD_REQUIRE(rows >= 0 && c > 0 && c % 8 == 0, "C must be a positive multiple of 8");
   if (rows == 0) return OMNIHD_OK;
   OMNIHD_REQUIRE(gy && x && coef_a && coef_b && coef_c && (gx || (gx_hi && gx_lo)), "null pointer");
   const int64_t n_vec = (int64_t)rows * (c / 8);
   const dim3 grid(grid_for(n_vec, 256 * 2));
-#define OMNIHD_APPLY(M)                                                                                                     \
-  hipLaunchKernelGGL((k_bn_bwd_apply<T, M>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gy, (const T*)y_mask,       \
-                     (const T*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (T*)gx, (T*)gres, n_vec, c / 8, gx_hi, gx_lo)
-  if (y_mask) OMNIHD_APPLY(1);
-  else if (fwd_scale_shift) OMNIHD_APPLY(2);
-  else OMNIHD_APPLY(0);
+#define OMNIHD_APPLY(M, A)                                                                                                  \
+  hipLaunchKernelGGL((k_bn_bwd_apply<T, M, A>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gy, (const T*)y_mask,    \
+                     (const T*)x, coef_a, coef_b, coef_c, fwd_scale_shift, (T*)gx, (T*)gres, n_vec, c / 8, gx_hi, gx_lo, amax_bits)
+  if (amax_bits) {
+    if constexpr (sizeof(T) == 4) {
+      if (y_mask) OMNIHD_APPLY(1, true);
+      else if (fwd_scale_shift) OMNIHD_APPLY(2, true);
+      else OMNIHD_APPLY(0, true);
+    } else {
+      OMNIHD_REQUIRE(false, "the amax form takes fp32 rows");
+    }
+  } else if (y_mask) OMNIHD_APPLY(1, false);
+  else if (fwd_scale_shift) OMNIHD_APPLY(2, false);
+  else OMNIHD_APPLY(0, false);
 #undef OMNIHD_APPLY
   return check_launch("bn_bwd_apply");
 }
@@ -475,7 +486,7 @@ int train_fwd_t(const void* x, const void* res, const float* gamma, const float*
 template <typename T>
 int train_bwd_t(const void* gy, const void* y_mask, int relu_from_x, const void* x, const float* gamma, const float* consts4c,
                 void* gx, void* gres, float* sums2c, float* out5c, long long rows, int c, void* workspace,
-                size_t workspace_bytes, void* stream, void* gx_hi = nullptr, void* gx_lo = nullptr) {
+                size_t workspace_bytes, void* stream, void* gx_hi = nullptr, void* gx_lo = nullptr, void* amax_bits = nullptr) {
   const float* fss = (relu_from_x && !y_mask) ? consts4c : nullptr;    // consts4c starts with scale, shift
   int blocks = 0;
   int rc = channel_sums_t<T>(gy, x, y_mask, fss, sums2c, rows, c, 1, 1.0f, workspace, workspace_bytes, stream, &blocks);
@@ -487,7 +498,7 @@ int train_bwd_t(const void* gy, const void* y_mask, int relu_from_x, const void*
   rc = check_launch("bn_bwd_consts");
   if (rc) return rc;
   return bwd_apply_t<T>(gy, y_mask, fss, x, out5c + 2 * c, out5c + 3 * c, out5c + 4 * c, gx, gres, rows, c, stream,
-                        static_cast<bf16_t*>(gx_hi), static_cast<bf16_t*>(gx_lo));
+                        static_cast<bf16_t*>(gx_hi), static_cast<bf16_t*>(gx_lo), static_cast<unsigned*>(amax_bits));
 }
 }  // namespace
 
@@ -517,7 +528,8 @@ extern "C" int omnihd_bn_train_fwd_f32_planes(const float* x, const float* res, 
                                               float var_correction, int relu, float* y, void* y_hi, void* y_lo, float* stats2c,
                                               float* consts4c, long long rows, int c, void* workspace, size_t workspace_bytes,
                                               void* stream) {
-  OMNIHD_REQUIRE(y_hi && y_lo && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15u) == 0, "plane pointers");
+  // (y_lo NULL: y_hi receives the IEEE-half plane of y for the next TF32-grade convolution instead of the two bf16 planes)
+  OMNIHD_REQUIRE(y_hi && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15u) == 0, "plane pointers");
   return train_fwd_t<float>(x, res, gamma, beta, running_mean, running_var, momentum, eps, var_correction, relu, y, stats2c,
                             consts4c, rows, c, workspace, workspace_bytes, stream, y_hi, y_lo);
 }
@@ -537,6 +549,17 @@ extern "C" int omnihd_bn_train_bwd_f32(const float* gy, const float* y_mask, int
                                        void* stream) {
   return train_bwd_t<float>(gy, y_mask, relu_from_x, x, gamma, consts4c, gx, gres, sums2c, out5c, rows, c, workspace,
                             workspace_bytes, stream);
+}
+
+/* ..._f32_amax: max |gx| additionally accumulated into *amax_bits (bit pattern of a float >= 0, zeroed by the caller): the scale of
+ * the half cast of gx for the TF32-grade convolution in front of this layer (omnihd_cast_f16, scaled == 3). */
+extern "C" int omnihd_bn_train_bwd_f32_amax(const float* gy, const float* y_mask, int relu_from_x, const float* x,
+                                            const float* gamma, const float* consts4c, float* gx, void* amax_bits, float* gres,
+                                            float* sums2c, float* out5c, long long rows, int c, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  OMNIHD_REQUIRE(gx && amax_bits, "null pointer");
+  return train_bwd_t<float>(gy, y_mask, relu_from_x, x, gamma, consts4c, gx, gres, sums2c, out5c, rows, c, workspace,
+                            workspace_bytes, stream, nullptr, nullptr, amax_bits);
 }
 
 /* ..._f32_planes: gx additionally written as its two bf16 planes for the convolution in front of this layer. */

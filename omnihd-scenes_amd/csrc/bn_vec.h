@@ -57,4 +57,33 @@ __device__ __forceinline__ void store_planes8(bf16_t* __restrict__ hi, bf16_t* _
   reinterpret_cast<u32x4*>(lo)[i] = rl;
 }
 
+// the IEEE-half plane of 8 fp32 values (round to nearest even; finite values beyond +-65504 saturate, infinities / NaNs pass): what
+// omnihd_cast_f16 writes without a scale — the operand of the TF32-grade convolutions (conv_igemm.hip, F16), from the producer's registers
+__device__ __forceinline__ void store_half8(bf16_t* __restrict__ h, int64_t i, const float (&v)[8]) {
+  u32x4 raw;
+  unsigned short* e = reinterpret_cast<unsigned short*>(&raw);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float a = fabsf(v[k]);
+    const float s = (a > 65504.f && a < __builtin_huge_valf()) ? copysignf(65504.f, v[k]) : v[k];
+    e[k] = __builtin_bit_cast(unsigned short, (_Float16)s);
+  }
+  reinterpret_cast<u32x4*>(h)[i] = raw;
+}
+
+// max |v| of a 256-thread workgroup into *amax_bits (bit pattern of a non-negative float; atomicMax is order-independent): ONE atomic
+// per workgroup, and only where it can still raise the value.  Every thread of the workgroup calls it, once, after its loop.
+__device__ __forceinline__ void block_amax_256(float m, unsigned* __restrict__ amax_bits) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wave_max[4];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+    const unsigned bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, bits);
+  }
+}
+
 }  // namespace omnihd

@@ -1019,9 +1019,11 @@ extern "C" int omnihd_cast_f16(const float* x, long long n, int scaled, void* ou
   unsigned* amax = nullptr;
   if (scaled) {                                   // scratch2[0]: amax bits (working value), scratch2[1]: the inverse scale (result)
     amax = reinterpret_cast<unsigned*>(scratch2);
-    if (scaled != 2) OMNIHD_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));      // (2: the caller hands a zeroed word)
-    const int blocks = grid_for(n / 4 + 1, 256 * 4);
-    hipLaunchKernelGGL(k_amax_f32, dim3(blocks > 4 * kCUs ? 4 * kCUs : blocks), dim3(256), 0, st, x, n, amax);
+    if (scaled == 1) OMNIHD_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));      // (2: the caller hands a zeroed word)
+    if (scaled != 3) {                                                                    // (3: the word already holds max |x|, from x's producer)
+      const int blocks = grid_for(n / 4 + 1, 256 * 4);
+      hipLaunchKernelGGL(k_amax_f32, dim3(blocks > 4 * kCUs ? 4 * kCUs : blocks), dim3(256), 0, st, x, n, amax);
+    }
   }
   hipLaunchKernelGGL(k_cast_f16, dim3(grid_for(n / 8 + 1, 256 * 2)), dim3(256), 0, st, x, n, amax, static_cast<unsigned short*>(out16),
                      scaled ? scratch2 + 1 : (float*)nullptr);

@@ -106,6 +106,8 @@ PROTOTYPES = {
     "omnihd_bn_train_fwd_f32_planes": (c_int, [c_void_p] * 6 + [c_float, c_float, c_float, c_int] + [c_void_p] * 5 + [c_int64, c_int,
                                                c_void_p, c_size_t, c_void_p]),
     "omnihd_bn_train_bwd_f32_planes": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 9 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "omnihd_bn_train_bwd_f32_amax": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "omnihd_affine_act_bwd_f32_amax": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p]),
     "omnihd_radar_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omnihd_depth_head_fwd": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),

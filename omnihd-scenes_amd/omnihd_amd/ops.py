@@ -1445,6 +1445,49 @@ def tag_producer(t, key):
     t._omnihd_planes = (None, t._version, key)
 
 
+# The TF32-grade form (OMNIHD_FP32_CONV=f16) uses the same tags with ONE plane: the IEEE half of the tensor, written by the producer's
+# epilogue instead of a cast pass (2 bytes per element written there against 4 read + 2 written here, and a launch less per layer:
+# ON whenever the policy is f16).  Its gradients travel as fp32 with the amax the producer's backward accumulated (``_omnihd_amax``).
+_HALF_WANTED = set()
+
+
+def f16_handover():
+    """TF32-grade policy with the producers' hand-over on (OMNIHD_F16_HANDOVER=0: every convolution runs its own cast / amax passes —
+    the A/B switch of tests/test_conv_f16_gpu.py and of DESIGN.md 4.6b's numbers)."""
+    return _fp32_policy() == "f16" and _env("OMNIHD_F16_HANDOVER", "1") != "0"
+
+
+def half_wanted(key):
+    return key in _HALF_WANTED and f16_handover()
+
+
+def tag_half(t, plane, key):
+    t._omnihd_planes = ((plane,), t._version, key)
+    n = _PLANES_UNUSED.get(key, 0) + 1
+    _PLANES_UNUSED[key] = n
+    if n > 8:                                      # eight tensors in a row that no TF32-grade convolution took: stop producing
+        _HALF_WANTED.discard(key)
+        _PLANES_UNUSED[key] = 0
+
+
+def take_half(t):
+    """The half plane a producer attached to ``t`` (fp32, dense, unmodified since), or None — in which case the producer, if there
+    is one, is asked to write it from now on."""
+    tag = getattr(t, "_omnihd_planes", None)
+    if tag is None:
+        return None
+    planes, version, key = tag
+    if planes is None or len(planes) != 1:
+        _HALF_WANTED.add(key)
+        return None
+    if version != t._version or planes[0].shape != t.shape or planes[0].stride() != t.stride():
+        HANDOVER_STATS["stale"] += 1
+        return None
+    _PLANES_UNUSED[key] = 0
+    HANDOVER_STATS["taken_half"] = HANDOVER_STATS.get("taken_half", 0) + 1
+    return planes[0]
+
+
 def take_planes(t):
     """The planes a producer attached to ``t`` (fp32, channels_last-dense, unmodified since), or None — in which case the
     producer, if there is one, is asked to write them from now on."""
@@ -1453,6 +1496,8 @@ def take_planes(t):
         HANDOVER_STATS["untagged"] += 1
         return None
     planes, version, key = tag
+    if planes is not None and len(planes) != 2:      # the half plane of the TF32-grade form: not ours
+        return None
     if planes is None:
         if _env("OMNIHD_SPLIT_HANDOVER", "0") == "1":
             _PLANES_WANTED.add(key)
@@ -2119,19 +2164,22 @@ _AMAX_SLOTS = 2048
 
 def _amax_slot(dev):
     """Two zeroed device words for a scaled cast whose scale is consumed by launches enqueued right behind it on the SAME stream
-    (the backward of _ConvF16): slots of a ring that one fill re-zeroes every _AMAX_SLOTS casts instead of a memset node per cast
-    (92 fills per step in the first profile of the form).  Stream order makes the re-zeroing safe: it is enqueued behind every
-    consumer of the slots it clears."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    (the backward of _ConvF16, or the backward of the BatchNorm / affine layer behind it, which accumulates the amax there):
+    slots of a ring that a fill re-zeroes every _AMAX_SLOTS / 2 casts instead of a memset node per cast (92 fills per step in the
+    first profile of the form).  Stream order makes the re-zeroing safe: it is enqueued behind every consumer of the slots it clears."""
+    key = (dev.index, _raw_stream())
     e = _AMAX_RING.get(key)
     if e is None:
-        e = _AMAX_RING[key] = [torch.zeros(2 * _AMAX_SLOTS, dtype=torch.float32, device=dev), 0]
-    if e[1] == _AMAX_SLOTS:
-        e[0].zero_()
-        e[1] = 0
-    slot = e[0][2 * e[1]:2 * e[1] + 2]
-    e[1] += 1
-    return slot
+        e = _AMAX_RING[key] = [torch.zeros(2 * _AMAX_SLOTS, dtype=torch.float32, device=dev), 0, False]
+    i = e[1]
+    if i == _AMAX_SLOTS:
+        i, e[2] = 0, True
+    # the ring is re-zeroed HALF by half, each half when the index enters it: a slot handed out just before (a producer's backward
+    # has accumulated its amax there, the consumer's cast is not enqueued yet) lies in the other half and stays intact
+    if e[2] and (i == 0 or i == _AMAX_SLOTS // 2):
+        e[0][2 * i:2 * i + _AMAX_SLOTS].zero_()
+    e[1] = i + 1
+    return e[0][2 * i:2 * i + 2]
 
 
 def f16_weight(weight, dgrad=False):
@@ -2257,7 +2305,7 @@ class _ConvF16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
         if not x.is_contiguous(memory_format=_CL):
-            x = x.contiguous(memory_format=_CL)
+            x = x.contiguous(memory_format=_CL)              # (a new tensor: no producer's tag on it)
         dev = x.device
         L = lib()
         B, cin, H, W = x.shape
@@ -2266,7 +2314,9 @@ class _ConvF16(torch.autograd.Function):
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev, memory_format=_CL)
         with _on(dev):
             st = _raw_stream()
-            x16 = _f16_plane(x, 0, None, L, st)
+            x16 = take_half(x)                               # written by x's producer (BatchNorm / affine epilogue), or cast here
+            if x16 is None:
+                x16 = _f16_plane(x, 0, None, L, st)
             _conv_timed("f16", (cin, cout, k, H, W), lambda: check(
                 L.omnihd_conv_fwd_f16(x16.data_ptr(), w16.data_ptr(), None if bias is None else _f32c(bias.detach()).data_ptr(),
                                       y.data_ptr(), None, B, H, W, cin, cout, k, dilation[0], 0, st), "omnihd_conv_fwd_f16"))
@@ -2280,10 +2330,13 @@ class _ConvF16(torch.autograd.Function):
     def backward(ctx, g):
         x16, weight = ctx.saved_tensors
         s, p, d = ctx.conv
+        amax = getattr(g, "_omnihd_amax", None)              # (slot, version): g's producer has accumulated max |g| on the device
         if g.dtype != torch.float32:
-            g = g.float()
+            g, amax = g.float(), None
         if not g.is_contiguous(memory_format=_CL):
-            g = g.contiguous(memory_format=_CL)
+            g, amax = g.contiguous(memory_format=_CL), None
+        if amax is not None and amax[1] != g._version:
+            amax = None
         gx = gw = gb = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if need_x or need_w:
@@ -2294,8 +2347,10 @@ class _ConvF16(torch.autograd.Function):
             wd = f16_weight(weight, dgrad=True) if need_x else None
             with _on(dev):
                 st = _raw_stream()
-                slot = _amax_slot(dev)
-                g16 = _f16_plane(g, 2, slot, L, st)
+                slot = amax[0] if amax is not None else _amax_slot(dev)
+                g16 = _f16_plane(g, 3 if amax is not None else 2, slot, L, st)
+                FAST_PATHS["f16_amax_from_producer" if amax is not None else "f16_amax_pass"] = \
+                    FAST_PATHS.get("f16_amax_from_producer" if amax is not None else "f16_amax_pass", 0) + 1
                 inv = slot.data_ptr() + 4
                 if need_x:
                     gx = torch.empty((B, cin, H, W), dtype=torch.float32, device=dev, memory_format=_CL)
@@ -2714,12 +2769,25 @@ class _AffineAct(torch.autograd.Function):
     def forward(ctx, x, scale, shift, res, relu):
         n, c, h, w = x.shape
         y = torch.empty_like(x)
+        # TF32-grade neighbours (OMNIHD_FP32_CONV=f16): y also as its half plane once a convolution has asked for it (see take_half)
+        f16 = x.dtype == torch.float32 and _fp32_policy() == "f16"
+        pkey = ("aff_y", scale.data_ptr()) if f16 else None
+        y16 = torch.empty_like(x, dtype=torch.float16) if (pkey is not None and half_wanted(pkey)) else None
         with _on(x.device):
-            fwd = lib().omnihd_affine_act_fwd_f32 if x.dtype == torch.float32 else lib().omnihd_affine_act_fwd
-            check(fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(),
-                      n * h * w, c, 1 if relu else 0, _raw_stream()), "omnihd_affine_act_fwd")
+            if y16 is not None:
+                check(lib().omnihd_affine_act_fwd_f32_planes(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if res is None else res.data_ptr(),
+                                                             y.data_ptr(), y16.data_ptr(), None, n * h * w, c, 1 if relu else 0, _raw_stream()),
+                      "omnihd_affine_act_fwd_f32_planes")
+            else:
+                fwd = lib().omnihd_affine_act_fwd_f32 if x.dtype == torch.float32 else lib().omnihd_affine_act_fwd
+                check(fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if res is None else res.data_ptr(), y.data_ptr(),
+                          n * h * w, c, 1 if relu else 0, _raw_stream()), "omnihd_affine_act_fwd")
         ctx.save_for_backward(y if relu else None, scale)
-        ctx.relu, ctx.has_res, ctx.dtype = relu, res is not None, x.dtype
+        ctx.relu, ctx.has_res, ctx.dtype, ctx.f16 = relu, res is not None, x.dtype, f16
+        if y16 is not None:
+            tag_half(y, y16, pkey)
+        elif pkey is not None:
+            tag_producer(y, pkey)
         return y
 
     @staticmethod
@@ -2730,10 +2798,18 @@ class _AffineAct(torch.autograd.Function):
         gx = torch.empty_like(gy)
         gres = torch.empty_like(gy) if ctx.has_res and ctx.needs_input_grad[3] else None
         with _on(gy.device):
-            bwd = lib().omnihd_affine_act_bwd_f32 if gy.dtype == torch.float32 else lib().omnihd_affine_act_bwd
-            check(bwd(gy.data_ptr(), None if y is None else y.data_ptr(), scale.data_ptr(), gx.data_ptr(),
-                      None if gres is None else gres.data_ptr(), n * h * w, c, 1 if ctx.relu else 0, _raw_stream()),
-                  "omnihd_affine_act_bwd")
+            if ctx.f16 and gy.dtype == torch.float32 and f16_handover():
+                # the convolution in front of this layer casts gx to half with a scale: max |gx| is accumulated here, on the way
+                slot = _amax_slot(gy.device)
+                check(lib().omnihd_affine_act_bwd_f32_amax(gy.data_ptr(), None if y is None else y.data_ptr(), scale.data_ptr(), gx.data_ptr(),
+                                                           None if gres is None else gres.data_ptr(), slot.data_ptr(), n * h * w, c,
+                                                           1 if ctx.relu else 0, _raw_stream()), "omnihd_affine_act_bwd_f32_amax")
+                gx._omnihd_amax = (slot, gx._version)
+            else:
+                bwd = lib().omnihd_affine_act_bwd_f32 if gy.dtype == torch.float32 else lib().omnihd_affine_act_bwd
+                check(bwd(gy.data_ptr(), None if y is None else y.data_ptr(), scale.data_ptr(), gx.data_ptr(),
+                          None if gres is None else gres.data_ptr(), n * h * w, c, 1 if ctx.relu else 0, _raw_stream()),
+                      "omnihd_affine_act_bwd")
         return gx, None, None, gres, None
 
 
@@ -2786,6 +2862,8 @@ class _BnTrainAct(torch.autograd.Function):
         # fp32 4-D outputs can be handed to the next split convolution as planes (see take_planes)
         pkey = ("bn_y", id(weight)) if (x.dtype == torch.float32 and x.dim() == 4 and ranks == 1) else None
         y_planes = _alloc_planes(y) if (pkey is not None and planes_wanted(pkey)) else None
+        if y_planes is None and pkey is not None and half_wanted(pkey):
+            y_planes = (torch.empty_like(y, dtype=torch.float16),)      # TF32-grade neighbour: the half plane of y (see take_half)
         rm = None if running_mean is None else running_mean.data_ptr()
         rv = None if running_var is None else running_var.data_ptr()
         resp = None if res is None else res.data_ptr()
@@ -2800,8 +2878,8 @@ class _BnTrainAct(torch.autograd.Function):
                 if y_planes is not None:
                     check(L.omnihd_bn_train_fwd_f32_planes(
                         x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr, 1 if relu else 0,
-                        y.data_ptr(), y_planes[0].data_ptr(), y_planes[1].data_ptr(), stats.data_ptr(), consts.data_ptr(), rows, c,
-                        ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd_f32_planes")
+                        y.data_ptr(), y_planes[0].data_ptr(), y_planes[1].data_ptr() if len(y_planes) == 2 else None, stats.data_ptr(),
+                        consts.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_fwd_f32_planes")
                 else:
                     check(getattr(L, "omnihd_bn_train_fwd" + sfx)(
                         x.data_ptr(), resp, gamma.data_ptr(), beta.data_ptr(), rm, rv, momentum, eps, corr, 1 if relu else 0,
@@ -2829,7 +2907,9 @@ class _BnTrainAct(torch.autograd.Function):
         ctx.has_res = res is not None
         ctx.gkey = ("bn_gx", id(weight)) if pkey is not None else None
         if pkey is not None:
-            if y_planes is not None:
+            if y_planes is not None and len(y_planes) == 1:
+                tag_half(y, y_planes[0], pkey)
+            elif y_planes is not None:
                 tag_planes(y, y_planes, pkey)
             else:
                 tag_producer(y, pkey)
@@ -2880,6 +2960,14 @@ class _BnTrainAct(torch.autograd.Function):
                     gx_planes[0].data_ptr(), gx_planes[1].data_ptr(), gresp, local.data_ptr(), out.data_ptr(), rows, c,
                     ws.data_ptr(), ws.numel(), st), "omnihd_bn_train_bwd_f32_planes")
                 tag_planes(gx, gx_planes, ctx.gkey)
+            elif ctx.ranks == 1 and ctx.gkey is not None and f16_handover():
+                # the TF32-grade convolution in front of this layer casts gx to half with a scale: max |gx| accumulated on the way
+                slot = _amax_slot(dev)
+                check(L.omnihd_bn_train_bwd_f32_amax(
+                    gy.data_ptr(), yp, 1 if ctx.relu else 0, x.data_ptr(), gamma.data_ptr(), consts.data_ptr(), gx.data_ptr(),
+                    slot.data_ptr(), gresp, local.data_ptr(), out.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st),
+                    "omnihd_bn_train_bwd_f32_amax")
+                gx._omnihd_amax = (slot, gx._version)
             elif ctx.ranks == 1:
                 if ctx.gkey is not None:
                     tag_producer(gx, ctx.gkey)

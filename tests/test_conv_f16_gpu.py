@@ -178,6 +178,60 @@ def test_temporary_weights_are_converted_directly_without_a_table_upload(cuda, m
     assert _rel(x.grad, x2.grad) <= 1e-3 and _rel(w.grad, w2.grad) <= 1e-3, (_rel(x.grad, x2.grad), _rel(w.grad, w2.grad))
 
 
+def test_producers_hand_over_the_half_plane_and_the_gradient_amax(cuda, monkeypatch):
+    """Under the policy the BatchNorm / frozen-BatchNorm epilogues write the half plane of their output once a TF32-grade convolution
+    has asked for it (no cast pass there), and their backward accumulates max |gx| for the scaled cast of the convolution in front of
+    them (no amax pass there).  Both are exact replacements: the results are BIT-identical to the passes they replace
+    (OMNIHD_F16_HANDOVER=0)."""
+    from omnihd_amd import ops
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "f16")
+    ops._HALF_WANTED.clear(); ops._PLANES_UNUSED.clear()
+    torch.manual_seed(8)
+    w1 = _cl(torch.randn(64, 64, 3, 3, device=cuda) * 0.05).requires_grad_()
+    w2 = _cl(torch.randn(128, 64, 1, 1, device=cuda) * 0.1).requires_grad_()
+    w3 = _cl(torch.randn(64, 128, 3, 3, device=cuda) * 0.03).requires_grad_()
+    gamma, beta = (torch.rand(64, device=cuda) + 0.5).requires_grad_(), (torch.randn(64, device=cuda) * 0.1).requires_grad_()
+    scale, shift = torch.rand(128, device=cuda) + 0.5, torch.randn(128, device=cuda) * 0.1
+    x0 = _cl(torch.randn(2, 64, 20, 28, device=cuda))
+
+    def run():
+        x = x0.clone().requires_grad_()
+        y1 = ops.conv_split(x, w1, None, (1, 1), (1, 1))
+        y2 = ops.bn_train_act(y1, gamma, beta, torch.zeros(64, device=cuda), torch.ones(64, device=cuda), 0.1, 1e-5, relu=True)
+        y3 = ops.conv_split(y2, w2, None, (1, 1), (0, 0))
+        y4 = ops.affine_act(y3, scale, shift, None, True)
+        y5 = ops.conv_split(y4, w3, None, (1, 1), (1, 1))
+        grads = torch.autograd.grad(y5.square().mean(), [x, w1, w2, w3, gamma, beta])
+        return [y5.detach()] + [g.detach() for g in grads]
+
+    def counters():
+        return ops.HANDOVER_STATS.get("taken_half", 0), ops.FAST_PATHS.get("f16_amax_from_producer", 0)
+
+    monkeypatch.setenv("OMNIHD_F16_HANDOVER", "0")
+    c0 = counters()
+    plain = run()
+    assert counters() == c0
+    monkeypatch.setenv("OMNIHD_F16_HANDOVER", "1")
+    run()                                                            # the convolutions ask; from now on the producers write half planes
+    c0 = counters()
+    handed = run()
+    assert counters() == (c0[0] + 2, c0[1] + 2)
+    for a, b in zip(plain, handed):
+        assert torch.equal(a, b)
+    # and against plain fp32 torch, to the grade of the form (gradients in relative L2: a ReLU whose input lies within the form's
+    # rounding of zero flips its mask and moves single entries by their full size)
+    x = x0.clone().requires_grad_()
+    y = F.conv2d(x, w1, None, padding=1)
+    y = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    y = F.relu(F.conv2d(y, w2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    y = F.conv2d(y, w3, None, padding=1)
+    want = [y.detach()] + list(torch.autograd.grad(y.square().mean(), [x, w1, w2, w3, gamma, beta]))
+    assert _rel(handed[0], want[0]) <= 4e-3, _rel(handed[0], want[0])
+    for a, b in zip(handed[1:], want[1:]):
+        l2 = float((a.double() - b.double()).norm() / b.double().norm())
+        assert l2 <= 3e-2, l2
+
+
 def test_half_images_follow_the_optimiser_with_one_launch(cuda, monkeypatch):
     from omnihd_amd import ops
     monkeypatch.setenv("OMNIHD_FP32_CONV", "f16")
