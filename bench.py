@@ -845,7 +845,7 @@ def main():
         import omnihd_amd.plan as plan_mod
         from omnihd_amd import ops as ops_mod
         plan_mod.TIMING = []                 # events around every pooling kernel launched inside the timed steps
-        ops_mod.CONV_TIMING, ops_mod.CONV_TIMING_GEOMETRY = [], CONV_GEOMETRY   # ... and around our kernel on the largest convolution
+        ops_mod.conv_kernels.CONV_TIMING, ops_mod.conv_kernels.CONV_TIMING_GEOMETRY = [], CONV_GEOMETRY   # ... and around our kernel on the largest convolution
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
         t0 = time.perf_counter()
         marks[0].record()
@@ -864,9 +864,9 @@ def main():
         for kind, e0, e1 in plan_mod.TIMING:
             pool.setdefault(kind, []).append(e0.elapsed_time(e1) * 1e-3)
         plan_mod.TIMING = None
-        for kind, e0, e1 in ops_mod.CONV_TIMING:
+        for kind, e0, e1 in ops_mod.conv_kernels.CONV_TIMING:
             pool.setdefault("conv_" + kind, []).append(e0.elapsed_time(e1) * 1e-3)
-        ops_mod.CONV_TIMING = None
+        ops_mod.conv_kernels.CONV_TIMING = None
         in_step = {k: sum(v) / len(v) for k, v in pool.items() if v}
         in_step.update({"n_" + k: len(v) for k, v in pool.items()})
         return float(el.item()), {"median": round(q(0.5), 3), "p10": round(q(0.1), 3), "p90": round(q(0.9), 3), "max": round(per[-1], 3),

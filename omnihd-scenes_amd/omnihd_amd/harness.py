@@ -387,7 +387,7 @@ class FusionTrainStep:
             if os.environ.get("OMNIHD_DDP_HOOK", "1") != "0":
                 from . import ops
                 # bucket all-reduces on a stream that also waits for the weight-gradient side stream; side-stream weight
-                # gradients written straight into the reducer's bucket views: the N > 1 step is the N = 1 step (ops.py)
+                # gradients written straight into the reducer's bucket views: the N > 1 step is the N = 1 step (ops/streams.py)
                 ops.ddp_wgrad_overlap(self.model)
         params = [p for p in model.parameters() if p.requires_grad]
         self.opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.05, fused=self.device.type == "cuda")

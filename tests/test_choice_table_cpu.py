@@ -1,4 +1,4 @@
-"""The persisted kernel-choice table (omnihd_amd/ops.py::_ChoiceTable): a lookup that misses the process's
+"""The persisted kernel-choice table (omnihd_amd/ops/policy.py::_ChoiceTable): a lookup that misses the process's
 own table falls back to the committed file before anything is measured; misses are counted; the file round-trips."""
 import json
 import os
@@ -15,8 +15,8 @@ def test_lookup_falls_back_to_the_persisted_table_and_counts_misses(tmp_path, mo
     doc = {"conv": {json.dumps(list(map(lambda v: list(v) if isinstance(v, tuple) else v, key))): "hip"}, "wgrad": {}, "split": {}}
     path.write_text(json.dumps(doc))
     monkeypatch.setenv("OMNIHD_CHOICE_TABLE", str(path))
-    monkeypatch.setattr(ops, "_PERSISTED", {})
-    monkeypatch.setattr(ops, "_CHOICE_INFO", {"path": None, "sha256": None, "entries": 0, "misses": 0, "loaded": False})
+    monkeypatch.setattr(ops.policy, "_PERSISTED", {})
+    monkeypatch.setattr(ops.policy, "_CHOICE_INFO", {"path": None, "sha256": None, "entries": 0, "misses": 0, "loaded": False})
     table = ops._ChoiceTable("conv")
     assert table.get(key + (3,)) == "hip" and table[key + (3,)] == "hip"              # any device index: the file has none
     assert table.get(("fwd", (1, 8, 8, 8), 8, 3, 1, 0)) is None
@@ -25,7 +25,7 @@ def test_lookup_falls_back_to_the_persisted_table_and_counts_misses(tmp_path, mo
     assert table.measured(("fwd", (1, 8, 8, 8), 8, 3, 1, 0), "miopen") == "miopen"
     assert ops.choice_table_info()["misses"] == 1
     # round trip: persisted + measured entries, device index dropped
-    monkeypatch.setattr(ops, "_CONV_CHOICE", table)
+    monkeypatch.setattr(ops.policy, "_CONV_CHOICE", table)
     out = tmp_path / "merged.json"
     n = ops.save_choice_table(str(out))
     merged = json.loads(out.read_text())

@@ -1,7 +1,7 @@
 """The cached kernel images of master weights (bf16 shadows, split planes) must notice EVERY optimiser step.
 Round 3 found that torch.optim.AdamW(fused=True) updates parameters without moving their autograd version counter, which the
 caches were keyed on: after the first step the convolutions kept reading step-0 weights.  The caches are now also keyed on a
-generation counter moved by torch's global optimiser-step hook (omnihd_amd/ops.py::_WEIGHT_GEN)."""
+generation counter moved by torch's global optimiser-step hook (omnihd_amd/ops/weights.py::_WEIGHT_GEN)."""
 import os
 import sys
 
