@@ -58,12 +58,16 @@ def _tuplify(x):
     return tuple(_tuplify(v) for v in x) if isinstance(x, list) else x
 
 
+# omnihd-scenes_amd/ (this file: omnihd-scenes_amd/omnihd_amd/ops/policy.py): kernel_choices/ lies beside the package
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
 def _persisted_choices():
     if not _CHOICE_INFO["loaded"]:
         _CHOICE_INFO["loaded"] = True
         path = _env("OMNIHD_CHOICE_TABLE")
         if path is None:
-            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kernel_choices", "gfx950.json")
+            path = os.path.join(_PKG_ROOT, "kernel_choices", "gfx950.json")
         if path and path != "off" and os.path.exists(path):
             import hashlib
             import json
@@ -107,7 +111,7 @@ def choice_table_info():
         if k in _CHOICE_INFO:
             info[k] = _CHOICE_INFO[k]
     if info["path"]:
-        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        root = os.path.dirname(_PKG_ROOT)
         if os.path.abspath(info["path"]).startswith(root + os.sep):
             info["path"] = os.path.relpath(info["path"], root)          # as committed, not where this checkout happens to live
     return info

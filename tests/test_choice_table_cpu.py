@@ -42,3 +42,8 @@ def test_committed_table_loads_when_present():
         for name in ("conv", "wgrad", "split"):
             for k, v in doc[name].items():
                 assert isinstance(json.loads(k), list) and v in ("hip", "hip128x256", "miopen", "split")
+        if os.environ.get("OMNIHD_CHOICE_TABLE") is None:
+            # ... and the package FINDS it (the path is computed from the module's location: it moved when ops.py became a package)
+            info = ops.choice_table_info()
+            assert info["path"] == os.path.join("omnihd-scenes_amd", "kernel_choices", "gfx950.json"), info
+            assert info["entries"] == sum(len(doc[n]) for n in ("conv", "wgrad", "split")), info
