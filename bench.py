@@ -842,6 +842,22 @@ def main():
         for _ in range(a.warmup):
             wl.step()
         barrier()
+        # Python's cyclic collector: this process has built (and dropped) several detectors by the time the later blocks run, and a
+        # full collection then walks that whole long-lived heap — 119 / 189 ms inside ONE timed step of the one-rank DDP block on two
+        # leases (profiles/round6/bench_r6_lease*.json, always the same step: the trigger counts allocations).  The heap of everything
+        # built so far is collected once and frozen (gc.freeze: out of the collector's sight) before the timed steps; the collector
+        # stays ON, what it costs on the objects the steps themselves create is inside the time, and is reported ("gc").
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc_log, gc_t0 = [], [0.0]
+
+        def gc_watch(phase, info):
+            if phase == "start":
+                gc_t0[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], (time.perf_counter() - gc_t0[0]) * 1e3))
+        gc.callbacks.append(gc_watch)
         import omnihd_amd.plan as plan_mod
         from omnihd_amd import ops as ops_mod
         plan_mod.TIMING = []                 # events around every pooling kernel launched inside the timed steps
@@ -854,6 +870,8 @@ def main():
             marks[k + 1].record()
         barrier()
         el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        gc.callbacks.remove(gc_watch)
+        gc.unfreeze()
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         raw = [marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps)]
@@ -870,7 +888,9 @@ def main():
         in_step = {k: sum(v) / len(v) for k, v in pool.items() if v}
         in_step.update({"n_" + k: len(v) for k, v in pool.items()})
         return float(el.item()), {"median": round(q(0.5), 3), "p10": round(q(0.1), 3), "p90": round(q(0.9), 3), "max": round(per[-1], 3),
-                                  "slow_steps": slow}, in_step
+                                  "slow_steps": slow,
+                                  "gc": {"collections": len(gc_log), "full": sum(1 for g, _ in gc_log if g == 2),
+                                         "ms_total": round(sum(t for _, t in gc_log), 2), "ms_max": round(max([t for _, t in gc_log] or [0.0]), 2)}}, in_step
 
     runs, flops, comm, fast, ddp1, r2_step, per_frame, tf32_error = {}, {}, None, {}, None, None, None, None
     if a.workload == "fusion":
