@@ -839,17 +839,18 @@ def main():
     def timed(wl):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks.  An event after every step
         gives the spread of the individual steps (no synchronisation inside the timed region)."""
-        for _ in range(a.warmup):
-            wl.step()
-        barrier()
         # Python's cyclic collector: this process has built (and dropped) several detectors by the time the later blocks run, and a
         # full collection then walks that whole long-lived heap — 119 / 189 ms inside ONE timed step of the one-rank DDP block on two
         # leases (profiles/round6/bench_r6_lease*.json, always the same step: the trigger counts allocations).  The heap of everything
         # built so far is collected once and frozen (gc.freeze: out of the collector's sight) before the timed steps; the collector
-        # stays ON, what it costs on the objects the steps themselves create is inside the time, and is reported ("gc").
+        # stays ON, what it costs on the objects the steps themselves create is inside the time, and is reported ("gc").  Done in
+        # front of the WARM-UP steps: the collection takes ~0.1 s in which the GPU runs dry, and the warm-up refills its queue (done
+        # behind them, the first timed step of every block ran 5-7 ms long: profiles/round6/bench_r6_lease3.json).
         import gc
         gc.collect()
         gc.freeze()
+        for _ in range(a.warmup):
+            wl.step()
         gc_log, gc_t0 = [], [0.0]
 
         def gc_watch(phase, info):
@@ -858,6 +859,7 @@ def main():
             else:
                 gc_log.append((info["generation"], (time.perf_counter() - gc_t0[0]) * 1e3))
         gc.callbacks.append(gc_watch)
+        barrier()
         import omnihd_amd.plan as plan_mod
         from omnihd_amd import ops as ops_mod
         plan_mod.TIMING = []                 # events around every pooling kernel launched inside the timed steps
