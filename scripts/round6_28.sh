@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 6: the default bench line on a third lease: the long-lived heap frozen before the timed steps
-export TMPDIR=/tmp; out=gpurun_out/r6_27; mkdir -p $out
+# Round 6: the default bench line on a fourth lease: the heap frozen in front of the warm-up steps
+export TMPDIR=/tmp; out=gpurun_out/r6_28; mkdir -p $out
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench rc $?"
 python3 - <<PY
 import json
