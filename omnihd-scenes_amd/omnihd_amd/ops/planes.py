@@ -49,15 +49,18 @@ def _alloc_planes(t):
 # output tensor OBJECT with (planes, version counter, producer key); the convolution uses the planes if the tag is there and the
 # tensor has not been written since; on a miss it notes the producer key, and from the next step on that producer writes planes.
 # A producer whose planes nobody picked up stops writing them.  Measured in the R1 fp32 step (alternating runs of
-# scripts/lab/step_times.py): 50.9 ms with, 50.6 ms without — the BatchNorm kernels' extra 4 B/element of stores cost what the
-# convolutions' split passes saved, so it is OFF by default (OMNIHD_SPLIT_HANDOVER=1 turns it on; results are bit-identical).
+# scripts/lab/step_times.py) in round 3: 50.9 ms with, 50.6 ms without — the BatchNorm kernels' extra 4 B/element of stores cost
+# what the convolutions' split passes saved, and it stayed OFF.  Round 6, the same A/B on the step as it is now (one stream; where
+# the step is bound by the in-order queue a launch less is worth more than its bytes): 45.09 / 45.11 ms without, 44.83 / 44.62 ms
+# with (alternating fresh processes on one box, gpurun r6_29) — ON by default (OMNIHD_SPLIT_HANDOVER=0 turns it off; results are
+# bit-identical: tests/test_conv_split_gpu.py::test_batchnorm_hands_its_planes_to_the_next_split_convolution).
 _PLANES_WANTED = set()
 _PLANES_UNUSED = {}
 HANDOVER_STATS = {"taken": 0, "stale": 0, "asked": 0, "untagged": 0}
 
 
 def planes_wanted(key):
-    return key in _PLANES_WANTED and _env("OMNIHD_SPLIT_HANDOVER", "0") == "1"
+    return key in _PLANES_WANTED and _env("OMNIHD_SPLIT_HANDOVER", "1") != "0"
 
 
 def tag_planes(t, planes, key):
@@ -121,7 +124,7 @@ def take_planes(t):
     if planes is not None and len(planes) != 2:      # the half plane of the TF32-grade form: not ours
         return None
     if planes is None:
-        if _env("OMNIHD_SPLIT_HANDOVER", "0") == "1":
+        if _env("OMNIHD_SPLIT_HANDOVER", "1") != "0":
             _PLANES_WANTED.add(key)
         HANDOVER_STATS["asked"] += 1
         return None

@@ -12,6 +12,7 @@ from .._env import env as _env
 from .._lib import check, lib
 from ._core import FAST_PATHS
 from .policy import _CHOICE_INFO
+from .planes import HANDOVER_STATS
 from .weights import WIMG_STATS
 
 
@@ -33,12 +34,14 @@ def fast_paths_report():
             "device_plans_built": int(__import__("omnihd_amd.pool_plan", fromlist=["BUILDS"]).BUILDS["device_plans"]),
             "choice_table_misses": int(_CHOICE_INFO["misses"]),
             # uploads of a weight-image table (a BLOCKING host-to-device copy each): 0 in a steady step
-            "weight_table_uploads": int(WIMG_STATS["miss"])}
+            "weight_table_uploads": int(WIMG_STATS["miss"]),
+            # operand planes written by the producer's epilogue instead of a split / cast pass of the consuming convolution
+            "planes_handed_over": {"split": int(HANDOVER_STATS["taken"]), "half": int(HANDOVER_STATS.get("taken_half", 0))}}
 
 
 def fast_paths_reset():
     from .. import plan as _plan
-    for d in (FAST_PATHS, _plan.FAST_PATHS, WIMG_STATS):
+    for d in (FAST_PATHS, _plan.FAST_PATHS, WIMG_STATS, HANDOVER_STATS):
         for k in d:
             d[k] = 0
 
