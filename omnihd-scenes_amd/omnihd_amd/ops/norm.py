@@ -24,14 +24,20 @@ class _AffineAct(torch.autograd.Function):
     def forward(ctx, x, scale, shift, res, relu):
         n, c, h, w = x.shape
         y = torch.empty_like(x)
-        # TF32-grade neighbours (OMNIHD_FP32_CONV=f16): y also as its half plane once a convolution has asked for it (see take_half)
-        f16 = x.dtype == torch.float32 and _fp32_policy() == "f16"
-        pkey = ("aff_y", scale.data_ptr()) if f16 else None
-        y16 = torch.empty_like(x, dtype=torch.float16) if (pkey is not None and half_wanted(pkey)) else None
+        # fp32 outputs are handed to the convolution that reads them next as operand planes once it has asked (see take_planes /
+        # take_half): the hi / lo bf16 planes of the fp32-grade form, or the half plane of the TF32-grade form (OMNIHD_FP32_CONV=f16)
+        # (the hi / lo hand-over from THIS epilogue is opt-in, OMNIHD_SPLIT_HANDOVER=all: bit-identical by test, not yet timed in the step)
+        f32 = x.dtype == torch.float32
+        f16 = f32 and _fp32_policy() == "f16"
+        split_all = f32 and not f16 and _env("OMNIHD_SPLIT_HANDOVER", "1") == "all"
+        pkey = ("aff_y", scale.data_ptr()) if (f16 or split_all) else None
+        y16 = torch.empty_like(x, dtype=torch.float16) if (f16 and half_wanted(pkey)) else None
+        y_planes = _alloc_planes(y) if (split_all and planes_wanted(pkey)) else None
         with _on(x.device):
-            if y16 is not None:
+            if y16 is not None or y_planes is not None:
+                hi, lo = (y16.data_ptr(), None) if y16 is not None else (y_planes[0].data_ptr(), y_planes[1].data_ptr())
                 check(lib().omnihd_affine_act_fwd_f32_planes(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), None if res is None else res.data_ptr(),
-                                                             y.data_ptr(), y16.data_ptr(), None, n * h * w, c, 1 if relu else 0, _raw_stream()),
+                                                             y.data_ptr(), hi, lo, n * h * w, c, 1 if relu else 0, _raw_stream()),
                       "omnihd_affine_act_fwd_f32_planes")
             else:
                 fwd = lib().omnihd_affine_act_fwd_f32 if x.dtype == torch.float32 else lib().omnihd_affine_act_fwd
@@ -41,6 +47,8 @@ class _AffineAct(torch.autograd.Function):
         ctx.relu, ctx.has_res, ctx.dtype, ctx.f16 = relu, res is not None, x.dtype, f16
         if y16 is not None:
             tag_half(y, y16, pkey)
+        elif y_planes is not None:
+            tag_planes(y, y_planes, pkey)
         elif pkey is not None:
             tag_producer(y, pkey)
         return y

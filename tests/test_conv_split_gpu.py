@@ -205,6 +205,39 @@ def test_batchnorm_hands_its_planes_to_the_next_split_convolution(cuda, monkeypa
     assert stats["taken"] >= 4, stats           # steps 2 and 3: at least the two forward hand-overs each
 
 
+def test_frozen_batchnorm_epilogue_hands_its_planes_to_the_next_split_convolution(cuda, monkeypatch):
+    """The same hand-over from the frozen-BatchNorm epilogue (affine + ReLU: every BatchNorm of the image backbone): from the second
+    step on it writes the hi / lo planes of its output and the convolution behind it skips its split pass; bit-identical."""
+    from omnihd_amd import ops
+    monkeypatch.setenv("OMNIHD_FP32_CONV", "split")
+    torch.manual_seed(9)
+    w1 = (torch.randn(128, 64, 3, 3, device=cuda) * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w2 = (torch.randn(64, 128, 3, 3, device=cuda) * 0.03).contiguous(memory_format=torch.channels_last).requires_grad_()
+    scale, shift = torch.rand(128, device=cuda) + 0.5, torch.randn(128, device=cuda) * 0.1
+    x0 = torch.randn(2, 64, 24, 40, device=cuda).contiguous(memory_format=torch.channels_last)
+
+    def run(handover, steps=3):
+        monkeypatch.setenv("OMNIHD_SPLIT_HANDOVER", "all" if handover else "1")      # (opt-in for this epilogue: not yet timed in the step)
+        ops._PLANES_WANTED.clear(); ops._PLANES_UNUSED.clear()
+        for k in ops.HANDOVER_STATS:
+            ops.HANDOVER_STATS[k] = 0
+        outs = []
+        for _ in range(steps):
+            x = x0.clone().requires_grad_()
+            y = ops.conv_split(x, w1, None, (1, 1), (1, 1))
+            y = ops.affine_act(y, scale, shift, None, True)
+            y = ops.conv_split(y, w2, None, (1, 1), (1, 1))
+            outs.append([y.detach()] + [g.detach() for g in torch.autograd.grad(y.square().mean(), [x, w1, w2])])
+        return outs, dict(ops.HANDOVER_STATS)
+
+    base, stats0 = run(False)
+    got, stats = run(True)
+    assert stats0["taken"] == 0 and stats["taken"] >= 2, (stats0, stats)      # steps 2 and 3
+    for a, b in zip(base, got):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_weight_images_follow_the_fused_optimiser_in_the_step_loop(cuda, dtype):
     """Regression (round 3): torch.optim.AdamW(fused=True) does not move the parameters' version counters, so version-keyed weight
