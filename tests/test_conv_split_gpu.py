@@ -217,7 +217,7 @@ def test_frozen_batchnorm_epilogue_hands_its_planes_to_the_next_split_convolutio
     x0 = torch.randn(2, 64, 24, 40, device=cuda).contiguous(memory_format=torch.channels_last)
 
     def run(handover, steps=3):
-        monkeypatch.setenv("OMNIHD_SPLIT_HANDOVER", "all" if handover else "1")      # (opt-in for this epilogue: not yet timed in the step)
+        monkeypatch.setenv("OMNIHD_SPLIT_HANDOVER", "all" if handover else "1")      # (opt-in for this epilogue: see docs/SWITCHES.md)
         ops._PLANES_WANTED.clear(); ops._PLANES_UNUSED.clear()
         for k in ops.HANDOVER_STATS:
             ops.HANDOVER_STATS[k] = 0
